@@ -1,0 +1,241 @@
+/*
+ * optable_hip.h — C-ABI of liboptable_hip.so, the MI355X (gfx950) trace engine that
+ * sits behind optable's OpticalTable.ray_tracing().
+ *
+ * The reference (tim4431/optable) is pure Python and has no FFI of its own; the boundary
+ * this library replaces is the body of
+ *     OpticalTable.ray_tracing / _single_ray_tracing      optable/optical_table.py:57-147
+ * and everything that loop calls per (segment, surface):
+ *     OpticalComponent.interact / intersect_point_local   optable/optical_component.py:151-233,337-378
+ *     ComponentGroup.interact (AABB prune + first-min)    optable/component_group.py:93-122
+ *     solve_ray_bboxes_intersections                      optable/solver.py:5-48
+ *     BaseMirror / BaseRefraciveSurface / Lens .interact_local
+ *                                                         optable/optical_component.py:536-570,617-717,930-948
+ *     Surface.f / normal / within_boundary                optable/surfaces.py
+ *     GaussianBeam.q_at_z, Ray.pathlength, Sellmeier n    optable/ray.py:17-19,145-147; material.py:106-120
+ *     Monitor.record                                      optable/monitor.py:183-193
+ *
+ * Conventions
+ *   - plain C, no torch types; every pointer in ot_rays / ot_segments is a DEVICE pointer
+ *     (hipMalloc'd or a torch tensor's data_ptr()), every pointer in the scene structs is HOST.
+ *   - every entry point returns 0 on success or a negative ot_status; the message for the last
+ *     failure on the calling thread is ot_last_error().
+ *   - the caller owns all ray / segment buffers; the library owns the uploaded scene and its
+ *     scratch.  Calls on one ot_ctx are serialised on the ctx's hipStream_t.
+ *   - there is NO CPU fallback in this library.
+ */
+#ifndef OPTABLE_HIP_H
+#define OPTABLE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OT_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------------------- */
+enum ot_status {
+    OT_OK = 0,
+    OT_ERR_INVALID = -1,      /* bad argument / shape mismatch                            */
+    OT_ERR_HIP = -2,          /* a HIP runtime call failed (message has hipGetErrorString) */
+    OT_ERR_UNSUPPORTED = -3,  /* scene needs a feature this build does not have           */
+    OT_ERR_CAPACITY = -4,     /* an output buffer was too small (branching trace)         */
+    OT_ERR_NOSCENE = -5       /* trace called before ot_scene_upload                      */
+};
+
+/* ---- scene description (host PODs, copied by ot_scene_upload) ------------------------- */
+
+/* node kinds: the scene is the depth-first flattening of OpticalTable.components
+ * (optical_table.py:119-123 iterates top-level components in list order; a ComponentGroup
+ * iterates its children in list order, component_group.py:110-120).  With a strict '<'
+ * nearest-hit update in that order the first minimum wins at every level, exactly as
+ * np.argmin + the strict '<' at optical_table.py:121 do. */
+enum ot_node_kind { OT_NODE_GROUP = 0, OT_NODE_LEAF = 1 };
+
+/* surface shapes in the leaf's local frame, normal along +x (optical_component.py:43-47) */
+enum ot_shape_kind {
+    OT_SHAPE_CIRCLE = 0,     /* surfaces.py:139-161   p[0]=radius                                   */
+    OT_SHAPE_RECT = 1,       /* surfaces.py:164-209   p[0]=width/2 p[1]=height/2                    */
+    OT_SHAPE_POLYGON2D = 2,  /* surfaces.py:426-568, planar=True: aux -> polygon record             */
+    OT_SHAPE_POLYGON3D = 3,  /* same, planar=False (plane not x=0): general root solve              */
+    OT_SHAPE_SPHERE = 4,     /* surfaces.py:284-336   p[0]=R p[1]=height                            */
+    OT_SHAPE_ASPHERE_PARAM = 5, /* component_group.py:1092-1097 p[0]=aperture radius p[1]=R p[2]=kappa p[3]=a4 p[4]=a6 p[5]=a8 */
+    OT_SHAPE_ASPHERE_EXACT = 6, /* component_group.py:1061-1064 p[0]=aperture radius p[1]=EFL p[2]=n */
+    OT_SHAPE_CYLINDER = 7,   /* surfaces.py:212-281   p[0]=R p[1]=height/2 p[2]=theta0 p[3]=theta1  */
+    OT_SHAPE_POINT = 8,      /* surfaces.py:68-86     never hit                                     */
+    OT_SHAPE_CSG = 9         /* Plane.union/subtract  surfaces.py:100-136: aux -> postfix program   */
+};
+
+/* interaction kinds (what interact_local does) */
+enum ot_interaction_kind {
+    OT_INT_MIRROR = 0,   /* BaseMirror.interact_local            optical_component.py:536-570 */
+    OT_INT_REFRACT = 1,  /* BaseRefraciveSurface.interact_local  optical_component.py:617-717 */
+    OT_INT_LENS = 2,     /* Lens.interact_local (thin lens)      optical_component.py:930-948 */
+    OT_INT_BLOCK = 3     /* Block.interact_local (absorb)        optical_component.py:501-503 */
+};
+
+/* radius-of-curvature source for the refractive ABCD update (optical_component.py:633-639) */
+enum ot_roc_kind {
+    OT_ROC_INF = 0,      /* flat: ROC = +inf                                   */
+    OT_ROC_CONST = 1,    /* SphereRefractive: ROC = radius (:847)              */
+    OT_ROC_ASPHERE = 2   /* ASphere.roc(P) finite differences (surfaces.py:355-373) */
+};
+
+enum ot_node_flags {
+    OT_NODE_CHECK_AABB = 1  /* set for groups and for children of groups (component_group.py:98-107) */
+};
+
+typedef struct ot_node {
+    double M[9];       /* leaf: transform_matrix, local->lab rotation, row major          */
+    double origin[3];  /* leaf: lab origin                                                */
+    double aabb[6];    /* lab AABB (xmin,xmax,ymin,ymax,zmin,zmax) = component.bbox       */
+    double lbox[6];    /* leaf, non-planar: surface.get_bbox_local()                      */
+    double p[8];       /* shape parameters, see ot_shape_kind                             */
+    double reflectivity;
+    double transmission;
+    double focal_length; /* OT_INT_LENS                                                   */
+    double roc;          /* OT_ROC_CONST                                                  */
+    int32_t kind;        /* ot_node_kind                                                  */
+    int32_t end;         /* index one past the last descendant (leaf: own index + 1)      */
+    int32_t flags;       /* ot_node_flags                                                 */
+    int32_t shape;       /* ot_shape_kind                                                 */
+    int32_t interaction; /* ot_interaction_kind                                           */
+    int32_t mat1, mat2;  /* material table indices of _n1 (x>0 side) and _n2 (x<0 side)   */
+    int32_t roc_kind;    /* ot_roc_kind                                                   */
+    int32_t max_interact_count; /* <0: unlimited (optical_component.py:140-149)           */
+    int32_t count_slot;  /* row in the interact-count table, -1 when unlimited            */
+    int32_t aux;         /* offset (in doubles) into the aux table, -1 when unused        */
+    int32_t leaf_id;     /* index among leaves (what ot_segments.surface reports)         */
+} ot_node;
+
+enum ot_material_kind { OT_MAT_CONST = 0, OT_MAT_SELLMEIER = 1 };
+
+/* material.py:48-85 (RefractiveIndex), :106-120 (Sellmeier, wavelength in metres -> microns) */
+typedef struct ot_material {
+    double n;        /* OT_MAT_CONST                        */
+    double B[3];     /* OT_MAT_SELLMEIER                    */
+    double C[3];     /* microns^2                           */
+    int32_t kind;
+    int32_t _pad;
+} ot_material;
+
+typedef struct ot_scene_desc {
+    const ot_node* nodes;
+    int32_t n_nodes;
+    const ot_material* materials;
+    int32_t n_materials;
+    const double* aux;     /* polygon records and CSG programs, see DESIGN.md               */
+    int32_t n_aux;
+    int32_t n_count_slots; /* leaves with max_interact_count set                            */
+    int32_t max_children;  /* most rays any interaction can emit (1 => non-branching scene) */
+    double unit;           /* metres per model length unit (OpticalTable(unit=...), 1e-2)   */
+} ot_scene_desc;
+
+/* ---- ray / segment streams (device pointers, structure of arrays) -------------------- */
+
+enum ot_ray_flags {
+    OT_RAY_HAS_Q = 1,   /* qo is not None (ray.py:98-104)        */
+    OT_RAY_DEAD = 2     /* alive == False on input (optical_component.py:349) */
+};
+
+/* One ray = one Ray object of the reference (ray.py:63-104): 12 reals + id + flags.
+ * "real" is double for the _f64 entry points and float for _f32. */
+typedef struct ot_rays {
+    void* ox; void* oy; void* oz;   /* origin                                 */
+    void* dx; void* dy; void* dz;   /* unit direction                         */
+    void* wavelength;               /* model units (0 when unset)             */
+    void* q_re; void* q_im;         /* Gaussian q at origin (ignored w/o HAS_Q) */
+    void* intensity;
+    void* n;                        /* refractive index of the medium the ray is in, _n(wavelength*unit) */
+    void* pathlength;               /* _pathlength                            */
+    int32_t* id;                    /* interact-count class of the ray (rays sharing a Python _id share a class) */
+    int32_t* flags;                 /* ot_ray_flags                           */
+    void* length;                   /* optional: finite input length, +inf = None; NULL = all None */
+} ot_rays;
+
+/* One segment = one element of the list OpticalTable.ray_tracing returns
+ * (optical_table.py:125-134): the parent truncated at the hit (alive=False, length=t) or the
+ * unchanged escaping ray (alive=True, length=None -> +inf here, surface = -1). */
+typedef struct ot_segments {
+    void* ox; void* oy; void* oz;
+    void* dx; void* dy; void* dz;
+    void* length;
+    void* intensity;
+    void* q_re; void* q_im;
+    void* n;
+    void* pathlength;
+    int32_t* ray;       /* index of the input ray whose tree this segment belongs to */
+    int32_t* surface;   /* leaf_id that terminated the segment, -1 = escaped        */
+} ot_segments;
+
+typedef struct ot_ctx ot_ctx;
+
+/* ---- lifecycle ------------------------------------------------------------------------ */
+int ot_abi_version(void);
+const char* ot_last_error(void);
+
+/* stream: a hipStream_t the caller owns (e.g. torch.cuda.current_stream().cuda_stream),
+ * or NULL to let the ctx create its own. */
+int ot_ctx_create(int device, void* stream, ot_ctx** out);
+int ot_ctx_destroy(ot_ctx* ctx);
+int ot_ctx_synchronize(ot_ctx* ctx);
+
+/* Copies the scene (converted to the f32 layout as well) to the device. */
+int ot_scene_upload(ot_ctx* ctx, const ot_scene_desc* scene);
+
+/* ---- the hot path ----------------------------------------------------------------------- */
+
+/* Non-branching trace (scene.max_children <= 1): one lane per ray, all segments of a ray in
+ * one launch.  Segment k of ray i is written at slot k*n_rays + i of every ot_segments array
+ * (capacity max_segments*n_rays); seg_count[i] = number of slots ray i used.  max_segments is
+ * the reference's perfomance_limit["max_trace_num"] (optical_table.py:87-97).
+ * counts: int32 [n_count_slots][n_count_classes] interact-count table indexed by rays.id, or
+ * NULL when the scene has no limited surface. */
+int ot_trace_f64(ot_ctx* ctx, const ot_rays* rays, int64_t n_rays, int32_t max_segments,
+                 const ot_segments* out, int32_t* seg_count, int32_t* counts,
+                 int32_t n_count_classes);
+int ot_trace_f32(ot_ctx* ctx, const ot_rays* rays, int64_t n_rays, int32_t max_segments,
+                 const ot_segments* out, int32_t* seg_count, int32_t* counts,
+                 int32_t n_count_classes);
+
+/* Branching trace, one generation of the breadth-first ray tree per call
+ * (optical_table.py:115-134).  Input: the generation's alive rays with their tree index
+ * (rays_tree) in BFS order.  budget[i] = how many more segments tree i may still process
+ * (max_trace_num minus what it already used); rays beyond the budget are dropped as the
+ * reference drops them (optical_table.py:138-144).  Output: one segment per processed ray
+ * appended at *seg_cursor, and the next generation's rays (stable order: parent order, then
+ * child order) in next/next_tree with *n_next.  All counters are device int64/int32 scalars. */
+int ot_trace_generation_f64(ot_ctx* ctx, const ot_rays* rays, const int32_t* rays_tree,
+                            int64_t n_rays, int32_t* budget, const ot_segments* out,
+                            int64_t out_capacity, int64_t* seg_cursor, const ot_rays* next,
+                            int32_t* next_tree, int64_t next_capacity, int64_t* n_next,
+                            int32_t* counts, int32_t n_count_classes);
+
+/* Monitor.record (monitor.py:183-193): intersect finished segments with a rectangular
+ * monitor plane, honouring segment length.  hit_index receives the indices of the segments
+ * that hit (ascending), P the local hit point, t the distance; *n_hits the count. */
+typedef struct ot_monitor {
+    double M[9];
+    double origin[3];
+    double half_width, half_height;
+} ot_monitor;
+int ot_monitor_record_f64(ot_ctx* ctx, const ot_monitor* mon, const ot_segments* segs,
+                          int64_t n_segments, int64_t* hit_index, void* Px, void* Py, void* Pz,
+                          void* t, int64_t* n_hits);
+
+/* ---- measurement ------------------------------------------------------------------------ */
+/* When enabled every trace launch is bracketed by hipEvents on the ctx stream. */
+int ot_timing_enable(ot_ctx* ctx, int enabled);
+/* Sum and count of kernel durations since the last reset (synchronises the stream). */
+int ot_timing_read(ot_ctx* ctx, double* total_ms, int64_t* launches);
+int ot_timing_reset(ot_ctx* ctx);
+
+/* Launch-geometry knobs (0 = library default); for tuning and tests only. */
+int ot_set_launch(ot_ctx* ctx, int32_t block_threads, int32_t rays_per_lane);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPTABLE_HIP_H */

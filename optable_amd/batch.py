@@ -1,0 +1,150 @@
+"""Structure-of-arrays containers for ray and segment streams.
+
+torch tensors are used only as the device-array container (allocation, dtype, device);
+every field is a separate contiguous 1-D tensor so a wave of 64 lanes reads/writes 64
+consecutive elements per field (coalesced 512 B at fp64, 256 B at fp32).  Layouts mirror
+`ot_rays` / `ot_segments` in include/optable_hip.h.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import abi
+
+_REAL = {"f64": torch.float64, "f32": torch.float32}
+
+
+def real_dtype(precision):
+    return _REAL[precision]
+
+
+class RayBatch:
+    """N rays (reference: N `Ray` objects, ray.py:63-104)."""
+
+    def __init__(self, n, precision="f64", device="cuda"):
+        self.n, self.precision, self.device = int(n), precision, torch.device(device)
+        dt = _REAL[precision]
+        for f in abi.RAY_FIELDS:
+            if f != "n":
+                setattr(self, f, torch.zeros(self.n, dtype=dt, device=self.device))
+        self.intensity.fill_(1.0)
+        self.n_index = torch.ones(self.n, dtype=dt, device=self.device)
+        self.id = torch.arange(self.n, dtype=torch.int32, device=self.device)
+        self.flags = torch.zeros(self.n, dtype=torch.int32, device=self.device)
+        self.length = None  # optional finite input lengths (+inf = None)
+
+    # `n` names both the ray count and the refractive-index field in the C struct; the tensor
+    # lives in `n_index` on the Python side.
+    def field(self, name):
+        return self.n_index if name == "n" else getattr(self, name)
+
+    @classmethod
+    def from_arrays(cls, origin, direction, wavelength=0.0, intensity=1.0, q=None, n_index=1.0,
+                    pathlength=0.0, ids=None, precision="f64", device="cuda", normalize=True):
+        """Build from host arrays: origin/direction (N,3); scalars broadcast."""
+        origin = np.asarray(origin, dtype=np.float64).reshape(-1, 3)
+        direction = np.asarray(direction, dtype=np.float64).reshape(-1, 3)
+        if normalize:  # Ray.direction setter normalises (ray.py:115-119)
+            direction = direction / np.linalg.norm(direction, axis=1, keepdims=True)
+        nrays = origin.shape[0]
+        b = cls(nrays, precision, device)
+        dt = _REAL[precision]
+
+        def put(name, values):
+            arr = np.broadcast_to(np.asarray(values, dtype=np.float64), (nrays,))
+            b.field(name).copy_(torch.from_numpy(np.ascontiguousarray(arr)).to(dt))
+
+        for k, ax in enumerate("xyz"):
+            put("o" + ax, origin[:, k])
+            put("d" + ax, direction[:, k])
+        put("wavelength", wavelength)
+        put("intensity", intensity)
+        put("n", n_index)
+        put("pathlength", pathlength)
+        if q is not None:
+            q = np.broadcast_to(np.asarray(q, dtype=np.complex128), (nrays,))
+            put("q_re", q.real)
+            put("q_im", q.imag)
+            b.flags.fill_(abi.RAY_HAS_Q)
+        if ids is not None:
+            b.id.copy_(torch.from_numpy(np.asarray(ids, dtype=np.int32)))
+        return b
+
+    def slice(self, lo, hi):
+        """Contiguous shard [lo, hi) sharing storage (multi-GPU sharding, tests)."""
+        out = object.__new__(RayBatch)
+        out.n, out.precision, out.device = hi - lo, self.precision, self.device
+        for f in abi.RAY_FIELDS:
+            name = "n_index" if f == "n" else f
+            setattr(out, name, self.field(f)[lo:hi])
+        out.id, out.flags = self.id[lo:hi], self.flags[lo:hi]
+        out.length = None if self.length is None else self.length[lo:hi]
+        return out
+
+    def c_struct(self):
+        s = abi.OtRays()
+        for f in abi.RAY_FIELDS:
+            setattr(s, f, self.field(f).data_ptr())
+        s.id, s.flags = self.id.data_ptr(), self.flags.data_ptr()
+        s.length = None if self.length is None else self.length.data_ptr()
+        return s
+
+    def to_host(self):
+        out = {f: self.field(f).cpu().numpy() for f in abi.RAY_FIELDS}
+        out["id"], out["flags"] = self.id.cpu().numpy(), self.flags.cpu().numpy()
+        return out
+
+
+class SegmentBatch:
+    """`capacity` segment slots (reference: the List[Ray] `ray_tracing` returns).
+
+    Non-branching trace: slot k*n_rays + i = k-th segment of ray i, valid for k < count[i].
+    """
+
+    def __init__(self, capacity, precision="f64", device="cuda"):
+        self.capacity, self.precision, self.device = int(capacity), precision, torch.device(device)
+        dt = _REAL[precision]
+        for f in abi.SEG_FIELDS:
+            name = "n_index" if f == "n" else f
+            setattr(self, name, torch.empty(self.capacity, dtype=dt, device=self.device))
+        self.ray = torch.empty(self.capacity, dtype=torch.int32, device=self.device)
+        self.surface = torch.empty(self.capacity, dtype=torch.int32, device=self.device)
+        self.count = None      # int32 [n_rays] (non-branching layout)
+        self.n_rays = None
+        self.n_valid = None    # number of valid slots when the layout is a flat list
+
+    def field(self, name):
+        return self.n_index if name == "n" else getattr(self, name)
+
+    def c_struct(self):
+        s = abi.OtSegments()
+        for f in abi.SEG_FIELDS:
+            setattr(s, f, self.field(f).data_ptr())
+        s.ray, s.surface = self.ray.data_ptr(), self.surface.data_ptr()
+        return s
+
+    def valid_mask(self):
+        """Boolean mask over slots (device)."""
+        if self.count is not None:
+            k = torch.arange(self.capacity // self.n_rays, device=self.device, dtype=torch.int32).unsqueeze(1)
+            return (k < self.count.unsqueeze(0)).reshape(-1)
+        m = torch.zeros(self.capacity, dtype=torch.bool, device=self.device)
+        m[: self.n_valid] = True
+        return m
+
+    def to_host(self, reference_order=True):
+        """Valid segments as numpy arrays.  reference_order: input-ray-major, then segment
+        order within the ray (the order OpticalTable.ray_tracing returns, optical_table.py:66-70)."""
+        if self.count is not None:
+            K = self.capacity // self.n_rays
+            cnt = self.count.cpu().numpy()
+            keep = np.arange(K)[:, None] < cnt[None, :]            # [K, N]
+            out = {}
+            for f in abi.SEG_FIELDS + ("ray", "surface"):
+                a = self.field(f).cpu().numpy().reshape(K, self.n_rays)
+                out[f] = a.T[keep.T] if reference_order else a[keep]
+            out["count"] = cnt
+            return out
+        out = {f: self.field(f)[: self.n_valid].cpu().numpy() for f in abi.SEG_FIELDS + ("ray", "surface")}
+        return out

@@ -1,0 +1,147 @@
+"""Python handle on the HIP trace engine (one `ot_ctx` per device).
+
+Everything that touches rays goes through liboptable_hip.so; this module only moves
+pointers.  If the library or a GPU is missing the constructor raises — there is no CPU path.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import abi
+from .batch import RayBatch, SegmentBatch
+
+_engines = {}
+
+
+class Engine:
+    def __init__(self, device=0):
+        self.lib = abi.load()
+        if not torch.cuda.is_available():
+            raise abi.EngineUnavailable("no GPU visible: optable_amd traces only on an MI355X (no CPU fallback)")
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self._ctx = C.c_void_p()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        abi.check(self.lib.ot_ctx_create(device, C.c_void_p(stream), C.byref(self._ctx)), self.lib)
+        self.scene = None
+
+    def close(self):
+        if self._ctx:
+            self.lib.ot_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    # -- scene -----------------------------------------------------------------------------
+    def upload(self, scene):
+        desc = scene.desc()
+        abi.check(self.lib.ot_scene_upload(self._ctx, C.byref(desc)), self.lib)
+        self.scene = scene
+
+    # -- non-branching trace ---------------------------------------------------------------
+    def trace(self, rays: RayBatch, max_segments, out: SegmentBatch = None, counts=None):
+        """All segments of every ray in one launch; returns the SegmentBatch ([k][ray] slots)."""
+        if self.scene is None:
+            raise RuntimeError("upload a scene first")
+        n, K = rays.n, int(max_segments)
+        if out is None:
+            out = SegmentBatch(n * K, rays.precision, rays.device)
+        elif out.capacity < n * K or out.precision != rays.precision:
+            raise ValueError("output SegmentBatch too small or of the wrong precision")
+        if out.count is None or out.count.numel() != n:
+            out.count = torch.empty(n, dtype=torch.int32, device=rays.device)
+        out.n_rays = n
+        n_slots = len(self.scene.limited)
+        if n_slots and counts is None:
+            counts = torch.zeros((n_slots, n), dtype=torch.int32, device=rays.device)
+        n_classes = 0 if counts is None else counts.shape[1]
+        fn = self.lib.ot_trace_f64 if rays.precision == "f64" else self.lib.ot_trace_f32
+        rs, ss = rays.c_struct(), out.c_struct()
+        abi.check(fn(self._ctx, C.byref(rs), n, K, C.byref(ss), out.count.data_ptr(),
+                     None if counts is None else counts.data_ptr(), n_classes), self.lib)
+        out.counts_table = counts
+        return out
+
+    # -- branching trace: breadth-first, one generation per launch ------------------------------
+    def trace_tree(self, rays: RayBatch, max_trace_num, counts=None, out_capacity=None):
+        """Full ray trees (beam splitters, partial reflections, any cap).  Returns a flat
+        SegmentBatch in generation order plus, per tree, whether the cap cut it short."""
+        if self.scene is None:
+            raise RuntimeError("upload a scene first")
+        if rays.precision != "f64":
+            raise NotImplementedError("branching trace is fp64 only")
+        dev, n = rays.device, rays.n
+        fan = max(self.scene.max_children, 1)
+        if out_capacity is None:
+            out_capacity = max(4 * n, 1024)
+        out = SegmentBatch(out_capacity, "f64", dev)
+        budget = torch.full((n,), int(max_trace_num), dtype=torch.int32, device=dev)
+        cursor = torch.zeros(1, dtype=torch.int64, device=dev)
+        n_next = torch.zeros(1, dtype=torch.int64, device=dev)
+        tree = torch.arange(n, dtype=torch.int32, device=dev)
+        n_slots = len(self.scene.limited)
+        if n_slots and counts is None:
+            counts = torch.zeros((n_slots, n), dtype=torch.int32, device=dev)
+        n_classes = 0 if counts is None else counts.shape[1]
+        cur, cur_n = rays, n
+        while cur_n > 0:
+            need = int(cursor.item()) + cur_n
+            if need > out.capacity:
+                out = _grow(out, max(need, 2 * out.capacity), int(cursor.item()))
+            nxt = RayBatch(cur_n * fan, "f64", dev)
+            nxt_tree = torch.empty(cur_n * fan, dtype=torch.int32, device=dev)
+            rs, ss, ns = cur.c_struct(), out.c_struct(), nxt.c_struct()
+            abi.check(self.lib.ot_trace_generation_f64(
+                self._ctx, C.byref(rs), tree.data_ptr(), cur_n, budget.data_ptr(), C.byref(ss), out.capacity,
+                cursor.data_ptr(), C.byref(ns), nxt_tree.data_ptr(), cur_n * fan, n_next.data_ptr(),
+                None if counts is None else counts.data_ptr(), n_classes), self.lib)
+            cur_n = int(n_next.item())
+            cur, tree = nxt.slice(0, cur_n), nxt_tree[:cur_n]
+        out.n_valid = int(cursor.item())
+        out.counts_table = counts
+        out.capped = budget <= 0  # cap reached: queued rays were dropped (optical_table.py:138-144)
+        return out
+
+    # -- monitors -------------------------------------------------------------------------------
+    def monitor_record(self, monitor_struct, segs: SegmentBatch, n_segments):
+        dev = segs.device
+        idx = torch.empty(n_segments, dtype=torch.int64, device=dev)
+        P = [torch.empty(n_segments, dtype=torch.float64, device=dev) for _ in range(3)]
+        t = torch.empty(n_segments, dtype=torch.float64, device=dev)
+        nh = torch.zeros(1, dtype=torch.int64, device=dev)
+        ss = segs.c_struct()
+        abi.check(self.lib.ot_monitor_record_f64(self._ctx, C.byref(monitor_struct), C.byref(ss), n_segments,
+                                                 idx.data_ptr(), P[0].data_ptr(), P[1].data_ptr(), P[2].data_ptr(),
+                                                 t.data_ptr(), nh.data_ptr()), self.lib)
+        k = int(nh.item())
+        return idx[:k], torch.stack([p[:k] for p in P], dim=1), t[:k]
+
+    # -- measurement ---------------------------------------------------------------------------
+    def timing(self, enabled=True):
+        abi.check(self.lib.ot_timing_enable(self._ctx, int(enabled)), self.lib)
+        abi.check(self.lib.ot_timing_reset(self._ctx), self.lib)
+
+    def timing_read(self):
+        ms, cnt = C.c_double(), C.c_int64()
+        abi.check(self.lib.ot_timing_read(self._ctx, C.byref(ms), C.byref(cnt)), self.lib)
+        return ms.value, cnt.value
+
+    def set_launch(self, block_threads=0, rays_per_lane=0):
+        abi.check(self.lib.ot_set_launch(self._ctx, block_threads, rays_per_lane), self.lib)
+
+    def synchronize(self):
+        abi.check(self.lib.ot_ctx_synchronize(self._ctx), self.lib)
+
+
+def _grow(segs, capacity, n_keep):
+    big = SegmentBatch(capacity, segs.precision, segs.device)
+    for f in abi.SEG_FIELDS + ("ray", "surface"):
+        big.field(f)[:n_keep].copy_(segs.field(f)[:n_keep])
+    return big
+
+
+def get_engine(device=None) -> Engine:
+    if device is None:
+        device = torch.cuda.current_device() if torch.cuda.is_available() else 0
+    if device not in _engines:
+        _engines[device] = Engine(device)
+    return _engines[device]

@@ -1,0 +1,149 @@
+"""Rectangular recorder plane (reference: optable/monitor.py).
+
+`record` is the step right after the trace inside `_single_ray_tracing`
+(optical_table.py:145-146): every finished segment is intersected with the monitor's
+rectangle, honouring the segment's length (monitor.py:183-193).  On the MI355X path the
+intersection pass runs on the device over the trace's segment stream
+(`ot_monitor_record_f64`); this class keeps the reference's accessors on top of the hits.
+Plots are out of scope.
+"""
+import numpy as np
+
+from .components import OpticalComponent
+from .shapes import Rectangle
+
+
+class Monitor(OpticalComponent):
+    def __init__(self, origin, width, height, **kwargs):
+        super().__init__(origin, **kwargs)
+        self.width, self.height = width, height
+        self.surface = Rectangle(width, height)
+        self._edge_color = "orange"
+        self._initialize()
+
+    def _initialize(self):
+        self._data_raw = []  # (P_local, intensity, t, ray)
+        self._sorted_data = []
+        self._updated = False
+        self._sort_method = None
+
+    def clear(self):
+        self._initialize()
+
+    def get_bbox(self):
+        return OpticalComponent.get_bbox(self)
+
+    # -- recording -------------------------------------------------------------------------
+    def record(self, rays):
+        """Record a list of finished `Ray` segments (device pass via the engine)."""
+        from .table import record_monitor_hits
+
+        record_monitor_hits(self, rays)
+
+    def _extend(self, hits):
+        self._data_raw.extend(hits)
+        self._updated = True
+
+    # -- accessors (monitor.py:24-156) -----------------------------------------------------
+    @property
+    def ndata(self):
+        return len(self._data_raw)
+
+    @property
+    def raw_yList(self):
+        return np.array([d[0][1] for d in self._data_raw])
+
+    @property
+    def raw_zList(self):
+        return np.array([d[0][2] for d in self._data_raw])
+
+    @property
+    def sortYZIndex(self):
+        return np.lexsort((self.raw_zList, self.raw_yList))
+
+    @property
+    def sortIDindex(self):
+        return np.argsort([d[3]._id for d in self._data_raw])
+
+    def get_data(self, sort="YZ"):
+        if (not self._sorted_data) or self._updated or self._sort_method != sort:
+            order = {"YZ": lambda: self.sortYZIndex, "ID": lambda: self.sortIDindex}.get(sort)
+            if order is not None:
+                self._sort_method = sort
+                self._sorted_data = [self._data_raw[i] for i in order()]
+            self._updated = False
+        return self._sorted_data
+
+    data = property(lambda self: self.get_data())
+
+    def _column(self, pick, sort):
+        if self.ndata == 0:
+            return np.array([])
+        return np.array([pick(d) for d in self.get_data(sort=sort)])
+
+    def get_rays(self, sort="YZ"):
+        return [] if self.ndata == 0 else [d[3] for d in self.get_data(sort=sort)]
+
+    def get_PList(self, sort="YZ"):
+        return self._column(lambda d: d[0], sort)
+
+    def get_yList(self, sort="YZ"):
+        axis = self.tangent_Y
+        return self._column(lambda d: np.dot(d[0], axis), sort)
+
+    def get_zList(self, sort="YZ"):
+        axis = self.tangent_Z
+        return self._column(lambda d: np.dot(d[0], axis), sort)
+
+    def get_IList(self, sort="YZ"):
+        return self._column(lambda d: d[1], sort)
+
+    def get_tList(self, sort="YZ"):
+        return self._column(lambda d: d[2], sort)
+
+    def get_directionList(self, sort="YZ"):
+        return self._column(lambda d: d[3].direction, sort)
+
+    def get_tYList(self, sort="YZ"):
+        return np.dot(self.get_directionList(sort=sort), self.tangent_Y)
+
+    def get_tZList(self, sort="YZ"):
+        return np.dot(self.get_directionList(sort=sort), self.tangent_Z)
+
+    rays = property(lambda self: self.get_rays())
+    PList = property(lambda self: self.get_PList())
+    yList = property(lambda self: self.get_yList())
+    zList = property(lambda self: self.get_zList())
+    IList = property(lambda self: self.get_IList())
+    tList = property(lambda self: self.get_tList())
+    directionList = property(lambda self: self.get_directionList())
+    tYList = property(lambda self: self.get_tYList())
+    tZList = property(lambda self: self.get_tZList())
+
+    def get_ray_i(self, idx):
+        return self.rays[idx], [self.yList[idx], self.zList[idx], self.tYList[idx], self.tZList[idx], self.IList[idx]]
+
+    def get_ray_id(self, ray_id):
+        for idx, r in enumerate(self.rays):
+            if r._id == ray_id:
+                return self.get_ray_i(idx)
+        return None, None
+
+    def get_waist_distance(self):
+        out = []
+        for r, t in zip(self.rays, self.tList):
+            z = r.distance_to_waist(r.q_at_z(t))
+            out.append(-z if np.dot(r.direction, self.normal) > 0 else z)
+        return np.array(out)
+
+    @property
+    def sum_intensity(self):
+        return np.sum([d[1] for d in self.get_data()])
+
+    @property
+    def avg_intensity(self):
+        return np.mean([d[1] for d in self.get_data()])
+
+    def export_rays_npz(self, filename: str):
+        print(f"Exporting {self.ndata} rays to {filename} ...")
+        np.savez(filename, xList=self.yList, yList=self.zList, tXList=self.tYList, tYList=self.tZList, IList=self.IList)

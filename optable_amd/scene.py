@@ -1,0 +1,165 @@
+"""Scene compiler: object graph -> plain tables the device can stage into LDS.
+
+Depth-first flattening of `OpticalTable.components`.  Order is the contract: the reference
+tests top-level components in list order and keeps the first strictly smaller t
+(optical_table.py:119-123); a ComponentGroup tests its own AABB, then every child's AABB, then
+the children that passed, and returns the first minimum (component_group.py:93-122).  Emitting
+`[group, child, child, ...]` in that order, with `end` = index past the last descendant and
+`CHECK_AABB` on groups and their children, lets one forward pass with a strict `<` reproduce
+the same winner, the same pruning, and the same interact-count side effects.
+
+Anything without a device form (custom Material callables, arbitrary f_asphere closures,
+unbounded planes) raises here; there is no host fallback.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+from .components import OpticalComponent, MIRROR, REFRACT, LENS, BLOCK, ROC_INF
+from .materials import Material
+
+
+class SceneError(NotImplementedError):
+    pass
+
+
+class CompiledScene:
+    """Owner of the ctypes tables handed to `ot_scene_upload`."""
+
+    def __init__(self, nodes, materials, aux, leaves, limited, max_children, unit):
+        self.nodes = (abi.OtNode * max(len(nodes), 1))(*nodes)
+        self.n_nodes = len(nodes)
+        self.materials = (abi.OtMaterial * max(len(materials), 1))(*materials)
+        self.n_materials = len(materials)
+        self.aux = (C.c_double * max(len(aux), 1))(*aux)
+        self.n_aux = len(aux)
+        self.leaves = leaves        # leaf_id -> component
+        self.limited = limited      # count_slot -> component
+        self.max_children = max_children
+        self.unit = unit
+
+    @property
+    def n_leaves(self):
+        return len(self.leaves)
+
+    def desc(self):
+        d = abi.OtSceneDesc()
+        d.nodes, d.n_nodes = self.nodes, self.n_nodes
+        d.materials, d.n_materials = self.materials, self.n_materials
+        d.aux, d.n_aux = self.aux, self.n_aux
+        d.n_count_slots = len(self.limited)
+        d.max_children = self.max_children
+        d.unit = self.unit
+        return d
+
+    def node_table(self):
+        """Numpy view of the node records (tests, oracle)."""
+        return np.ctypeslib.as_array(self.nodes)[: self.n_nodes] if self.n_nodes else np.zeros(0)
+
+
+class _Builder:
+    def __init__(self):
+        self.nodes, self.materials, self.aux = [], [], []
+        self.mat_index = {}
+        self.leaves, self.limited = [], []
+        self.max_children = 0
+
+    # -- materials -----------------------------------------------------------------------
+    def material(self, mat):
+        if not isinstance(mat, Material):
+            mat = Material("Constant", float(mat))
+        spec = mat.device_spec()
+        if spec is None:
+            raise SceneError(f"Material {mat.name!r} is defined by a Python callable and has no device form "
+                             "(use a constant or a SellmeierMaterial)")
+        key = (spec[0],) + tuple(np.ravel(spec[1:]).tolist())
+        if key not in self.mat_index:
+            rec = abi.OtMaterial()
+            if spec[0] == "const":
+                rec.kind, rec.n = abi.MAT_CONST, spec[1]
+            else:
+                rec.kind, rec.n = abi.MAT_SELLMEIER, 0.0
+                rec.B[:], rec.C[:] = spec[1], spec[2]
+            self.mat_index[key] = len(self.materials)
+            self.materials.append(rec)
+        return self.mat_index[key]
+
+    # -- nodes -----------------------------------------------------------------------------
+    def add(self, comp, in_group):
+        if hasattr(comp, "components"):
+            self.add_group(comp)
+        else:
+            self.add_leaf(comp, in_group)
+
+    def add_group(self, grp):
+        node = abi.OtNode()
+        node.kind, node.flags = abi.NODE_GROUP, abi.NODE_CHECK_AABB
+        node.aabb[:] = [float(x) for x in grp.bbox]
+        node.leaf_id = node.aux = node.count_slot = -1
+        node.max_interact_count = -1
+        slot = len(self.nodes)
+        self.nodes.append(node)
+        for child in grp.components:
+            self.add(child, in_group=True)
+        node.end = len(self.nodes)
+        return slot
+
+    def add_leaf(self, comp, in_group):
+        if not isinstance(comp, OpticalComponent):
+            raise SceneError(f"{type(comp).__name__} is not an OpticalComponent")
+        surf = comp.surface
+        try:
+            low = surf.lower()
+        except NotImplementedError as exc:
+            raise SceneError(f"{type(comp).__name__}: {exc}") from exc
+        inter = comp.lower_interaction()
+        node = abi.OtNode()
+        node.kind, node.end = abi.NODE_LEAF, len(self.nodes) + 1
+        node.flags = abi.NODE_CHECK_AABB if in_group else 0
+        node.M[:] = np.asarray(comp.transform_matrix, dtype=float).ravel().tolist()
+        node.origin[:] = np.asarray(comp.origin, dtype=float).tolist()
+        if in_group or not low.planar:
+            node.aabb[:] = [float(x) for x in comp.bbox]
+        if not low.planar:
+            node.lbox[:] = [float(x) for x in surf.get_bbox_local()]
+        node.shape = low.kind
+        for k, v in enumerate(low.params):
+            node.p[k] = v
+        if low.aux is not None:
+            node.aux = len(self.aux)
+            self.aux.extend(low.aux)
+        else:
+            node.aux = -1
+        node.interaction = kind = inter["kind"]
+        node.reflectivity = float(inter.get("reflectivity", 0.0))
+        node.transmission = float(inter.get("transmission", 0.0))
+        node.focal_length = float(inter.get("focal_length", 0.0))
+        node.roc_kind, node.roc = inter.get("roc_kind", ROC_INF), float(inter.get("roc", np.inf))
+        node.mat1 = self.material(inter["mat1"]) if kind == REFRACT else -1
+        node.mat2 = self.material(inter["mat2"]) if kind == REFRACT else -1
+        if comp.max_interact_count is None:
+            node.max_interact_count, node.count_slot = -1, -1
+        else:
+            node.max_interact_count, node.count_slot = int(comp.max_interact_count), len(self.limited)
+            self.limited.append(comp)
+        node.leaf_id = len(self.leaves)
+        self.leaves.append(comp)
+        self.nodes.append(node)
+        self.max_children = max(self.max_children, _fanout(kind, node.reflectivity, node.transmission))
+
+
+def _fanout(kind, refl, trans):
+    """Most children one hit can emit (optical_component.py:546-570, 678-715, 944-948)."""
+    if kind == MIRROR:
+        return int(refl > 0) + int(trans > 0)
+    if kind == REFRACT:
+        return 1 + int(refl > 0)  # transmitted-or-TIR, plus the partial reflection
+    return 1 if kind == LENS else 0
+
+
+def compile_scene(components, unit=1e-2) -> CompiledScene:
+    b = _Builder()
+    for comp in components:
+        b.add(comp, in_group=False)
+    return CompiledScene(b.nodes, b.materials, b.aux, b.leaves, b.limited, b.max_children, unit)

@@ -1,0 +1,244 @@
+"""Parity scenes (SURVEY.md §8c G1-G13 and §8d cfg 2-5), written against a namespace `ns` so
+the SAME builder runs on the reference (tools/make_golden.py, `ns = optable`) and on this
+package (`ns = optable_amd`).  Each builder returns a dict:
+    components, monitors, rays, limit (perfomance_limit or None)
+Scene contents follow the reference's example scripts (cited per scene); synthetic configs
+follow SURVEY.md §8(d) verbatim (seeds, draw order).
+"""
+import numpy as np
+
+WL, W0 = 780e-7, 61e-4  # every synthetic ray carries a Gaussian q
+
+
+def g01_gaussian_beam(ns):
+    """examples/gaussian_beam.py:16-44 — mirror, three thin lenses, slab n=2, mirror."""
+    wl, w0 = 780e-9, 10e-6
+    R = ns.Ray
+    rays = [R([-10, y, 0], [1, 0, 0], wavelength=wl, w0=w0) for y in (0, 2, 4, 6, 9)]
+    rays.append(R([-10, 21, 0], [1, 0, 0], wavelength=wl, w0=w0).RotZ(-np.pi / 4))
+    comps = [ns.Mirror([0, 0, 0]).RotZ(np.pi / 6), ns.Lens([0, 2, 0], radius=0.8, focal_length=5),
+             ns.Lens([0, 4, 0], radius=0.8, focal_length=10), ns.Lens([0, 6.5, 0], radius=0.8, focal_length=10),
+             ns.GlassSlab([0, 9, 0], n1=1, n2=2, thickness=5), ns.Mirror([0, 11, 0]).RotZ(-np.pi / 2)]
+    return dict(components=comps, monitors=[], rays=rays, limit=None)
+
+
+def cfg2_rays(n, seed=0):
+    """Point source at the lens focus, cone half-angle 0.15*sqrt(u) (SURVEY.md §8d cfg 2)."""
+    rng = np.random.default_rng(seed)
+    u = rng.uniform(0, 1, n)
+    phi = rng.uniform(0, 2 * np.pi, n)
+    theta = 0.15 * np.sqrt(u)
+    d = np.stack([np.cos(theta), np.sin(theta) * np.cos(phi), np.sin(theta) * np.sin(phi)], axis=1)
+    return np.zeros((n, 3)), d
+
+
+def cfg2_components(ns):
+    return [ns.Lens([5, 0, 0], focal_length=5, radius=1.0), ns.MirrorPair([10, 0, 0], 4, 4)]
+
+
+def g02_cfg2(ns, n=1000):
+    o, d = cfg2_rays(n, 0)
+    rays = [ns.Ray(o[i], d[i], wavelength=WL, w0=W0, id=i) for i in range(n)]
+    return dict(components=cfg2_components(ns), monitors=[], rays=rays, limit={"max_trace_num": 5})
+
+
+def g03_chromatic(ns):
+    """examples/chromatic_aberration.py:16-40 — NBK7 slab, reflectivity 0.2 (branching, shared _id)."""
+    r0 = [ns.Ray([-3, 2, 0], [np.cos(np.pi / 6), -np.sin(np.pi / 6), 0], wavelength=780e-7, w0=20e-4).Propagate(-2)]
+    rays = ns.multiplex_rays_in_wavelength(r0, [780e-7, 560e-7, 400e-7])
+    gs = ns.GlassSlab([0, 0, 0], width=2, height=2, thickness=0.5, n1=ns.Vacuum(), n2=ns.Glass_NBK7(), reflectivity=0.2)
+    return dict(components=[gs], monitors=[], rays=rays, limit=None)
+
+
+def g04_glass_slab(ns):
+    """examples/glass_slab.py:26-43."""
+    rays = [ns.Ray([-3, 2, 0], [np.cos(np.pi / 6), -np.sin(np.pi / 6), 0], wavelength=780e-7, w0=2e-4).Propagate(-2)]
+    gs = ns.GlassSlab([0, 0, 0], width=2, height=2, thickness=0.5, n1=1, n2=1.5, reflectivity=0.2)
+    return dict(components=[gs], monitors=[], rays=rays, limit=None)
+
+
+def g05_cavity(ns):
+    """examples/cavity_4mir.py:18-40 — R=0.9 ring cavity; branches until the 2000 cap."""
+    L, D, R = 10 * 4 / 3, 4, 0.9
+    dt1 = dt2 = 0.02
+    comps = [ns.Mirror([0, 0, 0], radius=D, reflectivity=R).RotZ(-np.pi / 4),
+             ns.Mirror([L, 0, 0], radius=D, reflectivity=R).RotZ(+np.pi / 4 + dt1),
+             ns.Mirror([L, -L, 0], radius=D, reflectivity=R).RotZ(-np.pi / 4 + dt2),
+             ns.Mirror([0, -L, 0], radius=D, reflectivity=R).RotZ(+np.pi / 4)]
+    return dict(components=comps, monitors=[], rays=[ns.Ray([2, 0, 0], [1, 0, 0])], limit={"max_trace_num": 300})
+
+
+def g06_mirror_pair(ns):
+    """examples/mirror_pair.py:28-39 — 3-D rotated MirrorPair and two monitors."""
+    r0 = ns.Ray([-10, 1, 0], [1, 0, 0])._RotAround([0, 1, 0], [0, 0, 0], 0.1)
+    mp = ns.MirrorPair([3, 0, 0], 4, 4).RotX(0.3)
+    mons = [ns.Monitor([1, 0, 0], 5, 5), ns.Monitor([-3, 0, 0], 5, 5)]
+    return dict(components=[mp], monitors=mons, rays=[r0], limit=None)
+
+
+def _fan(ns, N=3, D=0.6):
+    """examples/calibrate_4f.py:187-192 — 7-ray fan with explicit ids."""
+    return [ns.Ray([-10, i * D, 0], [1, 0, 0], wavelength=780e-7, w0=61e-4, id=int(i + N)).Propagate(-10)
+            for i in np.arange(-N, N + 1)]
+
+
+def g07_spherical_lenses(ns):
+    """BiConvexLens + Doublet(N-SK2 / N-SF57) (examples/calibrate_4f.py:103-125)."""
+    bi = ns.BiConvexLens([5, 0, 0], CT=0.6, R1=20.0, R2=-20.0, diameter=5.08, EFL=20.0, name="B0")
+    dbl = ns.Doublet([26.4975, 0, 0], CT1=0.85, CT2=0.50, R1=12.1, R2=-11.87, R3=-42.24,
+                     n12=ns.Glass_NSK2(), n23=ns.Glass_NSF57(), diameter=2.54 * 2, name="L0")
+    mon = ns.Monitor([60, 0, 0], 10, 10)
+    return dict(components=[bi, dbl], monitors=[mon], rays=_fan(ns), limit=None)
+
+
+def g08_asphere(ns):
+    """ASphericParametricLens LENS==9 (examples/calibrate_4f.py:149-180) + the 7-ray fan."""
+    EFL, CT = 43.17, 0.8
+    n = ns.Glass_UVFS()
+    R = EFL * (n.n(780e-9) - 1)
+    lens = ns.ASphericParametricLens([EFL, 0, 0], CT=CT, diameter=2.54 * 3, R=R, n=n, kappa=-1.03113,
+                                     a4=-0.00223 * (1e-3 / 1e-2) ** 4, a6=0.006353 * (1e-3 / 1e-2) ** 6, name="L0")
+    exact = ns.ASphericExactSphericalLens([70, 0, 0], EFL=20.0, CT=0.5, diameter=5.0, n=1.6)
+    mon = ns.Monitor([95, 0, 0], 10, 10)
+    return dict(components=[lens, exact], monitors=[mon], rays=_fan(ns, D=0.55), limit=None)
+
+
+def cfg5_components(ns, N=(16, 16)):
+    return [ns.SquareMirror([-1, 0, 0], 6, 6),
+            ns.ASphericParametricLens([5, 0, 0], CT=0.8, diameter=5, n=1.5, R=10, kappa=-1, a4=1e-5),
+            ns.MMA(origin=[15, 0, 0], N=N, pitch=0.2, roc=28, n=1.5, thickness=0.1, reflectivity=1, transmission=0)]
+
+
+def cfg5_rays(n, seed=3):
+    rng = np.random.default_rng(seed)
+    yz = rng.uniform(-1.4, 1.4, (n, 2))  # y then z per ray
+    o = np.concatenate([np.zeros((n, 1)), yz], axis=1)
+    d = np.tile([1.0, 0.0, 0.0], (n, 1))
+    return o, d
+
+
+def g09_cfg5(ns, n=40):
+    o, d = cfg5_rays(n, 3)
+    rays = [ns.Ray(o[i], d[i], wavelength=WL, w0=W0, id=i) for i in range(n)]
+    return dict(components=cfg5_components(ns), monitors=[], rays=rays, limit={"max_trace_num": 50})
+
+
+def cfg3_components(ns):
+    rng = np.random.default_rng(1)
+    comps = []
+    for ix in range(8):
+        for iy in range(4):
+            origin = [4 * (ix + 1), 3 * (iy - 1.5), 0]
+            kind = ["Mirror", "Lens", "GlassSlab", "Prism"][(ix + iy) % 4]
+            a = rng.uniform(-np.pi, np.pi)
+            if kind == "Mirror":
+                comps.append(ns.Mirror(origin, radius=1).RotZ(a))
+            elif kind == "Lens":
+                f = rng.uniform(4, 12)
+                comps.append(ns.Lens(origin, focal_length=f, radius=1).RotZ(0.2 * a))
+            elif kind == "GlassSlab":
+                comps.append(ns.GlassSlab(origin, width=2, height=2, thickness=0.5, n1=1, n2=1.5).RotZ(0.3 * a))
+            else:
+                comps.append(ns.Prism(origin, width=1.5, height=2, n1=1, n2=1.5).RotZ(a))
+    return comps
+
+
+def cfg3_rays(n, seed=2):
+    rng = np.random.default_rng(seed)
+    draws = rng.uniform(0, 1, (n, 4))
+    y0 = -5.5 + 11.0 * draws[:, 0]
+    z0 = -0.5 + 1.0 * draws[:, 1]
+    dy = -0.05 + 0.10 * draws[:, 2]
+    dz = -0.02 + 0.04 * draws[:, 3]
+    o = np.stack([np.zeros(n), y0, z0], axis=1)
+    d = np.stack([np.ones(n), dy, dz], axis=1)
+    return o, d / np.linalg.norm(d, axis=1, keepdims=True)
+
+
+def g10_cfg3(ns, n=400):
+    o, d = cfg3_rays(n, 2)
+    rays = [ns.Ray(o[i], d[i], wavelength=WL, w0=W0, id=i) for i in range(n)]
+    return dict(components=cfg3_components(ns), monitors=[], rays=rays, limit={"max_trace_num": 20})
+
+
+def g11_prism_refl(ns):
+    """examples/prism_refl.py:25-70 — TriangularPrism, TIR, max_interact_count, explicit ids."""
+    theta, L = 0.00956, 6
+    n = ns.Glass_NBK7().n(780e-9)
+    D = 3 - 210e-4
+    rays = [ns.Ray([3, y + L / 2, 0], [-1, 0, 0], wavelength=780e-7, w0=61e-4, id=i).Propagate(-3).RotZ(theta)
+            for i, y in enumerate(np.linspace(-D, D, 5))]
+    ps = ns.TriangularPrism(origin=[0, 0, 0], width=L, height=L, n1=1, n2=n, alpha=np.pi / 4, beta=np.pi / 2,
+                            reflectivity_1=1, reflectivity_3=0.01, max_interact_count_2=10, max_interact_count_3=10)
+    mon = ns.Monitor([-3, 0, 0], width=L, height=L, name="Monitor 0")
+    return dict(components=[ps], monitors=[mon], rays=rays, limit=None)
+
+
+def g12_dove(ns):
+    """examples/dove_prism.py:25-65 — planar and 3-D Polygon faces, TIR on the base."""
+    L, D, Ng = 6.34, 1.515, 1.515
+    dp = ns.DovePrism([0, 0, 0], L=L, D=D, Ng=Ng)
+    z0 = dp.z0
+    R = ns.Ray
+    rays = [R([x, -50, z0], [0, 1, 0]) for x in np.linspace(-0.6, 0.6, 7)]
+    rays += [R([3, y, z + 1], [-1, 0, -0.3]) for y in np.linspace(-1, 1, 3) for z in np.linspace(-1, 1, 3)]
+    rays += [R([x, y, 3], [-0.3, 0, -1]) for x in np.linspace(-1, 1, 3) for y in np.linspace(-1, 1, 3)]
+    rays += [R([x, 3, z], [0, -1, 0]) for x in np.linspace(-1, 1, 3) for z in np.linspace(-1, 1, 3)]
+    dp = dp.RotX(0.02).RotZ(-0.01).TX(0.05).TZ(-0.03).RotYAroundLocal([0, 0, D / 2], theta=0.015)
+    mon = ns.Monitor([0, 10, z0], width=2 * D, height=2 * D, name="Monitor 0").RotZ(np.pi / 2)
+    return dict(components=[dp], monitors=[mon], rays=rays, limit=None)
+
+
+def g13_count_shadow(ns):
+    """a far mirror with max_interact_count=1 spends its count while
+    shadowed by a nearer pass-through mirror, then becomes transparent."""
+    near = ns.Mirror([2, 0, 0], radius=1, reflectivity=0.0, transmission=1.0)
+    far = ns.Mirror([4, 0, 0], radius=1, max_interact_count=1)
+    back = ns.Mirror([8, 0, 0], radius=1)
+    rays = [ns.Ray([0, 0.1 * k, 0], [1, 0, 0], id=k) for k in range(3)]
+    rays.append(ns.Ray([0, 0.05, 0], [1, 0, 0], id=0))  # shares counters with ray 0
+    return dict(components=[near, far, back], monitors=[], rays=rays, limit={"max_trace_num": 12})
+
+
+def g15_cfg4(ns, nbase=20, nwl=8):
+    """Chromatic slab, non-branching (SURVEY.md §8d cfg 4, reflectivity=0)."""
+    rng = np.random.default_rng(4)
+    jit = rng.uniform(-0.3, 0.3, (nbase, 2))
+    base = [ns.Ray([-3, 2 + jit[i, 0], jit[i, 1]], [np.cos(np.pi / 6), -np.sin(np.pi / 6), 0], wavelength=WL, w0=W0, id=i)
+            for i in range(nbase)]
+    rays = ns.multiplex_rays_in_wavelength(base, list(np.linspace(400e-7, 1100e-7, nwl)))
+    gs = ns.GlassSlab([0, 0, 0], width=2, height=2, thickness=0.5, n1=ns.Vacuum(), n2=ns.Glass_NBK7(), reflectivity=0)
+    return dict(components=[gs], monitors=[], rays=rays, limit=None)
+
+
+def g16_misc(ns):
+    """Shapes not covered above: CylMirror, Block with a hole (Plane.subtract), BeamSplitter,
+    WedgePlate, CircleGlassSlab, MirrorCube, PlanoConvexLens, MLA, DMD, finite-length and dead rays."""
+    comps = [
+        ns.BeamSplitter([2, 0, 0], width=2, height=2, eta=0.3).RotZ(np.pi / 4),
+        ns.Block([4, 0, 0], hole=ns.Circle(0.3), width=2, height=2),
+        ns.WedgePlate([6, 0, 0], width=2, height=2, thickness=0.4, wedge_angle=0.05, n1=1.0, n2=1.45),
+        ns.CircleGlassSlab([8, 0, 0], radius=1.0, thickness=0.3, n1=1.0, n2=1.7, reflectivity2=0.1),
+        ns.PlanoConvexLens([10, 0, 0], EFL=15.0, CT=0.4, diameter=2.0, R=7.5),
+        ns.MLA([13, 0, 0], N=(3, 3), pitch=0.4, focal_length=3.0, radius=0.2),
+        ns.CylMirror([18, 0, 0], radius=2.0, height=3.0, theta_range=(np.pi / 2, np.pi)).RotZ(0.1),
+        ns.MirrorCube([2, 6, 0], L=2.0).RotZ(np.pi / 2),
+        ns.DMD([2, -6, 0], N=(3, 2), pitch=0.5, tilt_angle=np.pi / 5).RotZ(-np.pi / 2 + 0.2),
+    ]
+    R = ns.Ray
+    rays = [R([0, y, z], [1, 0.002 * k, 0.001], wavelength=WL, w0=W0, id=k)
+            for k, (y, z) in enumerate([(0, 0), (0.1, 0.05), (0.25, -0.1), (0.5, 0.2), (-0.45, 0.1), (0.05, 0.29)])]
+    rays.append(R([0, 0.2, 0], [1, 0, 0], length=1.5, id=10))          # too short to reach anything
+    rays.append(R([0, 0.2, 0], [1, 0, 0], alive=False, id=11))         # dead on input
+    rays.append(R([0, 0, 0], [0.1, 1, 0.02], wavelength=WL, w0=W0, id=12))   # up into the corner cube
+    rays.append(R([0, 0, 0], [0.12, -1, 0.0], wavelength=WL, w0=W0, id=13))  # down onto the DMD
+    return dict(components=comps, monitors=[ns.Monitor([30, 0, 0], 20, 20)], rays=rays, limit={"max_trace_num": 200})
+
+
+SCENES = {
+    "g01_gaussian_beam": g01_gaussian_beam, "g02_cfg2": g02_cfg2, "g03_chromatic": g03_chromatic,
+    "g04_glass_slab": g04_glass_slab, "g05_cavity": g05_cavity, "g06_mirror_pair": g06_mirror_pair,
+    "g07_spherical_lenses": g07_spherical_lenses, "g08_asphere": g08_asphere, "g09_cfg5": g09_cfg5,
+    "g10_cfg3": g10_cfg3, "g11_prism_refl": g11_prism_refl, "g12_dove": g12_dove,
+    "g13_count_shadow": g13_count_shadow, "g15_cfg4": g15_cfg4, "g16_misc": g16_misc,
+}

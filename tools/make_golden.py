@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE (tim4431/optable) on the parity scenes.
+
+Runs only in the build container, where /root/reference exists:
+    MPLBACKEND=Agg PYTHONDONTWRITEBYTECODE=1 python tools/make_golden.py [scene ...]
+The reference is imported from /root/reference (never copied); what is committed are data
+fixtures: the packed input rays, the geometry the reference built (per-leaf pose and boxes, for
+checking this package's scene compiler) and every field of every output segment in the order
+`OpticalTable.ray_tracing` returned them, plus monitor hits and interact counts.
+"""
+import os
+import sys
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(1, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import optable as ref  # noqa: E402  (the reference)
+import scenes  # noqa: E402
+
+assert ref.__file__.startswith("/root/reference"), ref.__file__
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def flatten(components):
+    """Depth-first leaves and groups, the order the scene compiler must reproduce."""
+    leaves, groups = [], []
+
+    def walk(c, in_group):
+        if hasattr(c, "components"):
+            groups.append(c)
+            for k in c.components:
+                walk(k, True)
+        else:
+            leaves.append((c, in_group))
+
+    for c in components:
+        walk(c, False)
+    return leaves, groups
+
+
+def ray_rows(rays):
+    rows = dict(
+        origin=np.array([r.origin for r in rays], dtype=float).reshape(-1, 3),
+        direction=np.array([r.direction for r in rays], dtype=float).reshape(-1, 3),
+        intensity=np.array([r.intensity for r in rays], dtype=float),
+        wavelength=np.array([r.wavelength for r in rays], dtype=float),
+        length=np.array([np.inf if r.length is None else r.length for r in rays], dtype=float),
+        alive=np.array([bool(r.alive) for r in rays]),
+        has_q=np.array([r.qo is not None for r in rays]),
+        q=np.array([complex(r.qo) if r.qo is not None else complex(np.nan, np.nan) for r in rays]),
+        n=np.array([r.n for r in rays], dtype=float),
+        pathlength=np.array([r._pathlength for r in rays], dtype=float),
+    )
+    return rows
+
+
+def run(name):
+    sc = scenes.SCENES[name](ref)
+    table = ref.OpticalTable()
+    table.add_components(sc["components"])
+    table.add_monitors(sc["monitors"])
+    rays = sc["rays"]
+    leaves, groups = flatten(table.components)
+    ids = [r._id for r in rays]
+    class_of = {}
+    cls = np.array([class_of.setdefault(i, len(class_of)) for i in ids], dtype=np.int32)
+
+    out = {}
+    for key, val in ray_rows(rays).items():
+        out["in_" + key] = val
+    out["in_class"] = cls
+    out["limit"] = np.array([-1 if not sc["limit"] else sc["limit"].get("max_trace_num", -1)])
+
+    # trace exactly as OpticalTable.ray_tracing does (optical_table.py:66-70), keeping the tree index
+    segs, tree = [], []
+    for i, ray in enumerate(rays):
+        traced = table._single_ray_tracing(ray, perfomance_limit=sc["limit"])
+        segs.extend(traced)
+        tree.extend([i] * len(traced))
+    for key, val in ray_rows(segs).items():
+        out["seg_" + key] = val
+    out["seg_tree"] = np.array(tree, dtype=np.int32)
+
+    # geometry as the reference built it
+    out["leaf_origin"] = np.array([c.origin for c, _ in leaves], dtype=float).reshape(-1, 3)
+    out["leaf_M"] = np.array([c.transform_matrix for c, _ in leaves], dtype=float).reshape(-1, 3, 3)
+    out["leaf_in_group"] = np.array([g for _, g in leaves])
+    out["leaf_bbox"] = np.array([c.bbox if g else (np.nan,) * 6 for c, g in leaves], dtype=float).reshape(-1, 6)
+    out["group_bbox"] = np.array([g.bbox for g in groups], dtype=float).reshape(-1, 6)
+    limited = [c for c, _ in leaves if c.max_interact_count is not None]
+    out["counts"] = np.array([[c._interact_count.get(rid, 0) for rid in class_of] for c in limited],
+                             dtype=np.int32).reshape(len(limited), len(class_of))
+
+    # monitors: raw hit lists (monitor.py:183-193)
+    seg_index = {id(s): k for k, s in enumerate(segs)}
+    for m, mon in enumerate(table.monitors):
+        raw = mon._data_raw
+        out[f"mon{m}_P"] = np.array([d[0] for d in raw], dtype=float).reshape(-1, 3)
+        out[f"mon{m}_I"] = np.array([d[1] for d in raw], dtype=float)
+        out[f"mon{m}_t"] = np.array([d[2] for d in raw], dtype=float)
+        out[f"mon{m}_seg"] = np.array([seg_index[id(d[3])] for d in raw], dtype=np.int64)
+    os.makedirs(OUT, exist_ok=True)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: {len(rays)} rays, {len(leaves)} leaves, {len(groups)} groups -> {len(segs)} segments")
+
+
+def slab_vectors():
+    """G14: solve_ray_bboxes_intersections unit vectors incl. axis-parallel and flat boxes."""
+    rng = np.random.default_rng(14)
+    boxes = [(-1, 1, -1, 1, -1, 1), (0, 0, -1, 1, -1, 1), (2, 3, 0, 0, -0.5, 0.5), (-1, 1, -2, -1, 5, 6)]
+    o = rng.uniform(-3, 3, (64, 3))
+    d = rng.normal(size=(64, 3))
+    d[::4, 0] = 0.0
+    d[1::8, 1] = 1e-9
+    d[2::8, 2] = -1e-8
+    o[3::16] = [0.5, 0.5, 0.5]
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    t1 = np.zeros((64, len(boxes)))
+    t2 = np.zeros_like(t1)
+    hit = np.zeros_like(t1, dtype=bool)
+    for i in range(64):
+        a, b, h = ref.solve_ray_bboxes_intersections(o[i], d[i], [tuple(bx) for bx in boxes])
+        t1[i], t2[i], hit[i] = a, b, h
+    np.savez_compressed(os.path.join(OUT, "g14_slab.npz"), o=o, d=d, boxes=np.array(boxes, dtype=float), t1=t1, t2=t2, hit=hit)
+    print("g14_slab: 64 rays x 4 boxes")
+
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(scenes.SCENES)
+    for nm in names:
+        if nm == "g14_slab":
+            continue
+        np.random.seed(12345)
+        run(nm)
+    if not sys.argv[1:] or "g14_slab" in sys.argv[1:]:
+        slab_vectors()
