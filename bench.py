@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py — ray-surface intersections/s of the OpticalTable.ray_tracing hot path on MI355X.
+
+Workload (BASELINE.json configs[1], SURVEY.md §8d cfg 2): 1e6 rays from a point source at the
+focus of Lens([5,0,0], f=5, r=1) followed by MirrorPair([10,0,0], 4, 4); S = 3 leaf surfaces;
+cap 5 segments (every ray uses exactly 5); fp64; inputs resident in HBM before the timed region.
+A "step" is one trace of the whole batch (one launch of k_trace_fused<double>).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+For N > 1 it is launched by torch.distributed.run, one rank per GPU; every rank traces its own
+1e6-ray shard (weak scaling, no collective in the data path); the single end-of-job gather of the
+per-ray final state over RCCL is timed separately and reported as `gather_ms`.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(1, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+N_RAYS = 1_000_000
+MAX_SEG = 5
+S_LEAVES = 3
+BYTES_RAY = 104  # fp64: 12 reals + id + flags   
+BYTES_SEG = 104  # fp64: 12 reals + ray + surface
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(table, batch_host, budget_s=10.0):
+    """The oracle (CPU restatement, single thread) on the same workload, timed on this box's host."""
+    from oracle import oracle as orc
+
+    orc.build()
+    scene = table.compile()
+    n = len(batch_host["ox"])
+    sample = {k: v[: min(n, 200_000)] for k, v in batch_host.items()}
+    t0 = time.perf_counter()
+    segs = 0
+    rays = 0
+    while True:
+        out = orc.trace(scene, sample, max_trace_num=MAX_SEG)
+        segs += len(out["ray"])
+        rays += len(sample["ox"])
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": segs * S_LEAVES / dt, "unit": "ray-surface intersections/s", "cores": 1, "kind": "port",
+            "sample": f"{rays} rays of the same cfg-2 batch ({segs} segments) in {dt:.2f} s, C oracle, 1 thread; "
+                      f"host has {os.cpu_count()} cores",
+            "segments_per_s": segs / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rays", type=int, default=N_RAYS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import optable_amd as oa
+    from optable_amd.batch import RayBatch, SegmentBatch
+    from optable_amd.engine import get_engine
+    from optable_amd import dist as odist
+    import scenes
+
+    n = args.rays
+    table = oa.OpticalTable()
+    table.add_components(scenes.cfg2_components(oa))
+    o, d = scenes.cfg2_rays(n, seed=rank)  # every rank its own shard of the job
+    q = 1j * np.pi * scenes.W0**2 / scenes.WL
+    batch = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=q, device=f"cuda:{local_rank}")
+    eng = get_engine(local_rank)
+    scene = table.compile()
+    eng.upload(scene)
+    out = SegmentBatch(n * MAX_SEG, "f64", batch.device)
+
+    for _ in range(args.warmup):
+        eng.trace(batch, MAX_SEG, out=out)
+    eng.timing(True)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.trace(batch, MAX_SEG, out=out)
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    kernel_ms, launches = eng.timing_read()
+    eng.timing(False)
+
+    segs_step = int(out.count.sum().item())
+    gather_ms = None
+    if distributed:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=batch.device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        tot = torch.tensor([segs_step], dtype=torch.int64, device=batch.device)
+        dist.all_reduce(tot)
+        segs_total_step = int(tot.item())
+        # the one collective of the job: per-ray final state to rank 0 (outside the timed steps)
+        local = odist.final_state(out)
+        torch.cuda.synchronize()
+        dist.barrier()
+        g0 = time.perf_counter()
+        gathered = odist.gather_final_state(local, dst=0)
+        torch.cuda.synchronize()
+        dist.barrier()
+        gather_ms = (time.perf_counter() - g0) * 1e3
+        if rank == 0:
+            assert gathered.shape == (12, n * world)
+    else:
+        segs_total_step = segs_step
+
+    if rank == 0:
+        value = segs_total_step * S_LEAVES * args.steps / dt
+        avg_kernel_s = kernel_ms / max(launches, 1) / 1e3
+        alg_bytes = n * BYTES_RAY + segs_step * BYTES_SEG  # per launch, this rank
+        achieved = alg_bytes / avg_kernel_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_cfg2_f64.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        line = {
+            "metric": "ray-surface intersections/sec", "value": value, "unit": "intersections/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "cfg2: 1e6 point-source rays -> Lens + MirrorPair (S=3 leaves), 5-segment cap",
+                       "rays_per_gpu": n, "segments_per_ray": segs_step / n, "leaf_surfaces": S_LEAVES,
+                       "parallelism": f"ray-shard x{world}, scene replicated"},
+            "segments_per_s": segs_total_step * args.steps / dt,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "k_trace_fused<double>", "kernel_us": avg_kernel_s * 1e6,
+                         "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if gather_ms is not None:
+            line["gather_ms"] = gather_ms
+            line["value_incl_gather"] = segs_total_step * S_LEAVES * args.steps / (dt + gather_ms / 1e3)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(table, batch.to_host())
+        print(json.dumps(line), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

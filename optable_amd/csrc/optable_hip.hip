@@ -1,0 +1,721 @@
+// optable_hip.hip — gfx950 kernels and the C-ABI of liboptable_hip.so (include/optable_hip.h).
+//
+// Kernels
+//   k_trace_fused<T>     one lane per ray, every segment of the ray in one launch (non-branching
+//                        scenes).  Streams: 12 reals + 2 int32 in per ray, 12 reals + 2 int32
+//                        out per segment, all structure-of-arrays => each wave instruction moves
+//                        64 consecutive elements of one field (coalesced).  HBM-bound for small
+//                        scenes; the scene tables live in LDS.
+//   k_gen_*              breadth-first generation step for branching ray trees
+//                        (optical_table.py:115-134): mark -> scan -> trace -> scan -> compact.
+//   k_mon_*              Monitor.record over a segment stream (monitor.py:183-193).
+// No CPU fallback lives here: without a GPU every entry point fails with OT_ERR_HIP.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "trace_core.h"
+
+using namespace ot;
+
+// ------------------------------------------------------------------------------------------
+// error plumbing
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return fail(OT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));            \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// typed views of the C structs
+template <class T> struct RaysT {
+    const T *ox, *oy, *oz, *dx, *dy, *dz, *wl, *qr, *qi, *I, *n, *pl;
+    const int32_t *id, *flags;
+    const T* len;
+};
+template <class T> struct RaysOutT {
+    T *ox, *oy, *oz, *dx, *dy, *dz, *wl, *qr, *qi, *I, *n, *pl;
+    int32_t *id, *flags;
+};
+template <class T> struct SegsT {
+    T *ox, *oy, *oz, *dx, *dy, *dz, *len, *I, *qr, *qi, *n, *pl;
+    int32_t *ray, *surface;
+};
+template <class T> static RaysT<T> view(const ot_rays* r) {
+    return {(const T*)r->ox, (const T*)r->oy, (const T*)r->oz, (const T*)r->dx, (const T*)r->dy, (const T*)r->dz,
+            (const T*)r->wavelength, (const T*)r->q_re, (const T*)r->q_im, (const T*)r->intensity, (const T*)r->n,
+            (const T*)r->pathlength, r->id, r->flags, (const T*)r->length};
+}
+template <class T> static RaysOutT<T> view_out(const ot_rays* r) {
+    return {(T*)r->ox, (T*)r->oy, (T*)r->oz, (T*)r->dx, (T*)r->dy, (T*)r->dz, (T*)r->wavelength, (T*)r->q_re,
+            (T*)r->q_im, (T*)r->intensity, (T*)r->n, (T*)r->pathlength, r->id, r->flags};
+}
+template <class T> static SegsT<T> view(const ot_segments* s) {
+    return {(T*)s->ox, (T*)s->oy, (T*)s->oz, (T*)s->dx, (T*)s->dy, (T*)s->dz, (T*)s->length, (T*)s->intensity,
+            (T*)s->q_re, (T*)s->q_im, (T*)s->n, (T*)s->pathlength, s->ray, s->surface};
+}
+
+// ------------------------------------------------------------------------------------------
+// scene blob: [DNode<T> x n_nodes][DMat<T> x n_mats][T x n_aux], staged into LDS word by word
+struct SceneBlob {
+    const uint32_t* words;
+    int32_t n_words, n_nodes, n_mats;
+};
+
+template <class T> __device__ __forceinline__ Scene<T> bind_scene(const uint32_t* base, const SceneBlob& b, T unit) {
+    Scene<T> sc;
+    sc.nodes = reinterpret_cast<const DNode<T>*>(base);
+    sc.mats = reinterpret_cast<const DMat<T>*>(sc.nodes + b.n_nodes);
+    sc.aux = reinterpret_cast<const T*>(sc.mats + b.n_mats);
+    sc.n_nodes = b.n_nodes;
+    sc.unit = unit;
+    return sc;
+}
+
+template <class T> __device__ __forceinline__ void store_segment(const SegsT<T>& out, int64_t slot, const RayState<T>& r, T len,
+                                                                  int32_t tree, int32_t surface) {
+    out.ox[slot] = r.ox; out.oy[slot] = r.oy; out.oz[slot] = r.oz;
+    out.dx[slot] = r.dx; out.dy[slot] = r.dy; out.dz[slot] = r.dz;
+    out.len[slot] = len; out.I[slot] = r.I;
+    out.qr[slot] = r.qr; out.qi[slot] = r.qi;
+    out.n[slot] = r.n; out.pl[slot] = r.pl;
+    out.ray[slot] = tree; out.surface[slot] = surface;
+}
+
+template <class T> __device__ __forceinline__ RayState<T> load_ray(const RaysT<T>& in, int64_t i, int32_t flags) {
+    RayState<T> r;
+    r.ox = in.ox[i]; r.oy = in.oy[i]; r.oz = in.oz[i];
+    r.dx = in.dx[i]; r.dy = in.dy[i]; r.dz = in.dz[i];
+    r.wl = in.wl[i]; r.qr = in.qr[i]; r.qi = in.qi[i];
+    r.I = in.I[i]; r.n = in.n[i]; r.pl = in.pl[i];
+    r.len = in.len ? in.len[i] : Num<T>::inf();
+    r.has_q = (flags & OT_RAY_HAS_Q) != 0;
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_trace_fused: the hot kernel
+template <class T, bool SCENE_IN_LDS>
+__global__ __launch_bounds__(256) void k_trace_fused(SceneBlob blob, T unit, RaysT<T> in, int64_t n, int32_t K, SegsT<T> out,
+                                                     int32_t* __restrict__ seg_count, int32_t* counts, int32_t n_classes) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    const uint32_t* base = blob.words;
+    if (SCENE_IN_LDS) {
+        for (int w = threadIdx.x; w < blob.n_words; w += blockDim.x) lds[w] = blob.words[w];
+        __syncthreads();
+        base = lds;
+    }
+    const Scene<T> sc = bind_scene<T>(base, blob, unit);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < n; i0 += stride) {
+        const int64_t i = i0 + threadIdx.x;
+        bool active = i < n;
+        RayState<T> r = {};
+        int32_t cls = 0, used = 0;
+        if (active) {
+            const int32_t fl = in.flags[i];
+            r = load_ray(in, i, fl);
+            cls = in.id[i];
+            if (fl & OT_RAY_DEAD) {  // optical_component.py:349: a dead ray hits nothing and is returned as is
+                store_segment(out, i, r, r.len, (int32_t)i, -2);
+                used = 1;
+                active = false;
+            }
+        }
+        for (int32_t k = 0; k < K; ++k) {  // wave-uniform trip count: lanes never leave the loop alone
+            if (!__any(active)) break;
+            const Hit<T> h = nearest_hit<T, false>(sc, r, active, counts, n_classes, cls);
+            if (active) {
+                const int64_t slot = (int64_t)k * n + i;
+                used = k + 1;
+                if (h.node < 0) {  // escaped: archived unchanged (optical_table.py:132-134)
+                    store_segment(out, slot, r, r.len, (int32_t)i, -1);
+                    active = false;
+                } else {
+                    store_segment(out, slot, r, h.t, (int32_t)i, sc.nodes[h.node].leaf_id);
+                    RayState<T> child;
+                    if (interact<T, 1>(sc, r, h, &child) == 0) active = false;
+                    else r = child;
+                }
+            }
+        }
+        if (i < n) seg_count[i] = used;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// breadth-first generation step
+__global__ void k_gen_heads(const int32_t* tree, int64_t n, int64_t* head) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) head[i] = (i == 0 || tree[i - 1] != tree[i]) ? i : 0;
+}
+__global__ void k_gen_mark(const int32_t* tree, const int64_t* head, const int32_t* budget, int64_t n, int32_t* proc) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) proc[i] = (i - head[i]) < (int64_t)budget[tree[i]] ? 1 : 0;
+}
+
+struct ChildStore {  // scratch for up to 2 children per ray, SoA with stride 2n
+    double* f[12];
+    int32_t* flags;
+};
+
+template <bool SCENE_IN_LDS>
+__global__ __launch_bounds__(256) void k_gen_trace(SceneBlob blob, double unit, RaysT<double> in, const int32_t* tree, int64_t n,
+                                                   const int32_t* proc, const int64_t* seg_off, const int64_t* cursor,
+                                                   SegsT<double> out, int64_t out_capacity, ChildStore kids, int32_t* nkids,
+                                                   int32_t* counts, int32_t n_classes) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    const uint32_t* base = blob.words;
+    if (SCENE_IN_LDS) {
+        for (int w = threadIdx.x; w < blob.n_words; w += blockDim.x) lds[w] = blob.words[w];
+        __syncthreads();
+        base = lds;
+    }
+    const Scene<double> sc = bind_scene<double>(base, blob, unit);
+    const int64_t cur0 = *cursor;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < n; i0 += stride) {
+        const int64_t i = i0 + threadIdx.x;
+        bool active = i < n && proc[i];
+        RayState<double> r = {};
+        int32_t cls = 0, fl = 0;
+        if (active) {
+            fl = in.flags[i];
+            r = load_ray(in, i, fl);
+            cls = in.id[i];
+        }
+        const bool dead = active && (fl & OT_RAY_DEAD);
+        const Hit<double> h = nearest_hit<double, true>(sc, r, active && !dead, counts, n_classes, cls);
+        if (active) {
+            const int64_t slot = cur0 + seg_off[i];
+            int32_t nk = 0;
+            RayState<double> ch[2];
+            const int32_t t = tree[i];
+            if (slot < out_capacity) {
+                if (dead) store_segment(out, slot, r, r.len, t, -2);
+                else if (h.node < 0) store_segment(out, slot, r, r.len, t, -1);
+                else store_segment(out, slot, r, h.t, t, sc.nodes[h.node].leaf_id);
+            }
+            if (!dead && h.node >= 0) nk = interact<double, 2>(sc, r, h, ch);
+            for (int c = 0; c < nk; ++c) {
+                const int64_t s = 2 * i + c;
+                const RayState<double>& k = ch[c];
+                kids.f[0][s] = k.ox; kids.f[1][s] = k.oy; kids.f[2][s] = k.oz;
+                kids.f[3][s] = k.dx; kids.f[4][s] = k.dy; kids.f[5][s] = k.dz;
+                kids.f[6][s] = k.wl; kids.f[7][s] = k.qr; kids.f[8][s] = k.qi;
+                kids.f[9][s] = k.I; kids.f[10][s] = k.n; kids.f[11][s] = k.pl;
+                kids.flags[s] = fl & OT_RAY_HAS_Q;
+            }
+            nkids[i] = nk;
+        } else if (i < n) {
+            nkids[i] = 0;
+        }
+    }
+}
+
+__global__ void k_gen_compact(const int32_t* tree, const int32_t* ids, int64_t n, ChildStore kids, const int32_t* nkids,
+                              const int64_t* child_off, RaysOutT<double> next, int32_t* next_tree, int64_t next_capacity) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t nk = nkids[i];
+    for (int c = 0; c < nk; ++c) {
+        const int64_t s = 2 * i + c, d = child_off[i] + c;
+        if (d >= next_capacity) return;
+        next.ox[d] = kids.f[0][s]; next.oy[d] = kids.f[1][s]; next.oz[d] = kids.f[2][s];
+        next.dx[d] = kids.f[3][s]; next.dy[d] = kids.f[4][s]; next.dz[d] = kids.f[5][s];
+        next.wl[d] = kids.f[6][s]; next.qr[d] = kids.f[7][s]; next.qi[d] = kids.f[8][s];
+        next.I[d] = kids.f[9][s]; next.n[d] = kids.f[10][s]; next.pl[d] = kids.f[11][s];
+        next.flags[d] = kids.flags[s];
+        next.id[d] = ids[i];
+        next_tree[d] = tree[i];
+    }
+}
+
+__global__ void k_gen_finish(const int32_t* tree, const int64_t* head, int64_t n, int32_t* budget, const int32_t* proc,
+                             const int64_t* seg_off, const int32_t* nkids, const int64_t* child_off, int64_t* cursor,
+                             int64_t* n_next) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (i == n - 1 || tree[i + 1] != tree[i]) {  // last ray of its tree in this generation
+        const int64_t in_gen = i - head[i] + 1;
+        const int32_t b = budget[tree[i]];
+        budget[tree[i]] = b - (int32_t)(in_gen < b ? in_gen : b);
+    }
+    if (i == n - 1) {
+        *cursor += seg_off[i] + proc[i];
+        *n_next = child_off[i] + nkids[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Monitor.record
+__global__ void k_mon_test(ot_monitor mon, SegsT<double> s, int64_t n, int32_t* hit, double* P, double* tt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double rx = s.ox[i] - mon.origin[0], ry = s.oy[i] - mon.origin[1], rz = s.oz[i] - mon.origin[2];
+    const double* M = mon.M;
+    const double ox = M[0] * rx + M[3] * ry + M[6] * rz, oy = M[1] * rx + M[4] * ry + M[7] * rz,
+                 oz = M[2] * rx + M[5] * ry + M[8] * rz;
+    double dx = M[0] * s.dx[i] + M[3] * s.dy[i] + M[6] * s.dz[i], dy = M[1] * s.dx[i] + M[4] * s.dy[i] + M[7] * s.dz[i],
+           dz = M[2] * s.dx[i] + M[5] * s.dy[i] + M[8] * s.dz[i];
+    const double inv = 1.0 / sqrt(dx * dx + dy * dy + dz * dz);  // ray_to_local_coordinates renormalises
+    dx *= inv; dy *= inv; dz *= inv;
+    int32_t ok = 0;
+    if (dx != 0.0) {
+        const double t = -ox / dx;
+        if (!(fabs(t) < 1e-9 || t < 0.0 || t > s.len[i])) {
+            const double Px = ox + t * dx, Py = oy + t * dy, Pz = oz + t * dz;
+            if (fabs(Py) <= mon.half_width && fabs(Pz) <= mon.half_height) {
+                ok = 1;
+                P[3 * i] = Px; P[3 * i + 1] = Py; P[3 * i + 2] = Pz;
+                tt[i] = t;
+            }
+        }
+    }
+    hit[i] = ok;
+}
+__global__ void k_mon_compact(const int32_t* hit, const int64_t* off, const double* P, const double* tt, int64_t n,
+                              int64_t* hit_index, double* Px, double* Py, double* Pz, double* t, int64_t* n_hits) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (hit[i]) {
+        const int64_t d = off[i];
+        hit_index[d] = i; Px[d] = P[3 * i]; Py[d] = P[3 * i + 1]; Pz[d] = P[3 * i + 2]; t[d] = tt[i];
+    }
+    if (i == n - 1) *n_hits = off[i] + hit[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// context
+struct Scratch {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+        if (hipMalloc(&p, need) != hipSuccess) return -1;
+        bytes = need;
+        return 0;
+    }
+};
+
+struct ot_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int n_cus = 256;
+    size_t lds_limit = 64 * 1024;
+    // scene
+    bool has_scene = false;
+    void *blob64 = nullptr, *blob32 = nullptr;
+    size_t bytes64 = 0, bytes32 = 0;
+    int32_t n_nodes = 0, n_mats = 0, n_aux = 0, n_slots = 0, max_children = 0;
+    double unit = 1e-2;
+    // timing
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t events_used = 0;
+    double total_ms = 0.0;
+    int64_t launches = 0;
+    // knobs
+    int32_t block_threads = 256, rays_per_lane = 1;
+    Scratch gen, scan_tmp, mon;
+};
+
+static int flush_events(ot_ctx* c) {
+    if (c->events_used == 0) return 0;
+    HIP_TRY(hipEventSynchronize(c->events[c->events_used - 1].second));
+    for (size_t k = 0; k < c->events_used; ++k) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, c->events[k].first, c->events[k].second));
+        c->total_ms += ms;
+        c->launches += 1;
+    }
+    c->events_used = 0;
+    return 0;
+}
+static int timing_begin(ot_ctx* c) {
+    if (!c->timing) return 0;
+    if (c->events_used == c->events.size()) {
+        if (c->events.size() >= 1024) {
+            int rc = flush_events(c);
+            if (rc) return rc;
+        } else {
+            hipEvent_t a, b;
+            HIP_TRY(hipEventCreate(&a));
+            HIP_TRY(hipEventCreate(&b));
+            c->events.push_back({a, b});
+        }
+    }
+    HIP_TRY(hipEventRecord(c->events[c->events_used].first, c->stream));
+    return 0;
+}
+static int timing_end(ot_ctx* c) {
+    if (!c->timing) return 0;
+    HIP_TRY(hipEventRecord(c->events[c->events_used].second, c->stream));
+    c->events_used += 1;
+    return 0;
+}
+
+// host -> device node conversion
+template <class T> static void fill_blob(const ot_scene_desc* s, std::vector<uint8_t>& out) {
+    const size_t nb = sizeof(DNode<T>) * s->n_nodes, mb = sizeof(DMat<T>) * s->n_materials, ab = sizeof(T) * s->n_aux;
+    out.assign(((nb + mb + ab + 15) / 16) * 16, 0);
+    DNode<T>* nodes = reinterpret_cast<DNode<T>*>(out.data());
+    for (int i = 0; i < s->n_nodes; ++i) {
+        const ot_node& h = s->nodes[i];
+        DNode<T>& d = nodes[i];
+        for (int k = 0; k < 9; ++k) d.M[k] = (T)h.M[k];
+        for (int k = 0; k < 3; ++k) d.org[k] = (T)h.origin[k];
+        for (int k = 0; k < 6; ++k) { d.aabb[k] = (T)h.aabb[k]; d.lbox[k] = (T)h.lbox[k]; }
+        for (int k = 0; k < 8; ++k) d.p[k] = (T)h.p[k];
+        d.refl = (T)h.reflectivity; d.trans = (T)h.transmission; d.focal = (T)h.focal_length; d.roc = (T)h.roc;
+        d.kind = h.kind; d.end = h.end; d.flags = h.flags; d.shape = h.shape; d.inter = h.interaction;
+        d.mat1 = h.mat1; d.mat2 = h.mat2; d.roc_kind = h.roc_kind; d.max_count = h.max_interact_count;
+        d.slot = h.count_slot; d.aux = h.aux; d.leaf_id = h.leaf_id;
+    }
+    DMat<T>* mats = reinterpret_cast<DMat<T>*>(out.data() + nb);
+    for (int i = 0; i < s->n_materials; ++i) {
+        const ot_material& h = s->materials[i];
+        mats[i].n = (T)h.n;
+        for (int k = 0; k < 3; ++k) { mats[i].B[k] = (T)h.B[k]; mats[i].C[k] = (T)h.C[k]; }
+        mats[i].kind = h.kind;
+        mats[i].pad = 0;
+    }
+    T* aux = reinterpret_cast<T*>(out.data() + nb + mb);
+    for (int i = 0; i < s->n_aux; ++i) aux[i] = (T)s->aux[i];
+}
+
+static int validate_scene(const ot_scene_desc* s) {
+    if (!s || s->n_nodes < 0 || s->n_materials < 0 || s->n_aux < 0) return fail(OT_ERR_INVALID, "bad scene sizes");
+    if (s->n_nodes && !s->nodes) return fail(OT_ERR_INVALID, "nodes is NULL");
+    for (int i = 0; i < s->n_nodes; ++i) {
+        const ot_node& nd = s->nodes[i];
+        if (nd.end <= i || nd.end > s->n_nodes) return fail(OT_ERR_INVALID, "node.end out of range at " + std::to_string(i));
+        if (nd.kind == OT_NODE_LEAF) {
+            if (nd.end != i + 1) return fail(OT_ERR_INVALID, "leaf.end must be index+1");
+            if (nd.shape < 0 || nd.shape > OT_SHAPE_CSG) return fail(OT_ERR_UNSUPPORTED, "unknown shape kind");
+            if (nd.interaction < 0 || nd.interaction > OT_INT_BLOCK) return fail(OT_ERR_UNSUPPORTED, "unknown interaction kind");
+            if (nd.interaction == OT_INT_REFRACT &&
+                (nd.mat1 < 0 || nd.mat1 >= s->n_materials || nd.mat2 < 0 || nd.mat2 >= s->n_materials))
+                return fail(OT_ERR_INVALID, "material index out of range");
+            const bool needs_aux = nd.shape == OT_SHAPE_POLYGON2D || nd.shape == OT_SHAPE_POLYGON3D || nd.shape == OT_SHAPE_CSG;
+            if (needs_aux && (nd.aux < 0 || nd.aux >= s->n_aux)) return fail(OT_ERR_INVALID, "aux offset out of range");
+            if (nd.max_interact_count >= 0 && (nd.count_slot < 0 || nd.count_slot >= s->n_count_slots))
+                return fail(OT_ERR_INVALID, "count_slot out of range");
+        } else if (nd.kind != OT_NODE_GROUP) {
+            return fail(OT_ERR_INVALID, "unknown node kind");
+        }
+    }
+    return 0;
+}
+
+extern "C" {
+
+int ot_abi_version(void) { return OT_ABI_VERSION; }
+const char* ot_last_error(void) { return g_err.c_str(); }
+
+int ot_ctx_create(int device, void* stream, ot_ctx** out) {
+    if (!out) return fail(OT_ERR_INVALID, "out is NULL");
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) return fail(OT_ERR_INVALID, "no such device");
+    HIP_TRY(hipSetDevice(device));
+    ot_ctx* c = new ot_ctx();
+    c->device = device;
+    if (stream) {
+        c->stream = (hipStream_t)stream;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete c; return fail(OT_ERR_HIP, hipGetErrorString(e)); }
+        c->own_stream = true;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+        c->n_cus = prop.multiProcessorCount;
+        c->lds_limit = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : prop.sharedMemPerBlock;
+    }
+    *out = c;
+    return 0;
+}
+
+int ot_ctx_destroy(ot_ctx* c) {
+    if (!c) return 0;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (auto& e : c->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (c->blob64) (void)hipFree(c->blob64);
+    if (c->blob32) (void)hipFree(c->blob32);
+    if (c->gen.p) (void)hipFree(c->gen.p);
+    if (c->scan_tmp.p) (void)hipFree(c->scan_tmp.p);
+    if (c->mon.p) (void)hipFree(c->mon.p);
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+int ot_ctx_synchronize(ot_ctx* c) {
+    if (!c) return fail(OT_ERR_INVALID, "ctx is NULL");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int ot_scene_upload(ot_ctx* c, const ot_scene_desc* s) {
+    if (!c) return fail(OT_ERR_INVALID, "ctx is NULL");
+    int rc = validate_scene(s);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<uint8_t> b64, b32;
+    fill_blob<double>(s, b64);
+    fill_blob<float>(s, b32);
+    HIP_TRY(hipStreamSynchronize(c->stream));  // previous launches may still read the old scene
+    if (c->blob64) { (void)hipFree(c->blob64); c->blob64 = nullptr; }
+    if (c->blob32) { (void)hipFree(c->blob32); c->blob32 = nullptr; }
+    HIP_TRY(hipMalloc(&c->blob64, b64.size() ? b64.size() : 16));
+    HIP_TRY(hipMalloc(&c->blob32, b32.size() ? b32.size() : 16));
+    if (!b64.empty()) HIP_TRY(hipMemcpy(c->blob64, b64.data(), b64.size(), hipMemcpyHostToDevice));
+    if (!b32.empty()) HIP_TRY(hipMemcpy(c->blob32, b32.data(), b32.size(), hipMemcpyHostToDevice));
+    c->bytes64 = b64.size(); c->bytes32 = b32.size();
+    c->n_nodes = s->n_nodes; c->n_mats = s->n_materials; c->n_aux = s->n_aux;
+    c->n_slots = s->n_count_slots; c->max_children = s->max_children; c->unit = s->unit;
+    c->has_scene = true;
+    return 0;
+}
+
+}  // extern "C"
+
+static int check_rays(const ot_rays* r, const char* what) {
+    if (!r) return fail(OT_ERR_INVALID, std::string(what) + " is NULL");
+    const void* f[] = {r->ox, r->oy, r->oz, r->dx, r->dy, r->dz, r->wavelength, r->q_re, r->q_im, r->intensity, r->n,
+                       r->pathlength, r->id, r->flags};
+    for (const void* p : f)
+        if (!p) return fail(OT_ERR_INVALID, std::string(what) + " has a NULL field");
+    return 0;
+}
+static int check_segs(const ot_segments* s) {
+    if (!s) return fail(OT_ERR_INVALID, "segments is NULL");
+    const void* f[] = {s->ox, s->oy, s->oz, s->dx, s->dy, s->dz, s->length, s->intensity, s->q_re, s->q_im, s->n,
+                       s->pathlength, s->ray, s->surface};
+    for (const void* p : f)
+        if (!p) return fail(OT_ERR_INVALID, "segments has a NULL field");
+    return 0;
+}
+
+template <class T>
+static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, const ot_segments* out, int32_t* seg_count,
+                       int32_t* counts, int32_t n_classes) {
+    if (!c) return fail(OT_ERR_INVALID, "ctx is NULL");
+    if (!c->has_scene) return fail(OT_ERR_NOSCENE, "ot_scene_upload has not been called");
+    if (c->max_children > 1)
+        return fail(OT_ERR_UNSUPPORTED, "scene branches (max_children > 1): use ot_trace_generation_f64");
+    int rc = check_rays(rays, "rays");
+    if (rc) return rc;
+    rc = check_segs(out);
+    if (rc) return rc;
+    if (n < 0 || K < 1 || !seg_count) return fail(OT_ERR_INVALID, "bad n / max_segments / seg_count");
+    if (n >= (int64_t)1 << 31) return fail(OT_ERR_INVALID, "n must be < 2^31 per launch (int32 ray index)");
+    if (c->n_slots > 0 && (!counts || n_classes < 1)) return fail(OT_ERR_INVALID, "scene has limited surfaces: counts table required");
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(c->device));
+    const bool f64 = sizeof(T) == 8;
+    SceneBlob blob;
+    blob.words = (const uint32_t*)(f64 ? c->blob64 : c->blob32);
+    const size_t bytes = f64 ? c->bytes64 : c->bytes32;
+    blob.n_words = (int32_t)(bytes / 4);
+    blob.n_nodes = c->n_nodes;
+    blob.n_mats = c->n_mats;
+    const int block = 256;
+    const bool in_lds = bytes <= 150 * 1024;
+    const int64_t blocks_needed = (n + block - 1) / block;
+    int per_cu = 8;
+    if (in_lds && bytes > 0) {
+        const int fit = (int)((160 * 1024) / (bytes + 512));
+        per_cu = fit < 1 ? 1 : (fit > 8 ? 8 : fit);
+    }
+    const int64_t cap = (int64_t)c->n_cus * per_cu;
+    const int grid = (int)(blocks_needed < cap ? blocks_needed : cap);
+    rc = timing_begin(c);
+    if (rc) return rc;
+    if (in_lds) {
+        auto kern = k_trace_fused<T, true>;
+        if (bytes > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), bytes, c->stream, blob, (T)c->unit, view<T>(rays), n, K, view<T>(out),
+                           seg_count, counts, n_classes);
+    } else {
+        hipLaunchKernelGGL((k_trace_fused<T, false>), dim3(grid), dim3(block), 0, c->stream, blob, (T)c->unit, view<T>(rays), n,
+                           K, view<T>(out), seg_count, counts, n_classes);
+    }
+    HIP_TRY(hipGetLastError());
+    return timing_end(c);
+}
+
+static size_t align_up(size_t x) { return (x + 255) / 256 * 256; }
+
+extern "C" {
+
+int ot_trace_f64(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, const ot_segments* out, int32_t* seg_count,
+                 int32_t* counts, int32_t n_classes) {
+    return trace_fused<double>(c, rays, n, K, out, seg_count, counts, n_classes);
+}
+int ot_trace_f32(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, const ot_segments* out, int32_t* seg_count,
+                 int32_t* counts, int32_t n_classes) {
+    return trace_fused<float>(c, rays, n, K, out, seg_count, counts, n_classes);
+}
+
+int ot_trace_generation_f64(ot_ctx* c, const ot_rays* rays, const int32_t* tree, int64_t n, int32_t* budget,
+                            const ot_segments* out, int64_t out_capacity, int64_t* seg_cursor, const ot_rays* next,
+                            int32_t* next_tree, int64_t next_capacity, int64_t* n_next, int32_t* counts,
+                            int32_t n_classes) {
+    if (!c) return fail(OT_ERR_INVALID, "ctx is NULL");
+    if (!c->has_scene) return fail(OT_ERR_NOSCENE, "ot_scene_upload has not been called");
+    int rc = check_rays(rays, "rays");
+    if (rc) return rc;
+    rc = check_rays(next, "next");
+    if (rc) return rc;
+    rc = check_segs(out);
+    if (rc) return rc;
+    if (n < 1 || !tree || !budget || !seg_cursor || !next_tree || !n_next) return fail(OT_ERR_INVALID, "bad generation arguments");
+    if (n >= (int64_t)1 << 30) return fail(OT_ERR_INVALID, "generation too large");
+    const int fan = c->max_children < 1 ? 1 : c->max_children;
+    if (fan > 2) return fail(OT_ERR_UNSUPPORTED, "more than two children per hit");
+    if (next_capacity < n * fan) return fail(OT_ERR_CAPACITY, "next_capacity < n * max_children");
+    if (c->n_slots > 0 && (!counts || n_classes < 1)) return fail(OT_ERR_INVALID, "scene has limited surfaces: counts table required");
+    HIP_TRY(hipSetDevice(c->device));
+    // scratch carve-up
+    const size_t sz_i64 = align_up(sizeof(int64_t) * n), sz_i32 = align_up(sizeof(int32_t) * n);
+    const size_t sz_kid = align_up(sizeof(double) * 2 * n), sz_kfl = align_up(sizeof(int32_t) * 2 * n);
+    const size_t total = 4 * sz_i64 + 2 * sz_i32 + 12 * sz_kid + sz_kfl;
+    if (c->gen.ensure(total)) return fail(OT_ERR_HIP, "hipMalloc of generation scratch failed");
+    uint8_t* p = (uint8_t*)c->gen.p;
+    int64_t* head = (int64_t*)p; p += sz_i64;
+    int64_t* head_scan = (int64_t*)p; p += sz_i64;
+    int64_t* seg_off = (int64_t*)p; p += sz_i64;
+    int64_t* child_off = (int64_t*)p; p += sz_i64;
+    int32_t* proc = (int32_t*)p; p += sz_i32;
+    int32_t* nkids = (int32_t*)p; p += sz_i32;
+    ChildStore kids;
+    for (int k = 0; k < 12; ++k) { kids.f[k] = (double*)p; p += sz_kid; }
+    kids.flags = (int32_t*)p;
+    // scan temp
+    size_t tmp_a = 0, tmp_b = 0, tmp_c = 0;
+    hipcub::DeviceScan::InclusiveScan((void*)nullptr, tmp_a, head, head_scan, hipcub::Max(), (int)n, c->stream);
+    hipcub::DeviceScan::ExclusiveSum((void*)nullptr, tmp_b, proc, seg_off, (int)n, c->stream);
+    hipcub::DeviceScan::ExclusiveSum((void*)nullptr, tmp_c, nkids, child_off, (int)n, c->stream);
+    size_t tmp = tmp_a > tmp_b ? tmp_a : tmp_b;
+    tmp = tmp > tmp_c ? tmp : tmp_c;
+    if (c->scan_tmp.ensure(tmp + 256)) return fail(OT_ERR_HIP, "hipMalloc of scan scratch failed");
+    const int block = 256;
+    const int g1 = (int)((n + block - 1) / block);
+    rc = timing_begin(c);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_gen_heads, dim3(g1), dim3(block), 0, c->stream, tree, n, head);
+    HIP_TRY(hipcub::DeviceScan::InclusiveScan(c->scan_tmp.p, tmp, head, head_scan, hipcub::Max(), (int)n, c->stream));
+    hipLaunchKernelGGL(k_gen_mark, dim3(g1), dim3(block), 0, c->stream, tree, head_scan, budget, n, proc);
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->scan_tmp.p, tmp, proc, seg_off, (int)n, c->stream));
+    SceneBlob blob;
+    blob.words = (const uint32_t*)c->blob64;
+    blob.n_words = (int32_t)(c->bytes64 / 4);
+    blob.n_nodes = c->n_nodes;
+    blob.n_mats = c->n_mats;
+    const bool in_lds = c->bytes64 <= 150 * 1024;
+    const int64_t cap = (int64_t)c->n_cus * 4;
+    const int grid = (int)(g1 < cap ? g1 : cap);
+    if (in_lds) {
+        auto kern = k_gen_trace<true>;
+        if (c->bytes64 > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->bytes64));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), c->bytes64, c->stream, blob, c->unit, view<double>(rays), tree, n, proc,
+                           seg_off, seg_cursor, view<double>(out), out_capacity, kids, nkids, counts, n_classes);
+    } else {
+        hipLaunchKernelGGL(k_gen_trace<false>, dim3(grid), dim3(block), 0, c->stream, blob, c->unit, view<double>(rays), tree, n,
+                           proc, seg_off, seg_cursor, view<double>(out), out_capacity, kids, nkids, counts, n_classes);
+    }
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->scan_tmp.p, tmp, nkids, child_off, (int)n, c->stream));
+    hipLaunchKernelGGL(k_gen_compact, dim3(g1), dim3(block), 0, c->stream, tree, rays->id, n, kids, nkids, child_off,
+                       view_out<double>(next), next_tree, next_capacity);
+    hipLaunchKernelGGL(k_gen_finish, dim3(g1), dim3(block), 0, c->stream, tree, head_scan, n, budget, proc, seg_off, nkids,
+                       child_off, seg_cursor, n_next);
+    HIP_TRY(hipGetLastError());
+    return timing_end(c);
+}
+
+int ot_monitor_record_f64(ot_ctx* c, const ot_monitor* mon, const ot_segments* segs, int64_t n, int64_t* hit_index, void* Px,
+                          void* Py, void* Pz, void* t, int64_t* n_hits) {
+    if (!c || !mon || !hit_index || !Px || !Py || !Pz || !t || !n_hits) return fail(OT_ERR_INVALID, "NULL argument");
+    int rc = check_segs(segs);
+    if (rc) return rc;
+    if (n < 0 || n >= (int64_t)1 << 31) return fail(OT_ERR_INVALID, "bad segment count");
+    HIP_TRY(hipSetDevice(c->device));
+    if (n == 0) {
+        HIP_TRY(hipMemsetAsync(n_hits, 0, sizeof(int64_t), c->stream));
+        return 0;
+    }
+    const size_t sz_hit = align_up(sizeof(int32_t) * n), sz_off = align_up(sizeof(int64_t) * n), sz_P = align_up(sizeof(double) * 3 * n),
+                 sz_t = align_up(sizeof(double) * n);
+    if (c->mon.ensure(sz_hit + sz_off + sz_P + sz_t)) return fail(OT_ERR_HIP, "hipMalloc of monitor scratch failed");
+    uint8_t* p = (uint8_t*)c->mon.p;
+    int32_t* hit = (int32_t*)p; p += sz_hit;
+    int64_t* off = (int64_t*)p; p += sz_off;
+    double* P = (double*)p; p += sz_P;
+    double* tt = (double*)p;
+    size_t tmp = 0;
+    hipcub::DeviceScan::ExclusiveSum((void*)nullptr, tmp, hit, off, (int)n, c->stream);
+    if (c->scan_tmp.ensure(tmp + 256)) return fail(OT_ERR_HIP, "hipMalloc of scan scratch failed");
+    const int block = 256, grid = (int)((n + block - 1) / block);
+    hipLaunchKernelGGL(k_mon_test, dim3(grid), dim3(block), 0, c->stream, *mon, view<double>(segs), n, hit, P, tt);
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->scan_tmp.p, tmp, hit, off, (int)n, c->stream));
+    hipLaunchKernelGGL(k_mon_compact, dim3(grid), dim3(block), 0, c->stream, hit, off, P, tt, n, hit_index, (double*)Px, (double*)Py,
+                       (double*)Pz, (double*)t, n_hits);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ot_timing_enable(ot_ctx* c, int enabled) {
+    if (!c) return fail(OT_ERR_INVALID, "ctx is NULL");
+    if (!enabled) {
+        int rc = flush_events(c);
+        if (rc) return rc;
+    }
+    c->timing = enabled != 0;
+    return 0;
+}
+int ot_timing_read(ot_ctx* c, double* total_ms, int64_t* launches) {
+    if (!c) return fail(OT_ERR_INVALID, "ctx is NULL");
+    int rc = flush_events(c);
+    if (rc) return rc;
+    if (total_ms) *total_ms = c->total_ms;
+    if (launches) *launches = c->launches;
+    return 0;
+}
+int ot_timing_reset(ot_ctx* c) {
+    if (!c) return fail(OT_ERR_INVALID, "ctx is NULL");
+    int rc = flush_events(c);
+    if (rc) return rc;
+    c->total_ms = 0.0;
+    c->launches = 0;
+    return 0;
+}
+int ot_set_launch(ot_ctx* c, int32_t block_threads, int32_t rays_per_lane) {
+    if (!c) return fail(OT_ERR_INVALID, "ctx is NULL");
+    if (block_threads != 0 && block_threads != 64 && block_threads != 128 && block_threads != 256 && block_threads != 512)
+        return fail(OT_ERR_INVALID, "block_threads must be 0, 64, 128, 256 or 512");
+    if (rays_per_lane < 0 || rays_per_lane > 2) return fail(OT_ERR_INVALID, "rays_per_lane must be 0, 1 or 2");
+    c->block_threads = block_threads ? block_threads : 256;
+    c->rays_per_lane = rays_per_lane ? rays_per_lane : 1;
+    return 0;
+}
+
+}  // extern "C"

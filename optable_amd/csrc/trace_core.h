@@ -1,0 +1,490 @@
+// trace_core.h — device-side ray/scene arithmetic for the gfx950 trace kernels.
+//
+// One lane owns one ray.  The scene (skip-list of nodes, materials, aux records) is staged
+// into LDS once per workgroup and read with wave-uniform indices, so every lane of a wave
+// reads the same LDS words (broadcast, no bank conflicts) while the per-ray state lives in
+// VGPRs.  Templated on the real type: double for the fp64 entry points, float for fp32.
+//
+// Semantics follow the reference (tim4431/optable); the arithmetic is organised differently:
+//   nearest_hit  — one forward pass over the depth-first node list with a per-lane
+//                  `skip_until` and a strict `<`: equals ComponentGroup.interact's AABB prune +
+//                  np.argmin and the table loop's first-strict-minimum
+//                  (component_group.py:93-122, optical_table.py:119-123).
+//   hit_leaf     — OpticalComponent.intersect_point_local (optical_component.py:151-233); the
+//                  reference's 10-point sign scan is kept bracket for bracket, the root inside a
+//                  bracket is polished by a safeguarded Newton iteration instead of brentq.
+//   interact     — BaseMirror / BaseRefraciveSurface / Lens .interact_local
+//                  (optical_component.py:536-570, 617-717, 930-948).
+// Redundant renormalisations of already-unit vectors in the reference (Ray.direction setter on
+// every copy) are not repeated per surface test; each child direction is normalised once.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/optable_hip.h"
+
+namespace ot {
+
+template <class T> struct Num;
+template <> struct Num<double> {
+    static __device__ __forceinline__ double inf() { return __builtin_inf(); }
+    static __device__ __forceinline__ double eps_t() { return 1e-9; }      // EPS, optical_component.py:163
+    static __device__ __forceinline__ double root_tol() { return 4.4e-16; }
+    static __device__ __forceinline__ double tiny() { return 1e-300; }
+};
+template <> struct Num<float> {
+    static __device__ __forceinline__ float inf() { return __builtin_inff(); }
+    // 1e-9 is below fp32 resolution at unit scale; the fp32 self-hit guard is scale aware
+    static __device__ __forceinline__ float eps_t() { return 1e-5f; }
+    static __device__ __forceinline__ float root_tol() { return 2.4e-7f; }
+    static __device__ __forceinline__ float tiny() { return 1e-37f; }
+};
+
+// Device copy of ot_node in the kernel's real type (built by the host in ot_scene_upload).
+template <class T> struct DNode {
+    T M[9];
+    T org[3];
+    T aabb[6];
+    T lbox[6];
+    T p[8];
+    T refl, trans, focal, roc;
+    int32_t kind, end, flags, shape, inter, mat1, mat2, roc_kind, max_count, slot, aux, leaf_id;
+};
+template <class T> struct DMat {
+    T n;
+    T B[3];
+    T C[3];
+    int32_t kind, pad;
+};
+
+template <class T> struct Scene {
+    const DNode<T>* nodes;
+    const DMat<T>* mats;
+    const T* aux;
+    int32_t n_nodes;
+    T unit;
+};
+
+template <class T> struct RayState {
+    T ox, oy, oz, dx, dy, dz;
+    T wl, qr, qi, I, n, pl;
+    T len;      // +inf == None
+    int32_t has_q;
+};
+
+template <class T> struct Hit {
+    T t;        // distance (local frame == lab frame: M is a rotation)
+    T px, py, pz; // local hit point
+    int32_t node; // -1: none
+};
+
+template <class T> __device__ __forceinline__ T rsqrt_t(T x);
+template <> __device__ __forceinline__ double rsqrt_t<double>(double x) { return 1.0 / sqrt(x); }
+template <> __device__ __forceinline__ float rsqrt_t<float>(float x) { return 1.0f / sqrtf(x); }
+template <class T> __device__ __forceinline__ T sqrt_t(T x);
+template <> __device__ __forceinline__ double sqrt_t<double>(double x) { return sqrt(x); }
+template <> __device__ __forceinline__ float sqrt_t<float>(float x) { return sqrtf(x); }
+template <class T> __device__ __forceinline__ T abs_t(T x) { return x < T(0) ? -x : x; }
+template <class T> __device__ __forceinline__ T min_t(T a, T b) { return a < b ? a : b; }
+template <class T> __device__ __forceinline__ T max_t(T a, T b) { return a < b ? b : a; }
+
+// ---------------------------------------------------------------------------------------------
+// solver.py:5-48.  Returns the hit flag; t1/t2 as the reference computes them.
+template <class T>
+__device__ __forceinline__ bool slab(T ox, T oy, T oz, T dx, T dy, T dz, const T* box, T& t1, T& t2) {
+    t1 = T(0);
+    t2 = Num<T>::inf();
+    const T o[3] = {ox, oy, oz}, d[3] = {dx, dy, dz};
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        const T lo = box[2 * ax], hi = box[2 * ax + 1];
+        if (abs_t(d[ax]) <= T(1e-8)) {  // np.isclose(d, 0)
+            if (o[ax] < lo || o[ax] > hi) { t1 = T(1); t2 = T(0); }
+        } else {
+            const T inv = T(1) / d[ax];
+            const T a = (lo - o[ax]) * inv, b = (hi - o[ax]) * inv;
+            t1 = max_t(t1, min_t(a, b));
+            t2 = min_t(t2, max_t(a, b));
+        }
+    }
+    return (t2 + T(1e-12) >= t1) && (t2 >= T(0));
+}
+
+// ---------------------------------------------------------------------------------------------
+// material.py:54-72, 106-120
+template <class T> __device__ __forceinline__ T material_index(const DMat<T>& m, T wavelength_m) {
+    if (m.kind == OT_MAT_CONST) return m.n;
+    const T um = wavelength_m / T(1e-6), um2 = um * um;
+    T n2 = T(1);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) n2 += m.B[k] * um2 / (um2 - m.C[k]);
+    return sqrt_t(n2);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Asphere sag F(r) and the reference's finite differences (surfaces.py:351-369).
+template <class T> __device__ __forceinline__ T sag(const DNode<T>& nd, T r) {
+    const T r2 = r * r;
+    if (nd.shape == OT_SHAPE_ASPHERE_PARAM) {  // component_group.py:1092-1097
+        const T R = nd.p[1], k = nd.p[2];
+        const T r4 = r2 * r2;
+        return r2 / (R * (T(1) + sqrt_t(T(1) - (T(1) + k) * r2 / (R * R)))) + nd.p[3] * r4 + nd.p[4] * r4 * r2 +
+               nd.p[5] * r4 * r4;
+    }
+    const T EFL = nd.p[1], n = nd.p[2];  // component_group.py:1061-1064
+    return (EFL / (n + T(1))) * (T(-1) + sqrt_t(T(1) + (n + T(1)) / (n - T(1)) * r2 / (EFL * EFL)));
+}
+template <class T> __device__ __forceinline__ T sag_d1(const DNode<T>& nd, T r) {
+    const T h = T(1e-4) * nd.p[0];
+    return (sag(nd, r + h) - sag(nd, r - h)) / (T(2) * h);
+}
+template <class T> __device__ __forceinline__ T sag_d2(const DNode<T>& nd, T r) {
+    const T h = T(1e-4) * nd.p[0];
+    return (sag(nd, r + h) - T(2) * sag(nd, r) + sag(nd, r - h)) / (h * h);
+}
+
+// polygon aux record: [nverts, n(3), v0(3), u(3), v(3), (x,y)*nverts]   (surfaces.py:534-558)
+template <class T> __device__ __forceinline__ bool poly_inside(const T* rec, T Px, T Py, T Pz) {
+    const T tol = T(1e-9);
+    const T rx = Px - rec[4], ry = Py - rec[5], rz = Pz - rec[6];
+    const T px = rx * rec[7] + ry * rec[8] + rz * rec[9];
+    const T py = rx * rec[10] + ry * rec[11] + rz * rec[12];
+    const int nv = (int)rec[0];
+    const T* v = rec + 13;
+    bool inside = false, on_edge = false;
+    for (int i = 0; i < nv; ++i) {
+        const int j = (i + 1 == nv) ? 0 : i + 1;
+        const T x1 = v[2 * i], y1 = v[2 * i + 1], x2 = v[2 * j], y2 = v[2 * j + 1];
+        const T cr = (x2 - x1) * (py - y1) - (y2 - y1) * (px - x1);
+        if (abs_t(cr) <= tol && min_t(x1, x2) - tol <= px && px <= max_t(x1, x2) + tol && min_t(y1, y2) - tol <= py &&
+            py <= max_t(y1, y2) + tol)
+            on_edge = true;
+        if ((y1 > py) != (y2 > py)) {
+            const T xc = x1 + (py - y1) * (x2 - x1) / (y2 - y1);
+            if (xc >= px) inside = !inside;
+        }
+    }
+    return on_edge || inside;
+}
+
+template <class T> __device__ __forceinline__ bool prim_inside(int kind, const T* body, T Px, T Py, T Pz) {
+    if (kind == OT_SHAPE_CIRCLE) return sqrt_t(Px * Px + Py * Py + Pz * Pz) <= body[0];  // 3-norm, surfaces.py:144-145
+    if (kind == OT_SHAPE_RECT) return abs_t(Py) <= body[0] && abs_t(Pz) <= body[1];
+    return poly_inside(body, Px, Py, Pz);
+}
+
+// Plane.union / subtract as a postfix program (surfaces.py:100-136); stack kept in a bit mask.
+template <class T> __device__ __forceinline__ bool csg_inside(const T* prog, T Px, T Py, T Pz) {
+    uint32_t stack = 0;
+    int sp = 0;
+    const int ntok = (int)prog[0];
+    const T* t = prog + 1;
+    for (int k = 0; k < ntok; ++k) {
+        const int kind = (int)t[0], len = (int)t[1];
+        if (kind >= 100) {
+            const bool b = (stack >> (sp - 1)) & 1u, a = (stack >> (sp - 2)) & 1u;
+            sp -= 2;
+            const bool r = (kind == 100) ? (a || b) : (a && !b);
+            stack = (stack & ~(1u << sp)) | (uint32_t(r) << sp);
+            ++sp;
+        } else {
+            const bool r = prim_inside(kind, t + 2, Px, Py, Pz);
+            stack = (stack & ~(1u << sp)) | (uint32_t(r) << sp);
+            ++sp;
+        }
+        t += 2 + len;
+    }
+    return stack & 1u;
+}
+
+template <class T> __device__ __forceinline__ bool within_boundary(const Scene<T>& sc, const DNode<T>& nd, T Px, T Py, T Pz) {
+    switch (nd.shape) {
+        case OT_SHAPE_CIRCLE:
+        case OT_SHAPE_RECT: return prim_inside(nd.shape, nd.p, Px, Py, Pz);
+        case OT_SHAPE_POLYGON2D:
+        case OT_SHAPE_POLYGON3D: return poly_inside(sc.aux + nd.aux, Px, Py, Pz);
+        case OT_SHAPE_CSG: return csg_inside(sc.aux + nd.aux, Px, Py, Pz);
+        case OT_SHAPE_SPHERE: return nd.p[0] - nd.p[1] - T(1e-12) <= Px && Px <= nd.p[0] + T(1e-12);
+        case OT_SHAPE_ASPHERE_PARAM:
+        case OT_SHAPE_ASPHERE_EXACT: return sqrt_t(Py * Py + Pz * Pz) <= nd.p[0] + T(1e-12);
+        case OT_SHAPE_CYLINDER: {
+            const T th = atan2(Py, Px);
+            return nd.p[2] <= th && th <= nd.p[3] && -nd.p[1] <= Pz && Pz <= nd.p[1];
+        }
+        default: return false;
+    }
+}
+
+// Implicit function g(t) = f(o + t d) of the non-planar shapes and its derivative.
+template <class T>
+__device__ __forceinline__ T surf_g(const Scene<T>& sc, const DNode<T>& nd, T ox, T oy, T oz, T dx, T dy, T dz, T t, T* dg) {
+    const T Px = ox + t * dx, Py = oy + t * dy, Pz = oz + t * dz;
+    switch (nd.shape) {
+        case OT_SHAPE_SPHERE: {
+            const T r = sqrt_t(Px * Px + Py * Py + Pz * Pz);
+            if (dg) *dg = (Px * dx + Py * dy + Pz * dz) / r;
+            return r - nd.p[0];
+        }
+        case OT_SHAPE_CYLINDER: {
+            const T r = sqrt_t(Px * Px + Py * Py);
+            if (dg) *dg = (Px * dx + Py * dy) / r;
+            return r - nd.p[0];
+        }
+        case OT_SHAPE_POLYGON3D: {
+            const T* rec = sc.aux + nd.aux;
+            if (dg) *dg = rec[1] * dx + rec[2] * dy + rec[3] * dz;
+            return rec[1] * (Px - rec[4]) + rec[2] * (Py - rec[5]) + rec[3] * (Pz - rec[6]);
+        }
+        default: {  // aspheres: x + F(r)
+            const T r = sqrt_t(Py * Py + Pz * Pz);
+            if (dg) *dg = dx + (r > T(1e-30) ? sag_d1(nd, r) * (Py * dy + Pz * dz) / r : T(0));
+            return Px + sag(nd, r);
+        }
+    }
+}
+
+// Root of g inside a bracket with a sign change: Newton steps kept inside the shrinking
+// bracket, bisection when a step leaves it (the reference polishes the same bracket with
+// scipy brentq to xtol 2e-12; both converge on the same root).
+template <class T>
+__device__ __forceinline__ T polish_root(const Scene<T>& sc, const DNode<T>& nd, T ox, T oy, T oz, T dx, T dy, T dz, T a, T b,
+                                         T ga, T gb) {
+    // false-position start
+    T t = a - ga * (b - a) / (gb - ga);
+    if (!(t > a && t < b)) t = T(0.5) * (a + b);
+    for (int it = 0; it < 48; ++it) {
+        T dg;
+        const T g = surf_g(sc, nd, ox, oy, oz, dx, dy, dz, t, &dg);
+        if (g == T(0)) return t;
+        if ((g < T(0)) == (ga < T(0))) { a = t; ga = g; } else { b = t; gb = g; }
+        T tn = t - g / dg;
+        if (!(tn > a && tn < b)) tn = T(0.5) * (a + b);
+        const T step = abs_t(tn - t);
+        t = tn;
+        if (step <= Num<T>::root_tol() * abs_t(t) + Num<T>::tiny()) break;
+        if (b - a <= Num<T>::root_tol() * abs_t(t)) break;
+    }
+    return t;
+}
+
+// ---------------------------------------------------------------------------------------------
+// intersect_point_local for one leaf; ray already in the leaf's frame.
+template <class T>
+__device__ __forceinline__ bool hit_leaf(const Scene<T>& sc, const DNode<T>& nd, T ox, T oy, T oz, T dx, T dy, T dz, T len, T& t_out,
+                                         T& Px, T& Py, T& Pz) {
+    const T EPS = Num<T>::eps_t();
+    const int sh = nd.shape;
+    if (sh == OT_SHAPE_CIRCLE || sh == OT_SHAPE_RECT || sh == OT_SHAPE_POLYGON2D || sh == OT_SHAPE_CSG) {
+        if (dx == T(0)) return false;  // parallel: t = 0 or none, both rejected (optical_component.py:173-190)
+        const T t = -ox / dx;
+        if (abs_t(t) < EPS || t < T(0) || t > len) return false;
+        Px = ox + t * dx; Py = oy + t * dy; Pz = oz + t * dz;
+        if (!within_boundary(sc, nd, Px, Py, Pz)) return false;
+        t_out = t;
+        return true;
+    }
+    if (sh == OT_SHAPE_POINT) return false;
+    T t1, t2;
+    slab(ox, oy, oz, dx, dy, dz, nd.lbox, t1, t2);
+    if (t2 + EPS < t1) return false;
+    t1 = max_t(t1, T(0));
+    t2 = min_t(t2, T(100));
+    // np.linspace(t1 - EPS, t2 + EPS, 10): strict sign change per sub-interval, roots ascending
+    const T a = t1 - EPS, b = t2 + EPS, step = (b - a) / T(9);
+    T tl = a, gl = surf_g(sc, nd, ox, oy, oz, dx, dy, dz, a, (T*)nullptr);
+    for (int i = 1; i < 10; ++i) {
+        const T tr = (i == 9) ? b : a + T(i) * step;
+        const T gr = surf_g(sc, nd, ox, oy, oz, dx, dy, dz, tr, (T*)nullptr);
+        if (gl * gr < T(0)) {
+            const T t = polish_root(sc, nd, ox, oy, oz, dx, dy, dz, tl, tr, gl, gr);
+            if (t >= T(0) && abs_t(t) >= EPS && t <= len) {
+                const T X = ox + t * dx, Y = oy + t * dy, Z = oz + t * dz;
+                if (within_boundary(sc, nd, X, Y, Z)) {
+                    t_out = t; Px = X; Py = Y; Pz = Z;
+                    return true;
+                }
+            }
+        }
+        tl = tr;
+        gl = gr;
+    }
+    return false;
+}
+
+template <class T> __device__ __forceinline__ void to_local(const DNode<T>& nd, T vx, T vy, T vz, T& lx, T& ly, T& lz) {
+    lx = nd.M[0] * vx + nd.M[3] * vy + nd.M[6] * vz;  // M^T v  (inverse of a rotation)
+    ly = nd.M[1] * vx + nd.M[4] * vy + nd.M[7] * vz;
+    lz = nd.M[2] * vx + nd.M[5] * vy + nd.M[8] * vz;
+}
+template <class T> __device__ __forceinline__ void to_lab(const DNode<T>& nd, T lx, T ly, T lz, T& vx, T& vy, T& vz) {
+    vx = nd.M[0] * lx + nd.M[1] * ly + nd.M[2] * lz;
+    vy = nd.M[3] * lx + nd.M[4] * ly + nd.M[5] * lz;
+    vz = nd.M[6] * lx + nd.M[7] * ly + nd.M[8] * lz;
+}
+
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int o = __shfl_xor(v, off, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+// Interact-count gate (optical_component.py:140-149, 359-362).  ATOMIC: several rays of one
+// launch may share a class (branching generations); plain otherwise.
+template <bool ATOMIC> __device__ __forceinline__ bool count_gate(int32_t* counts, int64_t idx, int32_t max_count) {
+    if (ATOMIC) {
+        const int32_t old = atomicAdd(&counts[idx], 1);
+        if (old < max_count) return true;
+        atomicSub(&counts[idx], 1);
+        return false;
+    }
+    const int32_t c = counts[idx];
+    if (c < max_count) { counts[idx] = c + 1; return true; }
+    return false;
+}
+
+// Nearest hit over the whole scene for one ray (all lanes of the wave walk the node list with
+// the same index; a lane that pruned a group idles until the list leaves that group, and when
+// every lane of the wave pruned it the wave jumps ahead to the smallest skip target).
+template <class T, bool ATOMIC>
+__device__ __forceinline__ Hit<T> nearest_hit(const Scene<T>& sc, const RayState<T>& r, bool active, int32_t* counts,
+                                              int32_t n_classes, int32_t cls) {
+    Hit<T> best;
+    best.t = Num<T>::inf();
+    best.node = -1;
+    best.px = best.py = best.pz = T(0);
+    int skip_until = active ? 0 : 0x7fffffff;
+    for (int i = 0; i < sc.n_nodes; ++i) {
+        const DNode<T>& nd = sc.nodes[i];
+        const bool live = i >= skip_until;
+        if (nd.flags & OT_NODE_CHECK_AABB) {
+            T t1, t2;
+            if (live && !slab(r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, nd.aabb, t1, t2)) skip_until = nd.end;
+        }
+        if (nd.kind == OT_NODE_GROUP) {
+            // every lane of the wave takes this branch (nd is wave-uniform); inactive lanes hold INT_MAX
+            const int target = __builtin_amdgcn_readfirstlane(wave_min_i32(skip_until));
+            if (target > i + 1) i = (target < sc.n_nodes ? target : sc.n_nodes) - 1;
+            continue;
+        }
+        if (i < skip_until) continue;
+        T ox, oy, oz, dx, dy, dz;
+        to_local(nd, r.ox - nd.org[0], r.oy - nd.org[1], r.oz - nd.org[2], ox, oy, oz);
+        to_local(nd, r.dx, r.dy, r.dz, dx, dy, dz);
+        T t, Px, Py, Pz;
+        if (!hit_leaf(sc, nd, ox, oy, oz, dx, dy, dz, r.len, t, Px, Py, Pz)) continue;
+        if (nd.max_count >= 0 && !count_gate<ATOMIC>(counts, (int64_t)nd.slot * n_classes + cls, nd.max_count)) continue;
+        if (t < best.t) {
+            best.t = t; best.node = i; best.px = Px; best.py = Py; best.pz = Pz;
+        }
+    }
+    return best;
+}
+
+template <class T> __device__ __forceinline__ void cdiv(T ar, T ai, T br, T bi, T& cr, T& ci) {
+    const T den = br * br + bi * bi;
+    cr = (ar * br + ai * bi) / den;
+    ci = (ai * br - ar * bi) / den;
+}
+
+template <class T> __device__ __forceinline__ void surf_normal(const Scene<T>& sc, const DNode<T>& nd, T Px, T Py, T Pz, T& nx, T& ny, T& nz) {
+    switch (nd.shape) {
+        case OT_SHAPE_SPHERE: nx = Px / nd.p[0]; ny = Py / nd.p[0]; nz = Pz / nd.p[0]; return;
+        case OT_SHAPE_CYLINDER: nx = Px / nd.p[0]; ny = Py / nd.p[0]; nz = T(0); return;
+        case OT_SHAPE_POLYGON2D:
+        case OT_SHAPE_POLYGON3D: {
+            const T* rec = sc.aux + nd.aux;
+            nx = rec[1]; ny = rec[2]; nz = rec[3];
+            return;
+        }
+        case OT_SHAPE_ASPHERE_PARAM:
+        case OT_SHAPE_ASPHERE_EXACT: {  // surfaces.py:380-388
+            const T r = sqrt_t(Py * Py + Pz * Pz);
+            if (r < T(1e-12)) { nx = T(1); ny = T(0); nz = T(0); return; }
+            const T s = sag_d1(nd, r);
+            const T ay = s * (Py / r), az = s * (Pz / r);
+            const T inv = rsqrt_t(T(1) + ay * ay + az * az);
+            nx = inv; ny = ay * inv; nz = az * inv;
+            return;
+        }
+        default: nx = T(1); ny = T(0); nz = T(0); return;
+    }
+}
+
+// Children of a hit.  MAXK = 1 compiles the non-branching form (at most the first child).
+// Writes lab-frame children into kids[0..nk).
+template <class T, int MAXK>
+__device__ __forceinline__ int interact(const Scene<T>& sc, const RayState<T>& r, const Hit<T>& h, RayState<T>* kids) {
+    const DNode<T>& nd = sc.nodes[h.node];
+    if (nd.inter == OT_INT_BLOCK) return 0;
+    // incoming direction in the leaf frame
+    T dx, dy, dz;
+    to_local(nd, r.dx, r.dy, r.dz, dx, dy, dz);
+    const T t = h.t;
+    const T q1r = r.qr + t, q1i = r.qi;  // q_at_z (ray.py:17-19)
+    const T pl_hit = r.pl + t * r.n;     // Ray.pathlength(t) (ray.py:145-147)
+    RayState<T> base = r;
+    to_lab(nd, h.px, h.py, h.pz, base.ox, base.oy, base.oz);
+    base.ox += nd.org[0]; base.oy += nd.org[1]; base.oz += nd.org[2];
+    base.len = Num<T>::inf();
+    int nk = 0;
+    auto emit = [&](T lx, T ly, T lz, T I, T qr, T qi, T n, T pl) {
+        RayState<T> k = base;
+        const T inv = rsqrt_t(lx * lx + ly * ly + lz * lz);
+        to_lab(nd, lx * inv, ly * inv, lz * inv, k.dx, k.dy, k.dz);
+        k.I = I; k.qr = qr; k.qi = qi; k.n = n; k.pl = pl;
+        if (nk < MAXK) kids[nk] = k;
+        ++nk;
+    };
+    if (nd.inter == OT_INT_LENS) {  // optical_component.py:930-948
+        T qr = r.qr, qi = r.qi;
+        const T f = nd.focal;
+        if (r.has_q) cdiv(q1r, q1i, T(1) - q1r / f, -q1i / f, qr, qi);
+        emit(dx - h.px / f, dy - h.py / f, dz - h.pz / f, r.I * nd.trans, qr, qi, r.n, r.pl);  // pathlength, n unchanged
+        return nk < MAXK ? nk : MAXK;
+    }
+    T nx, ny, nz;
+    surf_normal(sc, nd, h.px, h.py, h.pz, nx, ny, nz);
+    const T dn = dx * nx + dy * ny + dz * nz;
+    if (nd.inter == OT_INT_MIRROR) {  // optical_component.py:536-570
+        if (nd.refl > T(0)) emit(dx - T(2) * dn * nx, dy - T(2) * dn * ny, dz - T(2) * dn * nz, r.I * nd.refl, q1r, q1i, r.n, pl_hit);
+        if (nd.trans > T(0) && (MAXK > 1 || nk == 0)) emit(dx, dy, dz, r.I * nd.trans, q1r, q1i, r.n, pl_hit);
+        return nk < MAXK ? nk : MAXK;
+    }
+    // refraction, optical_component.py:617-717
+    const T wl_m = r.wl * sc.unit;
+    const T n1 = material_index(sc.mats[nd.mat1], wl_m), n2 = material_index(sc.mats[nd.mat2], wl_m);
+    T ROC = Num<T>::inf();
+    if (nd.roc_kind == OT_ROC_CONST) ROC = nd.roc;
+    else if (nd.roc_kind == OT_ROC_ASPHERE) {  // surfaces.py:362-373
+        const T rr = sqrt_t(h.py * h.py + h.pz * h.pz), s = sag_d1(nd, rr);
+        const T w = T(1) + s * s;
+        ROC = w * sqrt_t(w) / sag_d2(nd, rr);
+    }
+    T nin = n1, nout = n2;
+    if (!(dn < T(0))) { nin = n2; nout = n1; ROC = -ROC; }
+    T qtr = r.qr, qti = r.qi, qrr = r.qr, qri = r.qi;
+    if (r.has_q) {
+        const T Cc = (nin - nout) / (ROC * nout), Dd = nin / nout, Cr = T(2) / ROC;
+        cdiv(q1r, q1i, Cc * q1r + Dd, Cc * q1i, qtr, qti);
+        cdiv(q1r, q1i, Cr * q1r + T(1), Cr * q1i, qrr, qri);
+    }
+    const T ci = min_t(max_t(dn, T(-1)), T(1));
+    const T si = sqrt_t(T(1) - ci * ci), st = nin * si / nout;
+    if (st < T(1)) {
+        if (nd.trans > T(0)) {
+            const T ct = sqrt_t(T(1) - st * st), ratio = nin / nout, sgn = dn > T(0) ? T(1) : T(-1);
+            emit(ratio * (dx - dn * nx) + ct * sgn * nx, ratio * (dy - dn * ny) + ct * sgn * ny,
+                 ratio * (dz - dn * nz) + ct * sgn * nz, r.I * nd.trans, qtr, qti, nout, pl_hit);
+        }
+    } else {  // total internal reflection: full intensity
+        emit(dx - T(2) * ci * nx, dy - T(2) * ci * ny, dz - T(2) * ci * nz, r.I, qrr, qri, r.n, pl_hit);
+    }
+    if (MAXK > 1 && nd.refl > T(0))
+        emit(dx - T(2) * ci * nx, dy - T(2) * ci * ny, dz - T(2) * ci * nz, r.I * nd.refl, qrr, qri, r.n, pl_hit);
+    return nk < MAXK ? nk : MAXK;
+}
+
+}  // namespace ot

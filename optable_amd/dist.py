@@ -1,0 +1,44 @@
+"""Multi-GPU: rays are independent, so the path shards by contiguous ray ranges with the scene
+replicated and NO collective inside the trace.  The only communication is one gather of the
+per-ray final state at the end (RCCL over xGMI when the backend is "nccl"; "gloo" on CPU for
+tests).  Reference: the per-ray loop at optical_table.py:66-70 has no cross-ray coupling except
+shared `_id` counters — shard by id class when a scene has limited surfaces.
+"""
+import torch
+import torch.distributed as dist
+
+FINAL_FIELDS = ("ox", "oy", "oz", "dx", "dy", "dz", "length", "intensity", "q_re", "q_im", "n", "pathlength")
+
+
+def shard_range(n, rank, world):
+    """Contiguous [lo, hi) of rank `rank` out of `world` (sizes differ by at most 1)."""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def final_state(segs):
+    """[12, n_rays] tensor: each ray's last segment (non-branching [k][ray] layout)."""
+    n = segs.n_rays
+    last = (segs.count.long() - 1).clamp_(min=0) * n + torch.arange(n, device=segs.device)
+    return torch.stack([segs.field(f)[last] for f in FINAL_FIELDS])
+
+
+def gather_final_state(local, dst=0, group=None):
+    """One gather of every rank's [12, n_local] block to `dst`; returns [12, n_total] there,
+    None elsewhere.  Shard sizes may differ by one ray; blocks are padded to the largest."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n_local = torch.tensor([local.shape[1]], dtype=torch.int64, device=local.device)
+    sizes = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(sizes, n_local, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    width = max(sizes)
+    if local.shape[1] < width:
+        local = torch.cat([local, local.new_zeros(local.shape[0], width - local.shape[1])], dim=1)
+    local = local.contiguous()
+    bucket = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
+    dist.gather(local, bucket, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return torch.cat([b[:, :s] for b, s in zip(bucket, sizes)], dim=1)

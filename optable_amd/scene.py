@@ -54,7 +54,7 @@ class CompiledScene:
         return d
 
     def node_table(self):
-        """Numpy view of the node records (tests, oracle)."""
+        """Numpy view of the node records (for tests)."""
         return np.ctypeslib.as_array(self.nodes)[: self.n_nodes] if self.n_nodes else np.zeros(0)
 
 

@@ -1,0 +1,68 @@
+"""CPU: the C-ABI library loads and exports every symbol include/optable_hip.h declares; the
+product fails loudly without a GPU (no compute calls here)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from optable_amd import abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "optable_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ot_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree():
+    assert _declared_symbols() == sorted(abi.SYMBOLS)
+
+
+def test_library_exports_every_symbol():
+    if not os.path.exists(abi.LIB_PATH):
+        import __graft_entry__ as g
+
+        g.build()
+    lib = abi.load()
+    for name in _declared_symbols():
+        assert hasattr(lib, name), name
+    assert lib.ot_abi_version() == abi.ABI_VERSION
+
+
+def test_struct_sizes_match_header():
+    # 36 doubles + 12 int32 / 7 doubles + 2 int32, no padding surprises
+    assert C.sizeof(abi.OtNode) == 36 * 8 + 12 * 4
+    assert C.sizeof(abi.OtMaterial) == 7 * 8 + 8
+    assert C.sizeof(abi.OtRays) == 15 * 8
+    assert C.sizeof(abi.OtSegments) == 14 * 8
+    assert C.sizeof(abi.OtMonitor) == 14 * 8
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import optable_amd as oa
+
+    table = oa.OpticalTable()
+    table.add_components([oa.Mirror([1, 0, 0])])
+    with pytest.raises((abi.EngineUnavailable, RuntimeError)):
+        table.ray_tracing([oa.Ray([0, 0, 0], [1, 0, 0])])
+    lib = abi.load()
+    ctx = C.c_void_p()
+    rc = lib.ot_ctx_create(0, None, C.byref(ctx))
+    assert rc < 0 and lib.ot_last_error()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "optable_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle|oracle/|libot_oracle", src, flags=re.M), f
+
