@@ -176,8 +176,9 @@ typedef struct ot_ctx ot_ctx;
 int ot_abi_version(void);
 const char* ot_last_error(void);
 
-/* stream: a hipStream_t the caller owns (e.g. torch.cuda.current_stream().cuda_stream),
- * or NULL to let the ctx create its own. */
+/* stream: a hipStream_t the caller owns (e.g. torch.cuda.current_stream().cuda_stream);
+ * NULL is the device's default (null) stream — which is what torch uses unless told otherwise.
+ * Every launch, and the hipEvents of ot_timing_*, go to this stream. */
 int ot_ctx_create(int device, void* stream, ot_ctx** out);
 int ot_ctx_destroy(ot_ctx* ctx);
 int ot_ctx_synchronize(ot_ctx* ctx);

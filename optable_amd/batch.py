@@ -147,4 +147,7 @@ class SegmentBatch:
             out["count"] = cnt
             return out
         out = {f: self.field(f)[: self.n_valid].cpu().numpy() for f in abi.SEG_FIELDS + ("ray", "surface")}
+        if reference_order:  # generation order -> tree-major; within a tree generation order IS FIFO order
+            order = np.argsort(out["ray"], kind="stable")
+            out = {k: v[order] for k, v in out.items()}
         return out

@@ -436,13 +436,7 @@ int ot_ctx_create(int device, void* stream, ot_ctx** out) {
     HIP_TRY(hipSetDevice(device));
     ot_ctx* c = new ot_ctx();
     c->device = device;
-    if (stream) {
-        c->stream = (hipStream_t)stream;
-    } else {
-        hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-        if (e != hipSuccess) { delete c; return fail(OT_ERR_HIP, hipGetErrorString(e)); }
-        c->own_stream = true;
-    }
+    c->stream = (hipStream_t)stream;  // NULL is the device's default (null) stream, e.g. torch's default
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
         c->n_cus = prop.multiProcessorCount;

@@ -145,9 +145,7 @@ class OpticalTable:
                 capped = _fused_capped(host_segs, cap)
             else:
                 segs = eng.trace_tree(batch, cap, counts=counts)
-                host_segs = segs.to_host()
-                order = np.argsort(host_segs["ray"], kind="stable")
-                host_segs = {k: v[order] for k, v in host_segs.items()}
+                host_segs = segs.to_host(reference_order=True)
                 capped = int(segs.capped.sum().item())
             total_capped += capped
             _scatter_segments(host_segs, sub, pick, per_ray)

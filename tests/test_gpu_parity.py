@@ -66,10 +66,15 @@ def _table(components):
     return t
 
 
+# q tolerance: 1e-9 except through aspheres.  ASphere.roc is a 3-point finite difference with
+# h = 1e-4*radius (surfaces.py:355-369): rounding noise in F is amplified by 1/h^2 ~ 1.6e7, so a
+# 1-ulp change of the INPUT moves the reference algorithm's own q by up to ~1e-4 relative after 50
+# segments (tests/test_oracle_golden.py::test_asphere_q_is_ill_conditioned shows it on the oracle).
+# Positions, directions, lengths and path lengths stay at 1e-9 everywhere.
 CASES = {
-    "cfg2": (lambda oa: scenes.cfg2_components(oa), lambda n: scenes.cfg2_rays(n, 0), 20000, 5),
-    "cfg3": (lambda oa: scenes.cfg3_components(oa), lambda n: scenes.cfg3_rays(n, 2), 20000, 20),
-    "cfg5": (lambda oa: scenes.cfg5_components(oa), lambda n: scenes.cfg5_rays(n, 3), 3000, 50),
+    "cfg2": (lambda oa: scenes.cfg2_components(oa), lambda n: scenes.cfg2_rays(n, 0), 20000, 5, 1e-9),
+    "cfg3": (lambda oa: scenes.cfg3_components(oa), lambda n: scenes.cfg3_rays(n, 2), 20000, 20, 1e-9),
+    "cfg5": (lambda oa: scenes.cfg5_components(oa), lambda n: scenes.cfg5_rays(n, 3), 3000, 50, 2e-3),
 }
 
 
@@ -78,7 +83,7 @@ def test_batch_trace_matches_oracle(case, oracle):
     """Scalable API (RayBatch -> SegmentBatch), fused kernel, against the oracle on the same inputs."""
     import optable_amd as oa
 
-    comps, gen, n, K = CASES[case]
+    comps, gen, n, K, q_rtol = CASES[case]
     table = _table(comps(oa))
     o, d = gen(n)
     batch = _batch(o, d)
@@ -89,8 +94,10 @@ def test_batch_trace_matches_oracle(case, oracle):
     np.testing.assert_array_equal(got["ray"], ref["ray"])
     np.testing.assert_array_equal(got["surface"], ref["surface"])
     for f in abi.SEG_FIELDS:
-        np.testing.assert_allclose(got[f], ref[f], rtol=1e-9, atol=1e-9, err_msg=f)
-    np.testing.assert_array_equal(got["count"] >= K, ref["capped"].astype(bool))
+        rtol = q_rtol if f in ("q_re", "q_im") else 1e-9
+        np.testing.assert_allclose(got[f], ref[f], rtol=rtol, atol=1e-9 if rtol == 1e-9 else 1e-3, err_msg=f)
+    capped = (got["count"] >= K) if "count" in got else segs.capped.cpu().numpy()
+    np.testing.assert_array_equal(capped, ref["capped"].astype(bool))
 
 
 def test_cfg4_dispersion_matches_oracle(oracle):
@@ -126,9 +133,7 @@ def test_branching_batch_matches_oracle(oracle):
                     oa.BeamSplitter([3, 0, 0], width=3, height=3, eta=0.4).RotZ(0.3)])
     batch = _batch(o, d)
     segs = table.trace_batch(batch, max_segments=40)
-    got = segs.to_host()
-    order = np.argsort(got["ray"], kind="stable")
-    got = {k: v[order] for k, v in got.items()}
+    got = segs.to_host(reference_order=True)
     ref = oracle.trace(table.compile(), batch.to_host(), max_trace_num=40)
     assert len(got["ray"]) == len(ref["ray"])
     np.testing.assert_array_equal(got["ray"], ref["ray"])
