@@ -106,7 +106,7 @@ template <class T> __device__ __forceinline__ RayState<T> load_ray(const RaysT<T
 
 // ------------------------------------------------------------------------------------------
 // k_trace_fused: the hot kernel
-template <class T, bool SCENE_IN_LDS>
+template <class T, uint32_t F, bool SCENE_IN_LDS>
 __global__ __launch_bounds__(256) void k_trace_fused(SceneBlob blob, T unit, RaysT<T> in, int64_t n, int32_t K, SegsT<T> out,
                                                      int32_t* __restrict__ seg_count, int32_t* counts, int32_t n_classes) {
     extern __shared__ __align__(16) uint32_t lds[];
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void k_trace_fused(SceneBlob blob, T unit, Ray
         }
         for (int32_t k = 0; k < K; ++k) {  // wave-uniform trip count: lanes never leave the loop alone
             if (!__any(active)) break;
-            const Hit<T> h = nearest_hit<T, false>(sc, r, active, counts, n_classes, cls);
+            const Hit<T> h = nearest_hit<T, F, false>(sc, r, active, counts, n_classes, cls);
             if (active) {
                 const int64_t slot = (int64_t)k * n + i;
                 used = k + 1;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void k_trace_fused(SceneBlob blob, T unit, Ray
                 } else {
                     store_segment(out, slot, r, h.t, (int32_t)i, sc.nodes[h.node].leaf_id);
                     RayState<T> child;
-                    if (interact<T, 1>(sc, r, h, &child) == 0) active = false;
+                    if (interact<T, F, 1>(sc, r, h, &child) == 0) active = false;
                     else r = child;
                 }
             }
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void k_gen_trace(SceneBlob blob, double unit, 
             cls = in.id[i];
         }
         const bool dead = active && (fl & OT_RAY_DEAD);
-        const Hit<double> h = nearest_hit<double, true>(sc, r, active && !dead, counts, n_classes, cls);
+        const Hit<double> h = nearest_hit<double, F_ALL, true>(sc, r, active && !dead, counts, n_classes, cls);
         if (active) {
             const int64_t slot = cur0 + seg_off[i];
             int32_t nk = 0;
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void k_gen_trace(SceneBlob blob, double unit, 
                 else if (h.node < 0) store_segment(out, slot, r, r.len, t, -1);
                 else store_segment(out, slot, r, h.t, t, sc.nodes[h.node].leaf_id);
             }
-            if (!dead && h.node >= 0) nk = interact<double, 2>(sc, r, h, ch);
+            if (!dead && h.node >= 0) nk = interact<double, F_ALL, 2>(sc, r, h, ch);
             for (int c = 0; c < nk; ++c) {
                 const int64_t s = 2 * i + c;
                 const RayState<double>& k = ch[c];
@@ -324,6 +324,7 @@ struct ot_ctx {
     size_t bytes64 = 0, bytes32 = 0;
     int32_t n_nodes = 0, n_mats = 0, n_aux = 0, n_slots = 0, max_children = 0;
     double unit = 1e-2;
+    uint32_t features = 0;
     // timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -383,6 +384,9 @@ template <class T> static void fill_blob(const ot_scene_desc* s, std::vector<uin
         for (int k = 0; k < 6; ++k) { d.aabb[k] = (T)h.aabb[k]; d.lbox[k] = (T)h.lbox[k]; }
         for (int k = 0; k < 8; ++k) d.p[k] = (T)h.p[k];
         d.refl = (T)h.reflectivity; d.trans = (T)h.transmission; d.focal = (T)h.focal_length; d.roc = (T)h.roc;
+        d.inv_focal = (T)(h.focal_length != 0.0 ? 1.0 / h.focal_length : 0.0);
+        d.r2 = (T)(h.p[0] * h.p[0]);
+        d.pad0 = d.pad1 = (T)0;
         d.kind = h.kind; d.end = h.end; d.flags = h.flags; d.shape = h.shape; d.inter = h.interaction;
         d.mat1 = h.mat1; d.mat2 = h.mat2; d.roc_kind = h.roc_kind; d.max_count = h.max_interact_count;
         d.slot = h.count_slot; d.aux = h.aux; d.leaf_id = h.leaf_id;
@@ -397,6 +401,25 @@ template <class T> static void fill_blob(const ot_scene_desc* s, std::vector<uin
     }
     T* aux = reinterpret_cast<T*>(out.data() + nb + mb);
     for (int i = 0; i < s->n_aux; ++i) aux[i] = (T)s->aux[i];
+}
+
+// which code paths the scene needs (trace_core.h feature mask)
+static uint32_t scene_features(const ot_scene_desc* s) {
+    uint32_t f = 0;
+    for (int i = 0; i < s->n_nodes; ++i) {
+        const ot_node& nd = s->nodes[i];
+        if (nd.flags & OT_NODE_CHECK_AABB) f |= F_AABB;
+        if (nd.kind != OT_NODE_LEAF) continue;
+        if (nd.shape == OT_SHAPE_POLYGON2D || nd.shape == OT_SHAPE_CSG) f |= F_POLY;
+        if (nd.shape != OT_SHAPE_CIRCLE && nd.shape != OT_SHAPE_RECT && nd.shape != OT_SHAPE_POLYGON2D &&
+            nd.shape != OT_SHAPE_CSG)
+            f |= F_CURVED;
+        if (nd.shape == OT_SHAPE_POLYGON3D) f |= F_POLY;
+        if (nd.interaction == OT_INT_REFRACT) f |= F_REFRACT;
+        if (nd.interaction == OT_INT_LENS) f |= F_LENS;
+        if (nd.max_interact_count >= 0) f |= F_LIMIT;
+    }
+    return f;
 }
 
 static int validate_scene(const ot_scene_desc* s) {
@@ -485,6 +508,7 @@ int ot_scene_upload(ot_ctx* c, const ot_scene_desc* s) {
     c->bytes64 = b64.size(); c->bytes32 = b32.size();
     c->n_nodes = s->n_nodes; c->n_mats = s->n_materials; c->n_aux = s->n_aux;
     c->n_slots = s->n_count_slots; c->max_children = s->max_children; c->unit = s->unit;
+    c->features = scene_features(s);
     c->has_scene = true;
     return 0;
 }
@@ -543,15 +567,17 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
     const int grid = (int)(blocks_needed < cap ? blocks_needed : cap);
     rc = timing_begin(c);
     if (rc) return rc;
-    if (in_lds) {
-        auto kern = k_trace_fused<T, true>;
-        if (bytes > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), bytes, c->stream, blob, (T)c->unit, view<T>(rays), n, K, view<T>(out),
-                           seg_count, counts, n_classes);
-    } else {
-        hipLaunchKernelGGL((k_trace_fused<T, false>), dim3(grid), dim3(block), 0, c->stream, blob, (T)c->unit, view<T>(rays), n,
-                           K, view<T>(out), seg_count, counts, n_classes);
-    }
+    // smallest instantiation that covers the scene's features
+    constexpr uint32_t FA = F_AABB | F_LENS, FB = F_AABB | F_LENS | F_REFRACT;
+    const uint32_t need = c->features;
+    void (*kern)(SceneBlob, T, RaysT<T>, int64_t, int32_t, SegsT<T>, int32_t*, int32_t*, int32_t);
+    if ((need & ~FA) == 0) kern = in_lds ? k_trace_fused<T, FA, true> : k_trace_fused<T, FA, false>;
+    else if ((need & ~FB) == 0) kern = in_lds ? k_trace_fused<T, FB, true> : k_trace_fused<T, FB, false>;
+    else kern = in_lds ? k_trace_fused<T, F_ALL, true> : k_trace_fused<T, F_ALL, false>;
+    const size_t lds_bytes = in_lds ? bytes : 0;
+    if (lds_bytes > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds_bytes, c->stream, blob, (T)c->unit, view<T>(rays), n, K, view<T>(out),
+                       seg_count, counts, n_classes);
     HIP_TRY(hipGetLastError());
     return timing_end(c);
 }

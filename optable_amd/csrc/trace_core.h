@@ -3,7 +3,9 @@
 // One lane owns one ray.  The scene (skip-list of nodes, materials, aux records) is staged
 // into LDS once per workgroup and read with wave-uniform indices, so every lane of a wave
 // reads the same LDS words (broadcast, no bank conflicts) while the per-ray state lives in
-// VGPRs.  Templated on the real type: double for the fp64 entry points, float for fp32.
+// VGPRs.  Templated on the real type (double / float) and on a scene FEATURE MASK: the host
+// looks at what the uploaded scene contains and launches the smallest instantiation that covers
+// it, so a mirrors-and-lenses scene does not carry the registers of the asphere root solver.
 //
 // Semantics follow the reference (tim4431/optable); the arithmetic is organised differently:
 //   nearest_hit  — one forward pass over the depth-first node list with a per-lane
@@ -15,8 +17,12 @@
 //                  bracket is polished by a safeguarded Newton iteration instead of brentq.
 //   interact     — BaseMirror / BaseRefraciveSurface / Lens .interact_local
 //                  (optical_component.py:536-570, 617-717, 930-948).
-// Redundant renormalisations of already-unit vectors in the reference (Ray.direction setter on
-// every copy) are not repeated per surface test; each child direction is normalised once.
+// Deliberate differences in rounding only (all far inside the 1e-6 parity tolerance):
+//   * redundant renormalisations of already-unit vectors (Ray.direction setter on every copy)
+//     are not repeated per surface test; each child direction is normalised once;
+//   * 1/d per axis is computed once per segment and shared by every AABB slab test (the
+//     reference also forms 1/d, solver.py:34, but per box);
+//   * x/f is evaluated as x*(1/f) with 1/f formed on the host; |P| <= r as |P|^2 <= r^2.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -25,16 +31,27 @@
 
 namespace ot {
 
+// scene feature mask
+enum : uint32_t {
+    F_POLY = 1,      // polygon / boolean apertures
+    F_CURVED = 2,    // sphere, asphere, cylinder, tilted polygon: bracketed root solve
+    F_REFRACT = 4,   // Snell interfaces (and materials)
+    F_LENS = 8,      // thin lenses
+    F_AABB = 16,     // groups: AABB prune
+    F_LIMIT = 32,    // max_interact_count gates
+    F_ALL = 63
+};
+
 template <class T> struct Num;
 template <> struct Num<double> {
     static __device__ __forceinline__ double inf() { return __builtin_inf(); }
-    static __device__ __forceinline__ double eps_t() { return 1e-9; }      // EPS, optical_component.py:163
+    static __device__ __forceinline__ double eps_t() { return 1e-9; }  // EPS, optical_component.py:163
     static __device__ __forceinline__ double root_tol() { return 4.4e-16; }
     static __device__ __forceinline__ double tiny() { return 1e-300; }
 };
 template <> struct Num<float> {
     static __device__ __forceinline__ float inf() { return __builtin_inff(); }
-    // 1e-9 is below fp32 resolution at unit scale; the fp32 self-hit guard is scale aware
+    // 1e-9 is below fp32 resolution at unit scale; the fp32 self-hit guard is 1e-5
     static __device__ __forceinline__ float eps_t() { return 1e-5f; }
     static __device__ __forceinline__ float root_tol() { return 2.4e-7f; }
     static __device__ __forceinline__ float tiny() { return 1e-37f; }
@@ -48,6 +65,7 @@ template <class T> struct DNode {
     T lbox[6];
     T p[8];
     T refl, trans, focal, roc;
+    T inv_focal, r2, pad0, pad1;  // 1/focal_length; p[0]^2 (circle radius squared)
     int32_t kind, end, flags, shape, inter, mat1, mat2, roc_kind, max_count, slot, aux, leaf_id;
 };
 template <class T> struct DMat {
@@ -68,19 +86,16 @@ template <class T> struct Scene {
 template <class T> struct RayState {
     T ox, oy, oz, dx, dy, dz;
     T wl, qr, qi, I, n, pl;
-    T len;      // +inf == None
+    T len;  // +inf == None
     int32_t has_q;
 };
 
 template <class T> struct Hit {
-    T t;        // distance (local frame == lab frame: M is a rotation)
-    T px, py, pz; // local hit point
-    int32_t node; // -1: none
+    T t;           // distance (local frame == lab frame: M is a rotation)
+    T px, py, pz;  // local hit point
+    int32_t node;  // -1: none
 };
 
-template <class T> __device__ __forceinline__ T rsqrt_t(T x);
-template <> __device__ __forceinline__ double rsqrt_t<double>(double x) { return 1.0 / sqrt(x); }
-template <> __device__ __forceinline__ float rsqrt_t<float>(float x) { return 1.0f / sqrtf(x); }
 template <class T> __device__ __forceinline__ T sqrt_t(T x);
 template <> __device__ __forceinline__ double sqrt_t<double>(double x) { return sqrt(x); }
 template <> __device__ __forceinline__ float sqrt_t<float>(float x) { return sqrtf(x); }
@@ -88,21 +103,47 @@ template <class T> __device__ __forceinline__ T abs_t(T x) { return x < T(0) ? -
 template <class T> __device__ __forceinline__ T min_t(T a, T b) { return a < b ? a : b; }
 template <class T> __device__ __forceinline__ T max_t(T a, T b) { return a < b ? b : a; }
 
+// 1/sqrt(x): hardware estimate + Newton steps (x is a squared length, never denormal here)
+__device__ __forceinline__ double rsqrt_t(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double hx = 0.5 * x;
+    y = y * fma(-hx * y, y, 1.5);
+    y = y * fma(-hx * y, y, 1.5);
+    return y;
+}
+__device__ __forceinline__ float rsqrt_t(float x) {
+    float y = __builtin_amdgcn_rsqf(x);
+    return y * fmaf(-0.5f * x * y, y, 1.5f);
+}
+
 // ---------------------------------------------------------------------------------------------
-// solver.py:5-48.  Returns the hit flag; t1/t2 as the reference computes them.
+// solver.py:5-48 with the per-axis reciprocal hoisted out (RayInv is built once per segment).
+template <class T> struct RayInv {
+    T inv[3];
+    bool par[3];
+};
+template <class T> __device__ __forceinline__ RayInv<T> make_inv(T dx, T dy, T dz) {
+    RayInv<T> r;
+    const T d[3] = {dx, dy, dz};
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+        r.par[ax] = abs_t(d[ax]) <= T(1e-8);  // np.isclose(d, 0)
+        r.inv[ax] = T(1) / d[ax];
+    }
+    return r;
+}
 template <class T>
-__device__ __forceinline__ bool slab(T ox, T oy, T oz, T dx, T dy, T dz, const T* box, T& t1, T& t2) {
+__device__ __forceinline__ bool slab_inv(T ox, T oy, T oz, const RayInv<T>& ri, const T* box, T& t1, T& t2) {
     t1 = T(0);
     t2 = Num<T>::inf();
-    const T o[3] = {ox, oy, oz}, d[3] = {dx, dy, dz};
+    const T o[3] = {ox, oy, oz};
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) {
         const T lo = box[2 * ax], hi = box[2 * ax + 1];
-        if (abs_t(d[ax]) <= T(1e-8)) {  // np.isclose(d, 0)
+        if (ri.par[ax]) {
             if (o[ax] < lo || o[ax] > hi) { t1 = T(1); t2 = T(0); }
         } else {
-            const T inv = T(1) / d[ax];
-            const T a = (lo - o[ax]) * inv, b = (hi - o[ax]) * inv;
+            const T a = (lo - o[ax]) * ri.inv[ax], b = (hi - o[ax]) * ri.inv[ax];
             t1 = max_t(t1, min_t(a, b));
             t2 = min_t(t2, max_t(a, b));
         }
@@ -168,7 +209,7 @@ template <class T> __device__ __forceinline__ bool poly_inside(const T* rec, T P
 }
 
 template <class T> __device__ __forceinline__ bool prim_inside(int kind, const T* body, T Px, T Py, T Pz) {
-    if (kind == OT_SHAPE_CIRCLE) return sqrt_t(Px * Px + Py * Py + Pz * Pz) <= body[0];  // 3-norm, surfaces.py:144-145
+    if (kind == OT_SHAPE_CIRCLE) return Px * Px + Py * Py + Pz * Pz <= body[0] * body[0];  // 3-norm, surfaces.py:144-145
     if (kind == OT_SHAPE_RECT) return abs_t(Py) <= body[0] && abs_t(Pz) <= body[1];
     return poly_inside(body, Px, Py, Pz);
 }
@@ -181,29 +222,35 @@ template <class T> __device__ __forceinline__ bool csg_inside(const T* prog, T P
     const T* t = prog + 1;
     for (int k = 0; k < ntok; ++k) {
         const int kind = (int)t[0], len = (int)t[1];
+        bool r;
         if (kind >= 100) {
             const bool b = (stack >> (sp - 1)) & 1u, a = (stack >> (sp - 2)) & 1u;
             sp -= 2;
-            const bool r = (kind == 100) ? (a || b) : (a && !b);
-            stack = (stack & ~(1u << sp)) | (uint32_t(r) << sp);
-            ++sp;
+            r = (kind == 100) ? (a || b) : (a && !b);
         } else {
-            const bool r = prim_inside(kind, t + 2, Px, Py, Pz);
-            stack = (stack & ~(1u << sp)) | (uint32_t(r) << sp);
-            ++sp;
+            r = prim_inside(kind, t + 2, Px, Py, Pz);
         }
+        stack = (stack & ~(1u << sp)) | (uint32_t(r) << sp);
+        ++sp;
         t += 2 + len;
     }
     return stack & 1u;
 }
 
-template <class T> __device__ __forceinline__ bool within_boundary(const Scene<T>& sc, const DNode<T>& nd, T Px, T Py, T Pz) {
+template <class T, uint32_t F>
+__device__ __forceinline__ bool planar_boundary(const Scene<T>& sc, const DNode<T>& nd, T Px, T Py, T Pz) {
+    if (nd.shape == OT_SHAPE_CIRCLE) return Px * Px + Py * Py + Pz * Pz <= nd.r2;
+    if (nd.shape == OT_SHAPE_RECT) return abs_t(Py) <= nd.p[0] && abs_t(Pz) <= nd.p[1];
+    if constexpr (F & F_POLY) {
+        if (nd.shape == OT_SHAPE_POLYGON2D) return poly_inside(sc.aux + nd.aux, Px, Py, Pz);
+        return csg_inside(sc.aux + nd.aux, Px, Py, Pz);
+    }
+    return false;
+}
+
+template <class T> __device__ __forceinline__ bool curved_boundary(const Scene<T>& sc, const DNode<T>& nd, T Px, T Py, T Pz) {
     switch (nd.shape) {
-        case OT_SHAPE_CIRCLE:
-        case OT_SHAPE_RECT: return prim_inside(nd.shape, nd.p, Px, Py, Pz);
-        case OT_SHAPE_POLYGON2D:
         case OT_SHAPE_POLYGON3D: return poly_inside(sc.aux + nd.aux, Px, Py, Pz);
-        case OT_SHAPE_CSG: return csg_inside(sc.aux + nd.aux, Px, Py, Pz);
         case OT_SHAPE_SPHERE: return nd.p[0] - nd.p[1] - T(1e-12) <= Px && Px <= nd.p[0] + T(1e-12);
         case OT_SHAPE_ASPHERE_PARAM:
         case OT_SHAPE_ASPHERE_EXACT: return sqrt_t(Py * Py + Pz * Pz) <= nd.p[0] + T(1e-12);
@@ -249,8 +296,7 @@ __device__ __forceinline__ T surf_g(const Scene<T>& sc, const DNode<T>& nd, T ox
 template <class T>
 __device__ __forceinline__ T polish_root(const Scene<T>& sc, const DNode<T>& nd, T ox, T oy, T oz, T dx, T dy, T dz, T a, T b,
                                          T ga, T gb) {
-    // false-position start
-    T t = a - ga * (b - a) / (gb - ga);
+    T t = a - ga * (b - a) / (gb - ga);  // false-position start
     if (!(t > a && t < b)) t = T(0.5) * (a + b);
     for (int it = 0; it < 48; ++it) {
         T dg;
@@ -269,44 +315,49 @@ __device__ __forceinline__ T polish_root(const Scene<T>& sc, const DNode<T>& nd,
 
 // ---------------------------------------------------------------------------------------------
 // intersect_point_local for one leaf; ray already in the leaf's frame.
-template <class T>
+template <class T, uint32_t F>
 __device__ __forceinline__ bool hit_leaf(const Scene<T>& sc, const DNode<T>& nd, T ox, T oy, T oz, T dx, T dy, T dz, T len, T& t_out,
                                          T& Px, T& Py, T& Pz) {
     const T EPS = Num<T>::eps_t();
     const int sh = nd.shape;
-    if (sh == OT_SHAPE_CIRCLE || sh == OT_SHAPE_RECT || sh == OT_SHAPE_POLYGON2D || sh == OT_SHAPE_CSG) {
+    const bool planar = sh == OT_SHAPE_CIRCLE || sh == OT_SHAPE_RECT || sh == OT_SHAPE_POLYGON2D || sh == OT_SHAPE_CSG;
+    if (!(F & F_CURVED) || planar) {
+        if (!planar) return false;     // cannot happen when the mask matches the scene
         if (dx == T(0)) return false;  // parallel: t = 0 or none, both rejected (optical_component.py:173-190)
         const T t = -ox / dx;
         if (abs_t(t) < EPS || t < T(0) || t > len) return false;
         Px = ox + t * dx; Py = oy + t * dy; Pz = oz + t * dz;
-        if (!within_boundary(sc, nd, Px, Py, Pz)) return false;
+        if (!planar_boundary<T, F>(sc, nd, Px, Py, Pz)) return false;
         t_out = t;
         return true;
     }
-    if (sh == OT_SHAPE_POINT) return false;
-    T t1, t2;
-    slab(ox, oy, oz, dx, dy, dz, nd.lbox, t1, t2);
-    if (t2 + EPS < t1) return false;
-    t1 = max_t(t1, T(0));
-    t2 = min_t(t2, T(100));
-    // np.linspace(t1 - EPS, t2 + EPS, 10): strict sign change per sub-interval, roots ascending
-    const T a = t1 - EPS, b = t2 + EPS, step = (b - a) / T(9);
-    T tl = a, gl = surf_g(sc, nd, ox, oy, oz, dx, dy, dz, a, (T*)nullptr);
-    for (int i = 1; i < 10; ++i) {
-        const T tr = (i == 9) ? b : a + T(i) * step;
-        const T gr = surf_g(sc, nd, ox, oy, oz, dx, dy, dz, tr, (T*)nullptr);
-        if (gl * gr < T(0)) {
-            const T t = polish_root(sc, nd, ox, oy, oz, dx, dy, dz, tl, tr, gl, gr);
-            if (t >= T(0) && abs_t(t) >= EPS && t <= len) {
-                const T X = ox + t * dx, Y = oy + t * dy, Z = oz + t * dz;
-                if (within_boundary(sc, nd, X, Y, Z)) {
-                    t_out = t; Px = X; Py = Y; Pz = Z;
-                    return true;
+    if constexpr (F & F_CURVED) {
+        if (sh == OT_SHAPE_POINT) return false;
+        T t1, t2;
+        const RayInv<T> li = make_inv(dx, dy, dz);
+        slab_inv(ox, oy, oz, li, nd.lbox, t1, t2);
+        if (t2 + EPS < t1) return false;
+        t1 = max_t(t1, T(0));
+        t2 = min_t(t2, T(100));
+        // np.linspace(t1 - EPS, t2 + EPS, 10): strict sign change per sub-interval, roots ascending
+        const T a = t1 - EPS, b = t2 + EPS, step = (b - a) / T(9);
+        T tl = a, gl = surf_g(sc, nd, ox, oy, oz, dx, dy, dz, a, (T*)nullptr);
+        for (int i = 1; i < 10; ++i) {
+            const T tr = (i == 9) ? b : a + T(i) * step;
+            const T gr = surf_g(sc, nd, ox, oy, oz, dx, dy, dz, tr, (T*)nullptr);
+            if (gl * gr < T(0)) {
+                const T t = polish_root(sc, nd, ox, oy, oz, dx, dy, dz, tl, tr, gl, gr);
+                if (t >= T(0) && abs_t(t) >= EPS && t <= len) {
+                    const T X = ox + t * dx, Y = oy + t * dy, Z = oz + t * dz;
+                    if (curved_boundary(sc, nd, X, Y, Z)) {
+                        t_out = t; Px = X; Py = Y; Pz = Z;
+                        return true;
+                    }
                 }
             }
+            tl = tr;
+            gl = gr;
         }
-        tl = tr;
-        gl = gr;
     }
     return false;
 }
@@ -348,7 +399,7 @@ template <bool ATOMIC> __device__ __forceinline__ bool count_gate(int32_t* count
 // Nearest hit over the whole scene for one ray (all lanes of the wave walk the node list with
 // the same index; a lane that pruned a group idles until the list leaves that group, and when
 // every lane of the wave pruned it the wave jumps ahead to the smallest skip target).
-template <class T, bool ATOMIC>
+template <class T, uint32_t F, bool ATOMIC>
 __device__ __forceinline__ Hit<T> nearest_hit(const Scene<T>& sc, const RayState<T>& r, bool active, int32_t* counts,
                                               int32_t n_classes, int32_t cls) {
     Hit<T> best;
@@ -356,26 +407,31 @@ __device__ __forceinline__ Hit<T> nearest_hit(const Scene<T>& sc, const RayState
     best.node = -1;
     best.px = best.py = best.pz = T(0);
     int skip_until = active ? 0 : 0x7fffffff;
+    RayInv<T> ri;
+    if constexpr (F & F_AABB) ri = make_inv(r.dx, r.dy, r.dz);
     for (int i = 0; i < sc.n_nodes; ++i) {
         const DNode<T>& nd = sc.nodes[i];
-        const bool live = i >= skip_until;
-        if (nd.flags & OT_NODE_CHECK_AABB) {
-            T t1, t2;
-            if (live && !slab(r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, nd.aabb, t1, t2)) skip_until = nd.end;
-        }
-        if (nd.kind == OT_NODE_GROUP) {
-            // every lane of the wave takes this branch (nd is wave-uniform); inactive lanes hold INT_MAX
-            const int target = __builtin_amdgcn_readfirstlane(wave_min_i32(skip_until));
-            if (target > i + 1) i = (target < sc.n_nodes ? target : sc.n_nodes) - 1;
-            continue;
+        if constexpr (F & F_AABB) {
+            if (nd.flags & OT_NODE_CHECK_AABB) {
+                T t1, t2;
+                if (i >= skip_until && !slab_inv(r.ox, r.oy, r.oz, ri, nd.aabb, t1, t2)) skip_until = nd.end;
+            }
+            if (nd.kind == OT_NODE_GROUP) {
+                // every lane of the wave takes this branch (nd is wave-uniform); inactive lanes hold INT_MAX
+                const int target = __builtin_amdgcn_readfirstlane(wave_min_i32(skip_until));
+                if (target > i + 1) i = (target < sc.n_nodes ? target : sc.n_nodes) - 1;
+                continue;
+            }
         }
         if (i < skip_until) continue;
         T ox, oy, oz, dx, dy, dz;
         to_local(nd, r.ox - nd.org[0], r.oy - nd.org[1], r.oz - nd.org[2], ox, oy, oz);
         to_local(nd, r.dx, r.dy, r.dz, dx, dy, dz);
         T t, Px, Py, Pz;
-        if (!hit_leaf(sc, nd, ox, oy, oz, dx, dy, dz, r.len, t, Px, Py, Pz)) continue;
-        if (nd.max_count >= 0 && !count_gate<ATOMIC>(counts, (int64_t)nd.slot * n_classes + cls, nd.max_count)) continue;
+        if (!hit_leaf<T, F>(sc, nd, ox, oy, oz, dx, dy, dz, r.len, t, Px, Py, Pz)) continue;
+        if constexpr (F & F_LIMIT) {
+            if (nd.max_count >= 0 && !count_gate<ATOMIC>(counts, (int64_t)nd.slot * n_classes + cls, nd.max_count)) continue;
+        }
         if (t < best.t) {
             best.t = t; best.node = i; best.px = Px; best.py = Py; best.pz = Pz;
         }
@@ -383,107 +439,124 @@ __device__ __forceinline__ Hit<T> nearest_hit(const Scene<T>& sc, const RayState
     return best;
 }
 
+// a / b for complex numbers with one real division
 template <class T> __device__ __forceinline__ void cdiv(T ar, T ai, T br, T bi, T& cr, T& ci) {
-    const T den = br * br + bi * bi;
-    cr = (ar * br + ai * bi) / den;
-    ci = (ai * br - ar * bi) / den;
+    const T inv = T(1) / (br * br + bi * bi);
+    cr = (ar * br + ai * bi) * inv;
+    ci = (ai * br - ar * bi) * inv;
 }
 
-template <class T> __device__ __forceinline__ void surf_normal(const Scene<T>& sc, const DNode<T>& nd, T Px, T Py, T Pz, T& nx, T& ny, T& nz) {
-    switch (nd.shape) {
-        case OT_SHAPE_SPHERE: nx = Px / nd.p[0]; ny = Py / nd.p[0]; nz = Pz / nd.p[0]; return;
-        case OT_SHAPE_CYLINDER: nx = Px / nd.p[0]; ny = Py / nd.p[0]; nz = T(0); return;
-        case OT_SHAPE_POLYGON2D:
-        case OT_SHAPE_POLYGON3D: {
+template <class T, uint32_t F>
+__device__ __forceinline__ void surf_normal(const Scene<T>& sc, const DNode<T>& nd, T Px, T Py, T Pz, T& nx, T& ny, T& nz) {
+    nx = T(1); ny = T(0); nz = T(0);  // Plane._normal
+    if constexpr (F & F_POLY) {
+        if (nd.shape == OT_SHAPE_POLYGON2D) {
             const T* rec = sc.aux + nd.aux;
             nx = rec[1]; ny = rec[2]; nz = rec[3];
-            return;
         }
-        case OT_SHAPE_ASPHERE_PARAM:
-        case OT_SHAPE_ASPHERE_EXACT: {  // surfaces.py:380-388
-            const T r = sqrt_t(Py * Py + Pz * Pz);
-            if (r < T(1e-12)) { nx = T(1); ny = T(0); nz = T(0); return; }
-            const T s = sag_d1(nd, r);
-            const T ay = s * (Py / r), az = s * (Pz / r);
-            const T inv = rsqrt_t(T(1) + ay * ay + az * az);
-            nx = inv; ny = ay * inv; nz = az * inv;
-            return;
+    }
+    if constexpr (F & F_CURVED) {
+        switch (nd.shape) {
+            case OT_SHAPE_SPHERE: nx = Px / nd.p[0]; ny = Py / nd.p[0]; nz = Pz / nd.p[0]; return;
+            case OT_SHAPE_CYLINDER: nx = Px / nd.p[0]; ny = Py / nd.p[0]; nz = T(0); return;
+            case OT_SHAPE_POLYGON3D: {
+                const T* rec = sc.aux + nd.aux;
+                nx = rec[1]; ny = rec[2]; nz = rec[3];
+                return;
+            }
+            case OT_SHAPE_ASPHERE_PARAM:
+            case OT_SHAPE_ASPHERE_EXACT: {  // surfaces.py:380-388
+                const T r = sqrt_t(Py * Py + Pz * Pz);
+                if (r < T(1e-12)) return;
+                const T s = sag_d1(nd, r);
+                const T ay = s * (Py / r), az = s * (Pz / r);
+                const T inv = rsqrt_t(T(1) + ay * ay + az * az);
+                nx = inv; ny = ay * inv; nz = az * inv;
+                return;
+            }
+            default: return;
         }
-        default: nx = T(1); ny = T(0); nz = T(0); return;
     }
 }
 
 // Children of a hit.  MAXK = 1 compiles the non-branching form (at most the first child).
 // Writes lab-frame children into kids[0..nk).
-template <class T, int MAXK>
+template <class T, uint32_t F, int MAXK>
 __device__ __forceinline__ int interact(const Scene<T>& sc, const RayState<T>& r, const Hit<T>& h, RayState<T>* kids) {
     const DNode<T>& nd = sc.nodes[h.node];
     if (nd.inter == OT_INT_BLOCK) return 0;
-    // incoming direction in the leaf frame
-    T dx, dy, dz;
+    T dx, dy, dz;  // incoming direction in the leaf frame
     to_local(nd, r.dx, r.dy, r.dz, dx, dy, dz);
     const T t = h.t;
     const T q1r = r.qr + t, q1i = r.qi;  // q_at_z (ray.py:17-19)
     const T pl_hit = r.pl + t * r.n;     // Ray.pathlength(t) (ray.py:145-147)
-    RayState<T> base = r;
-    to_lab(nd, h.px, h.py, h.pz, base.ox, base.oy, base.oz);
-    base.ox += nd.org[0]; base.oy += nd.org[1]; base.oz += nd.org[2];
-    base.len = Num<T>::inf();
+    T Ox, Oy, Oz;
+    to_lab(nd, h.px, h.py, h.pz, Ox, Oy, Oz);
+    Ox += nd.org[0]; Oy += nd.org[1]; Oz += nd.org[2];
     int nk = 0;
     auto emit = [&](T lx, T ly, T lz, T I, T qr, T qi, T n, T pl) {
-        RayState<T> k = base;
-        const T inv = rsqrt_t(lx * lx + ly * ly + lz * lz);
-        to_lab(nd, lx * inv, ly * inv, lz * inv, k.dx, k.dy, k.dz);
-        k.I = I; k.qr = qr; k.qi = qi; k.n = n; k.pl = pl;
-        if (nk < MAXK) kids[nk] = k;
+        if (nk < MAXK) {
+            RayState<T>& k = kids[MAXK == 1 ? 0 : nk];  // static index keeps the child in registers
+            const T inv = rsqrt_t(lx * lx + ly * ly + lz * lz);
+            to_lab(nd, lx * inv, ly * inv, lz * inv, k.dx, k.dy, k.dz);
+            k.ox = Ox; k.oy = Oy; k.oz = Oz;
+            k.wl = r.wl; k.has_q = r.has_q; k.len = Num<T>::inf();
+            k.I = I; k.qr = qr; k.qi = qi; k.n = n; k.pl = pl;
+        }
         ++nk;
     };
-    if (nd.inter == OT_INT_LENS) {  // optical_component.py:930-948
-        T qr = r.qr, qi = r.qi;
-        const T f = nd.focal;
-        if (r.has_q) cdiv(q1r, q1i, T(1) - q1r / f, -q1i / f, qr, qi);
-        emit(dx - h.px / f, dy - h.py / f, dz - h.pz / f, r.I * nd.trans, qr, qi, r.n, r.pl);  // pathlength, n unchanged
-        return nk < MAXK ? nk : MAXK;
+    if constexpr (F & F_LENS) {
+        if (nd.inter == OT_INT_LENS) {  // optical_component.py:930-948
+            T qr = r.qr, qi = r.qi;
+            const T jf = nd.inv_focal;
+            if (r.has_q) cdiv(q1r, q1i, T(1) - q1r * jf, -q1i * jf, qr, qi);
+            emit(dx - h.px * jf, dy - h.py * jf, dz - h.pz * jf, r.I * nd.trans, qr, qi, r.n, r.pl);  // pathlength, n unchanged
+            return nk < MAXK ? nk : MAXK;
+        }
     }
     T nx, ny, nz;
-    surf_normal(sc, nd, h.px, h.py, h.pz, nx, ny, nz);
+    surf_normal<T, F>(sc, nd, h.px, h.py, h.pz, nx, ny, nz);
     const T dn = dx * nx + dy * ny + dz * nz;
-    if (nd.inter == OT_INT_MIRROR) {  // optical_component.py:536-570
+    if (!(F & F_REFRACT) || nd.inter == OT_INT_MIRROR) {  // optical_component.py:536-570
         if (nd.refl > T(0)) emit(dx - T(2) * dn * nx, dy - T(2) * dn * ny, dz - T(2) * dn * nz, r.I * nd.refl, q1r, q1i, r.n, pl_hit);
         if (nd.trans > T(0) && (MAXK > 1 || nk == 0)) emit(dx, dy, dz, r.I * nd.trans, q1r, q1i, r.n, pl_hit);
         return nk < MAXK ? nk : MAXK;
     }
-    // refraction, optical_component.py:617-717
-    const T wl_m = r.wl * sc.unit;
-    const T n1 = material_index(sc.mats[nd.mat1], wl_m), n2 = material_index(sc.mats[nd.mat2], wl_m);
-    T ROC = Num<T>::inf();
-    if (nd.roc_kind == OT_ROC_CONST) ROC = nd.roc;
-    else if (nd.roc_kind == OT_ROC_ASPHERE) {  // surfaces.py:362-373
-        const T rr = sqrt_t(h.py * h.py + h.pz * h.pz), s = sag_d1(nd, rr);
-        const T w = T(1) + s * s;
-        ROC = w * sqrt_t(w) / sag_d2(nd, rr);
-    }
-    T nin = n1, nout = n2;
-    if (!(dn < T(0))) { nin = n2; nout = n1; ROC = -ROC; }
-    T qtr = r.qr, qti = r.qi, qrr = r.qr, qri = r.qi;
-    if (r.has_q) {
-        const T Cc = (nin - nout) / (ROC * nout), Dd = nin / nout, Cr = T(2) / ROC;
-        cdiv(q1r, q1i, Cc * q1r + Dd, Cc * q1i, qtr, qti);
-        cdiv(q1r, q1i, Cr * q1r + T(1), Cr * q1i, qrr, qri);
-    }
-    const T ci = min_t(max_t(dn, T(-1)), T(1));
-    const T si = sqrt_t(T(1) - ci * ci), st = nin * si / nout;
-    if (st < T(1)) {
-        if (nd.trans > T(0)) {
-            const T ct = sqrt_t(T(1) - st * st), ratio = nin / nout, sgn = dn > T(0) ? T(1) : T(-1);
-            emit(ratio * (dx - dn * nx) + ct * sgn * nx, ratio * (dy - dn * ny) + ct * sgn * ny,
-                 ratio * (dz - dn * nz) + ct * sgn * nz, r.I * nd.trans, qtr, qti, nout, pl_hit);
+    if constexpr (F & F_REFRACT) {  // optical_component.py:617-717
+        const T wl_m = r.wl * sc.unit;
+        const T n1 = material_index(sc.mats[nd.mat1], wl_m), n2 = material_index(sc.mats[nd.mat2], wl_m);
+        T ROC = Num<T>::inf();
+        if (nd.roc_kind == OT_ROC_CONST) ROC = nd.roc;
+        if constexpr (F & F_CURVED) {
+            if (nd.roc_kind == OT_ROC_ASPHERE) {  // surfaces.py:362-373
+                const T rr = sqrt_t(h.py * h.py + h.pz * h.pz), s = sag_d1(nd, rr);
+                const T w = T(1) + s * s;
+                ROC = w * sqrt_t(w) / sag_d2(nd, rr);
+            }
         }
-    } else {  // total internal reflection: full intensity
-        emit(dx - T(2) * ci * nx, dy - T(2) * ci * ny, dz - T(2) * ci * nz, r.I, qrr, qri, r.n, pl_hit);
+        T nin = n1, nout = n2;
+        if (!(dn < T(0))) { nin = n2; nout = n1; ROC = -ROC; }
+        const T ratio = nin / nout;
+        T qtr = r.qr, qti = r.qi, qrr = r.qr, qri = r.qi;
+        if (r.has_q) {
+            const T Cc = (nin - nout) / (ROC * nout), Cr = T(2) / ROC;
+            cdiv(q1r, q1i, Cc * q1r + ratio, Cc * q1i, qtr, qti);
+            cdiv(q1r, q1i, Cr * q1r + T(1), Cr * q1i, qrr, qri);
+        }
+        const T ci = min_t(max_t(dn, T(-1)), T(1));
+        const T si = sqrt_t(T(1) - ci * ci), st = ratio * si;
+        if (st < T(1)) {
+            if (nd.trans > T(0)) {
+                const T ct = sqrt_t(T(1) - st * st), sgn = dn > T(0) ? T(1) : T(-1);
+                emit(ratio * (dx - dn * nx) + ct * sgn * nx, ratio * (dy - dn * ny) + ct * sgn * ny,
+                     ratio * (dz - dn * nz) + ct * sgn * nz, r.I * nd.trans, qtr, qti, nout, pl_hit);
+            }
+        } else {  // total internal reflection: full intensity
+            emit(dx - T(2) * ci * nx, dy - T(2) * ci * ny, dz - T(2) * ci * nz, r.I, qrr, qri, r.n, pl_hit);
+        }
+        if (MAXK > 1 && nd.refl > T(0))
+            emit(dx - T(2) * ci * nx, dy - T(2) * ci * ny, dz - T(2) * ci * nz, r.I * nd.refl, qrr, qri, r.n, pl_hit);
     }
-    if (MAXK > 1 && nd.refl > T(0))
-        emit(dx - T(2) * ci * nx, dy - T(2) * ci * ny, dz - T(2) * ci * nz, r.I * nd.refl, qrr, qri, r.n, pl_hit);
     return nk < MAXK ? nk : MAXK;
 }
 
