@@ -110,7 +110,13 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     kernel_ms, launches = eng.timing_read()
+    # roofline companion: the same streams with no tracing (what this access pattern can reach)
+    eng.timing_reset()
+    for _ in range(10):
+        eng.stream_ceiling(batch, MAX_SEG, out)
+    ceil_ms, ceil_n = eng.timing_read()
     eng.timing(False)
+    eng.trace(batch, MAX_SEG, out=out)  # leave real results in `out`
 
     segs_step = int(out.count.sum().item())
     gather_ms = None
@@ -155,7 +161,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_trace_fused<double>", "kernel_us": avg_kernel_s * 1e6,
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "stream_ceiling_gbs": alg_bytes / (ceil_ms / max(ceil_n, 1) / 1e3) / 1e9},
         }
         if gather_ms is not None:
             line["gather_ms"] = gather_ms

@@ -235,6 +235,17 @@ int ot_timing_reset(ot_ctx* ctx);
 
 /* Launch-geometry knobs (0 = library default); for tuning and tests only. */
 int ot_set_launch(ot_ctx* ctx, int32_t block_threads, int32_t rays_per_lane);
+enum ot_option {
+    OT_OPT_NT_STORES = 1,      /* segment records written with non-temporal stores (0/1)        */
+    OT_OPT_MIN_WAVES = 2,      /* 0: compiler's choice; 4: cap registers for 4 waves per SIMD  */
+    OT_OPT_BLOCKS_PER_CU = 3   /* persistent-grid size in 256-thread blocks per CU (0 = auto)  */
+};
+int ot_set_option(ot_ctx* ctx, int32_t option, int32_t value);
+
+/* Roofline companion of ot_trace_f64: the same streams (one ray record in, max_segments segment
+ * records out per ray) with no tracing in between — the ceiling of this access pattern. */
+int ot_bench_stream_f64(ot_ctx* ctx, const ot_rays* rays, int64_t n_rays, int32_t max_segments,
+                        const ot_segments* out, int32_t* seg_count);
 
 #ifdef __cplusplus
 }

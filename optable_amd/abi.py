@@ -65,6 +65,7 @@ NODE_GROUP, NODE_LEAF = 0, 1
 NODE_CHECK_AABB = 1
 MAT_CONST, MAT_SELLMEIER = 0, 1
 RAY_HAS_Q, RAY_DEAD = 1, 2
+OPT_NT_STORES, OPT_MIN_WAVES, OPT_BLOCKS_PER_CU = 1, 2, 3
 
 # every symbol the header declares, with its ctypes signature
 _vp, _i32, _i64 = C.c_void_p, C.c_int32, C.c_int64
@@ -86,6 +87,8 @@ SYMBOLS = {
     "ot_timing_read": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(_i64)]),
     "ot_timing_reset": (C.c_int, [_vp]),
     "ot_set_launch": (C.c_int, [_vp, _i32, _i32]),
+    "ot_set_option": (C.c_int, [_vp, _i32, _i32]),
+    "ot_bench_stream_f64": (C.c_int, [_vp, C.POINTER(OtRays), _i64, _i32, C.POINTER(OtSegments), _vp]),
 }
 
 _lib = None

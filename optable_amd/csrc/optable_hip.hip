@@ -83,14 +83,21 @@ template <class T> __device__ __forceinline__ Scene<T> bind_scene(const uint32_t
     return sc;
 }
 
-template <class T> __device__ __forceinline__ void store_segment(const SegsT<T>& out, int64_t slot, const RayState<T>& r, T len,
-                                                                  int32_t tree, int32_t surface) {
-    out.ox[slot] = r.ox; out.oy[slot] = r.oy; out.oz[slot] = r.oz;
-    out.dx[slot] = r.dx; out.dy[slot] = r.dy; out.dz[slot] = r.dz;
-    out.len[slot] = len; out.I[slot] = r.I;
-    out.qr[slot] = r.qr; out.qi[slot] = r.qi;
-    out.n[slot] = r.n; out.pl[slot] = r.pl;
-    out.ray[slot] = tree; out.surface[slot] = surface;
+// Segment records are written once and never re-read by the trace: NT = true marks the stores
+// non-temporal so they stream past L2 / Infinity Cache instead of evicting the scene and inputs.
+template <bool NT, class V> __device__ __forceinline__ void st(V* p, V v) {
+    if (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+template <class T, bool NT = false>
+__device__ __forceinline__ void store_segment(const SegsT<T>& out, int64_t slot, const RayState<T>& r, T len, int32_t tree,
+                                              int32_t surface) {
+    st<NT>(out.ox + slot, r.ox); st<NT>(out.oy + slot, r.oy); st<NT>(out.oz + slot, r.oz);
+    st<NT>(out.dx + slot, r.dx); st<NT>(out.dy + slot, r.dy); st<NT>(out.dz + slot, r.dz);
+    st<NT>(out.len + slot, len); st<NT>(out.I + slot, r.I);
+    st<NT>(out.qr + slot, r.qr); st<NT>(out.qi + slot, r.qi);
+    st<NT>(out.n + slot, r.n); st<NT>(out.pl + slot, r.pl);
+    st<NT>(out.ray + slot, tree); st<NT>(out.surface + slot, surface);
 }
 
 template <class T> __device__ __forceinline__ RayState<T> load_ray(const RaysT<T>& in, int64_t i, int32_t flags) {
@@ -106,8 +113,8 @@ template <class T> __device__ __forceinline__ RayState<T> load_ray(const RaysT<T
 
 // ------------------------------------------------------------------------------------------
 // k_trace_fused: the hot kernel
-template <class T, uint32_t F, bool SCENE_IN_LDS>
-__global__ __launch_bounds__(256) void k_trace_fused(SceneBlob blob, T unit, RaysT<T> in, int64_t n, int32_t K, SegsT<T> out,
+template <class T, uint32_t F, bool SCENE_IN_LDS, int MINW, bool NT>
+__global__ __launch_bounds__(256, MINW) void k_trace_fused(SceneBlob blob, T unit, RaysT<T> in, int64_t n, int32_t K, SegsT<T> out,
                                                      int32_t* __restrict__ seg_count, int32_t* counts, int32_t n_classes) {
     extern __shared__ __align__(16) uint32_t lds[];
     const uint32_t* base = blob.words;
@@ -128,7 +135,7 @@ __global__ __launch_bounds__(256) void k_trace_fused(SceneBlob blob, T unit, Ray
             r = load_ray(in, i, fl);
             cls = in.id[i];
             if (fl & OT_RAY_DEAD) {  // optical_component.py:349: a dead ray hits nothing and is returned as is
-                store_segment(out, i, r, r.len, (int32_t)i, -2);
+                store_segment<T, NT>(out, i, r, r.len, (int32_t)i, -2);
                 used = 1;
                 active = false;
             }
@@ -140,10 +147,10 @@ __global__ __launch_bounds__(256) void k_trace_fused(SceneBlob blob, T unit, Ray
                 const int64_t slot = (int64_t)k * n + i;
                 used = k + 1;
                 if (h.node < 0) {  // escaped: archived unchanged (optical_table.py:132-134)
-                    store_segment(out, slot, r, r.len, (int32_t)i, -1);
+                    store_segment<T, NT>(out, slot, r, r.len, (int32_t)i, -1);
                     active = false;
                 } else {
-                    store_segment(out, slot, r, h.t, (int32_t)i, sc.nodes[h.node].leaf_id);
+                    store_segment<T, NT>(out, slot, r, h.t, (int32_t)i, sc.nodes[h.node].leaf_id);
                     RayState<T> child;
                     if (interact<T, F, 1>(sc, r, h, &child) == 0) active = false;
                     else r = child;
@@ -151,6 +158,23 @@ __global__ __launch_bounds__(256) void k_trace_fused(SceneBlob blob, T unit, Ray
             }
         }
         if (i < n) seg_count[i] = used;
+    }
+}
+
+// k_stream_ceiling: the fused kernel's memory traffic with no tracing — reads one ray record,
+// writes K segment records per ray through the same SoA streams.  What this access pattern can
+// reach on the device; reported next to the trace kernel (bench.py).
+template <class T, bool NT>
+__global__ __launch_bounds__(256) void k_stream_ceiling(RaysT<T> in, int64_t n, int32_t K, SegsT<T> out, int32_t* seg_count) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        RayState<T> r = load_ray(in, i, in.flags[i]);
+        const int32_t cls = in.id[i];
+        for (int32_t k = 0; k < K; ++k) {
+            store_segment<T, NT>(out, (int64_t)k * n + i, r, r.len, (int32_t)i, cls);
+            r.ox += T(1);  // keep the K records distinct so the stores cannot be merged
+        }
+        seg_count[i] = K;
     }
 }
 
@@ -333,6 +357,7 @@ struct ot_ctx {
     int64_t launches = 0;
     // knobs
     int32_t block_threads = 256, rays_per_lane = 1;
+    int32_t opt_nt = 1, opt_minw = 4, opt_blocks_per_cu = 0;  // defaults from tools/tune.py on MI355X
     Scratch gen, scan_tmp, mon;
 };
 
@@ -558,22 +583,33 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
     const int block = 256;
     const bool in_lds = bytes <= 150 * 1024;
     const int64_t blocks_needed = (n + block - 1) / block;
-    int per_cu = 8;
-    if (in_lds && bytes > 0) {
+    // Grid: small scenes (staging the blob costs nothing) get ~one ray per lane, 16 blocks per CU;
+    // scenes with a large LDS image run persistent, as many blocks per CU as the image allows.
+    int per_cu = 16;
+    if (in_lds && bytes > 8 * 1024) {
         const int fit = (int)((160 * 1024) / (bytes + 512));
         per_cu = fit < 1 ? 1 : (fit > 8 ? 8 : fit);
     }
+    if (c->opt_blocks_per_cu > 0) per_cu = c->opt_blocks_per_cu;
     const int64_t cap = (int64_t)c->n_cus * per_cu;
     const int grid = (int)(blocks_needed < cap ? blocks_needed : cap);
     rc = timing_begin(c);
     if (rc) return rc;
-    // smallest instantiation that covers the scene's features
+    // smallest instantiation that covers the scene's features, then the launch options
     constexpr uint32_t FA = F_AABB | F_LENS, FB = F_AABB | F_LENS | F_REFRACT;
     const uint32_t need = c->features;
-    void (*kern)(SceneBlob, T, RaysT<T>, int64_t, int32_t, SegsT<T>, int32_t*, int32_t*, int32_t);
-    if ((need & ~FA) == 0) kern = in_lds ? k_trace_fused<T, FA, true> : k_trace_fused<T, FA, false>;
-    else if ((need & ~FB) == 0) kern = in_lds ? k_trace_fused<T, FB, true> : k_trace_fused<T, FB, false>;
-    else kern = in_lds ? k_trace_fused<T, F_ALL, true> : k_trace_fused<T, F_ALL, false>;
+    using Kern = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, SegsT<T>, int32_t*, int32_t*, int32_t);
+    const int fi = (need & ~FA) == 0 ? 0 : ((need & ~FB) == 0 ? 1 : 2);
+    const int mw = (c->opt_minw == 4 && fi < 2) ? 1 : 0, nt = c->opt_nt ? 1 : 0;
+#define OT_K(FM, L, W, N) k_trace_fused<T, FM, L, W, N>
+#define OT_ROW(FM) {{{OT_K(FM, false, 1, false), OT_K(FM, false, 1, true)}, {OT_K(FM, false, 4, false), OT_K(FM, false, 4, true)}}, \
+                    {{OT_K(FM, true, 1, false), OT_K(FM, true, 1, true)}, {OT_K(FM, true, 4, false), OT_K(FM, true, 4, true)}}}
+    static const Kern table[3][2][2][2] = {OT_ROW(FA), OT_ROW(FB),
+                                           {{{OT_K(F_ALL, false, 1, false), OT_K(F_ALL, false, 1, true)}, {nullptr, nullptr}},
+                                            {{OT_K(F_ALL, true, 1, false), OT_K(F_ALL, true, 1, true)}, {nullptr, nullptr}}}};
+#undef OT_ROW
+#undef OT_K
+    Kern kern = table[fi][in_lds ? 1 : 0][mw][nt];
     const size_t lds_bytes = in_lds ? bytes : 0;
     if (lds_bytes > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds_bytes, c->stream, blob, (T)c->unit, view<T>(rays), n, K, view<T>(out),
@@ -701,6 +737,41 @@ int ot_monitor_record_f64(ot_ctx* c, const ot_monitor* mon, const ot_segments* s
                        (double*)Pz, (double*)t, n_hits);
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+int ot_set_option(ot_ctx* c, int32_t option, int32_t value) {
+    if (!c) return fail(OT_ERR_INVALID, "ctx is NULL");
+    switch (option) {
+        case OT_OPT_NT_STORES: c->opt_nt = value != 0; return 0;
+        case OT_OPT_MIN_WAVES: 
+            if (value != 0 && value != 4) return fail(OT_ERR_INVALID, "OT_OPT_MIN_WAVES takes 0 or 4");
+            c->opt_minw = value; return 0;
+        case OT_OPT_BLOCKS_PER_CU:
+            if (value < 0 || value > 64) return fail(OT_ERR_INVALID, "OT_OPT_BLOCKS_PER_CU out of range");
+            c->opt_blocks_per_cu = value; return 0;
+        default: return fail(OT_ERR_INVALID, "unknown option");
+    }
+}
+
+int ot_bench_stream_f64(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, const ot_segments* out, int32_t* seg_count) {
+    if (!c) return fail(OT_ERR_INVALID, "ctx is NULL");
+    int rc = check_rays(rays, "rays");
+    if (rc) return rc;
+    rc = check_segs(out);
+    if (rc) return rc;
+    if (n < 1 || K < 1 || !seg_count || n >= (int64_t)1 << 31) return fail(OT_ERR_INVALID, "bad n / K / seg_count");
+    HIP_TRY(hipSetDevice(c->device));
+    const int block = 256;
+    const int64_t need = (n + block - 1) / block, cap = (int64_t)c->n_cus * (c->opt_blocks_per_cu > 0 ? c->opt_blocks_per_cu : 8);
+    const int grid = (int)(need < cap ? need : cap);
+    rc = timing_begin(c);
+    if (rc) return rc;
+    if (c->opt_nt)
+        hipLaunchKernelGGL((k_stream_ceiling<double, true>), dim3(grid), dim3(block), 0, c->stream, view<double>(rays), n, K, view<double>(out), seg_count);
+    else
+        hipLaunchKernelGGL((k_stream_ceiling<double, false>), dim3(grid), dim3(block), 0, c->stream, view<double>(rays), n, K, view<double>(out), seg_count);
+    HIP_TRY(hipGetLastError());
+    return timing_end(c);
 }
 
 int ot_timing_enable(ot_ctx* c, int enabled) {

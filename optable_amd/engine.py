@@ -120,6 +120,9 @@ class Engine:
         abi.check(self.lib.ot_timing_enable(self._ctx, int(enabled)), self.lib)
         abi.check(self.lib.ot_timing_reset(self._ctx), self.lib)
 
+    def timing_reset(self):
+        abi.check(self.lib.ot_timing_reset(self._ctx), self.lib)
+
     def timing_read(self):
         ms, cnt = C.c_double(), C.c_int64()
         abi.check(self.lib.ot_timing_read(self._ctx, C.byref(ms), C.byref(cnt)), self.lib)
@@ -127,6 +130,17 @@ class Engine:
 
     def set_launch(self, block_threads=0, rays_per_lane=0):
         abi.check(self.lib.ot_set_launch(self._ctx, block_threads, rays_per_lane), self.lib)
+
+    def set_option(self, option, value):
+        abi.check(self.lib.ot_set_option(self._ctx, option, value), self.lib)
+
+    def stream_ceiling(self, rays: RayBatch, max_segments, out: SegmentBatch):
+        """Same bytes as `trace` with no tracing (roofline companion)."""
+        if out.count is None or out.count.numel() != rays.n:
+            out.count = torch.empty(rays.n, dtype=torch.int32, device=rays.device)
+        rs, ss = rays.c_struct(), out.c_struct()
+        abi.check(self.lib.ot_bench_stream_f64(self._ctx, C.byref(rs), rays.n, int(max_segments), C.byref(ss),
+                                               out.count.data_ptr()), self.lib)
 
     def synchronize(self):
         abi.check(self.lib.ot_ctx_synchronize(self._ctx), self.lib)
