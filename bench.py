@@ -65,17 +65,24 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rays", type=int, default=N_RAYS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the real thing) or gloo (rehearsal on a 1-GPU box)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
+    if args.backend == "gloo":  # rehearsal: several ranks may share one card
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if distributed:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+    comm_dev = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")
 
     import optable_amd as oa
     from optable_amd.batch import RayBatch, SegmentBatch
@@ -121,10 +128,10 @@ def main():
     segs_step = int(out.count.sum().item())
     gather_ms = None
     if distributed:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=batch.device)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        tot = torch.tensor([segs_step], dtype=torch.int64, device=batch.device)
+        tot = torch.tensor([segs_step], dtype=torch.int64, device=comm_dev)
         dist.all_reduce(tot)
         segs_total_step = int(tot.item())
         # the one collective of the job: per-ray final state to rank 0 (outside the timed steps)

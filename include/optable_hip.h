@@ -192,6 +192,10 @@ int ot_scene_upload(ot_ctx* ctx, const ot_scene_desc* scene);
  * one launch.  Segment k of ray i is written at slot k*n_rays + i of every ot_segments array
  * (capacity max_segments*n_rays); seg_count[i] = number of slots ray i used.  max_segments is
  * the reference's perfomance_limit["max_trace_num"] (optical_table.py:87-97).
+ * Scenes in which a hit CAN emit two rays (max_children == 2) may still be traced here
+ * speculatively: a ray whose tree actually branches at its k-th segment gets
+ * seg_count[i] = -(k+1) (its first k+1 slots are valid, the tree is incomplete) and must be
+ * re-traced with ot_trace_generation_f64.
  * counts: int32 [n_count_slots][n_count_classes] interact-count table indexed by rays.id, or
  * NULL when the scene has no limited surface. */
 int ot_trace_f64(ot_ctx* ctx, const ot_rays* rays, int64_t n_rays, int32_t max_segments,
@@ -215,16 +219,18 @@ int ot_trace_generation_f64(ot_ctx* ctx, const ot_rays* rays, const int32_t* ray
                             int32_t* counts, int32_t n_count_classes);
 
 /* Monitor.record (monitor.py:183-193): intersect finished segments with a rectangular
- * monitor plane, honouring segment length.  hit_index receives the indices of the segments
- * that hit (ascending), P the local hit point, t the distance; *n_hits the count. */
+ * monitor plane, honouring segment length.  hit_index receives the slot indices of the segments
+ * that hit (ascending), P the local hit point, t the distance; *n_hits the count.
+ * seg_count/n_rays: pass ot_trace_*'s seg_count and n_rays to scan a [k][ray] slot array
+ * (n_segments = max_segments*n_rays; unused slots are skipped); NULL/0 for a flat list. */
 typedef struct ot_monitor {
     double M[9];
     double origin[3];
     double half_width, half_height;
 } ot_monitor;
 int ot_monitor_record_f64(ot_ctx* ctx, const ot_monitor* mon, const ot_segments* segs,
-                          int64_t n_segments, int64_t* hit_index, void* Px, void* Py, void* Pz,
-                          void* t, int64_t* n_hits);
+                          int64_t n_segments, const int32_t* seg_count, int64_t n_rays,
+                          int64_t* hit_index, void* Px, void* Py, void* Pz, void* t, int64_t* n_hits);
 
 /* ---- measurement ------------------------------------------------------------------------ */
 /* When enabled every trace launch is bracketed by hipEvents on the ctx stream. */

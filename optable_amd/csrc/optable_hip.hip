@@ -152,8 +152,12 @@ __global__ __launch_bounds__(256, MINW) void k_trace_fused(SceneBlob blob, T uni
                 } else {
                     store_segment<T, NT>(out, slot, r, h.t, (int32_t)i, sc.nodes[h.node].leaf_id);
                     RayState<T> child;
-                    if (interact<T, F, 1>(sc, r, h, &child) == 0) active = false;
-                    else r = child;
+                    const int nk = interact<T, F, 1>(sc, r, h, &child);
+                    if (nk == 1) r = child;
+                    else {
+                        active = false;
+                        if (nk > 1) used = -(k + 1);  // the tree branches here: not representable in [k][ray] slots
+                    }
                 }
             }
         }
@@ -284,9 +288,14 @@ __global__ void k_gen_finish(const int32_t* tree, const int64_t* head, int64_t n
 
 // ------------------------------------------------------------------------------------------
 // Monitor.record
-__global__ void k_mon_test(ot_monitor mon, SegsT<double> s, int64_t n, int32_t* hit, double* P, double* tt) {
+__global__ void k_mon_test(ot_monitor mon, SegsT<double> s, int64_t n, const int32_t* seg_count, int64_t n_rays, int32_t* hit,
+                           double* P, double* tt) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (seg_count) {  // [k][ray] layout of ot_trace_*: slot i is valid iff k < |seg_count[ray]|
+        const int32_t c = seg_count[i % n_rays];
+        if (i / n_rays >= (c < 0 ? -c : c)) { hit[i] = 0; return; }
+    }
     const double rx = s.ox[i] - mon.origin[0], ry = s.oy[i] - mon.origin[1], rz = s.oz[i] - mon.origin[2];
     const double* M = mon.M;
     const double ox = M[0] * rx + M[3] * ry + M[6] * rz, oy = M[1] * rx + M[4] * ry + M[7] * rz,
@@ -562,8 +571,7 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
                        int32_t* counts, int32_t n_classes) {
     if (!c) return fail(OT_ERR_INVALID, "ctx is NULL");
     if (!c->has_scene) return fail(OT_ERR_NOSCENE, "ot_scene_upload has not been called");
-    if (c->max_children > 1)
-        return fail(OT_ERR_UNSUPPORTED, "scene branches (max_children > 1): use ot_trace_generation_f64");
+    if (c->max_children > 2) return fail(OT_ERR_UNSUPPORTED, "more than two children per hit");
     int rc = check_rays(rays, "rays");
     if (rc) return rc;
     rc = check_segs(out);
@@ -708,12 +716,13 @@ int ot_trace_generation_f64(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
     return timing_end(c);
 }
 
-int ot_monitor_record_f64(ot_ctx* c, const ot_monitor* mon, const ot_segments* segs, int64_t n, int64_t* hit_index, void* Px,
-                          void* Py, void* Pz, void* t, int64_t* n_hits) {
+int ot_monitor_record_f64(ot_ctx* c, const ot_monitor* mon, const ot_segments* segs, int64_t n, const int32_t* seg_count,
+                          int64_t n_rays, int64_t* hit_index, void* Px, void* Py, void* Pz, void* t, int64_t* n_hits) {
     if (!c || !mon || !hit_index || !Px || !Py || !Pz || !t || !n_hits) return fail(OT_ERR_INVALID, "NULL argument");
     int rc = check_segs(segs);
     if (rc) return rc;
     if (n < 0 || n >= (int64_t)1 << 31) return fail(OT_ERR_INVALID, "bad segment count");
+    if (seg_count && (n_rays < 1 || n % n_rays != 0)) return fail(OT_ERR_INVALID, "n_segments must be a multiple of n_rays");
     HIP_TRY(hipSetDevice(c->device));
     if (n == 0) {
         HIP_TRY(hipMemsetAsync(n_hits, 0, sizeof(int64_t), c->stream));
@@ -731,7 +740,7 @@ int ot_monitor_record_f64(ot_ctx* c, const ot_monitor* mon, const ot_segments* s
     hipcub::DeviceScan::ExclusiveSum((void*)nullptr, tmp, hit, off, (int)n, c->stream);
     if (c->scan_tmp.ensure(tmp + 256)) return fail(OT_ERR_HIP, "hipMalloc of scan scratch failed");
     const int block = 256, grid = (int)((n + block - 1) / block);
-    hipLaunchKernelGGL(k_mon_test, dim3(grid), dim3(block), 0, c->stream, *mon, view<double>(segs), n, hit, P, tt);
+    hipLaunchKernelGGL(k_mon_test, dim3(grid), dim3(block), 0, c->stream, *mon, view<double>(segs), n, seg_count, n_rays, hit, P, tt);
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->scan_tmp.p, tmp, hit, off, (int)n, c->stream));
     hipLaunchKernelGGL(k_mon_compact, dim3(grid), dim3(block), 0, c->stream, hit, off, P, tt, n, hit_index, (double*)Px, (double*)Py,
                        (double*)Pz, (double*)t, n_hits);

@@ -424,11 +424,35 @@ __device__ __forceinline__ Hit<T> nearest_hit(const Scene<T>& sc, const RayState
             }
         }
         if (i < skip_until) continue;
-        T ox, oy, oz, dx, dy, dz;
-        to_local(nd, r.ox - nd.org[0], r.oy - nd.org[1], r.oz - nd.org[2], ox, oy, oz);
-        to_local(nd, r.dx, r.dy, r.dz, dx, dy, dz);
+        const T rx = r.ox - nd.org[0], ry = r.oy - nd.org[1], rz = r.oz - nd.org[2];
+        const int sh = nd.shape;
+        const bool planar = sh == OT_SHAPE_CIRCLE || sh == OT_SHAPE_RECT || sh == OT_SHAPE_POLYGON2D || sh == OT_SHAPE_CSG;
         T t, Px, Py, Pz;
-        if (!hit_leaf<T, F>(sc, nd, ox, oy, oz, dx, dy, dz, r.len, t, Px, Py, Pz)) continue;
+        if (!(F & F_CURVED) || planar) {
+            // Planar leaf, evaluated lazily: only the local x row is needed to know t
+            // (t = -o_x/d_x, optical_component.py:171-179).  Exact rejections first: parallel,
+            // behind the ray (sign test == t < 0), t == 0.  Then a CONSERVATIVE far test (1e-9
+            // slack) drops leaves that cannot beat the current best under the strict '<'; it is
+            // skipped for count-limited leaves, whose gate must see every geometric hit.
+            const T lox = nd.M[0] * rx + nd.M[3] * ry + nd.M[6] * rz;
+            const T ldx = nd.M[0] * r.dx + nd.M[3] * r.dy + nd.M[6] * r.dz;
+            const T s = -lox;
+            if (ldx == T(0) || s == T(0) || ((s > T(0)) != (ldx > T(0)))) continue;
+            const bool limited = (F & F_LIMIT) && nd.max_count >= 0;
+            if (!limited && abs_t(s) > best.t * abs_t(ldx) * (T(1) + T(1e-9))) continue;
+            t = s / ldx;
+            if (abs_t(t) < Num<T>::eps_t() || t < T(0) || t > r.len) continue;
+            if (!limited && !(t < best.t)) continue;
+            const T loy = nd.M[1] * rx + nd.M[4] * ry + nd.M[7] * rz, loz = nd.M[2] * rx + nd.M[5] * ry + nd.M[8] * rz;
+            const T ldy = nd.M[1] * r.dx + nd.M[4] * r.dy + nd.M[7] * r.dz, ldz = nd.M[2] * r.dx + nd.M[5] * r.dy + nd.M[8] * r.dz;
+            Px = lox + t * ldx; Py = loy + t * ldy; Pz = loz + t * ldz;
+            if (!planar_boundary<T, F>(sc, nd, Px, Py, Pz)) continue;
+        } else {
+            T ox, oy, oz, dx, dy, dz;
+            to_local(nd, rx, ry, rz, ox, oy, oz);
+            to_local(nd, r.dx, r.dy, r.dz, dx, dy, dz);
+            if (!hit_leaf<T, F>(sc, nd, ox, oy, oz, dx, dy, dz, r.len, t, Px, Py, Pz)) continue;
+        }
         if constexpr (F & F_LIMIT) {
             if (nd.max_count >= 0 && !count_gate<ATOMIC>(counts, (int64_t)nd.slot * n_classes + cls, nd.max_count)) continue;
         }
@@ -479,8 +503,9 @@ __device__ __forceinline__ void surf_normal(const Scene<T>& sc, const DNode<T>& 
     }
 }
 
-// Children of a hit.  MAXK = 1 compiles the non-branching form (at most the first child).
-// Writes lab-frame children into kids[0..nk).
+// Children of a hit.  Writes the first MAXK lab-frame children into kids[] and returns how many
+// the interaction emits (which can exceed MAXK = 1: the fused kernel treats that as "this tree
+// branches" and hands the ray back to the host, see k_trace_fused).
 template <class T, uint32_t F, int MAXK>
 __device__ __forceinline__ int interact(const Scene<T>& sc, const RayState<T>& r, const Hit<T>& h, RayState<T>* kids) {
     const DNode<T>& nd = sc.nodes[h.node];
@@ -511,7 +536,7 @@ __device__ __forceinline__ int interact(const Scene<T>& sc, const RayState<T>& r
             const T jf = nd.inv_focal;
             if (r.has_q) cdiv(q1r, q1i, T(1) - q1r * jf, -q1i * jf, qr, qi);
             emit(dx - h.px * jf, dy - h.py * jf, dz - h.pz * jf, r.I * nd.trans, qr, qi, r.n, r.pl);  // pathlength, n unchanged
-            return nk < MAXK ? nk : MAXK;
+            return nk;
         }
     }
     T nx, ny, nz;
@@ -519,8 +544,8 @@ __device__ __forceinline__ int interact(const Scene<T>& sc, const RayState<T>& r
     const T dn = dx * nx + dy * ny + dz * nz;
     if (!(F & F_REFRACT) || nd.inter == OT_INT_MIRROR) {  // optical_component.py:536-570
         if (nd.refl > T(0)) emit(dx - T(2) * dn * nx, dy - T(2) * dn * ny, dz - T(2) * dn * nz, r.I * nd.refl, q1r, q1i, r.n, pl_hit);
-        if (nd.trans > T(0) && (MAXK > 1 || nk == 0)) emit(dx, dy, dz, r.I * nd.trans, q1r, q1i, r.n, pl_hit);
-        return nk < MAXK ? nk : MAXK;
+        if (nd.trans > T(0)) emit(dx, dy, dz, r.I * nd.trans, q1r, q1i, r.n, pl_hit);
+        return nk;
     }
     if constexpr (F & F_REFRACT) {  // optical_component.py:617-717
         const T wl_m = r.wl * sc.unit;
@@ -554,10 +579,10 @@ __device__ __forceinline__ int interact(const Scene<T>& sc, const RayState<T>& r
         } else {  // total internal reflection: full intensity
             emit(dx - T(2) * ci * nx, dy - T(2) * ci * ny, dz - T(2) * ci * nz, r.I, qrr, qri, r.n, pl_hit);
         }
-        if (MAXK > 1 && nd.refl > T(0))
+        if (nd.refl > T(0))
             emit(dx - T(2) * ci * nx, dy - T(2) * ci * ny, dz - T(2) * ci * nz, r.I * nd.refl, qrr, qri, r.n, pl_hit);
     }
-    return nk < MAXK ? nk : MAXK;
+    return nk;
 }
 
 }  // namespace ot

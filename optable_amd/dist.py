@@ -29,6 +29,8 @@ def gather_final_state(local, dst=0, group=None):
     None elsewhere.  Shard sizes may differ by one ray; blocks are padded to the largest."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    if dist.get_backend(group) == "gloo":  # CPU rehearsal of the collective (tests, 1-GPU boxes)
+        local = local.cpu()
     n_local = torch.tensor([local.shape[1]], dtype=torch.int64, device=local.device)
     sizes = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(sizes, n_local, group=group)

@@ -102,14 +102,22 @@ class Engine:
         return out
 
     # -- monitors -------------------------------------------------------------------------------
-    def monitor_record(self, monitor_struct, segs: SegmentBatch, n_segments):
+    def monitor_record(self, monitor_struct, segs: SegmentBatch, n_segments=None):
+        """Device pass of Monitor.record over a SegmentBatch.  Returns (slot index, P_local [h,3], t)
+        in ascending slot order.  For the [k][ray] layout every slot is scanned and unused ones
+        are skipped on the device."""
         dev = segs.device
+        if segs.count is not None:
+            n_segments, count_ptr, n_rays = segs.capacity // segs.n_rays * segs.n_rays, segs.count.data_ptr(), segs.n_rays
+        else:
+            n_segments = segs.n_valid if n_segments is None else n_segments
+            count_ptr, n_rays = None, 0
         idx = torch.empty(n_segments, dtype=torch.int64, device=dev)
         P = [torch.empty(n_segments, dtype=torch.float64, device=dev) for _ in range(3)]
         t = torch.empty(n_segments, dtype=torch.float64, device=dev)
         nh = torch.zeros(1, dtype=torch.int64, device=dev)
         ss = segs.c_struct()
-        abi.check(self.lib.ot_monitor_record_f64(self._ctx, C.byref(monitor_struct), C.byref(ss), n_segments,
+        abi.check(self.lib.ot_monitor_record_f64(self._ctx, C.byref(monitor_struct), C.byref(ss), n_segments, count_ptr, n_rays,
                                                  idx.data_ptr(), P[0].data_ptr(), P[1].data_ptr(), P[2].data_ptr(),
                                                  t.data_ptr(), nh.data_ptr()), self.lib)
         k = int(nh.item())

@@ -101,9 +101,51 @@ class OpticalTable:
         scene = self.compile()
         eng.upload(scene)
         cap = MAX_TRACE_NUM if max_segments is None else int(max_segments)
-        if scene.max_children <= 1 and max_segments is not None:
-            return eng.trace(batch, cap, counts=counts)
+        if max_segments is not None and scene.max_children <= 2 and not (scene.max_children == 2 and scene.limited):
+            # max_children == 2: speculate that no tree actually branches (e.g. mirror-coated
+            # interfaces only split on total internal reflection); fall back when one does.
+            segs = eng.trace(batch, cap, counts=counts)
+            if scene.max_children <= 1 or not bool((segs.count < 0).any()):
+                return segs
         return eng.trace_tree(batch, cap, counts=counts)
+
+    def record_batch(self, monitor, segs):
+        """Monitor.record over a SegmentBatch without Python objects: returns device tensors
+        (slot index int64 [h], P_local float64 [h,3], t float64 [h]); the hit's intensity, ray index
+        etc. are `segs.<field>[slot]`."""
+        return _engine().monitor_record(monitor_struct(monitor), segs)
+
+    # -- ABCD extraction (optical_table.py:211-297), a caller of the hot path ----------------------
+    def calculate_abcd_matrix(self, mon0, mon1, rays, disp=1e-5, rot=1e-5, debugaxs=None):
+        """Per-ray 2x2 ABCD matrix between two monitors by finite differences: three traces
+        (nominal, displaced along mon0's Y tangent, rotated about mon0's Z tangent at the nominal
+        hit point).  Each trace is one device batch.  The reference's in-place biasing is kept:
+        the angular probe is applied to the already displaced rays (optical_table.py:272-284)."""
+        y_axis, z_axis = mon0.tangent_Y, mon0.tangent_Z
+
+        def simulate(batch):
+            self.rays = []
+            mon0.clear()
+            mon1.clear()
+            self.ray_tracing(batch)
+
+        assert len(rays) > 0, "No rays to trace in ABCD calculation."
+        ids = [r._id for r in rays]
+        assert len(set(ids)) == len(rays), "Redundant ray ids in ABCD calculation."
+        probe = [copy.deepcopy(rays[i]) for i in np.argsort(ids)]
+        simulate(probe)
+        for mon, label in ((mon0, "mon0"), (mon1, "mon1")):
+            assert set(ids) == {r._id for r in mon.get_rays(sort="ID")}, f"Rays at {label} do not match the input rays."
+        pivots = mon0.get_PList(sort="ID")
+        y0, ty0 = mon1.get_yList(sort="ID"), mon1.get_tYList(sort="ID")
+        simulate([r._Translate(y_axis * disp) for r in probe])
+        y1, ty1 = mon1.get_yList(sort="ID"), mon1.get_tYList(sort="ID")
+        simulate([r._RotAround(z_axis, pivots[k], rot) for k, r in enumerate(probe)])
+        y2, ty2 = mon1.get_yList(sort="ID"), mon1.get_tYList(sort="ID")
+        Ms = np.zeros((len(rays), 2, 2))
+        Ms[:, 0, 0], Ms[:, 1, 0] = (y1 - y0) / disp, (ty1 - ty0) / disp
+        Ms[:, 0, 1], Ms[:, 1, 1] = (y2 - y0) / rot, (ty2 - ty0) / rot
+        return Ms
 
     # -- List[Ray] plumbing ------------------------------------------------------------------------
     def _trace_objects(self, rays, cap):
@@ -213,6 +255,15 @@ def _scatter_segments(host_segs, sources, pick, per_ray):
         per_ray[pick[int(tree[s])]].append(seg)
 
 
+def monitor_struct(monitor):
+    """ot_monitor for a Monitor's current pose."""
+    mon = abi.OtMonitor()
+    mon.M[:] = np.asarray(monitor.transform_matrix, dtype=float).ravel().tolist()
+    mon.origin[:] = np.asarray(monitor.origin, dtype=float).tolist()
+    mon.half_width, mon.half_height = monitor.width / 2, monitor.height / 2
+    return mon
+
+
 def record_monitor_hits(monitor, rays):
     """Monitor.record (monitor.py:183-193) through `ot_monitor_record_f64`."""
     if not rays:
@@ -232,10 +283,7 @@ def record_monitor_hits(monitor, rays):
     }
     for name, values in cols.items():
         segs.field(name).copy_(torch.tensor(values, dtype=torch.float64))
-    mon = abi.OtMonitor()
-    mon.M[:] = np.asarray(monitor.transform_matrix, dtype=float).ravel().tolist()
-    mon.origin[:] = np.asarray(monitor.origin, dtype=float).tolist()
-    mon.half_width, mon.half_height = monitor.width / 2, monitor.height / 2
-    idx, P, t = eng.monitor_record(mon, segs, n)
+    segs.n_valid = n
+    idx, P, t = eng.monitor_record(monitor_struct(monitor), segs)
     idx, P, t = idx.cpu().numpy(), P.cpu().numpy(), t.cpu().numpy()
     monitor._extend([(P[k].copy(), rays[int(i)].intensity, float(t[k]), rays[int(i)]) for k, i in enumerate(idx)])

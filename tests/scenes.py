@@ -235,6 +235,19 @@ def g16_misc(ns):
     return dict(components=comps, monitors=[ns.Monitor([30, 0, 0], 20, 20)], rays=rays, limit={"max_trace_num": 200})
 
 
+def abcd_4f(ns):
+    """4f relay of two bi-convex lenses between two monitors (the system calibrate_symmetric_4f builds,
+    optical_table.py:328-340); used for calculate_abcd_matrix parity (optical_table.py:211-297)."""
+    F1, F2 = 19.7, 20.4
+    mk = lambda x: ns.BiConvexLens([x, 0, 0], CT=0.6, R1=20.0, R2=-20.0, diameter=5.08, EFL=20.0)
+    l0, l1 = mk(F1), mk(F1 + 2 * F2).RotZ(np.pi)
+    mon0 = ns.Monitor(origin=[0, 0, 0], width=5, height=5)
+    mon1 = ns.Monitor(origin=[2 * F1 + 2 * F2, 0, 0], width=5, height=5)
+    rays = [ns.Ray([-10, i * 0.3, 0], [1, 0, 0], wavelength=780e-7, w0=61e-4, id=int(i + 3)).Propagate(-10)
+            for i in np.arange(-3, 4)]
+    return dict(components=[l0, l1], monitors=[mon0, mon1], rays=rays, limit=None)
+
+
 SCENES = {
     "g01_gaussian_beam": g01_gaussian_beam, "g02_cfg2": g02_cfg2, "g03_chromatic": g03_chromatic,
     "g04_glass_slab": g04_glass_slab, "g05_cavity": g05_cavity, "g06_mirror_pair": g06_mirror_pair,

@@ -208,3 +208,62 @@ def test_fp32_trace_tracks_fp64():
     np.testing.assert_array_equal(s64["surface"], s32["surface"])
     for f in ("ox", "oy", "oz", "dx", "dy", "dz", "length"):
         np.testing.assert_allclose(s32[f], s64[f], rtol=2e-4, atol=2e-4, err_msg=f)
+
+
+def test_calculate_abcd_matrix_matches_reference():
+    """f2: three device traces + monitor accessors reproduce the reference's ABCD matrices."""
+    import optable_amd as oa
+
+    sc = scenes.abcd_4f(oa)
+    table = oa.OpticalTable()
+    table.add_components(sc["components"])
+    table.add_monitors(sc["monitors"])
+    Ms = table.calculate_abcd_matrix(sc["monitors"][0], sc["monitors"][1], sc["rays"])
+    gold = helpers.golden("g17_abcd")["Ms"]
+    # finite differences with disp = rot = 1e-5 amplify 1e-12 trace noise to ~1e-7
+    np.testing.assert_allclose(Ms, gold, rtol=1e-5, atol=1e-5)
+
+
+def test_record_batch_matches_object_api():
+    """f1: Monitor.record on a SegmentBatch (no Python objects) == the List[Ray] path."""
+    import optable_amd as oa
+
+    table, sc = helpers.build("g07_spherical_lenses")
+    out = table.ray_tracing(sc["rays"])
+    mon = table.monitors[0]
+    from optable_amd.table import _pack
+
+    batch = _pack(sc["rays"], np.arange(len(sc["rays"]), dtype=np.int32), "cuda")
+    segs = table.trace_batch(batch, max_segments=16)
+    slot, P, t = table.record_batch(mon, segs)
+    assert len(slot) == mon.ndata
+    ray_of = segs.ray[slot].cpu().numpy()
+    order = np.argsort(ray_of, kind="stable")
+    np.testing.assert_allclose(P.cpu().numpy()[order], np.array([d[0] for d in mon._data_raw]), rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(t.cpu().numpy()[order], [d[2] for d in mon._data_raw], rtol=1e-12, atol=1e-12)
+
+
+def test_launch_options_do_not_change_results():
+    """NT stores, register cap and grid size are performance knobs only: bit-identical outputs."""
+    import torch
+    import optable_amd as oa
+    from optable_amd.engine import get_engine
+
+    n, K = 100_003, 5
+    table = _table(scenes.cfg2_components(oa))
+    o, d = scenes.cfg2_rays(n, 1)
+    batch = _batch(o, d)
+    eng = get_engine()
+    base = table.trace_batch(batch, max_segments=K)
+    try:
+        for nt, mw, bpc in ((0, 0, 2), (1, 0, 8), (0, 4, 1), (1, 4, 16)):
+            eng.set_option(abi.OPT_NT_STORES, nt)
+            eng.set_option(abi.OPT_MIN_WAVES, mw)
+            eng.set_option(abi.OPT_BLOCKS_PER_CU, bpc)
+            other = table.trace_batch(batch, max_segments=K)
+            for f in abi.SEG_FIELDS + ("ray", "surface"):
+                assert torch.equal(base.field(f), other.field(f)), (f, nt, mw, bpc)
+    finally:
+        eng.set_option(abi.OPT_NT_STORES, 1)
+        eng.set_option(abi.OPT_MIN_WAVES, 4)
+        eng.set_option(abi.OPT_BLOCKS_PER_CU, 0)

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Throughput of the BASELINE configs 2-5 on one GPU (device-resident batches, library hipEvent
+timing).  Not the bench.py line: a survey table for DESIGN.md.  Sizes via env N2..N5."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(1, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+import optable_amd as oa
+from optable_amd.batch import RayBatch, SegmentBatch
+from optable_amd.engine import get_engine
+import scenes
+
+eng = get_engine()
+Q = lambda wl: 1j * np.pi * scenes.W0**2 / wl
+
+
+def run(name, comps, o, d, wl, K, prec, reps=5):
+    table = oa.OpticalTable()
+    table.add_components(comps)
+    scene = table.compile()
+    eng.upload(scene)
+    n = len(o)
+    batch = RayBatch.from_arrays(o, d, wavelength=wl, q=Q(wl), precision=prec)
+    S = scene.n_leaves
+    b = 104 if prec == "f64" else 56
+    fused = scene.max_children <= 1
+    if scene.max_children == 2 and not scene.limited:
+        out = SegmentBatch(n * K, prec, batch.device)
+        eng.trace(batch, K, out=out)
+        fused = not bool((out.count < 0).any())
+    if fused:
+        out = SegmentBatch(n * K, prec, batch.device)
+        eng.trace(batch, K, out=out)
+        eng.timing(True)
+        for _ in range(reps):
+            eng.trace(batch, K, out=out)
+        ms, cnt = eng.timing_read()
+        eng.timing(False)
+        segs = int(out.count.sum().item())
+        t = ms / cnt / 1e3
+        mode = "fused"
+    else:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = eng.trace_tree(batch, K)
+        torch.cuda.synchronize()
+        t = time.perf_counter() - t0
+        segs = out.n_valid
+        mode = "generations"
+    gbs = (n * b + segs * b) / t / 1e9
+    print(f"{name:28s} {prec} {mode:11s} n={n:9d} S={S:3d} K={K:2d} segs/ray={segs / n:5.2f} time={t * 1e3:9.3f} ms "
+          f"{segs / t:10.3e} seg/s {segs * S / t:10.3e} isect/s  {gbs:7.1f} GB/s ({gbs / 80:4.1f}% of 8 TB/s)", flush=True)
+    del out, batch
+    torch.cuda.empty_cache()
+
+
+n2 = int(os.environ.get("N2", 1_000_000))
+n3 = int(os.environ.get("N3", 2_000_000))
+n4 = int(os.environ.get("N4", 100_000))
+n5 = int(os.environ.get("N5", 200_000))
+for prec in ("f64", "f32"):
+    o, d = scenes.cfg2_rays(n2, 0)
+    run("cfg2 lens+mirrorpair", scenes.cfg2_components(oa), o, d, scenes.WL, 5, prec)
+    o, d = scenes.cfg3_rays(n3, 2)
+    run("cfg3 32 mixed components", scenes.cfg3_components(oa), o, d, scenes.WL, 20, prec)
+    nwl = 64
+    rng = np.random.default_rng(4)
+    jit = rng.uniform(-0.3, 0.3, (n4, 2))
+    ob = np.stack([np.full(n4, -3.0), 2 + jit[:, 0], jit[:, 1]], 1)
+    db = np.tile([np.cos(np.pi / 6), -np.sin(np.pi / 6), 0.0], (n4, 1))
+    wl = np.repeat(np.linspace(400e-7, 1100e-7, nwl), n4)
+    slab = [oa.GlassSlab([0, 0, 0], width=2, height=2, thickness=0.5, n1=oa.Vacuum(), n2=oa.Glass_NBK7(), reflectivity=0)]
+    run("cfg4 NBK7 slab x64 wl", slab, np.tile(ob, (nwl, 1)), np.tile(db, (nwl, 1)), wl, 8, prec)
+    if True:
+        o, d = scenes.cfg5_rays(n5, 3)
+        run("cfg5 asphere+MMA16x16", scenes.cfg5_components(oa), o, d, scenes.WL, 50, prec)

@@ -108,6 +108,17 @@ def run(name):
     print(f"{name}: {len(rays)} rays, {len(leaves)} leaves, {len(groups)} groups -> {len(segs)} segments")
 
 
+def abcd_fixture():
+    """g17: OpticalTable.calculate_abcd_matrix on a 4f relay (a caller of the hot path)."""
+    sc = scenes.abcd_4f(ref)
+    table = ref.OpticalTable()
+    table.add_components(sc["components"])
+    table.add_monitors(sc["monitors"])
+    Ms = table.calculate_abcd_matrix(sc["monitors"][0], sc["monitors"][1], sc["rays"])
+    np.savez_compressed(os.path.join(OUT, "g17_abcd.npz"), Ms=Ms)
+    print("g17_abcd:", Ms.shape, Ms[3].round(6).tolist())
+
+
 def slab_vectors():
     """G14: solve_ray_bboxes_intersections unit vectors incl. axis-parallel and flat boxes."""
     rng = np.random.default_rng(14)
@@ -132,9 +143,11 @@ def slab_vectors():
 if __name__ == "__main__":
     names = sys.argv[1:] or list(scenes.SCENES)
     for nm in names:
-        if nm == "g14_slab":
+        if nm in ("g14_slab", "g17_abcd"):
             continue
         np.random.seed(12345)
         run(nm)
     if not sys.argv[1:] or "g14_slab" in sys.argv[1:]:
         slab_vectors()
+    if not sys.argv[1:] or "g17_abcd" in sys.argv[1:]:
+        abcd_fixture()
