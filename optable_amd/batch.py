@@ -52,8 +52,8 @@ class RayBatch:
         dt = _REAL[precision]
 
         def put(name, values):
-            arr = np.broadcast_to(np.asarray(values, dtype=np.float64), (nrays,))
-            b.field(name).copy_(torch.from_numpy(np.ascontiguousarray(arr)).to(dt))
+            arr = np.array(np.broadcast_to(np.asarray(values, dtype=np.float64), (nrays,)))  # writable copy
+            b.field(name).copy_(torch.from_numpy(arr).to(dt))
 
         for k, ax in enumerate("xyz"):
             put("o" + ax, origin[:, k])

@@ -142,7 +142,8 @@ __global__ __launch_bounds__(256, MINW) void k_trace_fused(SceneBlob blob, T uni
         }
         for (int32_t k = 0; k < K; ++k) {  // wave-uniform trip count: lanes never leave the loop alone
             if (!__any(active)) break;
-            const Hit<T> h = nearest_hit<T, F, false>(sc, r, active, counts, n_classes, cls);
+            const GateCtx gate = {counts, n_classes, cls, nullptr, nullptr, 0, 0};
+            const Hit<T> h = nearest_hit<T, F, GATE_PLAIN>(sc, r, active, gate);
             if (active) {
                 const int64_t slot = (int64_t)k * n + i;
                 used = k + 1;
@@ -198,11 +199,12 @@ struct ChildStore {  // scratch for up to 2 children per ray, SoA with stride 2n
     int32_t* flags;
 };
 
-template <bool SCENE_IN_LDS>
+// PROBE = true: the pre-pass that records geometric hits of count-limited leaves (no outputs).
+template <bool SCENE_IN_LDS, bool PROBE>
 __global__ __launch_bounds__(256) void k_gen_trace(SceneBlob blob, double unit, RaysT<double> in, const int32_t* tree, int64_t n,
                                                    const int32_t* proc, const int64_t* seg_off, const int64_t* cursor,
                                                    SegsT<double> out, int64_t out_capacity, ChildStore kids, int32_t* nkids,
-                                                   int32_t* counts, int32_t n_classes) {
+                                                   int32_t* counts, int32_t n_classes, const int32_t* rank, int32_t* probe) {
     extern __shared__ __align__(16) uint32_t lds[];
     const uint32_t* base = blob.words;
     if (SCENE_IN_LDS) {
@@ -224,7 +226,12 @@ __global__ __launch_bounds__(256) void k_gen_trace(SceneBlob blob, double unit, 
             cls = in.id[i];
         }
         const bool dead = active && (fl & OT_RAY_DEAD);
-        const Hit<double> h = nearest_hit<double, F_ALL, true>(sc, r, active && !dead, counts, n_classes, cls);
+        const GateCtx gate = {counts, n_classes, cls, rank, probe, n, i};
+        if (PROBE) {
+            (void)nearest_hit<double, F_ALL, GATE_PROBE>(sc, r, active && !dead, gate);
+            continue;
+        }
+        const Hit<double> h = nearest_hit<double, F_ALL, GATE_TABLE>(sc, r, active && !dead, gate);
         if (active) {
             const int64_t slot = cur0 + seg_off[i];
             int32_t nk = 0;
@@ -248,6 +255,26 @@ __global__ __launch_bounds__(256) void k_gen_trace(SceneBlob blob, double unit, 
             nkids[i] = nk;
         } else if (i < n) {
             nkids[i] = 0;
+        }
+    }
+}
+
+// rank[slot][i] = how many earlier rays of i's tree (this generation) hit limited leaf `slot`
+__global__ void k_gen_rank(const int64_t* head, int64_t n, int32_t n_slots, const int32_t* ex, int32_t* rank) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int s = 0; s < n_slots; ++s) rank[(int64_t)s * n + i] = ex[(int64_t)s * n + i] - ex[(int64_t)s * n + head[i]];
+}
+// after the trace: each tree's last ray of the generation folds the generation's hits into the table
+__global__ void k_gen_counts(const int32_t* tree, const int32_t* ids, int64_t n, int32_t n_slots, const int32_t* rank,
+                             const int32_t* probe, const int32_t* slot_max, int32_t* counts, int32_t n_classes) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (i == n - 1 || tree[i + 1] != tree[i]) {
+        for (int s = 0; s < n_slots; ++s) {
+            int32_t* c = counts + (int64_t)s * n_classes + ids[i];
+            const int32_t total = *c + rank[(int64_t)s * n + i] + probe[(int64_t)s * n + i];
+            *c = total < slot_max[s] ? total : (*c > slot_max[s] ? *c : slot_max[s]);
         }
     }
 }
@@ -358,6 +385,7 @@ struct ot_ctx {
     int32_t n_nodes = 0, n_mats = 0, n_aux = 0, n_slots = 0, max_children = 0;
     double unit = 1e-2;
     uint32_t features = 0;
+    int32_t* slot_max = nullptr;  // device [n_slots]: max_interact_count per count slot
     // timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -510,6 +538,7 @@ int ot_ctx_destroy(ot_ctx* c) {
     for (auto& e : c->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->blob64) (void)hipFree(c->blob64);
     if (c->blob32) (void)hipFree(c->blob32);
+    if (c->slot_max) (void)hipFree(c->slot_max);
     if (c->gen.p) (void)hipFree(c->gen.p);
     if (c->scan_tmp.p) (void)hipFree(c->scan_tmp.p);
     if (c->mon.p) (void)hipFree(c->mon.p);
@@ -543,6 +572,14 @@ int ot_scene_upload(ot_ctx* c, const ot_scene_desc* s) {
     c->n_nodes = s->n_nodes; c->n_mats = s->n_materials; c->n_aux = s->n_aux;
     c->n_slots = s->n_count_slots; c->max_children = s->max_children; c->unit = s->unit;
     c->features = scene_features(s);
+    if (c->slot_max) { (void)hipFree(c->slot_max); c->slot_max = nullptr; }
+    if (s->n_count_slots > 0) {
+        std::vector<int32_t> smax(s->n_count_slots, 0);
+        for (int i = 0; i < s->n_nodes; ++i)
+            if (s->nodes[i].kind == OT_NODE_LEAF && s->nodes[i].max_interact_count >= 0) smax[s->nodes[i].count_slot] = s->nodes[i].max_interact_count;
+        HIP_TRY(hipMalloc((void**)&c->slot_max, sizeof(int32_t) * smax.size()));
+        HIP_TRY(hipMemcpy(c->slot_max, smax.data(), sizeof(int32_t) * smax.size(), hipMemcpyHostToDevice));
+    }
     c->has_scene = true;
     return 0;
 }
@@ -661,7 +698,9 @@ int ot_trace_generation_f64(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
     // scratch carve-up
     const size_t sz_i64 = align_up(sizeof(int64_t) * n), sz_i32 = align_up(sizeof(int32_t) * n);
     const size_t sz_kid = align_up(sizeof(double) * 2 * n), sz_kfl = align_up(sizeof(int32_t) * 2 * n);
-    const size_t total = 4 * sz_i64 + 2 * sz_i32 + 12 * sz_kid + sz_kfl;
+    const int ns = c->n_slots;
+    const size_t sz_slot = align_up(sizeof(int32_t) * n * (ns > 0 ? ns : 1));
+    const size_t total = 4 * sz_i64 + 2 * sz_i32 + 12 * sz_kid + sz_kfl + 3 * sz_slot;
     if (c->gen.ensure(total)) return fail(OT_ERR_HIP, "hipMalloc of generation scratch failed");
     uint8_t* p = (uint8_t*)c->gen.p;
     int64_t* head = (int64_t*)p; p += sz_i64;
@@ -672,14 +711,21 @@ int ot_trace_generation_f64(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
     int32_t* nkids = (int32_t*)p; p += sz_i32;
     ChildStore kids;
     for (int k = 0; k < 12; ++k) { kids.f[k] = (double*)p; p += sz_kid; }
-    kids.flags = (int32_t*)p;
+    kids.flags = (int32_t*)p; p += sz_kfl;
+    int32_t* probe = (int32_t*)p; p += sz_slot;
+    int32_t* probe_ex = (int32_t*)p; p += sz_slot;
+    int32_t* rank = (int32_t*)p;
     // scan temp
     size_t tmp_a = 0, tmp_b = 0, tmp_c = 0;
     hipcub::DeviceScan::InclusiveScan((void*)nullptr, tmp_a, head, head_scan, hipcub::Max(), (int)n, c->stream);
     hipcub::DeviceScan::ExclusiveSum((void*)nullptr, tmp_b, proc, seg_off, (int)n, c->stream);
     hipcub::DeviceScan::ExclusiveSum((void*)nullptr, tmp_c, nkids, child_off, (int)n, c->stream);
-    size_t tmp = tmp_a > tmp_b ? tmp_a : tmp_b;
+    size_t tmp = tmp_a > tmp_b ? tmp_a : tmp_b, tmp_d = 0;
     tmp = tmp > tmp_c ? tmp : tmp_c;
+    if (ns > 0) {
+        hipcub::DeviceScan::ExclusiveSum((void*)nullptr, tmp_d, probe, probe_ex, (int)n, c->stream);
+        tmp = tmp > tmp_d ? tmp : tmp_d;
+    }
     if (c->scan_tmp.ensure(tmp + 256)) return fail(OT_ERR_HIP, "hipMalloc of scan scratch failed");
     const int block = 256;
     const int g1 = (int)((n + block - 1) / block);
@@ -697,16 +743,28 @@ int ot_trace_generation_f64(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
     const bool in_lds = c->bytes64 <= 150 * 1024;
     const int64_t cap = (int64_t)c->n_cus * 4;
     const int grid = (int)(g1 < cap ? g1 : cap);
-    if (in_lds) {
-        auto kern = k_gen_trace<true>;
-        if (c->bytes64 > 48 * 1024)
-            HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->bytes64));
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), c->bytes64, c->stream, blob, c->unit, view<double>(rays), tree, n, proc,
-                           seg_off, seg_cursor, view<double>(out), out_capacity, kids, nkids, counts, n_classes);
-    } else {
-        hipLaunchKernelGGL(k_gen_trace<false>, dim3(grid), dim3(block), 0, c->stream, blob, c->unit, view<double>(rays), tree, n,
-                           proc, seg_off, seg_cursor, view<double>(out), out_capacity, kids, nkids, counts, n_classes);
+    const size_t lds_bytes = in_lds ? c->bytes64 : 0;
+    auto k_probe = in_lds ? k_gen_trace<true, true> : k_gen_trace<false, true>;
+    auto k_main = in_lds ? k_gen_trace<true, false> : k_gen_trace<false, false>;
+    if (lds_bytes > 48 * 1024) {
+        HIP_TRY(hipFuncSetAttribute((const void*)k_probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_main, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     }
+    if (ns > 0) {  // FIFO-exact interact-count gating: probe -> per-slot scan -> rank within the tree
+        HIP_TRY(hipMemsetAsync(probe, 0, sizeof(int32_t) * n * ns, c->stream));
+        hipLaunchKernelGGL(k_probe, dim3(grid), dim3(block), lds_bytes, c->stream, blob, c->unit, view<double>(rays), tree, n, proc,
+                           seg_off, seg_cursor, view<double>(out), out_capacity, kids, nkids, counts, n_classes,
+                           (const int32_t*)nullptr, probe);
+        for (int s = 0; s < ns; ++s)
+            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->scan_tmp.p, tmp, probe + (int64_t)s * n, probe_ex + (int64_t)s * n, (int)n, c->stream));
+        hipLaunchKernelGGL(k_gen_rank, dim3(g1), dim3(block), 0, c->stream, head_scan, n, ns, probe_ex, rank);
+    }
+    hipLaunchKernelGGL(k_main, dim3(grid), dim3(block), lds_bytes, c->stream, blob, c->unit, view<double>(rays), tree, n, proc, seg_off,
+                       seg_cursor, view<double>(out), out_capacity, kids, nkids, counts, n_classes, (const int32_t*)rank,
+                       (int32_t*)nullptr);
+    if (ns > 0)
+        hipLaunchKernelGGL(k_gen_counts, dim3(g1), dim3(block), 0, c->stream, tree, rays->id, n, ns, rank, probe, c->slot_max, counts,
+                           n_classes);
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->scan_tmp.p, tmp, nkids, child_off, (int)n, c->stream));
     hipLaunchKernelGGL(k_gen_compact, dim3(g1), dim3(block), 0, c->stream, tree, rays->id, n, kids, nkids, child_off,
                        view_out<double>(next), next_tree, next_capacity);

@@ -382,26 +382,35 @@ __device__ __forceinline__ int wave_min_i32(int v) {
     return v;
 }
 
-// Interact-count gate (optical_component.py:140-149, 359-362).  ATOMIC: several rays of one
-// launch may share a class (branching generations); plain otherwise.
-template <bool ATOMIC> __device__ __forceinline__ bool count_gate(int32_t* counts, int64_t idx, int32_t max_count) {
-    if (ATOMIC) {
-        const int32_t old = atomicAdd(&counts[idx], 1);
-        if (old < max_count) return true;
-        atomicSub(&counts[idx], 1);
-        return false;
-    }
-    const int32_t c = counts[idx];
-    if (c < max_count) { counts[idx] = c + 1; return true; }
+// Interact-count gate (optical_component.py:140-149, 359-362): a limited leaf that is
+// geometrically hit consumes one count while count < max, otherwise it is transparent.
+//   GATE_PLAIN  one ray per class in the launch (fused kernel): read-modify-write.
+//   GATE_PROBE  pre-pass of a branching generation: only record which limited leaves the ray
+//               hits geometrically (probe[slot*stride + idx] = 1); nothing else is evaluated.
+//   GATE_TABLE  branching generation proper: pass iff counts + (number of EARLIER rays of this
+//               tree in this generation that hit the leaf) < max, i.e. the reference's FIFO order;
+//               the table is updated once per tree afterwards (k_gen_finish).
+enum { GATE_PLAIN = 0, GATE_PROBE = 1, GATE_TABLE = 2 };
+struct GateCtx {
+    int32_t* counts;      // [n_slots][n_classes]
+    int32_t n_classes, cls;
+    const int32_t* rank;  // GATE_TABLE: [n_slots][stride]
+    int32_t* probe;       // GATE_PROBE: [n_slots][stride]
+    int64_t stride, idx;
+};
+template <int GATE> __device__ __forceinline__ bool count_gate(const GateCtx& g, int32_t slot, int32_t max_count) {
+    int32_t* c = g.counts + (int64_t)slot * g.n_classes + g.cls;
+    if (GATE == GATE_TABLE) return *c + g.rank[(int64_t)slot * g.stride + g.idx] < max_count;
+    const int32_t v = *c;
+    if (v < max_count) { *c = v + 1; return true; }
     return false;
 }
 
 // Nearest hit over the whole scene for one ray (all lanes of the wave walk the node list with
 // the same index; a lane that pruned a group idles until the list leaves that group, and when
 // every lane of the wave pruned it the wave jumps ahead to the smallest skip target).
-template <class T, uint32_t F, bool ATOMIC>
-__device__ __forceinline__ Hit<T> nearest_hit(const Scene<T>& sc, const RayState<T>& r, bool active, int32_t* counts,
-                                              int32_t n_classes, int32_t cls) {
+template <class T, uint32_t F, int GATE>
+__device__ __forceinline__ Hit<T> nearest_hit(const Scene<T>& sc, const RayState<T>& r, bool active, const GateCtx& gate) {
     Hit<T> best;
     best.t = Num<T>::inf();
     best.node = -1;
@@ -424,6 +433,7 @@ __device__ __forceinline__ Hit<T> nearest_hit(const Scene<T>& sc, const RayState
             }
         }
         if (i < skip_until) continue;
+        if (GATE == GATE_PROBE && nd.max_count < 0) continue;  // the probe pass only looks at limited leaves
         const T rx = r.ox - nd.org[0], ry = r.oy - nd.org[1], rz = r.oz - nd.org[2];
         const int sh = nd.shape;
         const bool planar = sh == OT_SHAPE_CIRCLE || sh == OT_SHAPE_RECT || sh == OT_SHAPE_POLYGON2D || sh == OT_SHAPE_CSG;
@@ -454,7 +464,11 @@ __device__ __forceinline__ Hit<T> nearest_hit(const Scene<T>& sc, const RayState
             if (!hit_leaf<T, F>(sc, nd, ox, oy, oz, dx, dy, dz, r.len, t, Px, Py, Pz)) continue;
         }
         if constexpr (F & F_LIMIT) {
-            if (nd.max_count >= 0 && !count_gate<ATOMIC>(counts, (int64_t)nd.slot * n_classes + cls, nd.max_count)) continue;
+            if (GATE == GATE_PROBE) {
+                gate.probe[(int64_t)nd.slot * gate.stride + gate.idx] = 1;
+                continue;
+            }
+            if (nd.max_count >= 0 && !count_gate<GATE>(gate, nd.slot, nd.max_count)) continue;
         }
         if (t < best.t) {
             best.t = t; best.node = i; best.px = Px; best.py = Py; best.pz = Pz;

@@ -235,6 +235,19 @@ def g16_misc(ns):
     return dict(components=comps, monitors=[ns.Monitor([30, 0, 0], 20, 20)], rays=rays, limit={"max_trace_num": 200})
 
 
+def g18_fifo_gate(ns):
+    """Two siblings of one tree reach a max_interact_count=1 mirror in the SAME generation: the
+    beam-splitter's reflected branch (queued first, optical_component.py:546-570) must win the count
+    and the transmitted branch must find the mirror transparent (optical_component.py:140-149)."""
+    a = -np.pi / 4
+    comps = [ns.BeamSplitter([2, 0, 0], width=2, height=2, eta=0.5).RotZ(a),
+             ns.Mirror([2, 3, 0], radius=1).RotZ(a), ns.Mirror([5, 0, 0], radius=1).RotZ(a),
+             ns.Mirror([5, 3, 0], radius=1, max_interact_count=1).RotZ(5 * np.pi / 4),
+             ns.Mirror([5, 6, 0], radius=1).RotZ(-np.pi / 2), ns.Mirror([9, 3, 0], radius=1).RotZ(np.pi)]
+    rays = [ns.Ray([0, 0, 0.05 * k], [1, 0, 0], wavelength=WL, w0=W0, id=k) for k in range(3)]
+    return dict(components=comps, monitors=[], rays=rays, limit={"max_trace_num": 30})
+
+
 def abcd_4f(ns):
     """4f relay of two bi-convex lenses between two monitors (the system calibrate_symmetric_4f builds,
     optical_table.py:328-340); used for calculate_abcd_matrix parity (optical_table.py:211-297)."""
@@ -253,5 +266,5 @@ SCENES = {
     "g04_glass_slab": g04_glass_slab, "g05_cavity": g05_cavity, "g06_mirror_pair": g06_mirror_pair,
     "g07_spherical_lenses": g07_spherical_lenses, "g08_asphere": g08_asphere, "g09_cfg5": g09_cfg5,
     "g10_cfg3": g10_cfg3, "g11_prism_refl": g11_prism_refl, "g12_dove": g12_dove,
-    "g13_count_shadow": g13_count_shadow, "g15_cfg4": g15_cfg4, "g16_misc": g16_misc,
+    "g13_count_shadow": g13_count_shadow, "g15_cfg4": g15_cfg4, "g16_misc": g16_misc, "g18_fifo_gate": g18_fifo_gate,
 }
