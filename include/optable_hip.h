@@ -84,7 +84,9 @@ enum ot_roc_kind {
 };
 
 enum ot_node_flags {
-    OT_NODE_CHECK_AABB = 1  /* set for groups and for children of groups (component_group.py:98-107) */
+    OT_NODE_CHECK_AABB = 1, /* set for groups and for children of groups (component_group.py:98-107) */
+    OT_NODE_GRID = 2        /* group: aux -> 2-D grid over the children's AABBs (acceleration only: the
+                               children found through it still pass their own AABB test)             */
 };
 
 typedef struct ot_node {
@@ -244,7 +246,9 @@ int ot_set_launch(ot_ctx* ctx, int32_t block_threads, int32_t rays_per_lane);
 enum ot_option {
     OT_OPT_NT_STORES = 1,      /* segment records written with non-temporal stores (0/1)        */
     OT_OPT_MIN_WAVES = 2,      /* 0: compiler's choice; 4: cap registers for 4 waves per SIMD  */
-    OT_OPT_BLOCKS_PER_CU = 3   /* persistent-grid size in 256-thread blocks per CU (0 = auto)  */
+    OT_OPT_BLOCKS_PER_CU = 3,  /* persistent-grid size in 256-thread blocks per CU (0 = auto)  */
+    OT_OPT_KERNEL = 4,         /* 0 auto; 1 lane-per-ray kernel; 2 chunk-per-workgroup kernel   */
+    OT_OPT_LDS_LIMIT_KB = 5    /* scene images above this many KB are read from global memory   */
 };
 int ot_set_option(ot_ctx* ctx, int32_t option, int32_t value);
 

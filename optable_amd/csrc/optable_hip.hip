@@ -166,6 +166,117 @@ __global__ __launch_bounds__(256, MINW) void k_trace_fused(SceneBlob blob, T uni
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_trace_blocked: the same trace for HEAVY scenes (many nodes, long and uneven paths).
+// One lane per ray wastes lanes twice there: rays of a wave end after different numbers of
+// segments, and the segment loop runs as long as its longest ray.  Here a workgroup owns a chunk
+// of CHUNK consecutive rays and advances them generation by generation: after every segment the
+// surviving rays are compacted (ORDER-PRESERVING, ballot + 4-wave prefix in LDS) into a dense
+// index list, so every pass runs with full waves until the chunk drains.  The state of a live
+// ray travels through a per-ray scratch record in global memory (L2/MALL resident: a chunk is
+// ~100 KB); segment records go to the same [k][ray] slots as k_trace_fused, so the two kernels
+// are interchangeable bit for bit.
+template <class T> struct StateT {
+    T* f[11];  // ox oy oz dx dy dz qr qi I n pl  (wavelength, id, flags stay in the input arrays)
+};
+
+template <class T, uint32_t F, bool SCENE_IN_LDS, bool NT, int CHUNK>
+__global__ __launch_bounds__(256) void k_trace_blocked(SceneBlob blob, T unit, RaysT<T> in, int64_t n, int32_t K, SegsT<T> out,
+                                                       int32_t* __restrict__ seg_count, int32_t* counts, int32_t n_classes,
+                                                       StateT<T> st) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    const uint32_t* base = blob.words;
+    uint32_t* tail = lds;
+    if (SCENE_IN_LDS) {
+        for (int w = threadIdx.x; w < blob.n_words; w += blockDim.x) lds[w] = blob.words[w];
+        base = lds;
+        tail = lds + ((blob.n_words + 3) & ~3);
+    }
+    int32_t* cur = reinterpret_cast<int32_t*>(tail);
+    int32_t* nxt = cur + CHUNK;
+    int32_t* wave_cnt = nxt + CHUNK;  // [4]
+    __syncthreads();
+    const Scene<T> sc = bind_scene<T>(base, blob, unit);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n_chunks = (n + CHUNK - 1) / CHUNK;
+    for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+        const int64_t first = ch * CHUNK;
+        int alive = (int)((n - first) < CHUNK ? (n - first) : CHUNK);
+        for (int32_t k = 0; k < K && alive > 0; ++k) {  // block-uniform
+            int next_alive = 0;
+            for (int p0 = 0; p0 < alive; p0 += 256) {
+                const int p = p0 + threadIdx.x;
+                bool active = p < alive;
+                const int j = active ? (k == 0 ? p : cur[p]) : 0;
+                const int64_t i = first + j;
+                RayState<T> r = {};
+                int32_t cls = 0;
+                bool survive = false;
+                if (active) {
+                    const int32_t fl = in.flags[i];
+                    cls = in.id[i];
+                    if (k == 0) {
+                        r = load_ray(in, i, fl);
+                        if (fl & OT_RAY_DEAD) {
+                            store_segment<T, NT>(out, i, r, r.len, (int32_t)i, -2);
+                            seg_count[i] = 1;
+                            active = false;
+                        }
+                    } else {
+                        r.ox = st.f[0][i]; r.oy = st.f[1][i]; r.oz = st.f[2][i];
+                        r.dx = st.f[3][i]; r.dy = st.f[4][i]; r.dz = st.f[5][i];
+                        r.qr = st.f[6][i]; r.qi = st.f[7][i]; r.I = st.f[8][i]; r.n = st.f[9][i]; r.pl = st.f[10][i];
+                        r.wl = in.wl[i];
+                        r.len = Num<T>::inf();
+                        r.has_q = (fl & OT_RAY_HAS_Q) != 0;
+                    }
+                }
+                const GateCtx gate = {counts, n_classes, cls, nullptr, nullptr, 0, 0};
+                const Hit<T> h = nearest_hit<T, F, GATE_PLAIN>(sc, r, active, gate);
+                if (active) {
+                    const int64_t slot = (int64_t)k * n + i;
+                    int32_t used = k + 1;
+                    if (h.node < 0) {
+                        store_segment<T, NT>(out, slot, r, r.len, (int32_t)i, -1);
+                    } else {
+                        store_segment<T, NT>(out, slot, r, h.t, (int32_t)i, sc.nodes[h.node].leaf_id);
+                        RayState<T> child;
+                        const int nk = interact<T, F, 1>(sc, r, h, &child);
+                        if (nk == 1) {
+                            survive = k + 1 < K;
+                            if (survive) {
+                                st.f[0][i] = child.ox; st.f[1][i] = child.oy; st.f[2][i] = child.oz;
+                                st.f[3][i] = child.dx; st.f[4][i] = child.dy; st.f[5][i] = child.dz;
+                                st.f[6][i] = child.qr; st.f[7][i] = child.qi; st.f[8][i] = child.I;
+                                st.f[9][i] = child.n; st.f[10][i] = child.pl;
+                            }
+                        } else if (nk > 1) {
+                            used = -(k + 1);
+                        }
+                    }
+                    if (!survive) seg_count[i] = used;
+                }
+                // order-preserving append of the survivors of this pass
+                const unsigned long long mask = __ballot(survive);
+                if (lane == 0) wave_cnt[wave] = __popcll(mask);
+                __syncthreads();
+                int before = 0, total = 0;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const int c = wave_cnt[w];
+                    if (w < wave) before += c;
+                    total += c;
+                }
+                if (survive) nxt[next_alive + before + __popcll(mask & ((1ull << lane) - 1ull))] = j;
+                next_alive += total;
+                __syncthreads();
+            }
+            int32_t* t = cur; cur = nxt; nxt = t;
+            alive = next_alive;
+        }
+    }
+}
+
 // k_stream_ceiling: the fused kernel's memory traffic with no tracing — reads one ray record,
 // writes K segment records per ray through the same SoA streams.  What this access pattern can
 // reach on the device; reported next to the trace kernel (bench.py).
@@ -394,6 +505,11 @@ struct ot_ctx {
     int64_t launches = 0;
     // knobs
     int32_t block_threads = 256, rays_per_lane = 1;
+    // scene images above this stay in global memory (L2): a 100+ KB LDS image leaves one block per CU,
+    // and on cfg 5 the lost occupancy cost 1.5x (tools/bench_configs.py)
+    int32_t opt_lds_limit_kb = 64;
+    int32_t opt_kernel = 0;  // 0 auto, 1 fused (lane per ray), 2 blocked (chunk per workgroup)
+    Scratch blocked;
     int32_t opt_nt = 1, opt_minw = 4, opt_blocks_per_cu = 0;  // defaults from tools/tune.py on MI355X
     Scratch gen, scan_tmp, mon;
 };
@@ -471,6 +587,7 @@ static uint32_t scene_features(const ot_scene_desc* s) {
     for (int i = 0; i < s->n_nodes; ++i) {
         const ot_node& nd = s->nodes[i];
         if (nd.flags & OT_NODE_CHECK_AABB) f |= F_AABB;
+        if (nd.flags & OT_NODE_GRID) f |= F_GRID;
         if (nd.kind != OT_NODE_LEAF) continue;
         if (nd.shape == OT_SHAPE_POLYGON2D || nd.shape == OT_SHAPE_CSG) f |= F_POLY;
         if (nd.shape != OT_SHAPE_CIRCLE && nd.shape != OT_SHAPE_RECT && nd.shape != OT_SHAPE_POLYGON2D &&
@@ -503,6 +620,24 @@ static int validate_scene(const ot_scene_desc* s) {
                 return fail(OT_ERR_INVALID, "count_slot out of range");
         } else if (nd.kind != OT_NODE_GROUP) {
             return fail(OT_ERR_INVALID, "unknown node kind");
+        } else if (nd.flags & OT_NODE_GRID) {  // grid record: [a0 a1 g0 g1 org0 org1 inv0 inv1 margin | start[] | items]
+            if (nd.aux < 0 || nd.aux + 9 > s->n_aux) return fail(OT_ERR_INVALID, "grid record out of range");
+            const double* g = s->aux + nd.aux;
+            const int a0 = (int)g[0], a1 = (int)g[1], g0 = (int)g[2], g1 = (int)g[3];
+            if (a0 < 0 || a0 > 2 || a1 < 0 || a1 > 2 || a0 == a1 || g0 < 1 || g1 < 1 || (int64_t)g0 * g1 > 1 << 20)
+                return fail(OT_ERR_INVALID, "bad grid header");
+            const int64_t cells = (int64_t)g0 * g1;
+            if (nd.aux + 9 + cells + 1 > s->n_aux) return fail(OT_ERR_INVALID, "grid starts out of range");
+            const double* start = g + 9;
+            const int64_t n_items = (int64_t)start[cells];
+            if (start[0] != 0 || nd.aux + 9 + cells + 1 + n_items > s->n_aux) return fail(OT_ERR_INVALID, "grid items out of range");
+            for (int64_t k = 0; k < cells; ++k)
+                if (start[k + 1] < start[k]) return fail(OT_ERR_INVALID, "grid starts not monotone");
+            const double* items = start + cells + 1;
+            for (int64_t k = 0; k < n_items; ++k) {
+                const int ci = (int)items[k];
+                if (ci <= i || ci >= nd.end || s->nodes[ci].kind != OT_NODE_LEAF) return fail(OT_ERR_INVALID, "grid item is not a leaf child");
+            }
         }
     }
     return 0;
@@ -542,6 +677,7 @@ int ot_ctx_destroy(ot_ctx* c) {
     if (c->gen.p) (void)hipFree(c->gen.p);
     if (c->scan_tmp.p) (void)hipFree(c->scan_tmp.p);
     if (c->mon.p) (void)hipFree(c->mon.p);
+    if (c->blocked.p) (void)hipFree(c->blocked.p);
     if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
@@ -603,6 +739,8 @@ static int check_segs(const ot_segments* s) {
     return 0;
 }
 
+static size_t align_up(size_t x) { return (x + 255) / 256 * 256; }
+
 template <class T>
 static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, const ot_segments* out, int32_t* seg_count,
                        int32_t* counts, int32_t n_classes) {
@@ -626,7 +764,7 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
     blob.n_nodes = c->n_nodes;
     blob.n_mats = c->n_mats;
     const int block = 256;
-    const bool in_lds = bytes <= 150 * 1024;
+    const bool in_lds = bytes <= (size_t)c->opt_lds_limit_kb * 1024;
     const int64_t blocks_needed = (n + block - 1) / block;
     // Grid: small scenes (staging the blob costs nothing) get ~one ray per lane, 16 blocks per CU;
     // scenes with a large LDS image run persistent, as many blocks per CU as the image allows.
@@ -638,11 +776,43 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
     if (c->opt_blocks_per_cu > 0) per_cu = c->opt_blocks_per_cu;
     const int64_t cap = (int64_t)c->n_cus * per_cu;
     const int grid = (int)(blocks_needed < cap ? blocks_needed : cap);
-    rc = timing_begin(c);
-    if (rc) return rc;
     // smallest instantiation that covers the scene's features, then the launch options
     constexpr uint32_t FA = F_AABB | F_LENS, FB = F_AABB | F_LENS | F_REFRACT;
     const uint32_t need = c->features;
+    // Heavy scenes (many nodes per segment => VALU-bound, uneven path lengths) use the blocked
+    // kernel; light ones are HBM-bound and keep one lane per ray with perfectly coalesced streams.
+    const bool use_blocked = c->opt_kernel == 2 || (c->opt_kernel == 0 && c->n_nodes >= 24 && K > 2);
+    if (use_blocked) {
+        constexpr int CHUNK = 1024;
+        const size_t per_field = align_up(sizeof(T) * (size_t)n);
+        if (c->blocked.ensure(11 * per_field)) return fail(OT_ERR_HIP, "hipMalloc of blocked-trace scratch failed");
+        StateT<T> st;
+        for (int k = 0; k < 11; ++k) st.f[k] = (T*)((uint8_t*)c->blocked.p + k * per_field);
+        using KernB = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, SegsT<T>, int32_t*, int32_t*, int32_t, StateT<T>);
+        const int fb = (need & ~FB) == 0 ? 0 : 1, ntb = c->opt_nt ? 1 : 0;
+        static const KernB tb[2][2][2] = {
+            {{k_trace_blocked<T, FB, false, false, CHUNK>, k_trace_blocked<T, FB, false, true, CHUNK>},
+             {k_trace_blocked<T, FB, true, false, CHUNK>, k_trace_blocked<T, FB, true, true, CHUNK>}},
+            {{k_trace_blocked<T, F_ALL, false, false, CHUNK>, k_trace_blocked<T, F_ALL, false, true, CHUNK>},
+             {k_trace_blocked<T, F_ALL, true, false, CHUNK>, k_trace_blocked<T, F_ALL, true, true, CHUNK>}}};
+        KernB kb = tb[fb][in_lds ? 1 : 0][ntb];
+        const size_t lds_b = (in_lds ? ((bytes + 15) / 16) * 16 : 0) + (2 * CHUNK + 4) * sizeof(int32_t);
+        if (lds_b > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+        const int64_t n_chunks = (n + CHUNK - 1) / CHUNK;
+        int fitb = (int)((160 * 1024) / (lds_b + 512));
+        fitb = fitb < 1 ? 1 : (fitb > 8 ? 8 : fitb);
+        if (c->opt_blocks_per_cu > 0) fitb = c->opt_blocks_per_cu;
+        const int64_t capb = (int64_t)c->n_cus * fitb;
+        const int gridb = (int)(n_chunks < capb ? n_chunks : capb);
+        rc = timing_begin(c);
+        if (rc) return rc;
+        hipLaunchKernelGGL(kb, dim3(gridb), dim3(block), lds_b, c->stream, blob, (T)c->unit, view<T>(rays), n, K, view<T>(out),
+                           seg_count, counts, n_classes, st);
+        HIP_TRY(hipGetLastError());
+        return timing_end(c);
+    }
+    rc = timing_begin(c);
+    if (rc) return rc;
     using Kern = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, SegsT<T>, int32_t*, int32_t*, int32_t);
     const int fi = (need & ~FA) == 0 ? 0 : ((need & ~FB) == 0 ? 1 : 2);
     const int mw = (c->opt_minw == 4 && fi < 2) ? 1 : 0, nt = c->opt_nt ? 1 : 0;
@@ -663,7 +833,6 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
     return timing_end(c);
 }
 
-static size_t align_up(size_t x) { return (x + 255) / 256 * 256; }
 
 extern "C" {
 
@@ -740,7 +909,7 @@ int ot_trace_generation_f64(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
     blob.n_words = (int32_t)(c->bytes64 / 4);
     blob.n_nodes = c->n_nodes;
     blob.n_mats = c->n_mats;
-    const bool in_lds = c->bytes64 <= 150 * 1024;
+    const bool in_lds = c->bytes64 <= (size_t)c->opt_lds_limit_kb * 1024;
     const int64_t cap = (int64_t)c->n_cus * 4;
     const int grid = (int)(g1 < cap ? g1 : cap);
     const size_t lds_bytes = in_lds ? c->bytes64 : 0;
@@ -813,6 +982,12 @@ int ot_set_option(ot_ctx* c, int32_t option, int32_t value) {
         case OT_OPT_MIN_WAVES: 
             if (value != 0 && value != 4) return fail(OT_ERR_INVALID, "OT_OPT_MIN_WAVES takes 0 or 4");
             c->opt_minw = value; return 0;
+        case OT_OPT_KERNEL:
+            if (value < 0 || value > 2) return fail(OT_ERR_INVALID, "OT_OPT_KERNEL takes 0 (auto), 1 (fused) or 2 (blocked)");
+            c->opt_kernel = value; return 0;
+        case OT_OPT_LDS_LIMIT_KB:
+            if (value < 0 || value > 150) return fail(OT_ERR_INVALID, "OT_OPT_LDS_LIMIT_KB takes 0..150");
+            c->opt_lds_limit_kb = value; return 0;
         case OT_OPT_BLOCKS_PER_CU:
             if (value < 0 || value > 64) return fail(OT_ERR_INVALID, "OT_OPT_BLOCKS_PER_CU out of range");
             c->opt_blocks_per_cu = value; return 0;

@@ -39,7 +39,8 @@ enum : uint32_t {
     F_LENS = 8,      // thin lenses
     F_AABB = 16,     // groups: AABB prune
     F_LIMIT = 32,    // max_interact_count gates
-    F_ALL = 63
+    F_GRID = 64,     // large groups carry a 2-D grid over their children's boxes
+    F_ALL = 127
 };
 
 template <class T> struct Num;
@@ -406,6 +407,94 @@ template <int GATE> __device__ __forceinline__ bool count_gate(const GateCtx& g,
     return false;
 }
 
+// One leaf against one ray; updates `best`.  ORDERED = the caller visits leaves in increasing
+// node index (strict '<' keeps the first minimum); otherwise an exact tie goes to the lower index,
+// which is the same rule.
+template <class T, uint32_t F, int GATE, bool ORDERED>
+__device__ __forceinline__ void test_leaf(const Scene<T>& sc, const DNode<T>& nd, int idx, const RayState<T>& r, Hit<T>& best,
+                                          const GateCtx& gate) {
+    if (GATE == GATE_PROBE && nd.max_count < 0) return;  // the probe pass only looks at limited leaves
+    const T rx = r.ox - nd.org[0], ry = r.oy - nd.org[1], rz = r.oz - nd.org[2];
+    const int sh = nd.shape;
+    const bool planar = sh == OT_SHAPE_CIRCLE || sh == OT_SHAPE_RECT || sh == OT_SHAPE_POLYGON2D || sh == OT_SHAPE_CSG;
+    const bool limited = (F & F_LIMIT) && nd.max_count >= 0;
+    T t, Px, Py, Pz;
+    if (!(F & F_CURVED) || planar) {
+        // Planar leaf, evaluated lazily: only the local x row is needed to know t
+        // (t = -o_x/d_x, optical_component.py:171-179).  Exact rejections first: parallel,
+        // behind the ray (sign test == t < 0), t == 0.  Then a CONSERVATIVE far test (1e-9
+        // slack) drops leaves that cannot beat the current best; it is skipped for
+        // count-limited leaves, whose gate must see every geometric hit.
+        const T lox = nd.M[0] * rx + nd.M[3] * ry + nd.M[6] * rz;
+        const T ldx = nd.M[0] * r.dx + nd.M[3] * r.dy + nd.M[6] * r.dz;
+        const T s = -lox;
+        if (ldx == T(0) || s == T(0) || ((s > T(0)) != (ldx > T(0)))) return;
+        if (!limited && abs_t(s) > best.t * abs_t(ldx) * (T(1) + T(1e-9))) return;
+        t = s / ldx;
+        if (abs_t(t) < Num<T>::eps_t() || t < T(0) || t > r.len) return;
+        if (!limited && !(t < best.t || (!ORDERED && t == best.t && idx < best.node))) return;
+        const T loy = nd.M[1] * rx + nd.M[4] * ry + nd.M[7] * rz, loz = nd.M[2] * rx + nd.M[5] * ry + nd.M[8] * rz;
+        const T ldy = nd.M[1] * r.dx + nd.M[4] * r.dy + nd.M[7] * r.dz, ldz = nd.M[2] * r.dx + nd.M[5] * r.dy + nd.M[8] * r.dz;
+        Px = lox + t * ldx; Py = loy + t * ldy; Pz = loz + t * ldz;
+        if (!planar_boundary<T, F>(sc, nd, Px, Py, Pz)) return;
+    } else {
+        T ox, oy, oz, dx, dy, dz;
+        to_local(nd, rx, ry, rz, ox, oy, oz);
+        to_local(nd, r.dx, r.dy, r.dz, dx, dy, dz);
+        if (!hit_leaf<T, F>(sc, nd, ox, oy, oz, dx, dy, dz, r.len, t, Px, Py, Pz)) return;
+    }
+    if constexpr (F & F_LIMIT) {
+        if (GATE == GATE_PROBE) {
+            gate.probe[(int64_t)nd.slot * gate.stride + gate.idx] = 1;
+            return;
+        }
+        if (limited && !count_gate<GATE>(gate, nd.slot, nd.max_count)) return;
+    }
+    if (t < best.t || (!ORDERED && t == best.t && idx < best.node)) {
+        best.t = t; best.node = idx; best.px = Px; best.py = Py; best.pz = Pz;
+    }
+}
+
+template <class T> __device__ __forceinline__ T pick(int axis, T x, T y, T z) { return axis == 0 ? x : (axis == 1 ? y : z); }
+
+// Children of a gridded group (OT_NODE_GRID): instead of testing every child's AABB like
+// ComponentGroup.interact does (component_group.py:104-115), look up the cells the ray can touch
+// while it is inside the group's box and run the SAME per-child AABB + leaf tests on that
+// superset only.  aux record: [a0 a1 g0 g1 org0 org1 inv0 inv1 margin | start[g0*g1+1] | items...].
+template <class T, uint32_t F, int GATE>
+__device__ __forceinline__ void grid_children(const Scene<T>& sc, const DNode<T>& grp, const RayState<T>& r, const RayInv<T>& ri,
+                                              T t1, T t2, Hit<T>& best, const GateCtx& gate) {
+    const T* g = sc.aux + grp.aux;
+    const int a0 = (int)g[0], a1 = (int)g[1], g0 = (int)g[2], g1 = (int)g[3];
+    const T margin = g[8];
+    const T ta = max_t(t1, T(0)), tb = t2;
+    const T o0 = pick(a0, r.ox, r.oy, r.oz), o1 = pick(a1, r.ox, r.oy, r.oz);
+    const T d0 = pick(a0, r.dx, r.dy, r.dz), d1 = pick(a1, r.dx, r.dy, r.dz);
+    const T p0a = o0 + ta * d0, p0b = o0 + tb * d0, p1a = o1 + ta * d1, p1b = o1 + tb * d1;
+    const T lo0 = min_t(p0a, p0b) - margin, hi0 = max_t(p0a, p0b) + margin;
+    const T lo1 = min_t(p1a, p1b) - margin, hi1 = max_t(p1a, p1b) + margin;
+    auto cell = [](T v, T org, T inv, int n) {
+        const T c = (v - org) * inv;
+        return c <= T(0) ? 0 : (c >= T(n - 1) ? n - 1 : (int)c);
+    };
+    const int c0lo = cell(lo0, g[4], g[6], g0), c0hi = cell(hi0, g[4], g[6], g0);
+    const int c1lo = cell(lo1, g[5], g[7], g1), c1hi = cell(hi1, g[5], g[7], g1);
+    const T* start = g + 9;
+    const T* items = start + (g0 * g1 + 1);
+    for (int c1 = c1lo; c1 <= c1hi; ++c1)
+        for (int c0 = c0lo; c0 <= c0hi; ++c0) {
+            const int cidx = c1 * g0 + c0;
+            const int kb = (int)start[cidx], ke = (int)start[cidx + 1];
+            for (int k = kb; k < ke; ++k) {
+                const int ci = (int)items[k];
+                const DNode<T>& ch = sc.nodes[ci];
+                T u1, u2;
+                if (!slab_inv(r.ox, r.oy, r.oz, ri, ch.aabb, u1, u2)) continue;  // the child's own AABB test, unchanged
+                test_leaf<T, F, GATE, false>(sc, ch, ci, r, best, gate);
+            }
+        }
+}
+
 // Nearest hit over the whole scene for one ray (all lanes of the wave walk the node list with
 // the same index; a lane that pruned a group idles until the list leaves that group, and when
 // every lane of the wave pruned it the wave jumps ahead to the smallest skip target).
@@ -421,11 +510,23 @@ __device__ __forceinline__ Hit<T> nearest_hit(const Scene<T>& sc, const RayState
     for (int i = 0; i < sc.n_nodes; ++i) {
         const DNode<T>& nd = sc.nodes[i];
         if constexpr (F & F_AABB) {
+            bool inside = false;
+            T t1 = T(0), t2 = T(0);
             if (nd.flags & OT_NODE_CHECK_AABB) {
-                T t1, t2;
-                if (i >= skip_until && !slab_inv(r.ox, r.oy, r.oz, ri, nd.aabb, t1, t2)) skip_until = nd.end;
+                if (i >= skip_until) {
+                    inside = slab_inv(r.ox, r.oy, r.oz, ri, nd.aabb, t1, t2);
+                    if (!inside) skip_until = nd.end;
+                }
             }
             if (nd.kind == OT_NODE_GROUP) {
+                if constexpr (F & F_GRID) {
+                    if (nd.flags & OT_NODE_GRID) {  // wave-uniform branch; lanes that missed the box idle inside
+                        if (inside) {
+                            grid_children<T, F, GATE>(sc, nd, r, ri, t1, t2, best, gate);
+                            skip_until = nd.end;
+                        }
+                    }
+                }
                 // every lane of the wave takes this branch (nd is wave-uniform); inactive lanes hold INT_MAX
                 const int target = __builtin_amdgcn_readfirstlane(wave_min_i32(skip_until));
                 if (target > i + 1) i = (target < sc.n_nodes ? target : sc.n_nodes) - 1;
@@ -433,46 +534,7 @@ __device__ __forceinline__ Hit<T> nearest_hit(const Scene<T>& sc, const RayState
             }
         }
         if (i < skip_until) continue;
-        if (GATE == GATE_PROBE && nd.max_count < 0) continue;  // the probe pass only looks at limited leaves
-        const T rx = r.ox - nd.org[0], ry = r.oy - nd.org[1], rz = r.oz - nd.org[2];
-        const int sh = nd.shape;
-        const bool planar = sh == OT_SHAPE_CIRCLE || sh == OT_SHAPE_RECT || sh == OT_SHAPE_POLYGON2D || sh == OT_SHAPE_CSG;
-        T t, Px, Py, Pz;
-        if (!(F & F_CURVED) || planar) {
-            // Planar leaf, evaluated lazily: only the local x row is needed to know t
-            // (t = -o_x/d_x, optical_component.py:171-179).  Exact rejections first: parallel,
-            // behind the ray (sign test == t < 0), t == 0.  Then a CONSERVATIVE far test (1e-9
-            // slack) drops leaves that cannot beat the current best under the strict '<'; it is
-            // skipped for count-limited leaves, whose gate must see every geometric hit.
-            const T lox = nd.M[0] * rx + nd.M[3] * ry + nd.M[6] * rz;
-            const T ldx = nd.M[0] * r.dx + nd.M[3] * r.dy + nd.M[6] * r.dz;
-            const T s = -lox;
-            if (ldx == T(0) || s == T(0) || ((s > T(0)) != (ldx > T(0)))) continue;
-            const bool limited = (F & F_LIMIT) && nd.max_count >= 0;
-            if (!limited && abs_t(s) > best.t * abs_t(ldx) * (T(1) + T(1e-9))) continue;
-            t = s / ldx;
-            if (abs_t(t) < Num<T>::eps_t() || t < T(0) || t > r.len) continue;
-            if (!limited && !(t < best.t)) continue;
-            const T loy = nd.M[1] * rx + nd.M[4] * ry + nd.M[7] * rz, loz = nd.M[2] * rx + nd.M[5] * ry + nd.M[8] * rz;
-            const T ldy = nd.M[1] * r.dx + nd.M[4] * r.dy + nd.M[7] * r.dz, ldz = nd.M[2] * r.dx + nd.M[5] * r.dy + nd.M[8] * r.dz;
-            Px = lox + t * ldx; Py = loy + t * ldy; Pz = loz + t * ldz;
-            if (!planar_boundary<T, F>(sc, nd, Px, Py, Pz)) continue;
-        } else {
-            T ox, oy, oz, dx, dy, dz;
-            to_local(nd, rx, ry, rz, ox, oy, oz);
-            to_local(nd, r.dx, r.dy, r.dz, dx, dy, dz);
-            if (!hit_leaf<T, F>(sc, nd, ox, oy, oz, dx, dy, dz, r.len, t, Px, Py, Pz)) continue;
-        }
-        if constexpr (F & F_LIMIT) {
-            if (GATE == GATE_PROBE) {
-                gate.probe[(int64_t)nd.slot * gate.stride + gate.idx] = 1;
-                continue;
-            }
-            if (nd.max_count >= 0 && !count_gate<GATE>(gate, nd.slot, nd.max_count)) continue;
-        }
-        if (t < best.t) {
-            best.t = t; best.node = i; best.px = Px; best.py = Py; best.pz = Pz;
-        }
+        test_leaf<T, F, GATE, true>(sc, nd, i, r, best, gate);
     }
     return best;
 }

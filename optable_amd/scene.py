@@ -103,7 +103,55 @@ class _Builder:
         for child in grp.components:
             self.add(child, in_group=True)
         node.end = len(self.nodes)
+        self._maybe_grid(node, slot)
         return slot
+
+    GRID_MIN_CHILDREN = 24
+
+    def _maybe_grid(self, node, slot):
+        """Large flat groups (MLA / MMA / DMD ...): a 2-D grid over the children's lab AABBs so the
+        kernel visits only the children near the ray instead of all of them.  Pure acceleration:
+        every child found through the grid still passes its own AABB test, and a child the grid
+        misses could not have passed it (boxes are binned with a margin far above the slab test's
+        1e-12 / 1e-8 tolerances).  Not built when a child is itself a group or count-limited
+        (its gate must see every geometric hit)."""
+        kids = list(range(slot + 1, node.end))
+        if len(kids) < self.GRID_MIN_CHILDREN:
+            return
+        if any(self.nodes[k].kind != abi.NODE_LEAF or self.nodes[k].max_interact_count >= 0 for k in kids):
+            return
+        gbox = np.array(node.aabb[:], dtype=float).reshape(3, 2)
+        extent = gbox[:, 1] - gbox[:, 0]
+        a0, a1 = sorted(np.argsort(extent)[-2:].tolist())
+        if extent[a0] <= 0 or extent[a1] <= 0:
+            return
+        boxes = np.array([self.nodes[k].aabb[:] for k in kids], dtype=float).reshape(-1, 3, 2)
+        # cells about half the size of a typical child (children of a lattice touch cell borders), at most 64 x 64
+        typical = np.median(boxes[:, [a0, a1], 1] - boxes[:, [a0, a1], 0], axis=0)
+        dims = [int(min(64, max(1, np.floor(extent[a] / max(typical[j] / 2, extent[a] / 64))))) for j, a in enumerate((a0, a1))]
+        margin = 1e-7 + 1e-9 * float(extent.max())
+        org = [gbox[a0, 0], gbox[a1, 0]]
+        inv = [dims[0] / extent[a0], dims[1] / extent[a1]]
+        cells = [[] for _ in range(dims[0] * dims[1])]
+        for k, bx in zip(kids, boxes):
+            lo0 = int(np.clip(np.floor((bx[a0, 0] - margin - org[0]) * inv[0]), 0, dims[0] - 1))
+            hi0 = int(np.clip(np.floor((bx[a0, 1] + margin - org[0]) * inv[0]), 0, dims[0] - 1))
+            lo1 = int(np.clip(np.floor((bx[a1, 0] - margin - org[1]) * inv[1]), 0, dims[1] - 1))
+            hi1 = int(np.clip(np.floor((bx[a1, 1] + margin - org[1]) * inv[1]), 0, dims[1] - 1))
+            for c1 in range(lo1, hi1 + 1):
+                for c0 in range(lo0, hi0 + 1):
+                    cells[c1 * dims[0] + c0].append(k)
+        starts, items = [0], []
+        for lst in cells:
+            items.extend(lst)
+            starts.append(len(items))
+        if len(items) > 32 * len(kids) + 64:   # pathological overlap: the grid would not help
+            return
+        node.aux = len(self.aux)
+        node.flags |= abi.NODE_GRID
+        self.aux.extend([float(a0), float(a1), float(dims[0]), float(dims[1]), org[0], org[1], inv[0], inv[1], 2 * margin])
+        self.aux.extend(float(x) for x in starts)
+        self.aux.extend(float(x) for x in items)
 
     def add_leaf(self, comp, in_group):
         if not isinstance(comp, OpticalComponent):

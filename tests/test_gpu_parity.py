@@ -267,3 +267,30 @@ def test_launch_options_do_not_change_results():
         eng.set_option(abi.OPT_NT_STORES, 1)
         eng.set_option(abi.OPT_MIN_WAVES, 4)
         eng.set_option(abi.OPT_BLOCKS_PER_CU, 0)
+
+
+@pytest.mark.parametrize("case", ["cfg2", "cfg3", "cfg5"])
+def test_blocked_kernel_equals_lane_per_ray_kernel(case):
+    """k_trace_blocked (chunk per workgroup, compaction between generations) and k_trace_fused (lane per
+    ray) are interchangeable: same slots, same bits."""
+    import torch
+    import optable_amd as oa
+    from optable_amd.engine import get_engine
+
+    comps, gen, n, K, _ = CASES[case]
+    n = min(n, 5000) + 37  # ragged last chunk
+    table = _table(comps(oa))
+    o, d = gen(n)
+    batch = _batch(o, d)
+    eng = get_engine()
+    try:
+        eng.set_option(abi.OPT_KERNEL, 1)
+        a = table.trace_batch(batch, max_segments=K)
+        eng.set_option(abi.OPT_KERNEL, 2)
+        b = table.trace_batch(batch, max_segments=K)
+    finally:
+        eng.set_option(abi.OPT_KERNEL, 0)
+    assert torch.equal(a.count, b.count)
+    valid = a.valid_mask()
+    for f in abi.SEG_FIELDS + ("ray", "surface"):
+        assert torch.equal(a.field(f)[valid], b.field(f)[valid]), f

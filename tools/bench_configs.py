@@ -11,15 +11,27 @@ sys.path.insert(1, os.path.join(ROOT, "tests"))
 import numpy as np
 import torch
 import optable_amd as oa
+from optable_amd import abi
 from optable_amd.batch import RayBatch, SegmentBatch
 from optable_amd.engine import get_engine
 import scenes
 
 eng = get_engine()
+if os.environ.get('LDSKB'):
+    eng.set_option(abi.OPT_LDS_LIMIT_KB, int(os.environ['LDSKB']))
+if os.environ.get('BPC'):
+    eng.set_option(abi.OPT_BLOCKS_PER_CU, int(os.environ['BPC']))
 Q = lambda wl: 1j * np.pi * scenes.W0**2 / wl
 
 
 def run(name, comps, o, d, wl, K, prec, reps=5):
+    for kern in ((1, 2) if os.environ.get('BOTH') else (0,)):
+        eng.set_option(abi.OPT_KERNEL, kern)
+        _run(f'{name} k{kern}', comps, o, d, wl, K, prec, reps)
+    eng.set_option(abi.OPT_KERNEL, 0)
+
+
+def _run(name, comps, o, d, wl, K, prec, reps=5):
     table = oa.OpticalTable()
     table.add_components(comps)
     scene = table.compile()
