@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define OT_ABI_VERSION 1
+#define OT_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------------------- */
 enum ot_status {
@@ -133,6 +133,10 @@ typedef struct ot_scene_desc {
     int32_t n_count_slots; /* leaves with max_interact_count set                            */
     int32_t max_children;  /* most rays any interaction can emit (1 => non-branching scene) */
     double unit;           /* metres per model length unit (OpticalTable(unit=...), 1e-2)   */
+    int32_t root_grid;     /* aux offset of a 2-D grid over the top-level components (walked
+                              cell by cell instead of the linear pass), -1 for none.  Record:
+                              [a0 a1 g0 g1 org0 org1 inv0 inv1 margin size0 size1 | start | items] */
+    int32_t _pad;
 } ot_scene_desc;
 
 /* ---- ray / segment streams (device pointers, structure of arrays) -------------------- */

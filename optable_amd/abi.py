@@ -7,7 +7,7 @@ __graft_entry__ as g; g.build()"` or `make -C optable_amd/csrc`).
 import ctypes as C
 import os
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "liboptable_hip.so")
 
@@ -40,6 +40,7 @@ class OtSceneDesc(C.Structure):
         ("materials", C.POINTER(OtMaterial)), ("n_materials", C.c_int32),
         ("aux", C.POINTER(C.c_double)), ("n_aux", C.c_int32),
         ("n_count_slots", C.c_int32), ("max_children", C.c_int32), ("unit", C.c_double),
+        ("root_grid", C.c_int32), ("_pad", C.c_int32),
     ]
 
 

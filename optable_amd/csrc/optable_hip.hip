@@ -70,7 +70,7 @@ template <class T> static SegsT<T> view(const ot_segments* s) {
 // scene blob: [DNode<T> x n_nodes][DMat<T> x n_mats][T x n_aux], staged into LDS word by word
 struct SceneBlob {
     const uint32_t* words;
-    int32_t n_words, n_nodes, n_mats;
+    int32_t n_words, n_nodes, n_mats, root;
 };
 
 template <class T> __device__ __forceinline__ Scene<T> bind_scene(const uint32_t* base, const SceneBlob& b, T unit) {
@@ -79,6 +79,7 @@ template <class T> __device__ __forceinline__ Scene<T> bind_scene(const uint32_t
     sc.mats = reinterpret_cast<const DMat<T>*>(sc.nodes + b.n_nodes);
     sc.aux = reinterpret_cast<const T*>(sc.mats + b.n_mats);
     sc.n_nodes = b.n_nodes;
+    sc.root = b.root;
     sc.unit = unit;
     return sc;
 }
@@ -496,6 +497,7 @@ struct ot_ctx {
     int32_t n_nodes = 0, n_mats = 0, n_aux = 0, n_slots = 0, max_children = 0;
     double unit = 1e-2;
     uint32_t features = 0;
+    int32_t root_grid = -1;  // aux offset of the top-level grid
     int32_t* slot_max = nullptr;  // device [n_slots]: max_interact_count per count slot
     // timing
     bool timing = false;
@@ -601,6 +603,31 @@ static uint32_t scene_features(const ot_scene_desc* s) {
     return f;
 }
 
+static int validate_root_grid(const ot_scene_desc* s) {
+    if (s->root_grid < 0) return 0;
+    if (s->root_grid + 11 > s->n_aux) return fail(OT_ERR_INVALID, "root grid out of range");
+    const double* g = s->aux + s->root_grid;
+    const int a0 = (int)g[0], a1 = (int)g[1], g0 = (int)g[2], g1 = (int)g[3];
+    if (a0 < 0 || a0 > 2 || a1 < 0 || a1 > 2 || a0 == a1 || g0 < 1 || g1 < 1 || (int64_t)g0 * g1 > 1 << 20)
+        return fail(OT_ERR_INVALID, "bad root grid header");
+    const int64_t cells = (int64_t)g0 * g1;
+    if (s->root_grid + 11 + cells + 1 > s->n_aux) return fail(OT_ERR_INVALID, "root grid starts out of range");
+    const double* start = g + 11;
+    const int64_t n_items = (int64_t)start[cells];
+    if (start[0] != 0 || s->root_grid + 11 + cells + 1 + n_items > s->n_aux) return fail(OT_ERR_INVALID, "root grid items out of range");
+    for (int64_t k = 0; k < cells; ++k)
+        if (start[k + 1] < start[k]) return fail(OT_ERR_INVALID, "root grid starts not monotone");
+    const double* items = start + cells + 1;
+    for (int64_t k = 0; k < n_items; ++k) {
+        const int ni = (int)items[k];
+        if (ni < 0 || ni >= s->n_nodes) return fail(OT_ERR_INVALID, "root grid item out of range");
+    }
+    for (int i = 0; i < s->n_nodes; ++i)
+        if (s->nodes[i].kind == OT_NODE_LEAF && s->nodes[i].max_interact_count >= 0)
+            return fail(OT_ERR_INVALID, "a root grid cannot be combined with count-limited leaves");
+    return 0;
+}
+
 static int validate_scene(const ot_scene_desc* s) {
     if (!s || s->n_nodes < 0 || s->n_materials < 0 || s->n_aux < 0) return fail(OT_ERR_INVALID, "bad scene sizes");
     if (s->n_nodes && !s->nodes) return fail(OT_ERR_INVALID, "nodes is NULL");
@@ -693,6 +720,8 @@ int ot_scene_upload(ot_ctx* c, const ot_scene_desc* s) {
     if (!c) return fail(OT_ERR_INVALID, "ctx is NULL");
     int rc = validate_scene(s);
     if (rc) return rc;
+    rc = validate_root_grid(s);
+    if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
     std::vector<uint8_t> b64, b32;
     fill_blob<double>(s, b64);
@@ -708,6 +737,8 @@ int ot_scene_upload(ot_ctx* c, const ot_scene_desc* s) {
     c->n_nodes = s->n_nodes; c->n_mats = s->n_materials; c->n_aux = s->n_aux;
     c->n_slots = s->n_count_slots; c->max_children = s->max_children; c->unit = s->unit;
     c->features = scene_features(s);
+    c->root_grid = s->root_grid;
+    if (c->root_grid >= 0) c->features |= F_ROOT | F_AABB;
     if (c->slot_max) { (void)hipFree(c->slot_max); c->slot_max = nullptr; }
     if (s->n_count_slots > 0) {
         std::vector<int32_t> smax(s->n_count_slots, 0);
@@ -763,6 +794,7 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
     blob.n_words = (int32_t)(bytes / 4);
     blob.n_nodes = c->n_nodes;
     blob.n_mats = c->n_mats;
+    blob.root = c->root_grid;
     const int block = 256;
     const bool in_lds = bytes <= (size_t)c->opt_lds_limit_kb * 1024;
     const int64_t blocks_needed = (n + block - 1) / block;
@@ -777,7 +809,7 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
     const int64_t cap = (int64_t)c->n_cus * per_cu;
     const int grid = (int)(blocks_needed < cap ? blocks_needed : cap);
     // smallest instantiation that covers the scene's features, then the launch options
-    constexpr uint32_t FA = F_AABB | F_LENS, FB = F_AABB | F_LENS | F_REFRACT;
+    constexpr uint32_t FA = F_AABB | F_LENS, FB = F_AABB | F_LENS | F_REFRACT, FC = FB | F_GRID | F_ROOT;
     const uint32_t need = c->features;
     // Heavy scenes (many nodes per segment => VALU-bound, uneven path lengths) use the blocked
     // kernel; light ones are HBM-bound and keep one lane per ray with perfectly coalesced streams.
@@ -789,10 +821,10 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
         StateT<T> st;
         for (int k = 0; k < 11; ++k) st.f[k] = (T*)((uint8_t*)c->blocked.p + k * per_field);
         using KernB = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, SegsT<T>, int32_t*, int32_t*, int32_t, StateT<T>);
-        const int fb = (need & ~FB) == 0 ? 0 : 1, ntb = c->opt_nt ? 1 : 0;
+        const int fb = (need & ~FC) == 0 ? 0 : 1, ntb = c->opt_nt ? 1 : 0;
         static const KernB tb[2][2][2] = {
-            {{k_trace_blocked<T, FB, false, false, CHUNK>, k_trace_blocked<T, FB, false, true, CHUNK>},
-             {k_trace_blocked<T, FB, true, false, CHUNK>, k_trace_blocked<T, FB, true, true, CHUNK>}},
+            {{k_trace_blocked<T, FC, false, false, CHUNK>, k_trace_blocked<T, FC, false, true, CHUNK>},
+             {k_trace_blocked<T, FC, true, false, CHUNK>, k_trace_blocked<T, FC, true, true, CHUNK>}},
             {{k_trace_blocked<T, F_ALL, false, false, CHUNK>, k_trace_blocked<T, F_ALL, false, true, CHUNK>},
              {k_trace_blocked<T, F_ALL, true, false, CHUNK>, k_trace_blocked<T, F_ALL, true, true, CHUNK>}}};
         KernB kb = tb[fb][in_lds ? 1 : 0][ntb];
@@ -909,6 +941,7 @@ int ot_trace_generation_f64(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
     blob.n_words = (int32_t)(c->bytes64 / 4);
     blob.n_nodes = c->n_nodes;
     blob.n_mats = c->n_mats;
+    blob.root = c->root_grid;
     const bool in_lds = c->bytes64 <= (size_t)c->opt_lds_limit_kb * 1024;
     const int64_t cap = (int64_t)c->n_cus * 4;
     const int grid = (int)(g1 < cap ? g1 : cap);

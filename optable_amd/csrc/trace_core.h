@@ -40,7 +40,8 @@ enum : uint32_t {
     F_AABB = 16,     // groups: AABB prune
     F_LIMIT = 32,    // max_interact_count gates
     F_GRID = 64,     // large groups carry a 2-D grid over their children's boxes
-    F_ALL = 127
+    F_ROOT = 128,    // the top-level component list carries a 2-D grid walked cell by cell (DDA)
+    F_ALL = 255
 };
 
 template <class T> struct Num;
@@ -81,6 +82,7 @@ template <class T> struct Scene {
     const DMat<T>* mats;
     const T* aux;
     int32_t n_nodes;
+    int32_t root;  // aux offset of the top-level grid, -1 when the scene has none
     T unit;
 };
 
@@ -495,6 +497,79 @@ __device__ __forceinline__ void grid_children(const Scene<T>& sc, const DNode<T>
         }
 }
 
+// Per-lane walk of one top-level component (a leaf, or a group with everything below it): the
+// skip-list logic of nearest_hit for a single subtree, with a lane-private index.
+template <class T, uint32_t F, int GATE>
+__device__ __forceinline__ void walk_subtree(const Scene<T>& sc, int first, const RayState<T>& r, const RayInv<T>& ri, Hit<T>& best,
+                                             const GateCtx& gate) {
+    const int last = sc.nodes[first].end;
+    for (int j = first; j < last;) {
+        const DNode<T>& nd = sc.nodes[j];
+        T t1 = T(0), t2 = T(0);
+        if (nd.flags & OT_NODE_CHECK_AABB) {
+            if (!slab_inv(r.ox, r.oy, r.oz, ri, nd.aabb, t1, t2)) { j = nd.end; continue; }
+        }
+        if (nd.kind == OT_NODE_GROUP) {
+            if constexpr (F & F_GRID) {
+                if (nd.flags & OT_NODE_GRID) {
+                    grid_children<T, F, GATE>(sc, nd, r, ri, t1, t2, best, gate);
+                    j = nd.end;
+                    continue;
+                }
+            }
+            ++j;
+            continue;
+        }
+        test_leaf<T, F, GATE, false>(sc, nd, j, r, best, gate);
+        ++j;
+    }
+}
+
+// Nearest hit through the top-level grid: clip the ray to the scene box, visit the cells it
+// crosses in order (2-D DDA) and stop as soon as the best hit lies inside the part of the ray
+// already covered.  Candidates are top-level components binned by their lab AABB (with margin);
+// each is examined with exactly the tests the linear pass applies, and ties go to the lower node
+// index, so the winner is the one optical_table.py:119-123 picks.
+// aux record: [a0 a1 g0 g1 org0 org1 inv0 inv1 margin size0 size1 | start[g0*g1+1] | items...]
+template <class T, uint32_t F, int GATE>
+__device__ __forceinline__ void root_grid_hit(const Scene<T>& sc, const RayState<T>& r, const RayInv<T>& ri, Hit<T>& best,
+                                              const GateCtx& gate) {
+    const T* g = sc.aux + sc.root;
+    const int a0 = (int)g[0], a1 = (int)g[1], g0 = (int)g[2], g1 = (int)g[3];
+    const T org0 = g[4], org1 = g[5], inv0 = g[6], inv1 = g[7], margin = g[8], size0 = g[9], size1 = g[10];
+    const T o0 = pick(a0, r.ox, r.oy, r.oz), o1 = pick(a1, r.ox, r.oy, r.oz);
+    const T d0 = pick(a0, r.dx, r.dy, r.dz), d1 = pick(a1, r.dx, r.dy, r.dz);
+    const T i0 = pick(a0, ri.inv[0], ri.inv[1], ri.inv[2]), i1 = pick(a1, ri.inv[0], ri.inv[1], ri.inv[2]);
+    const bool par0 = abs_t(d0) <= T(1e-12), par1 = abs_t(d1) <= T(1e-12);
+    // clip to the grid rectangle
+    T tin = T(0), tout = Num<T>::inf();
+    const T hi0 = org0 + size0 * T(g0), hi1 = org1 + size1 * T(g1);
+    if (par0) { if (o0 < org0 || o0 > hi0) return; }
+    else { const T a = (org0 - o0) * i0, b = (hi0 - o0) * i0; tin = max_t(tin, min_t(a, b)); tout = min_t(tout, max_t(a, b)); }
+    if (par1) { if (o1 < org1 || o1 > hi1) return; }
+    else { const T a = (org1 - o1) * i1, b = (hi1 - o1) * i1; tin = max_t(tin, min_t(a, b)); tout = min_t(tout, max_t(a, b)); }
+    if (!(tin <= tout)) return;
+    // starting cell and stepping
+    auto clampi = [](T c, int n) { return c <= T(0) ? 0 : (c >= T(n - 1) ? n - 1 : (int)c); };
+    int c0 = clampi((o0 + tin * d0 - org0) * inv0, g0), c1 = clampi((o1 + tin * d1 - org1) * inv1, g1);
+    const int s0 = d0 > T(0) ? 1 : -1, s1 = d1 > T(0) ? 1 : -1;
+    T tmax0 = par0 ? Num<T>::inf() : (org0 + size0 * T(c0 + (s0 > 0 ? 1 : 0)) - o0) * i0;
+    T tmax1 = par1 ? Num<T>::inf() : (org1 + size1 * T(c1 + (s1 > 0 ? 1 : 0)) - o1) * i1;
+    const T dt0 = par0 ? Num<T>::inf() : size0 * abs_t(i0), dt1 = par1 ? Num<T>::inf() : size1 * abs_t(i1);
+    const T* start = g + 11;
+    const T* items = start + (g0 * g1 + 1);
+    const T slack = T(4) * margin;
+    for (int guard = 0; guard < g0 + g1 + 2; ++guard) {
+        const int cidx = c1 * g0 + c0;
+        const int kb = (int)start[cidx], ke = (int)start[cidx + 1];
+        for (int k = kb; k < ke; ++k) walk_subtree<T, F, GATE>(sc, (int)items[k], r, ri, best, gate);
+        const T texit = min_t(tmax0, tmax1);
+        if (best.t + slack < texit) return;  // nothing in later cells can be nearer (or tie)
+        if (tmax0 < tmax1) { c0 += s0; tmax0 += dt0; if (c0 < 0 || c0 >= g0) return; }
+        else { c1 += s1; tmax1 += dt1; if (c1 < 0 || c1 >= g1) return; }
+    }
+}
+
 // Nearest hit over the whole scene for one ray (all lanes of the wave walk the node list with
 // the same index; a lane that pruned a group idles until the list leaves that group, and when
 // every lane of the wave pruned it the wave jumps ahead to the smallest skip target).
@@ -507,6 +582,12 @@ __device__ __forceinline__ Hit<T> nearest_hit(const Scene<T>& sc, const RayState
     int skip_until = active ? 0 : 0x7fffffff;
     RayInv<T> ri;
     if constexpr (F & F_AABB) ri = make_inv(r.dx, r.dy, r.dz);
+    if constexpr (F & F_ROOT) {
+        if (sc.root >= 0) {  // scene-uniform branch
+            if (active) root_grid_hit<T, F, GATE>(sc, r, ri, best, gate);
+            return best;
+        }
+    }
     for (int i = 0; i < sc.n_nodes; ++i) {
         const DNode<T>& nd = sc.nodes[i];
         if constexpr (F & F_AABB) {

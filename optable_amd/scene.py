@@ -27,7 +27,8 @@ class SceneError(NotImplementedError):
 class CompiledScene:
     """Owner of the ctypes tables handed to `ot_scene_upload`."""
 
-    def __init__(self, nodes, materials, aux, leaves, limited, max_children, unit):
+    def __init__(self, nodes, materials, aux, leaves, limited, max_children, unit, root_grid=-1):
+        self.root_grid = root_grid
         self.nodes = (abi.OtNode * max(len(nodes), 1))(*nodes)
         self.n_nodes = len(nodes)
         self.materials = (abi.OtMaterial * max(len(materials), 1))(*materials)
@@ -51,6 +52,7 @@ class CompiledScene:
         d.n_count_slots = len(self.limited)
         d.max_children = self.max_children
         d.unit = self.unit
+        d.root_grid = self.root_grid
         return d
 
     def node_table(self):
@@ -59,7 +61,8 @@ class CompiledScene:
 
 
 class _Builder:
-    def __init__(self):
+    def __init__(self, accelerate=True):
+        self.accelerate = accelerate
         self.nodes, self.materials, self.aux = [], [], []
         self.mat_index = {}
         self.leaves, self.limited = [], []
@@ -116,7 +119,7 @@ class _Builder:
         1e-12 / 1e-8 tolerances).  Not built when a child is itself a group or count-limited
         (its gate must see every geometric hit)."""
         kids = list(range(slot + 1, node.end))
-        if len(kids) < self.GRID_MIN_CHILDREN:
+        if not self.accelerate or len(kids) < self.GRID_MIN_CHILDREN:
             return
         if any(self.nodes[k].kind != abi.NODE_LEAF or self.nodes[k].max_interact_count >= 0 for k in kids):
             return
@@ -206,8 +209,65 @@ def _fanout(kind, refl, trans):
     return 1 if kind == LENS else 0
 
 
-def compile_scene(components, unit=1e-2) -> CompiledScene:
-    b = _Builder()
+ROOT_GRID_MIN_TOP = 12
+
+
+def _root_grid(b, tops):
+    """2-D grid over the top-level components (binned by lab AABB) for scenes with many of them.
+    The kernel walks the cells a ray crosses in order and stops once its best hit lies inside the
+    part of the ray already covered, instead of testing every component on every segment
+    (optical_table.py:119-123 does the latter).  Acceleration only: a component found through the
+    grid gets exactly the tests the linear pass applies, ties go to the lower index.  Skipped when
+    a leaf is count-limited (its gate must see every geometric hit) or a box is not finite."""
+    if len(tops) < ROOT_GRID_MIN_TOP or b.limited:
+        return -1
+    boxes = np.array([b.nodes[i].aabb[:] for i in tops], dtype=float).reshape(-1, 3, 2)
+    if not np.all(np.isfinite(boxes)):
+        return -1
+    lo, hi = boxes[:, :, 0].min(axis=0), boxes[:, :, 1].max(axis=0)
+    extent = hi - lo
+    a0, a1 = sorted(np.argsort(extent)[-2:].tolist())
+    if extent[a0] <= 0 or extent[a1] <= 0:
+        return -1
+    margin = 1e-7 + 1e-9 * float(extent.max())
+    pad = 4 * margin
+    org = [lo[a0] - pad, lo[a1] - pad]
+    span = [extent[a0] + 2 * pad, extent[a1] + 2 * pad]
+    # about 4 cells per component, shaped like the scene, at most 64 x 64
+    cells_target = 4.0 * len(tops)
+    g0 = int(np.clip(round(np.sqrt(cells_target * span[0] / span[1])), 1, 64))
+    g1 = int(np.clip(round(np.sqrt(cells_target * span[1] / span[0])), 1, 64))
+    size = [span[0] / g0, span[1] / g1]
+    inv = [1.0 / size[0], 1.0 / size[1]]
+    cells = [[] for _ in range(g0 * g1)]
+    for idx, bx in zip(tops, boxes):
+        lo0 = int(np.clip(np.floor((bx[a0, 0] - margin - org[0]) * inv[0]), 0, g0 - 1))
+        hi0 = int(np.clip(np.floor((bx[a0, 1] + margin - org[0]) * inv[0]), 0, g0 - 1))
+        lo1 = int(np.clip(np.floor((bx[a1, 0] - margin - org[1]) * inv[1]), 0, g1 - 1))
+        hi1 = int(np.clip(np.floor((bx[a1, 1] + margin - org[1]) * inv[1]), 0, g1 - 1))
+        for c1 in range(lo1, hi1 + 1):
+            for c0 in range(lo0, hi0 + 1):
+                cells[c1 * g0 + c0].append(idx)
+    starts, items = [0], []
+    for lst in cells:
+        items.extend(lst)  # ascending node index inside a cell
+        starts.append(len(items))
+    offset = len(b.aux)
+    b.aux.extend([float(a0), float(a1), float(g0), float(g1), org[0], org[1], inv[0], inv[1], margin, size[0], size[1]])
+    b.aux.extend(float(x) for x in starts)
+    b.aux.extend(float(x) for x in items)
+    return offset
+
+
+def compile_scene(components, unit=1e-2, accelerate=True) -> CompiledScene:
+    b = _Builder(accelerate)
+    tops = []
     for comp in components:
+        tops.append(len(b.nodes))
         b.add(comp, in_group=False)
-    return CompiledScene(b.nodes, b.materials, b.aux, b.leaves, b.limited, b.max_children, unit)
+    for i in tops:  # top-level leaves carry no AABB test in the reference; the grid still needs their boxes
+        nd = b.nodes[i]
+        if nd.kind == abi.NODE_LEAF and not any(nd.aabb[:]):
+            nd.aabb[:] = [float(x) for x in b.leaves[nd.leaf_id].bbox]
+    root = _root_grid(b, tops) if accelerate else -1
+    return CompiledScene(b.nodes, b.materials, b.aux, b.leaves, b.limited, b.max_children, unit, root)

@@ -72,9 +72,11 @@ class OpticalTable:
         self._bbox = base_merge_bboxs([c.bbox for c in self.components])
         return self._bbox
 
+    accelerate = True  # attach the acceleration grids (scene.py); results do not depend on it
+
     def compile(self):
         """Flatten the current components into device tables (poses are read now)."""
-        return compile_scene(self.components, self.unit)
+        return compile_scene(self.components, self.unit, accelerate=self.accelerate)
 
     # -- the hot path ---------------------------------------------------------------------------
     def ray_tracing(self, rays: Union[Ray, List[Ray]], perfomance_limit=None):

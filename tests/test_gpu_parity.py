@@ -294,3 +294,24 @@ def test_blocked_kernel_equals_lane_per_ray_kernel(case):
     valid = a.valid_mask()
     for f in abi.SEG_FIELDS + ("ray", "surface"):
         assert torch.equal(a.field(f)[valid], b.field(f)[valid]), f
+
+
+@pytest.mark.parametrize("case", ["cfg3", "cfg5"])
+def test_acceleration_grids_do_not_change_results(case):
+    """Group grids and the top-level grid only choose WHICH nodes get tested; every bit of the output
+    must equal the plain linear pass (component_group.py:104-115, optical_table.py:119-123)."""
+    import torch
+    import optable_amd as oa
+
+    comps, gen, n, K, _ = CASES[case]
+    n = min(n, 6000)
+    o, d = gen(n)
+    batch = _batch(o, d)
+    table = _table(comps(oa))
+    fast = table.trace_batch(batch, max_segments=K)
+    table.accelerate = False
+    plain = table.trace_batch(batch, max_segments=K)
+    assert torch.equal(fast.count, plain.count)
+    valid = fast.valid_mask()
+    for f in abi.SEG_FIELDS + ("ray", "surface"):
+        assert torch.equal(fast.field(f)[valid], plain.field(f)[valid]), f

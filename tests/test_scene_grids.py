@@ -1,0 +1,107 @@
+"""CPU: the acceleration grids the scene compiler attaches are supersets — every child (or top-level
+component) whose AABB a ray hits under the reference's slab test (solver.py:5-48) is listed in a cell
+the kernel's footprint / DDA visits.  Checked with the host slab test on random rays; no GPU needed."""
+import numpy as np
+import pytest
+
+import optable_amd as oa
+from optable_amd import abi
+from optable_amd.slab import solve_ray_bboxes_intersections
+import scenes
+
+
+def _rays(rng, box, n):
+    """Rays aimed at / through / beside a box, plus axis-parallel and grazing ones."""
+    lo, hi = box[0::2], box[1::2]
+    size = np.maximum(hi - lo, 1e-3)
+    o = lo - 2 * size + rng.uniform(0, 1, (n, 3)) * (5 * size)
+    tgt = lo + rng.uniform(-0.1, 1.1, (n, 3)) * size
+    d = tgt - o
+    d[::7, 1] = 0.0
+    d[3::11, 2] = 0.0
+    d[5::13] = [1.0, 0.0, 0.0]
+    o[5::13, 0] = lo[0] - 1.0
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return o, d
+
+
+def _footprint_cells(g, o, d, t1, t2):
+    a0, a1, g0, g1 = (int(g[k]) for k in range(4))
+    margin = g[8]
+    ta, tb = max(t1, 0.0), t2
+    out = set()
+    lo0, hi0 = sorted((o[a0] + ta * d[a0], o[a0] + tb * d[a0]))
+    lo1, hi1 = sorted((o[a1] + ta * d[a1], o[a1] + tb * d[a1]))
+
+    def cell(v, org, inv, n):
+        c = (v - org) * inv
+        return 0 if c <= 0 else (n - 1 if c >= n - 1 else int(c))
+
+    for c1 in range(cell(lo1 - margin, g[5], g[7], g1), cell(hi1 + margin, g[5], g[7], g1) + 1):
+        for c0 in range(cell(lo0 - margin, g[4], g[6], g0), cell(hi0 + margin, g[4], g[6], g0) + 1):
+            out.add(c1 * g0 + c0)
+    return out
+
+
+@pytest.mark.parametrize("builder", ["mma", "mla", "dmd"])
+def test_group_grid_is_a_superset(builder):
+    comp = {"mma": lambda: oa.MMA(origin=[15, 0, 0], N=(16, 16), pitch=0.2, roc=28, n=1.5, thickness=0.1, reflectivity=1, transmission=0),
+            "mla": lambda: oa.MLA([3, 1, 0], N=(9, 7), pitch=0.4, focal_length=3.0, radius=0.2).RotZ(0.3),
+            "dmd": lambda: oa.DMD([2, -6, 0], N=(8, 6), pitch=0.5, tilt_angle=np.pi / 5).RotY(0.2)}[builder]()
+    scene = oa.compile_scene([comp])
+    nodes = scene.node_table()
+    assert nodes["flags"][0] & abi.NODE_GRID, "expected a gridded group"
+    aux = np.ctypeslib.as_array(scene.aux)[: scene.n_aux]
+    g = aux[nodes["aux"][0]:]
+    cells = int(g[2] * g[3])
+    start = g[9:9 + cells + 1].astype(int)
+    items = g[9 + cells + 1: 9 + cells + 1 + start[-1]].astype(int)
+    kids = np.arange(1, nodes["end"][0])
+    boxes = [tuple(nodes["aabb"][k]) for k in kids]
+    rng = np.random.default_rng(5)
+    o, d = _rays(rng, nodes["aabb"][0], 400)
+    checked = 0
+    for k in range(len(o)):
+        t1, t2, hit = solve_ray_bboxes_intersections(o[k], d[k], tuple(nodes["aabb"][0]))
+        if not hit[0]:
+            continue
+        _, _, child_hit = solve_ray_bboxes_intersections(o[k], d[k], boxes)
+        listed = set()
+        for c in _footprint_cells(g, o[k], d[k], float(t1[0]), float(t2[0])):
+            listed.update(items[start[c]:start[c + 1]].tolist())
+        missing = set(kids[child_hit].tolist()) - listed
+        assert not missing, (k, missing)
+        checked += int(child_hit.sum())
+    assert checked > 100
+
+
+def test_root_grid_lists_every_component_in_the_cells_it_overlaps():
+    scene = oa.compile_scene(scenes.cfg3_components(oa))
+    assert scene.root_grid >= 0
+    nodes = scene.node_table()
+    aux = np.ctypeslib.as_array(scene.aux)[: scene.n_aux]
+    g = aux[scene.root_grid:]
+    a0, a1, g0, g1 = (int(g[k]) for k in range(4))
+    cells = g0 * g1
+    start = g[11:11 + cells + 1].astype(int)
+    items = g[11 + cells + 1: 11 + cells + 1 + start[-1]].astype(int)
+    tops, i = [], 0
+    while i < scene.n_nodes:
+        tops.append(i)
+        i = int(nodes["end"][i])
+    assert sorted(set(items.tolist())) == tops
+    for t in tops:
+        box = nodes["aabb"][t].reshape(3, 2)
+        for c1 in range(g1):
+            for c0 in range(g0):
+                lo0, lo1 = g[4] + c0 * g[9], g[5] + c1 * g[10]
+                overlaps = (box[a0, 0] <= lo0 + g[9] and box[a0, 1] >= lo0 and box[a1, 0] <= lo1 + g[10] and box[a1, 1] >= lo1)
+                if overlaps:
+                    assert t in items[start[c1 * g0 + c0]:start[c1 * g0 + c0 + 1]]
+
+
+def test_no_grids_when_a_leaf_is_count_limited():
+    comps = scenes.cfg3_components(oa) + [oa.Mirror([40, 0, 0], radius=1, max_interact_count=3)]
+    scene = oa.compile_scene(comps)
+    assert scene.root_grid < 0
+    assert oa.compile_scene(scenes.cfg3_components(oa), accelerate=False).root_grid < 0
