@@ -566,6 +566,10 @@ template <class T> static void fill_blob(const ot_scene_desc* s, std::vector<uin
         d.refl = (T)h.reflectivity; d.trans = (T)h.transmission; d.focal = (T)h.focal_length; d.roc = (T)h.roc;
         d.inv_focal = (T)(h.focal_length != 0.0 ? 1.0 / h.focal_length : 0.0);
         d.r2 = (T)(h.p[0] * h.p[0]);
+        if (h.shape == OT_SHAPE_SPHERE) {  // cap aperture radius squared when the cap is shallower than a hemisphere, else 0
+            const double R = h.p[0], ht = h.p[1];
+            d.r2 = (T)(ht < R ? R * R - (R - ht) * (R - ht) : 0.0);
+        }
         d.pad0 = d.pad1 = (T)0;
         d.kind = h.kind; d.end = h.end; d.flags = h.flags; d.shape = h.shape; d.inter = h.interaction;
         d.mat1 = h.mat1; d.mat2 = h.mat2; d.roc_kind = h.roc_kind; d.max_count = h.max_interact_count;

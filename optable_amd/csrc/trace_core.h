@@ -178,11 +178,34 @@ template <class T> __device__ __forceinline__ T sag(const DNode<T>& nd, T r) {
     const T EFL = nd.p[1], n = nd.p[2];  // component_group.py:1061-1064
     return (EFL / (n + T(1))) * (T(-1) + sqrt_t(T(1) + (n + T(1)) / (n - T(1)) * r2 / (EFL * EFL)));
 }
+// fp64: the reference's central differences, h = 1e-4*radius, reproduced term by term.
+// fp32: the differences would lose 4-5 digits to cancellation (F ~ 0.3, h ~ 2.5e-4), far more than
+// their own O(h^2) ~ 1e-8 truncation error, so the float kernel uses the analytic derivatives —
+// closer to what the reference computes in double than a float finite difference could be.
 template <class T> __device__ __forceinline__ T sag_d1(const DNode<T>& nd, T r) {
+    if (sizeof(T) == 4) {
+        const T r2 = r * r;
+        if (nd.shape == OT_SHAPE_ASPHERE_PARAM) {
+            const T R = nd.p[1], sq = sqrt_t(T(1) - (T(1) + nd.p[2]) * r2 / (R * R));
+            return r / (R * sq) + r * r2 * (T(4) * nd.p[3] + r2 * (T(6) * nd.p[4] + r2 * T(8) * nd.p[5]));
+        }
+        const T E = nd.p[1], n = nd.p[2], A = (n + T(1)) / (n - T(1));
+        return A * r / ((n + T(1)) * E * sqrt_t(T(1) + A * r2 / (E * E)));
+    }
     const T h = T(1e-4) * nd.p[0];
     return (sag(nd, r + h) - sag(nd, r - h)) / (T(2) * h);
 }
 template <class T> __device__ __forceinline__ T sag_d2(const DNode<T>& nd, T r) {
+    if (sizeof(T) == 4) {
+        const T r2 = r * r;
+        if (nd.shape == OT_SHAPE_ASPHERE_PARAM) {
+            const T R = nd.p[1], k1 = T(1) + nd.p[2], sq = sqrt_t(T(1) - k1 * r2 / (R * R));
+            return T(1) / (R * sq) + k1 * r2 / (R * R * R * sq * sq * sq) +
+                   r2 * (T(12) * nd.p[3] + r2 * (T(30) * nd.p[4] + r2 * T(56) * nd.p[5]));
+        }
+        const T E = nd.p[1], n = nd.p[2], A = (n + T(1)) / (n - T(1)), u = sqrt_t(T(1) + A * r2 / (E * E));
+        return A / ((n + T(1)) * E) * (T(1) / u - A * r2 / (E * E * u * u * u));
+    }
     const T h = T(1e-4) * nd.p[0];
     return (sag(nd, r + h) - T(2) * sag(nd, r) + sag(nd, r - h)) / (h * h);
 }
@@ -254,7 +277,12 @@ __device__ __forceinline__ bool planar_boundary(const Scene<T>& sc, const DNode<
 template <class T> __device__ __forceinline__ bool curved_boundary(const Scene<T>& sc, const DNode<T>& nd, T Px, T Py, T Pz) {
     switch (nd.shape) {
         case OT_SHAPE_POLYGON3D: return poly_inside(sc.aux + nd.aux, Px, Py, Pz);
-        case OT_SHAPE_SPHERE: return nd.p[0] - nd.p[1] - T(1e-12) <= Px && Px <= nd.p[0] + T(1e-12);
+        case OT_SHAPE_SPHERE:
+            // surfaces.py:300-303 bounds the cap by x.  For a shallow cap (R >> aperture) that test is
+            // ill-conditioned in single precision (dr = dx*R/r), so the fp32 kernel applies the same
+            // bound to the radial distance instead: r^2 <= R^2 - (R-h)^2 (host-computed in fp64).
+            if (sizeof(T) == 4 && nd.r2 > T(0)) return Px > T(0) && Py * Py + Pz * Pz <= nd.r2;
+            return nd.p[0] - nd.p[1] - T(1e-12) <= Px && Px <= nd.p[0] + T(1e-12);
         case OT_SHAPE_ASPHERE_PARAM:
         case OT_SHAPE_ASPHERE_EXACT: return sqrt_t(Py * Py + Pz * Pz) <= nd.p[0] + T(1e-12);
         case OT_SHAPE_CYLINDER: {
@@ -348,7 +376,11 @@ __device__ __forceinline__ bool hit_leaf(const Scene<T>& sc, const DNode<T>& nd,
         for (int i = 1; i < 10; ++i) {
             const T tr = (i == 9) ? b : a + T(i) * step;
             const T gr = surf_g(sc, nd, ox, oy, oz, dx, dy, dz, tr, (T*)nullptr);
-            if (gl * gr < T(0)) {
+            // fp64: the reference's strict product test (optical_component.py:131).  fp32: |P| - R is
+            // quantised to ~2e-6 at R ~ 30, so a sample lands on g == 0 exactly for several percent of
+            // the rays and the product test would drop those roots; compare signs instead.
+            const bool crossing = sizeof(T) == 4 ? ((gl < T(0)) != (gr < T(0))) : (gl * gr < T(0));
+            if (crossing) {
                 const T t = polish_root(sc, nd, ox, oy, oz, dx, dy, dz, tl, tr, gl, gr);
                 if (t >= T(0) && abs_t(t) >= EPS && t <= len) {
                     const T X = ox + t * dx, Y = oy + t * dy, Z = oz + t * dz;

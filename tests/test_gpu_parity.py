@@ -315,3 +315,32 @@ def test_acceleration_grids_do_not_change_results(case):
     valid = fast.valid_mask()
     for f in abi.SEG_FIELDS + ("ray", "surface"):
         assert torch.equal(fast.field(f)[valid], plain.field(f)[valid]), f
+
+
+@pytest.mark.parametrize("case,min_same", [("cfg3", 0.97), ("cfg5", 0.90)])
+def test_fp32_heavy_scenes_track_fp64(case, min_same):
+    """BASELINE cfg 3 / cfg 5 are quoted in fp32.  Single precision cannot promise per-ray identity over
+    20-50 bounces (a ray grazing an aperture edge flips between hit and miss at 6e-8 relative), so the
+    contract is statistical: at least `min_same` of the rays visit exactly the same surface sequence as
+    fp64, and on those rays every segment origin agrees to 2e-3 absolute (scene size ~30, path ~100)."""
+    import optable_amd as oa
+    from optable_amd.batch import RayBatch
+
+    comps, gen, n, K, _ = CASES[case]
+    n = min(n, 8000)
+    table = _table(comps(oa))
+    o, d = gen(n)
+    q = 1j * np.pi * scenes.W0**2 / scenes.WL
+    s64 = table.trace_batch(RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=q), max_segments=K)
+    s32 = table.trace_batch(RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=q, precision="f32"), max_segments=K)
+    c64, c32 = s64.count.cpu().numpy(), s32.count.cpu().numpy()
+    surf64 = s64.surface.cpu().numpy().reshape(K, n)
+    surf32 = s32.surface.cpu().numpy().reshape(K, n)
+    valid = np.arange(K)[:, None] < c64[None, :]
+    same = (c64 == c32) & np.all((surf64 == surf32) | ~valid, axis=0)
+    assert same.mean() >= min_same, same.mean()
+    for f in ("ox", "oy", "oz"):
+        a = s64.field(f).cpu().numpy().reshape(K, n)
+        b = s32.field(f).cpu().numpy().reshape(K, n).astype(np.float64)
+        err = np.abs(a - b)[valid & same[None, :]]
+        assert err.max() < 2e-3, (f, err.max())
