@@ -70,7 +70,7 @@ template <class T> static SegsT<T> view(const ot_segments* s) {
 // scene blob: [DNode<T> x n_nodes][DMat<T> x n_mats][T x n_aux], staged into LDS word by word
 struct SceneBlob {
     const uint32_t* words;
-    int32_t n_words, n_nodes, n_mats, root;
+    int32_t n_words, n_nodes, n_mats, root, cache_mat;
 };
 
 template <class T> __device__ __forceinline__ Scene<T> bind_scene(const uint32_t* base, const SceneBlob& b, T unit) {
@@ -79,6 +79,8 @@ template <class T> __device__ __forceinline__ Scene<T> bind_scene(const uint32_t
     sc.mats = reinterpret_cast<const DMat<T>*>(sc.nodes + b.n_nodes);
     sc.aux = reinterpret_cast<const T*>(sc.mats + b.n_mats);
     sc.n_nodes = b.n_nodes;
+    sc.n_mats = b.n_mats;
+    sc.cache_mat = b.cache_mat;
     sc.root = b.root;
     sc.unit = unit;
     return sc;
@@ -131,9 +133,11 @@ __global__ __launch_bounds__(256, MINW) void k_trace_fused(SceneBlob blob, T uni
         bool active = i < n;
         RayState<T> r = {};
         int32_t cls = 0, used = 0;
+        MatCache<T> mc = {T(1)};
         if (active) {
             const int32_t fl = in.flags[i];
             r = load_ray(in, i, fl);
+            if constexpr (F & F_REFRACT) mc = make_matcache(sc, r.wl);
             cls = in.id[i];
             if (fl & OT_RAY_DEAD) {  // optical_component.py:349: a dead ray hits nothing and is returned as is
                 store_segment<T, NT>(out, i, r, r.len, (int32_t)i, -2);
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(256, MINW) void k_trace_fused(SceneBlob blob, T uni
                 } else {
                     store_segment<T, NT>(out, slot, r, h.t, (int32_t)i, sc.nodes[h.node].leaf_id);
                     RayState<T> child;
-                    const int nk = interact<T, F, 1>(sc, r, h, &child);
+                    const int nk = interact<T, F, 1>(sc, r, h, &child, mc);
                     if (nk == 1) r = child;
                     else {
                         active = false;
@@ -242,7 +246,9 @@ __global__ __launch_bounds__(256) void k_trace_blocked(SceneBlob blob, T unit, R
                     } else {
                         store_segment<T, NT>(out, slot, r, h.t, (int32_t)i, sc.nodes[h.node].leaf_id);
                         RayState<T> child;
-                        const int nk = interact<T, F, 1>(sc, r, h, &child);
+                        MatCache<T> mc = {T(1)};
+                        if constexpr (F & F_REFRACT) mc = make_matcache(sc, r.wl);
+                        const int nk = interact<T, F, 1>(sc, r, h, &child, mc);
                         if (nk == 1) {
                             survive = k + 1 < K;
                             if (survive) {
@@ -354,7 +360,7 @@ __global__ __launch_bounds__(256) void k_gen_trace(SceneBlob blob, double unit, 
                 else if (h.node < 0) store_segment(out, slot, r, r.len, t, -1);
                 else store_segment(out, slot, r, h.t, t, sc.nodes[h.node].leaf_id);
             }
-            if (!dead && h.node >= 0) nk = interact<double, F_ALL, 2>(sc, r, h, ch);
+            if (!dead && h.node >= 0) nk = interact<double, F_ALL, 2>(sc, r, h, ch, make_matcache(sc, r.wl));
             for (int c = 0; c < nk; ++c) {
                 const int64_t s = 2 * i + c;
                 const RayState<double>& k = ch[c];
@@ -498,6 +504,7 @@ struct ot_ctx {
     double unit = 1e-2;
     uint32_t features = 0;
     int32_t root_grid = -1;  // aux offset of the top-level grid
+    int32_t cache_mat = -1;  // first Sellmeier material
     int32_t* slot_max = nullptr;  // device [n_slots]: max_interact_count per count slot
     // timing
     bool timing = false;
@@ -742,6 +749,9 @@ int ot_scene_upload(ot_ctx* c, const ot_scene_desc* s) {
     c->n_slots = s->n_count_slots; c->max_children = s->max_children; c->unit = s->unit;
     c->features = scene_features(s);
     c->root_grid = s->root_grid;
+    c->cache_mat = -1;
+    for (int i = 0; i < s->n_materials; ++i)
+        if (s->materials[i].kind == OT_MAT_SELLMEIER) { c->cache_mat = i; break; }
     if (c->root_grid >= 0) c->features |= F_ROOT | F_AABB;
     if (c->slot_max) { (void)hipFree(c->slot_max); c->slot_max = nullptr; }
     if (s->n_count_slots > 0) {
@@ -799,6 +809,7 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
     blob.n_nodes = c->n_nodes;
     blob.n_mats = c->n_mats;
     blob.root = c->root_grid;
+    blob.cache_mat = c->cache_mat;
     const int block = 256;
     const bool in_lds = bytes <= (size_t)c->opt_lds_limit_kb * 1024;
     const int64_t blocks_needed = (n + block - 1) / block;
@@ -851,7 +862,8 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
     if (rc) return rc;
     using Kern = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, SegsT<T>, int32_t*, int32_t*, int32_t);
     const int fi = (need & ~FA) == 0 ? 0 : ((need & ~FB) == 0 ? 1 : 2);
-    const int mw = (c->opt_minw == 4 && fi < 2) ? 1 : 0, nt = c->opt_nt ? 1 : 0;
+    // the 128-register cap pays for the mirror/lens kernel only; the Snell kernel would spill (fp64: 145 VGPRs)
+    const int mw = (c->opt_minw == 4 && (fi == 0 || (fi == 1 && !f64))) ? 1 : 0, nt = c->opt_nt ? 1 : 0;
 #define OT_K(FM, L, W, N) k_trace_fused<T, FM, L, W, N>
 #define OT_ROW(FM) {{{OT_K(FM, false, 1, false), OT_K(FM, false, 1, true)}, {OT_K(FM, false, 4, false), OT_K(FM, false, 4, true)}}, \
                     {{OT_K(FM, true, 1, false), OT_K(FM, true, 1, true)}, {OT_K(FM, true, 4, false), OT_K(FM, true, 4, true)}}}
@@ -946,6 +958,7 @@ int ot_trace_generation_f64(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
     blob.n_nodes = c->n_nodes;
     blob.n_mats = c->n_mats;
     blob.root = c->root_grid;
+    blob.cache_mat = c->cache_mat;
     const bool in_lds = c->bytes64 <= (size_t)c->opt_lds_limit_kb * 1024;
     const int64_t cap = (int64_t)c->n_cus * 4;
     const int grid = (int)(g1 < cap ? g1 : cap);

@@ -82,6 +82,8 @@ template <class T> struct Scene {
     const DMat<T>* mats;
     const T* aux;
     int32_t n_nodes;
+    int32_t n_mats;
+    int32_t cache_mat;  // first Sellmeier material, -1 when every material is a constant
     int32_t root;  // aux offset of the top-level grid, -1 when the scene has none
     T unit;
 };
@@ -158,11 +160,28 @@ __device__ __forceinline__ bool slab_inv(T ox, T oy, T oz, const RayInv<T>& ri, 
 // material.py:54-72, 106-120
 template <class T> __device__ __forceinline__ T material_index(const DMat<T>& m, T wavelength_m) {
     if (m.kind == OT_MAT_CONST) return m.n;
+    // 1 + sum_i B_i L^2/(L^2 - C_i) over a common denominator: one division instead of three
     const T um = wavelength_m / T(1e-6), um2 = um * um;
-    T n2 = T(1);
-#pragma unroll
-    for (int k = 0; k < 3; ++k) n2 += m.B[k] * um2 / (um2 - m.C[k]);
-    return sqrt_t(n2);
+    const T p0 = um2 - m.C[0], p1 = um2 - m.C[1], p2 = um2 - m.C[2];
+    const T num = m.B[0] * p1 * p2 + m.B[1] * p0 * p2 + m.B[2] * p0 * p1;
+    return sqrt_t(T(1) + um2 * num / (p0 * p1 * p2));
+}
+
+// n(lambda) depends only on the ray's wavelength and the material, and a ray keeps its wavelength
+// (ray.py:441-444), so the kernels evaluate the scene's first dispersive material once per ray
+// instead of at every refraction (the reference re-evaluates per hit, optical_component.py:627-628).
+// One cached value: more would cost the registers that keep 4 waves per SIMD resident.
+template <class T> struct MatCache {
+    T v;
+};
+template <class T> __device__ __forceinline__ MatCache<T> make_matcache(const Scene<T>& sc, T wl) {
+    MatCache<T> m = {T(1)};
+    if (sc.cache_mat >= 0) m.v = material_index(sc.mats[sc.cache_mat], wl * sc.unit);
+    return m;
+}
+template <class T> __device__ __forceinline__ T cached_index(const Scene<T>& sc, const MatCache<T>& m, int idx, T wl) {
+    if (idx == sc.cache_mat) return m.v;
+    return material_index(sc.mats[idx], wl * sc.unit);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -696,7 +715,8 @@ __device__ __forceinline__ void surf_normal(const Scene<T>& sc, const DNode<T>& 
 // the interaction emits (which can exceed MAXK = 1: the fused kernel treats that as "this tree
 // branches" and hands the ray back to the host, see k_trace_fused).
 template <class T, uint32_t F, int MAXK>
-__device__ __forceinline__ int interact(const Scene<T>& sc, const RayState<T>& r, const Hit<T>& h, RayState<T>* kids) {
+__device__ __forceinline__ int interact(const Scene<T>& sc, const RayState<T>& r, const Hit<T>& h, RayState<T>* kids,
+                                        const MatCache<T>& mc) {
     const DNode<T>& nd = sc.nodes[h.node];
     if (nd.inter == OT_INT_BLOCK) return 0;
     T dx, dy, dz;  // incoming direction in the leaf frame
@@ -737,8 +757,7 @@ __device__ __forceinline__ int interact(const Scene<T>& sc, const RayState<T>& r
         return nk;
     }
     if constexpr (F & F_REFRACT) {  // optical_component.py:617-717
-        const T wl_m = r.wl * sc.unit;
-        const T n1 = material_index(sc.mats[nd.mat1], wl_m), n2 = material_index(sc.mats[nd.mat2], wl_m);
+        const T n1 = cached_index(sc, mc, nd.mat1, r.wl), n2 = cached_index(sc, mc, nd.mat2, r.wl);
         T ROC = Num<T>::inf();
         if (nd.roc_kind == OT_ROC_CONST) ROC = nd.roc;
         if constexpr (F & F_CURVED) {
@@ -753,9 +772,14 @@ __device__ __forceinline__ int interact(const Scene<T>& sc, const RayState<T>& r
         const T ratio = nin / nout;
         T qtr = r.qr, qti = r.qi, qrr = r.qr, qri = r.qi;
         if (r.has_q) {
-            const T Cc = (nin - nout) / (ROC * nout), Cr = T(2) / ROC;
-            cdiv(q1r, q1i, Cc * q1r + ratio, Cc * q1i, qtr, qti);
-            cdiv(q1r, q1i, Cr * q1r + T(1), Cr * q1i, qrr, qri);
+            if (nd.roc_kind == OT_ROC_INF) {  // flat interface: C = 0, so q_t = q1 / (nin/nout) and q_r = q1
+                const T back = T(1) / ratio;
+                qtr = q1r * back; qti = q1i * back; qrr = q1r; qri = q1i;
+            } else {
+                const T Cc = (nin - nout) / (ROC * nout), Cr = T(2) / ROC;
+                cdiv(q1r, q1i, Cc * q1r + ratio, Cc * q1i, qtr, qti);
+                cdiv(q1r, q1i, Cr * q1r + T(1), Cr * q1i, qrr, qri);
+            }
         }
         const T ci = min_t(max_t(dn, T(-1)), T(1));
         const T si = sqrt_t(T(1) - ci * ci), st = ratio * si;

@@ -19,6 +19,8 @@ import scenes
 eng = get_engine()
 if os.environ.get('LDSKB'):
     eng.set_option(abi.OPT_LDS_LIMIT_KB, int(os.environ['LDSKB']))
+if os.environ.get('MINW'):
+    eng.set_option(abi.OPT_MIN_WAVES, int(os.environ['MINW']))
 if os.environ.get('BPC'):
     eng.set_option(abi.OPT_BLOCKS_PER_CU, int(os.environ['BPC']))
 Q = lambda wl: 1j * np.pi * scenes.W0**2 / wl
