@@ -188,6 +188,8 @@ const char* ot_last_error(void);
 int ot_ctx_create(int device, void* stream, ot_ctx** out);
 int ot_ctx_destroy(ot_ctx* ctx);
 int ot_ctx_synchronize(ot_ctx* ctx);
+/* Re-target the ctx at another stream of the same device (synchronises the old one first). */
+int ot_ctx_set_stream(ot_ctx* ctx, void* stream);
 
 /* Copies the scene (converted to the f32 layout as well) to the device. */
 int ot_scene_upload(ot_ctx* ctx, const ot_scene_desc* scene);
@@ -245,8 +247,7 @@ int ot_timing_enable(ot_ctx* ctx, int enabled);
 int ot_timing_read(ot_ctx* ctx, double* total_ms, int64_t* launches);
 int ot_timing_reset(ot_ctx* ctx);
 
-/* Launch-geometry knobs (0 = library default); for tuning and tests only. */
-int ot_set_launch(ot_ctx* ctx, int32_t block_threads, int32_t rays_per_lane);
+/* Tuning knobs (tools/tune.py, tests); the defaults are the measured best on MI355X. */
 enum ot_option {
     OT_OPT_NT_STORES = 1,      /* segment records written with non-temporal stores (0/1)        */
     OT_OPT_MIN_WAVES = 2,      /* 0: compiler's choice; 4: cap registers for 4 waves per SIMD  */

@@ -77,6 +77,7 @@ SYMBOLS = {
     "ot_ctx_create": (C.c_int, [C.c_int, _vp, C.POINTER(_vp)]),
     "ot_ctx_destroy": (C.c_int, [_vp]),
     "ot_ctx_synchronize": (C.c_int, [_vp]),
+    "ot_ctx_set_stream": (C.c_int, [_vp, _vp]),
     "ot_scene_upload": (C.c_int, [_vp, C.POINTER(OtSceneDesc)]),
     "ot_trace_f64": (C.c_int, _TRACE_ARGS),
     "ot_trace_f32": (C.c_int, _TRACE_ARGS),
@@ -87,7 +88,6 @@ SYMBOLS = {
     "ot_timing_enable": (C.c_int, [_vp, C.c_int]),
     "ot_timing_read": (C.c_int, [_vp, C.POINTER(C.c_double), C.POINTER(_i64)]),
     "ot_timing_reset": (C.c_int, [_vp]),
-    "ot_set_launch": (C.c_int, [_vp, _i32, _i32]),
     "ot_set_option": (C.c_int, [_vp, _i32, _i32]),
     "ot_bench_stream_f64": (C.c_int, [_vp, C.POINTER(OtRays), _i64, _i32, C.POINTER(OtSegments), _vp]),
 }

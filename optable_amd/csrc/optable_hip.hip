@@ -493,7 +493,6 @@ struct Scratch {
 struct ot_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    bool own_stream = false;
     int n_cus = 256;
     size_t lds_limit = 64 * 1024;
     // scene
@@ -513,7 +512,6 @@ struct ot_ctx {
     double total_ms = 0.0;
     int64_t launches = 0;
     // knobs
-    int32_t block_threads = 256, rays_per_lane = 1;
     // scene images above this stay in global memory (L2): a 100+ KB LDS image leaves one block per CU,
     // and on cfg 5 the lost occupancy cost 1.5x (tools/bench_configs.py)
     int32_t opt_lds_limit_kb = 64;
@@ -716,7 +714,6 @@ int ot_ctx_destroy(ot_ctx* c) {
     if (c->scan_tmp.p) (void)hipFree(c->scan_tmp.p);
     if (c->mon.p) (void)hipFree(c->mon.p);
     if (c->blocked.p) (void)hipFree(c->blocked.p);
-    if (c->own_stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
 }
@@ -724,6 +721,15 @@ int ot_ctx_destroy(ot_ctx* c) {
 int ot_ctx_synchronize(ot_ctx* c) {
     if (!c) return fail(OT_ERR_INVALID, "ctx is NULL");
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int ot_ctx_set_stream(ot_ctx* c, void* stream) {
+    if (!c) return fail(OT_ERR_INVALID, "ctx is NULL");
+    int rc = flush_events(c);  // pending timing events belong to the old stream
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->stream = (hipStream_t)stream;
     return 0;
 }
 
@@ -1091,14 +1097,4 @@ int ot_timing_reset(ot_ctx* c) {
     c->launches = 0;
     return 0;
 }
-int ot_set_launch(ot_ctx* c, int32_t block_threads, int32_t rays_per_lane) {
-    if (!c) return fail(OT_ERR_INVALID, "ctx is NULL");
-    if (block_threads != 0 && block_threads != 64 && block_threads != 128 && block_threads != 256 && block_threads != 512)
-        return fail(OT_ERR_INVALID, "block_threads must be 0, 64, 128, 256 or 512");
-    if (rays_per_lane < 0 || rays_per_lane > 2) return fail(OT_ERR_INVALID, "rays_per_lane must be 0, 1 or 2");
-    c->block_threads = block_threads ? block_threads : 256;
-    c->rays_per_lane = rays_per_lane ? rays_per_lane : 1;
-    return 0;
-}
-
 }  // extern "C"

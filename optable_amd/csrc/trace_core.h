@@ -121,6 +121,23 @@ __device__ __forceinline__ float rsqrt_t(float x) {
     return y * fmaf(-0.5f * x * y, y, 1.5f);
 }
 
+// a/b and 1/b without the IEEE special-case scaffolding (v_div_scale / v_div_fmas / v_div_fixup):
+// hardware reciprocal estimate + two Newton steps + one residual correction, <= 1 ulp for normal
+// operands.  Callers never pass b == 0 (guarded) or denormals (lengths, direction components).
+__device__ __forceinline__ double rcp_t(double b) {
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
+    r = fma(fma(-b, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double div_t(double a, double b) {
+    const double r = rcp_t(b);
+    const double q = a * r;
+    return fma(fma(-b, q, a), r, q);
+}
+__device__ __forceinline__ float rcp_t(float b) { return 1.0f / b; }
+__device__ __forceinline__ float div_t(float a, float b) { return a / b; }
+
 // ---------------------------------------------------------------------------------------------
 // solver.py:5-48 with the per-axis reciprocal hoisted out (RayInv is built once per segment).
 template <class T> struct RayInv {
@@ -133,7 +150,7 @@ template <class T> __device__ __forceinline__ RayInv<T> make_inv(T dx, T dy, T d
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) {
         r.par[ax] = abs_t(d[ax]) <= T(1e-8);  // np.isclose(d, 0)
-        r.inv[ax] = T(1) / d[ax];
+        r.inv[ax] = rcp_t(d[ax]);  // unused when par[ax] (d ~ 0)
     }
     return r;
 }
@@ -364,32 +381,22 @@ __device__ __forceinline__ T polish_root(const Scene<T>& sc, const DNode<T>& nd,
 }
 
 // ---------------------------------------------------------------------------------------------
-// intersect_point_local for one leaf; ray already in the leaf's frame.
+// intersect_point_local, non-planar branch (optical_component.py:197-233), ray already in the
+// leaf's frame: local-box slab -> [t1, min(t2, 100)] -> 10-point sign scan -> first root that is
+// far enough, inside the length and inside the shape's boundary.  Planar leaves: test_leaf.
 template <class T, uint32_t F>
 __device__ __forceinline__ bool hit_leaf(const Scene<T>& sc, const DNode<T>& nd, T ox, T oy, T oz, T dx, T dy, T dz, T len, T& t_out,
                                          T& Px, T& Py, T& Pz) {
-    const T EPS = Num<T>::eps_t();
-    const int sh = nd.shape;
-    const bool planar = sh == OT_SHAPE_CIRCLE || sh == OT_SHAPE_RECT || sh == OT_SHAPE_POLYGON2D || sh == OT_SHAPE_CSG;
-    if (!(F & F_CURVED) || planar) {
-        if (!planar) return false;     // cannot happen when the mask matches the scene
-        if (dx == T(0)) return false;  // parallel: t = 0 or none, both rejected (optical_component.py:173-190)
-        const T t = -ox / dx;
-        if (abs_t(t) < EPS || t < T(0) || t > len) return false;
-        Px = ox + t * dx; Py = oy + t * dy; Pz = oz + t * dz;
-        if (!planar_boundary<T, F>(sc, nd, Px, Py, Pz)) return false;
-        t_out = t;
-        return true;
-    }
     if constexpr (F & F_CURVED) {
-        if (sh == OT_SHAPE_POINT) return false;
+        const T EPS = Num<T>::eps_t();
+        if (nd.shape == OT_SHAPE_POINT) return false;  // f = |P| never changes sign (surfaces.py:73-80)
         T t1, t2;
         const RayInv<T> li = make_inv(dx, dy, dz);
         slab_inv(ox, oy, oz, li, nd.lbox, t1, t2);
         if (t2 + EPS < t1) return false;
         t1 = max_t(t1, T(0));
         t2 = min_t(t2, T(100));
-        // np.linspace(t1 - EPS, t2 + EPS, 10): strict sign change per sub-interval, roots ascending
+        // np.linspace(t1 - EPS, t2 + EPS, 10): sign change per sub-interval, roots ascending
         const T a = t1 - EPS, b = t2 + EPS, step = (b - a) / T(9);
         T tl = a, gl = surf_g(sc, nd, ox, oy, oz, dx, dy, dz, a, (T*)nullptr);
         for (int i = 1; i < 10; ++i) {
@@ -463,9 +470,12 @@ template <int GATE> __device__ __forceinline__ bool count_gate(const GateCtx& g,
 // One leaf against one ray; updates `best`.  ORDERED = the caller visits leaves in increasing
 // node index (strict '<' keeps the first minimum); otherwise an exact tie goes to the lower index,
 // which is the same rule.
-template <class T, uint32_t F, int GATE, bool ORDERED>
+// DEFER_AABB: the caller has NOT yet applied this leaf's own AABB test (component_group.py:104-107).
+// A planar leaf is cheaper to reject by its sign/distance tests than by the slab test, and a hit
+// needs both, so the slab test runs last and only for leaves that would otherwise be hits.
+template <class T, uint32_t F, int GATE, bool ORDERED, bool DEFER_AABB = false>
 __device__ __forceinline__ void test_leaf(const Scene<T>& sc, const DNode<T>& nd, int idx, const RayState<T>& r, Hit<T>& best,
-                                          const GateCtx& gate) {
+                                          const GateCtx& gate, const RayInv<T>* ri = nullptr) {
     if (GATE == GATE_PROBE && nd.max_count < 0) return;  // the probe pass only looks at limited leaves
     const T rx = r.ox - nd.org[0], ry = r.oy - nd.org[1], rz = r.oz - nd.org[2];
     const int sh = nd.shape;
@@ -483,14 +493,22 @@ __device__ __forceinline__ void test_leaf(const Scene<T>& sc, const DNode<T>& nd
         const T s = -lox;
         if (ldx == T(0) || s == T(0) || ((s > T(0)) != (ldx > T(0)))) return;
         if (!limited && abs_t(s) > best.t * abs_t(ldx) * (T(1) + T(1e-9))) return;
-        t = s / ldx;
+        t = div_t(s, ldx);
         if (abs_t(t) < Num<T>::eps_t() || t < T(0) || t > r.len) return;
         if (!limited && !(t < best.t || (!ORDERED && t == best.t && idx < best.node))) return;
+        if (DEFER_AABB && (nd.flags & OT_NODE_CHECK_AABB)) {  // the leaf's own AABB test, after the cheap rejections
+            T u1, u2;
+            if (!slab_inv(r.ox, r.oy, r.oz, *ri, nd.aabb, u1, u2)) return;
+        }
         const T loy = nd.M[1] * rx + nd.M[4] * ry + nd.M[7] * rz, loz = nd.M[2] * rx + nd.M[5] * ry + nd.M[8] * rz;
         const T ldy = nd.M[1] * r.dx + nd.M[4] * r.dy + nd.M[7] * r.dz, ldz = nd.M[2] * r.dx + nd.M[5] * r.dy + nd.M[8] * r.dz;
         Px = lox + t * ldx; Py = loy + t * ldy; Pz = loz + t * ldz;
         if (!planar_boundary<T, F>(sc, nd, Px, Py, Pz)) return;
     } else {
+        if (DEFER_AABB && (nd.flags & OT_NODE_CHECK_AABB)) {  // curved leaves: the slab test is the cheap one
+            T u1, u2;
+            if (!slab_inv(r.ox, r.oy, r.oz, *ri, nd.aabb, u1, u2)) return;
+        }
         T ox, oy, oz, dx, dy, dz;
         to_local(nd, rx, ry, rz, ox, oy, oz);
         to_local(nd, r.dx, r.dy, r.dz, dx, dy, dz);
@@ -644,7 +662,7 @@ __device__ __forceinline__ Hit<T> nearest_hit(const Scene<T>& sc, const RayState
         if constexpr (F & F_AABB) {
             bool inside = false;
             T t1 = T(0), t2 = T(0);
-            if (nd.flags & OT_NODE_CHECK_AABB) {
+            if (nd.kind == OT_NODE_GROUP && (nd.flags & OT_NODE_CHECK_AABB)) {
                 if (i >= skip_until) {
                     inside = slab_inv(r.ox, r.oy, r.oz, ri, nd.aabb, t1, t2);
                     if (!inside) skip_until = nd.end;
@@ -666,14 +684,14 @@ __device__ __forceinline__ Hit<T> nearest_hit(const Scene<T>& sc, const RayState
             }
         }
         if (i < skip_until) continue;
-        test_leaf<T, F, GATE, true>(sc, nd, i, r, best, gate);
+        test_leaf<T, F, GATE, true, (F & F_AABB) != 0>(sc, nd, i, r, best, gate, &ri);
     }
     return best;
 }
 
 // a / b for complex numbers with one real division
 template <class T> __device__ __forceinline__ void cdiv(T ar, T ai, T br, T bi, T& cr, T& ci) {
-    const T inv = T(1) / (br * br + bi * bi);
+    const T inv = rcp_t(br * br + bi * bi);
     cr = (ar * br + ai * bi) * inv;
     ci = (ai * br - ar * bi) * inv;
 }
@@ -769,11 +787,11 @@ __device__ __forceinline__ int interact(const Scene<T>& sc, const RayState<T>& r
         }
         T nin = n1, nout = n2;
         if (!(dn < T(0))) { nin = n2; nout = n1; ROC = -ROC; }
-        const T ratio = nin / nout;
+        const T ratio = div_t(nin, nout);
         T qtr = r.qr, qti = r.qi, qrr = r.qr, qri = r.qi;
         if (r.has_q) {
             if (nd.roc_kind == OT_ROC_INF) {  // flat interface: C = 0, so q_t = q1 / (nin/nout) and q_r = q1
-                const T back = T(1) / ratio;
+                const T back = rcp_t(ratio);
                 qtr = q1r * back; qti = q1i * back; qrr = q1r; qri = q1i;
             } else {
                 const T Cc = (nin - nout) / (ROC * nout), Cr = T(2) / ROC;

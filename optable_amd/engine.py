@@ -5,7 +5,6 @@ pointers.  If the library or a GPU is missing the constructor raises — there i
 """
 import ctypes as C
 
-import numpy as np
 import torch
 
 from . import abi
@@ -25,6 +24,11 @@ class Engine:
         stream = torch.cuda.current_stream(self.device).cuda_stream
         abi.check(self.lib.ot_ctx_create(device, C.c_void_p(stream), C.byref(self._ctx)), self.lib)
         self.scene = None
+
+    def use_stream(self, stream=None):
+        """Launch on `stream` (a torch.cuda.Stream; default: torch's current stream) from now on."""
+        handle = (stream or torch.cuda.current_stream(self.device)).cuda_stream
+        abi.check(self.lib.ot_ctx_set_stream(self._ctx, C.c_void_p(handle)), self.lib)
 
     def close(self):
         if self._ctx:
@@ -135,9 +139,6 @@ class Engine:
         ms, cnt = C.c_double(), C.c_int64()
         abi.check(self.lib.ot_timing_read(self._ctx, C.byref(ms), C.byref(cnt)), self.lib)
         return ms.value, cnt.value
-
-    def set_launch(self, block_threads=0, rays_per_lane=0):
-        abi.check(self.lib.ot_set_launch(self._ctx, block_threads, rays_per_lane), self.lib)
 
     def set_option(self, option, value):
         abi.check(self.lib.ot_set_option(self._ctx, option, value), self.lib)

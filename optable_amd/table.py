@@ -42,7 +42,6 @@ class OpticalTable:
         self.norender_set = set()
         self._bbox = _NO_BOX
         self.unit = kwargs.get("unit", 1e-2)
-        self._scene_cache = None
 
     # -- scene building (optical_table.py:25-43) ------------------------------------------------
     def add_components(self, component: Union[OpticalComponent, List]):
@@ -152,7 +151,6 @@ class OpticalTable:
     # -- List[Ray] plumbing ------------------------------------------------------------------------
     def _trace_objects(self, rays, cap):
         import torch
-        from .batch import RayBatch
 
         eng = _engine()
         scene = self.compile()

@@ -344,3 +344,30 @@ def test_fp32_heavy_scenes_track_fp64(case, min_same):
         b = s32.field(f).cpu().numpy().reshape(K, n).astype(np.float64)
         err = np.abs(a - b)[valid & same[None, :]]
         assert err.max() < 2e-3, (f, err.max())
+
+
+@pytest.mark.parametrize("prec,tol", [("f64", 1e-9), ("f32", 2e-4)])
+@pytest.mark.parametrize("case", ["cfg2", "cfg3", "cfg5"])
+def test_segment_chain_is_continuous(case, prec, tol):
+    """Oracle-free invariant for every kernel variant and precision: segment k+1 starts exactly where
+    segment k ended (origin + length*direction), directions are unit vectors, lengths are positive."""
+    import optable_amd as oa
+    from optable_amd.batch import RayBatch
+
+    comps, gen, n, K, _ = CASES[case]
+    n = min(n, 6000)
+    table = _table(comps(oa))
+    o, d = gen(n)
+    q = 1j * np.pi * scenes.W0**2 / scenes.WL
+    segs = table.trace_batch(RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=q, precision=prec), max_segments=K)
+    cnt = segs.count.cpu().numpy()
+    assert (cnt > 0).all()
+    f = {name: segs.field(name).cpu().numpy().reshape(K, n).astype(np.float64) for name in ("ox", "oy", "oz", "dx", "dy", "dz", "length")}
+    link = np.arange(K - 1)[:, None] < (cnt - 1)[None, :]   # segment k has a successor
+    for a in "xyz":
+        end = f["o" + a][:-1] + f["length"][:-1] * f["d" + a][:-1]
+        assert np.abs(end - f["o" + a][1:])[link].max() < tol * 30, a
+    valid = np.arange(K)[:, None] < cnt[None, :]
+    norm = np.sqrt(f["dx"] ** 2 + f["dy"] ** 2 + f["dz"] ** 2)
+    assert np.abs(norm - 1)[valid].max() < (1e-12 if prec == "f64" else 1e-6)
+    assert (f["length"][valid] > 0).all()
