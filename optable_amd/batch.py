@@ -136,9 +136,13 @@ class SegmentBatch:
     def to_host(self, reference_order=True):
         """Valid segments as numpy arrays.  reference_order: input-ray-major, then segment
         order within the ray (the order OpticalTable.ray_tracing returns, optical_table.py:66-70)."""
+        if self.count is not None and self.n_rays == 0:
+            out = {f: np.zeros(0) for f in abi.SEG_FIELDS}
+            out.update(ray=np.zeros(0, np.int32), surface=np.zeros(0, np.int32), count=np.zeros(0, np.int32))
+            return out
         if self.count is not None:
             K = self.capacity // self.n_rays
-            cnt = self.count.cpu().numpy()
+            cnt = np.abs(self.count.cpu().numpy())  # a negative count marks a tree that branched (its slots are still valid)
             keep = np.arange(K)[:, None] < cnt[None, :]            # [K, N]
             out = {}
             for f in abi.SEG_FIELDS + ("ray", "surface"):

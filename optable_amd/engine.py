@@ -54,6 +54,9 @@ class Engine:
         if out.count is None or out.count.numel() != n:
             out.count = torch.empty(n, dtype=torch.int32, device=rays.device)
         out.n_rays = n
+        out.counts_table = counts
+        if n == 0:  # nothing to launch (zero-size tensors have no address to hand over)
+            return out
         n_slots = len(self.scene.limited)
         if n_slots and counts is None:
             counts = torch.zeros((n_slots, n), dtype=torch.int32, device=rays.device)
@@ -74,6 +77,11 @@ class Engine:
         if rays.precision != "f64":
             raise NotImplementedError("branching trace is fp64 only")
         dev, n = rays.device, rays.n
+        if n == 0:
+            out = SegmentBatch(0, "f64", dev)
+            out.n_valid, out.counts_table = 0, counts
+            out.capped = torch.zeros(0, dtype=torch.bool, device=dev)
+            return out
         fan = max(self.scene.max_children, 1)
         if out_capacity is None:
             out_capacity = max(4 * n, 1024)

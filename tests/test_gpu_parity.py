@@ -371,3 +371,44 @@ def test_segment_chain_is_continuous(case, prec, tol):
     norm = np.sqrt(f["dx"] ** 2 + f["dy"] ** 2 + f["dz"] ** 2)
     assert np.abs(norm - 1)[valid].max() < (1e-12 if prec == "f64" else 1e-6)
     assert (f["length"][valid] > 0).all()
+
+
+def test_fused_path_honours_input_length_and_dead_flags(oracle):
+    """Finite input lengths (`t > ray.length` rejects the hit, optical_component.py:184-190) and dead input
+    rays (optical_component.py:349) through the one-launch kernel, against the oracle."""
+    import torch
+    import optable_amd as oa
+
+    n, K = 4096, 5
+    table = _table(scenes.cfg2_components(oa))
+    o, d = scenes.cfg2_rays(n, 9)
+    batch = _batch(o, d)
+    rng = np.random.default_rng(9)
+    length = np.where(rng.uniform(size=n) < 0.5, rng.uniform(1.0, 9.0, n), np.inf)  # some stop before the lens at t~5
+    flags = batch.flags.cpu().numpy()
+    flags[::7] |= abi.RAY_DEAD
+    batch.flags.copy_(torch.from_numpy(flags))
+    batch.length = torch.from_numpy(length).to(batch.device)
+    got = table.trace_batch(batch, max_segments=K).to_host(reference_order=True)
+    host = batch.to_host()
+    host["length"] = length
+    ref = oracle.trace(table.compile(), host, max_trace_num=K)
+    np.testing.assert_array_equal(got["ray"], ref["ray"])
+    np.testing.assert_array_equal(got["surface"], ref["surface"])
+    for f in abi.SEG_FIELDS:
+        np.testing.assert_allclose(got[f], ref[f], rtol=1e-9, atol=1e-9, err_msg=f)
+    assert (got["surface"] == -2).sum() == len(flags[::7])
+
+
+def test_zero_rays_and_empty_scene():
+    import optable_amd as oa
+    from optable_amd.batch import RayBatch
+
+    table = _table(scenes.cfg2_components(oa))
+    empty = table.trace_batch(RayBatch(0), max_segments=5)
+    assert empty.to_host()["ox"].size == 0
+    void = oa.OpticalTable()  # no components: every ray escapes unchanged
+    o, d = scenes.cfg2_rays(100, 3)
+    segs = void.trace_batch(_batch(o, d), max_segments=3).to_host()
+    assert segs["count"].tolist() == [1] * 100 and (segs["surface"] == -1).all()
+    np.testing.assert_allclose(segs["dx"], d[:, 0], rtol=0, atol=1e-15)
