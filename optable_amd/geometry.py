@@ -129,3 +129,15 @@ class Color:
     SCIENCE_RED_DARK: str = "#fa331a"
     SCIENCE_BLUE_LIGHT: str = "#bdd3ec"
     SCIENCE_BLUE_DARK: str = "#2556ae"
+
+
+def to_mathematical_str(text):
+    """Python list / complex literals -> Mathematica syntax (base.py:248-251), used by the CSV export."""
+    if text == "None":
+        return "None"
+    return text.replace("[", "{").replace("]", "}").replace("e", "*10^").replace("j", "I")
+
+
+def get_attr_str(obj, attr_name, default=None):
+    value = getattr(obj, attr_name, None)
+    return value if value else default

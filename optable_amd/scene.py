@@ -27,8 +27,9 @@ class SceneError(NotImplementedError):
 class CompiledScene:
     """Owner of the ctypes tables handed to `ot_scene_upload`."""
 
-    def __init__(self, nodes, materials, aux, leaves, limited, max_children, unit, root_grid=-1):
+    def __init__(self, nodes, materials, aux, leaves, limited, max_children, unit, root_grid=-1, always_branches=False):
         self.root_grid = root_grid
+        self.always_branches = always_branches
         self.nodes = (abi.OtNode * max(len(nodes), 1))(*nodes)
         self.n_nodes = len(nodes)
         self.materials = (abi.OtMaterial * max(len(materials), 1))(*materials)
@@ -67,6 +68,7 @@ class _Builder:
         self.mat_index = {}
         self.leaves, self.limited = [], []
         self.max_children = 0
+        self.always_branches = False
 
     # -- materials -----------------------------------------------------------------------
     def material(self, mat):
@@ -198,6 +200,8 @@ class _Builder:
         self.leaves.append(comp)
         self.nodes.append(node)
         self.max_children = max(self.max_children, _fanout(kind, node.reflectivity, node.transmission))
+        if kind in (MIRROR, REFRACT) and node.reflectivity > 0 and node.transmission > 0:
+            self.always_branches = True  # every ordinary hit on this leaf emits two rays
 
 
 def _fanout(kind, refl, trans):
@@ -270,4 +274,4 @@ def compile_scene(components, unit=1e-2, accelerate=True) -> CompiledScene:
         if nd.kind == abi.NODE_LEAF and not any(nd.aabb[:]):
             nd.aabb[:] = [float(x) for x in b.leaves[nd.leaf_id].bbox]
     root = _root_grid(b, tops) if accelerate else -1
-    return CompiledScene(b.nodes, b.materials, b.aux, b.leaves, b.limited, b.max_children, unit, root)
+    return CompiledScene(b.nodes, b.materials, b.aux, b.leaves, b.limited, b.max_children, unit, root, b.always_branches)

@@ -11,6 +11,7 @@ Not modelled: the 600 s wall-clock cap (`max_trace_time`) — a device trace is 
 `max_trace_num` alone; the per-second progress print.  Render / CSV / GUI are out of scope.
 """
 import copy
+import csv
 from typing import List, Union
 
 import numpy as np
@@ -19,7 +20,7 @@ from . import abi
 from .assemblies import *  # noqa: F401,F403  (reference re-exports, optical_table.py:1-3)
 from .components import *  # noqa: F401,F403
 from .components import OpticalComponent
-from .geometry import base_merge_bboxs, _NO_BOX
+from .geometry import base_merge_bboxs, _NO_BOX, to_mathematical_str, get_attr_str
 from .monitors import Monitor
 from .rays import Ray
 from .scene import compile_scene
@@ -102,7 +103,8 @@ class OpticalTable:
         scene = self.compile()
         eng.upload(scene)
         cap = MAX_TRACE_NUM if max_segments is None else int(max_segments)
-        if max_segments is not None and scene.max_children <= 2 and not (scene.max_children == 2 and scene.limited):
+        speculate = scene.max_children == 2 and not scene.limited and not scene.always_branches
+        if max_segments is not None and (scene.max_children <= 1 or speculate):
             # max_children == 2: speculate that no tree actually branches (e.g. mirror-coated
             # interfaces only split on total internal reflection); fall back when one does.
             segs = eng.trace(batch, cap, counts=counts)
@@ -147,6 +149,74 @@ class OpticalTable:
         Ms[:, 0, 0], Ms[:, 1, 0] = (y1 - y0) / disp, (ty1 - ty0) / disp
         Ms[:, 0, 1], Ms[:, 1, 1] = (y2 - y0) / rot, (ty2 - ty0) / rot
         return Ms
+
+    @staticmethod
+    def calibrate_symmetric_4f(lens, rays, F10, F20, criterion="M=-I", debugaxs=None, optimize=True, display_M=False):
+        """Tune the distances of mon0 - F1 - lens - 2 F2 - lens(turned) - F1 - mon1 with Nelder-Mead
+        (optical_table.py:299-422).  A caller of the hot path: every cost evaluation is one
+        `ray_tracing` + one `calculate_abcd_matrix` (4 device traces)."""
+        def simulate(F1, F2):
+            first = lens.copy()._Translate(np.array([F1, 0, 0]) - lens.origin)
+            second = lens.copy()._Translate(np.array([F1 + 2 * F2, 0, 0]) - lens.origin).RotZ(np.pi)
+            mon0 = Monitor(origin=[0, 0, 0], width=5, height=5)
+            mon1 = Monitor(origin=[2 * F1 + 2 * F2, 0, 0], width=5, height=5)
+            table = OpticalTable()
+            table.add_components([first, second])
+            table.add_monitors([mon0, mon1])
+            table.ray_tracing(rays)
+            y, ty = mon1.get_yList(), mon1.get_tYList()
+            Ms = table.calculate_abcd_matrix(mon0, mon1, rays)
+            if display_M:
+                for M in Ms:
+                    print(M)
+            return Ms, y, ty
+
+        costs = {
+            "M=-I": lambda Ms, ty: np.mean([np.linalg.norm(M + np.eye(2)) for M in Ms]),
+            "flat_field": lambda Ms, ty: np.mean([abs((1.5 * M[0, 0] - M[0, 1]) / (M[1, 1] - M[1, 0] * 1.5) - 1.5) for M in Ms]),
+            "min_stdtY": lambda Ms, ty: float(np.std(ty)),
+        }
+        if criterion not in costs:
+            raise ValueError(f"Unknown criterion: {criterion}")
+        if not optimize:
+            return simulate(F10, F20)
+        from scipy.optimize import minimize
+
+        def cost(x):
+            Ms, _, ty = simulate(x[0], x[1])
+            return costs[criterion](Ms, ty)
+
+        res = minimize(cost, x0=[F10, F20], method="Nelder-Mead", options={"disp": True, "xatol": 1e-5, "maxiter": 50})
+        return res.x[0], res.x[1]
+
+    # -- exports (optical_table.py:448-500) -----------------------------------------------------------
+    def gather_rays_csv(self):
+        return [{"origin": to_mathematical_str(str(r.origin.tolist())),
+                 "transform_matrix": to_mathematical_str(str(r.transform_matrix.tolist())),
+                 "intensity": get_attr_str(r, "intensity", "None"), "length": get_attr_str(r, "length", "None"),
+                 "qo": to_mathematical_str(str(get_attr_str(r, "qo", "None"))),
+                 "n": to_mathematical_str(str(get_attr_str(r, "n", "None")))} for r in self.rays]
+
+    def export_rays_csv(self, filename: str):
+        rows = self.gather_rays_csv()
+        print(f"Exporting rays to {filename} ...")
+        with open(filename, "w", newline="") as fh:
+            writer = csv.writer(fh)
+            writer.writerow(rows[0].keys() if rows else [])
+            for row in rows:
+                writer.writerow(row.values())
+
+    def materialize(self, segs, sources, select=None):
+        """SegmentBatch -> List[Ray] for the input rays in `select` only (all when None), in the
+        reference's order; `sources` are the input Ray objects (ids, wavelengths, custom attributes
+        are inherited from them as upstream copies do).  Lets plotting code consume a device trace
+        without building millions of objects."""
+        host = segs.to_host(reference_order=True)
+        keep = np.ones(len(host["ray"]), dtype=bool) if select is None else np.isin(host["ray"], np.asarray(list(select)))
+        host = {k: (v[keep] if k != "count" else v) for k, v in host.items()}
+        per_ray = [None] * len(sources)
+        _scatter_segments(host, sources, np.arange(len(sources)), per_ray)
+        return [seg for chunk in per_ray if chunk for seg in chunk]
 
     # -- List[Ray] plumbing ------------------------------------------------------------------------
     def _trace_objects(self, rays, cap):

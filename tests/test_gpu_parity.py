@@ -412,3 +412,26 @@ def test_zero_rays_and_empty_scene():
     segs = void.trace_batch(_batch(o, d), max_segments=3).to_host()
     assert segs["count"].tolist() == [1] * 100 and (segs["surface"] == -1).all()
     np.testing.assert_allclose(segs["dx"], d[:, 0], rtol=0, atol=1e-15)
+
+
+def test_lazy_materialisation_and_csv_export(tmp_path):
+    """f3/f4: pull only some rays of a device trace back as Ray objects; CSV export of table.rays."""
+    import optable_amd as oa
+    from optable_amd.table import _pack
+
+    table, sc = helpers.build("g01_gaussian_beam")
+    rays = sc["rays"]
+    full = table.ray_tracing(rays)
+    batch = _pack(rays, np.arange(len(rays), dtype=np.int32), "cuda")
+    segs = table.trace_batch(batch, max_segments=8)
+    some = table.materialize(segs, rays, select=[1, 4])
+    want = [r for r in full if r._id in (rays[1]._id, rays[4]._id)]
+    assert len(some) == len(want) == 5
+    for a, b in zip(some, want):
+        np.testing.assert_allclose(a.origin, b.origin, atol=1e-12)
+        np.testing.assert_allclose(a.direction, b.direction, atol=1e-12)
+        assert a.alive == b.alive and a._id == b._id and (a.length is None) == (b.length is None)
+    out = tmp_path / "rays.csv"
+    table.export_rays_csv(str(out))
+    lines = out.read_text().strip().splitlines()
+    assert lines[0].startswith("origin,transform_matrix,intensity") and len(lines) == 1 + len(table.rays)
