@@ -21,6 +21,7 @@ from .assemblies import (ComponentGroup, GlassSlab, CircleGlassSlab, MLA, MMA, M
 from .monitors import Monitor
 from .table import OpticalTable
 from .scene import compile_scene, CompiledScene, SceneError
+from .adapter import install
 import numpy as np  # noqa: F401  (the reference's star import leaks np; scripts rely on it)
 
 __version__ = "0.1.0"

@@ -1,0 +1,170 @@
+"""Route the ORIGINAL optable package's `OpticalTable.ray_tracing` through the MI355X engine.
+
+    import optable, optable_amd
+    optable_amd.install(optable)      # patches optable.OpticalTable.ray_tracing (and Monitor.record)
+    ...                               # the user's script, rendering, GUI etc. stay untouched
+
+Everything but the hot path remains the reference's own code.  The scene compiler needs a device
+form for every shape / interaction / material; objects of this package provide it themselves
+(`lower()`, `lower_interaction()`, `device_spec()`), objects of the reference are recognised here by
+class name and attributes (duck typing — no reference code is imported or copied).  Anything that
+cannot be recognised raises `SceneError`; nothing is silently evaluated on the host.
+"""
+import numpy as np
+
+from . import shapes
+from .components import MIRROR, REFRACT, LENS, BLOCK, ROC_INF, ROC_CONST, ROC_ASPHERE
+from .shapes import Lowered
+
+
+class AdapterError(NotImplementedError):
+    pass
+
+
+def _mro_names(obj):
+    return [c.__name__ for c in type(obj).__mro__]
+
+
+# ---------------------------------------------------------------------------------------------
+# surfaces (reference optable/surfaces.py, recognised by class name + the attributes they carry)
+def _polygon(surf):
+    u, v = surf._basis
+    rec = [float(len(surf._verts2d))] + list(surf._normal) + list(surf.vertices[0]) + list(u) + list(v)
+    rec += [c for xy in surf._verts2d for c in xy]
+    return Lowered(shapes.POLYGON2D if surf.planar else shapes.POLYGON3D, aux=rec, planar=bool(surf.planar))
+
+
+def _asphere(surf):
+    """The reference builds the sag as a closure; recover its parameters from the closure cells and
+    CHECK them by evaluating both forms."""
+    f = surf.f_asphere
+    spec = getattr(f, "device_spec", None)
+    if spec is None:
+        cells = dict(zip(getattr(f.__code__, "co_freevars", ()), [c.cell_contents for c in (f.__closure__ or ())]))
+        if {"R", "kappa", "a4", "a6", "a8"} <= set(cells):
+            spec = (shapes.ASPHERE_PARAM, tuple(float(cells[k]) for k in ("R", "kappa", "a4", "a6", "a8")))
+            mine = shapes.sag_parametric(*spec[1])
+        elif {"EFL", "n"} <= set(cells):
+            spec = (shapes.ASPHERE_EXACT, (float(cells["EFL"]), float(cells["n"])))
+            mine = shapes.sag_exact(*spec[1])
+        else:
+            raise AdapterError("ASphere with an unrecognised f_asphere closure has no device form")
+        probe = np.linspace(0.0, float(surf.radius), 7)
+        if not np.allclose([f(r) for r in probe], [mine(r) for r in probe], rtol=1e-13, atol=1e-15):
+            raise AdapterError("ASphere closure does not match the recognised sag formula")
+    return Lowered(spec[0], [surf.radius] + list(spec[1]), planar=False)
+
+
+_SURFACES = {
+    "Circle": lambda s: Lowered(shapes.CIRCLE, [s.radius]),
+    "Rectangle": lambda s: Lowered(shapes.RECT, [s.width / 2, s.height / 2]),
+    "Polygon": _polygon,
+    "Sphere": lambda s: Lowered(shapes.SPHERE, [s.radius, s.height], planar=False),
+    "ASphere": _asphere,
+    "Cylinder": lambda s: Lowered(shapes.CYLINDER, [s.radius, s.height / 2, s.theta_range[0], s.theta_range[1]], planar=False),
+    "Point": lambda s: Lowered(shapes.POINT, planar=False),
+}
+
+
+def lower_surface(surf):
+    if hasattr(surf, "lower"):
+        return surf.lower()
+    fn = _SURFACES.get(type(surf).__name__)
+    if fn is None:  # a bare Plane (unbounded) or the closure-based Plane.union / subtract of the reference
+        raise AdapterError(f"surface {type(surf).__name__} has no device form (boolean apertures of the reference are "
+                           "closures; build them with optable_amd.Plane.union/subtract)")
+    return fn(surf)
+
+
+# ---------------------------------------------------------------------------------------------
+# materials (reference optable/material.py)
+class _Spec:
+    def __init__(self, spec, name):
+        self._spec, self.name = spec, name
+
+    def device_spec(self):
+        return self._spec
+
+
+def lower_material(mat):
+    if hasattr(mat, "device_spec"):
+        return mat
+    if hasattr(mat, "Bs") and hasattr(mat, "Cs") and len(mat.Bs) == len(mat.Cs) <= 3:
+        pad = 3 - len(mat.Bs)
+        return _Spec(("sellmeier", list(mat.Bs) + [0.0] * pad, list(mat.Cs) + [1.0] * pad), getattr(mat, "name", "?"))
+    if hasattr(mat, "n_func"):
+        vals = [float(mat.n_func(w)) for w in (0.0, 4e-7, 7.8e-7, 1.55e-6)]
+        if max(vals) == min(vals):
+            return _Spec(("const", vals[0]), getattr(mat, "name", "?"))
+    return _Spec(None, getattr(mat, "name", "?"))  # the scene compiler reports it
+
+
+# ---------------------------------------------------------------------------------------------
+# interactions (reference optable/optical_component.py)
+def lower_interaction(comp):
+    if hasattr(comp, "lower_interaction"):
+        return comp.lower_interaction()
+    names = _mro_names(comp)
+    if "Monitor" in names:
+        raise AdapterError("a Monitor inside `components` would re-emit its own ray forever (monitor.py:174-175)")
+    if "Lens" in names:
+        return dict(kind=LENS, transmission=comp.transmission, focal_length=comp.focal_length)
+    if "BaseMirror" in names:
+        return dict(kind=MIRROR, reflectivity=comp.reflectivity, transmission=comp.transmission)
+    if "BaseRefraciveSurface" in names:
+        roc = getattr(comp, "roc", np.inf)
+        if callable(roc):
+            if getattr(roc, "__self__", None) is not comp.surface:
+                raise AdapterError("callable roc that is not the surface's own ASphere.roc has no device form")
+            kind, val = ROC_ASPHERE, 0.0
+        elif np.isinf(roc):
+            kind, val = ROC_INF, np.inf
+        else:
+            kind, val = ROC_CONST, float(roc)
+        return dict(kind=REFRACT, reflectivity=comp.reflectivity, transmission=comp.transmission,
+                    mat1=lower_material(comp.__dict__["_n1"]), mat2=lower_material(comp.__dict__["_n2"]),
+                    roc_kind=kind, roc=val)
+    if "Block" in names or "PointObj" in names:
+        return dict(kind=BLOCK)
+    raise AdapterError(f"{type(comp).__name__} has no device interaction")
+
+
+# ---------------------------------------------------------------------------------------------
+def install(optable_module):
+    """Patch `optable_module.OpticalTable.ray_tracing` (and `Monitor.record`) to run on the engine.
+    Returns a function that undoes the patch."""
+    import copy
+
+    from . import table as _table
+
+    OT, Mon = optable_module.OpticalTable, optable_module.Monitor
+    original = (OT.ray_tracing, Mon.record)
+
+    def ray_tracing(self, rays, perfomance_limit=None):
+        if isinstance(rays, optable_module.Ray):
+            rays = [rays]
+        cap = _table.MAX_TRACE_NUM
+        if perfomance_limit is not None and "max_trace_num" in perfomance_limit:
+            cap = int(perfomance_limit["max_trace_num"])
+        if len(rays) and cap > 0:
+            traced, capped = _table.OpticalTable._trace_objects(self, list(rays), cap)
+            if capped:
+                print(f"Ray tracing time exceeds the maximum tracing time after {cap} traces. ({capped} ray tree(s) truncated)")
+            self.rays.extend(traced)
+        return copy.deepcopy(self.rays)
+
+    def record(self, rays):
+        _table.record_monitor_hits(self, rays)
+
+    def compile_(self):
+        from .scene import compile_scene
+
+        return compile_scene(self.components, getattr(self, "unit", 1e-2))
+
+    OT.ray_tracing, OT.compile, Mon.record = ray_tracing, compile_, record
+
+    def uninstall():
+        OT.ray_tracing, Mon.record = original
+        del OT.compile
+
+    return uninstall

@@ -72,7 +72,7 @@ class _Builder:
 
     # -- materials -----------------------------------------------------------------------
     def material(self, mat):
-        if not isinstance(mat, Material):
+        if not hasattr(mat, "device_spec"):
             mat = Material("Constant", float(mat))
         spec = mat.device_spec()
         if spec is None:
@@ -159,14 +159,16 @@ class _Builder:
         self.aux.extend(float(x) for x in items)
 
     def add_leaf(self, comp, in_group):
-        if not isinstance(comp, OpticalComponent):
-            raise SceneError(f"{type(comp).__name__} is not an OpticalComponent")
+        from . import adapter  # objects of the reference package are recognised by duck typing there
+
+        if not hasattr(comp, "surface") or not hasattr(comp, "transform_matrix"):
+            raise SceneError(f"{type(comp).__name__} is not an optical component")
         surf = comp.surface
         try:
-            low = surf.lower()
+            low = adapter.lower_surface(surf)
+            inter = adapter.lower_interaction(comp)
         except NotImplementedError as exc:
             raise SceneError(f"{type(comp).__name__}: {exc}") from exc
-        inter = comp.lower_interaction()
         node = abi.OtNode()
         node.kind, node.end = abi.NODE_LEAF, len(self.nodes) + 1
         node.flags = abi.NODE_CHECK_AABB if in_group else 0

@@ -356,4 +356,5 @@ def record_monitor_hits(monitor, rays):
     segs.n_valid = n
     idx, P, t = eng.monitor_record(monitor_struct(monitor), segs)
     idx, P, t = idx.cpu().numpy(), P.cpu().numpy(), t.cpu().numpy()
-    monitor._extend([(P[k].copy(), rays[int(i)].intensity, float(t[k]), rays[int(i)]) for k, i in enumerate(idx)])
+    monitor._data_raw.extend([(P[k].copy(), rays[int(i)].intensity, float(t[k]), rays[int(i)]) for k, i in enumerate(idx)])
+    monitor._updated = True
