@@ -174,12 +174,15 @@ __global__ __launch_bounds__(256, MINW) void k_trace_fused(SceneBlob blob, T uni
 // ------------------------------------------------------------------------------------------
 // k_trace_blocked: the same trace for HEAVY scenes (many nodes, long and uneven paths).
 // One lane per ray wastes lanes twice there: rays of a wave end after different numbers of
-// segments, and the segment loop runs as long as its longest ray.  Here a workgroup owns a chunk
-// of CHUNK consecutive rays and advances them generation by generation: after every segment the
-// surviving rays are compacted (ORDER-PRESERVING, ballot + 4-wave prefix in LDS) into a dense
-// index list, so every pass runs with full waves until the chunk drains.  The state of a live
-// ray travels through a per-ray scratch record in global memory (L2/MALL resident: a chunk is
-// ~100 KB); segment records go to the same [k][ray] slots as k_trace_fused, so the two kernels
+// segments, and the segment loop runs as long as its longest ray.  Here every WAVE owns a chunk of
+// CHUNK consecutive rays and advances them generation by generation: after every segment the
+// surviving rays are compacted (order preserving: ballot + popcount) into a dense index list in
+// LDS, so every pass runs with a full wave until the chunk drains.  The four waves of a workgroup
+// share only the staged scene image; each has its own lists and its own chunks, so there is no
+// workgroup barrier inside the loop (a first version with one 1024-ray chunk per workgroup spent
+// 57 % of its wave-cycles waiting, mostly at the two barriers per pass: profiles/).
+// The state of a live ray travels through a per-ray scratch record in global memory (L2/MALL
+// resident); segment records go to the same [k][ray] slots as k_trace_fused, so the two kernels
 // are interchangeable bit for bit.
 template <class T> struct StateT {
     T* f[11];  // ox oy oz dx dy dz qr qi I n pl  (wavelength, id, flags stay in the input arrays)
@@ -197,20 +200,19 @@ __global__ __launch_bounds__(256) void k_trace_blocked(SceneBlob blob, T unit, R
         base = lds;
         tail = lds + ((blob.n_words + 3) & ~3);
     }
-    int32_t* cur = reinterpret_cast<int32_t*>(tail);
-    int32_t* nxt = cur + CHUNK;
-    int32_t* wave_cnt = nxt + CHUNK;  // [4]
-    __syncthreads();
-    const Scene<T> sc = bind_scene<T>(base, blob, unit);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int32_t* cur = reinterpret_cast<int32_t*>(tail) + wave * 2 * CHUNK;  // wave-private lists
+    int32_t* nxt = cur + CHUNK;
+    __syncthreads();  // the only workgroup barrier: the scene image is staged
+    const Scene<T> sc = bind_scene<T>(base, blob, unit);
     const int64_t n_chunks = (n + CHUNK - 1) / CHUNK;
-    for (int64_t ch = blockIdx.x; ch < n_chunks; ch += gridDim.x) {
+    for (int64_t ch = (int64_t)blockIdx.x * 4 + wave; ch < n_chunks; ch += (int64_t)gridDim.x * 4) {  // wave-uniform
         const int64_t first = ch * CHUNK;
         int alive = (int)((n - first) < CHUNK ? (n - first) : CHUNK);
-        for (int32_t k = 0; k < K && alive > 0; ++k) {  // block-uniform
+        for (int32_t k = 0; k < K && alive > 0; ++k) {
             int next_alive = 0;
-            for (int p0 = 0; p0 < alive; p0 += 256) {
-                const int p = p0 + threadIdx.x;
+            for (int p0 = 0; p0 < alive; p0 += 64) {
+                const int p = p0 + lane;
                 bool active = p < alive;
                 const int j = active ? (k == 0 ? p : cur[p]) : 0;
                 const int64_t i = first + j;
@@ -263,21 +265,15 @@ __global__ __launch_bounds__(256) void k_trace_blocked(SceneBlob blob, T unit, R
                     }
                     if (!survive) seg_count[i] = used;
                 }
-                // order-preserving append of the survivors of this pass
+                // order-preserving append of this pass's survivors (wave-private list: no barrier)
                 const unsigned long long mask = __ballot(survive);
-                if (lane == 0) wave_cnt[wave] = __popcll(mask);
-                __syncthreads();
-                int before = 0, total = 0;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const int c = wave_cnt[w];
-                    if (w < wave) before += c;
-                    total += c;
-                }
-                if (survive) nxt[next_alive + before + __popcll(mask & ((1ull << lane) - 1ull))] = j;
-                next_alive += total;
-                __syncthreads();
+                if (survive) nxt[next_alive + __popcll(mask & ((1ull << lane) - 1ull))] = j;
+                next_alive += __popcll(mask);
             }
+            // the list written above is read by other lanes of this wave in the next generation, and
+            // so is the scratch state: LDS and global accesses of one wave complete in issue order,
+            // the fence only stops the compiler from moving them
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             int32_t* t = cur; cur = nxt; nxt = t;
             alive = next_alive;
         }
@@ -836,7 +832,7 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
     // kernel; light ones are HBM-bound and keep one lane per ray with perfectly coalesced streams.
     const bool use_blocked = c->opt_kernel == 2 || (c->opt_kernel == 0 && c->n_nodes >= 24 && K > 2);
     if (use_blocked) {
-        constexpr int CHUNK = 1024;
+        constexpr int CHUNK = 256;  // rays per wave-owned chunk
         const size_t per_field = align_up(sizeof(T) * (size_t)n);
         if (c->blocked.ensure(11 * per_field)) return fail(OT_ERR_HIP, "hipMalloc of blocked-trace scratch failed");
         StateT<T> st;
@@ -849,9 +845,9 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
             {{k_trace_blocked<T, F_ALL, false, false, CHUNK>, k_trace_blocked<T, F_ALL, false, true, CHUNK>},
              {k_trace_blocked<T, F_ALL, true, false, CHUNK>, k_trace_blocked<T, F_ALL, true, true, CHUNK>}}};
         KernB kb = tb[fb][in_lds ? 1 : 0][ntb];
-        const size_t lds_b = (in_lds ? ((bytes + 15) / 16) * 16 : 0) + (2 * CHUNK + 4) * sizeof(int32_t);
+        const size_t lds_b = (in_lds ? ((bytes + 15) / 16) * 16 : 0) + 4 * 2 * CHUNK * sizeof(int32_t);
         if (lds_b > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
-        const int64_t n_chunks = (n + CHUNK - 1) / CHUNK;
+        const int64_t n_chunks = (n + 4 * CHUNK - 1) / (4 * CHUNK);  // workgroups needed: 4 wave-chunks each
         int fitb = (int)((160 * 1024) / (lds_b + 512));
         fitb = fitb < 1 ? 1 : (fitb > 8 ? 8 : fitb);
         if (c->opt_blocks_per_cu > 0) fitb = c->opt_blocks_per_cu;
