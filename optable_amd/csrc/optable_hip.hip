@@ -11,6 +11,7 @@
 //   k_mon_*              Monitor.record over a segment stream (monitor.py:183-193).
 // No CPU fallback lives here: without a GPU every entry point fails with OT_ERR_HIP.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <hipcub/hipcub.hpp>
 
 #include <cmath>
@@ -545,6 +546,28 @@ static int timing_begin(ot_ctx* c) {
     HIP_TRY(hipEventRecord(c->events[c->events_used].first, c->stream));
     return 0;
 }
+// Single-kernel launches attach the event pair to the dispatch itself (hipExtLaunchKernelGGL): the
+// timestamps are the kernel's own begin/end and no extra marker packets sit between launches.
+static int timing_pair(ot_ctx* c, hipEvent_t* start, hipEvent_t* stop) {
+    *start = *stop = nullptr;
+    if (!c->timing) return 0;
+    if (c->events_used == c->events.size()) {
+        if (c->events.size() >= 1024) {
+            int rc = flush_events(c);
+            if (rc) return rc;
+        } else {
+            hipEvent_t a, b;
+            HIP_TRY(hipEventCreate(&a));
+            HIP_TRY(hipEventCreate(&b));
+            c->events.push_back({a, b});
+        }
+    }
+    *start = c->events[c->events_used].first;
+    *stop = c->events[c->events_used].second;
+    c->events_used += 1;
+    return 0;
+}
+
 static int timing_end(ot_ctx* c) {
     if (!c->timing) return 0;
     HIP_TRY(hipEventRecord(c->events[c->events_used].second, c->stream));
@@ -853,14 +876,16 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
         if (c->opt_blocks_per_cu > 0) fitb = c->opt_blocks_per_cu;
         const int64_t capb = (int64_t)c->n_cus * fitb;
         const int gridb = (int)(n_chunks < capb ? n_chunks : capb);
-        rc = timing_begin(c);
+        hipEvent_t ev0, ev1;
+        rc = timing_pair(c, &ev0, &ev1);
         if (rc) return rc;
-        hipLaunchKernelGGL(kb, dim3(gridb), dim3(block), lds_b, c->stream, blob, (T)c->unit, view<T>(rays), n, K, view<T>(out),
-                           seg_count, counts, n_classes, st);
+        hipExtLaunchKernelGGL(kb, dim3(gridb), dim3(block), (uint32_t)lds_b, c->stream, ev0, ev1, 0u, blob, (T)c->unit, view<T>(rays), n, K,
+                              view<T>(out), seg_count, counts, n_classes, st);
         HIP_TRY(hipGetLastError());
-        return timing_end(c);
+        return 0;
     }
-    rc = timing_begin(c);
+    hipEvent_t ev0, ev1;
+    rc = timing_pair(c, &ev0, &ev1);
     if (rc) return rc;
     using Kern = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, SegsT<T>, int32_t*, int32_t*, int32_t);
     const int fi = (need & ~FA) == 0 ? 0 : ((need & ~FB) == 0 ? 1 : 2);
@@ -877,10 +902,10 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
     Kern kern = table[fi][in_lds ? 1 : 0][mw][nt];
     const size_t lds_bytes = in_lds ? bytes : 0;
     if (lds_bytes > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds_bytes, c->stream, blob, (T)c->unit, view<T>(rays), n, K, view<T>(out),
-                       seg_count, counts, n_classes);
+    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), (uint32_t)lds_bytes, c->stream, ev0, ev1, 0u, blob, (T)c->unit, view<T>(rays), n, K,
+                          view<T>(out), seg_count, counts, n_classes);
     HIP_TRY(hipGetLastError());
-    return timing_end(c);
+    return 0;
 }
 
 
