@@ -250,7 +250,7 @@ class OpticalTable:
         for rnd in range(int(rounds.max()) + 1):
             pick = np.nonzero(rounds == rnd)[0]
             sub = [rays[k] for k in pick]
-            batch = _pack(sub, cls[pick], eng.device)
+            batch = _pack(sub, cls[pick], eng.device, scene.unit)
             if scene.max_children <= 1 and cap <= _FUSED_MAX_SEGMENTS:
                 segs = eng.trace(batch, cap, counts=counts)
                 host_segs = segs.to_host(reference_order=True)
@@ -273,8 +273,10 @@ class OpticalTable:
         return traced, total_capped
 
 
-def _pack(rays, cls, device):
-    """List[Ray] -> RayBatch (fp64)."""
+def _pack(rays, cls, device, scene_unit=1e-2):
+    """List[Ray] -> RayBatch (fp64).  The reference evaluates materials at `ray.wavelength * ray.unit`
+    — the RAY's unit (optical_component.py:627-628, base.py:31) — while the kernel multiplies by the
+    scene's; the wavelength column is rescaled so that both give the same metres for every ray."""
     from .batch import RayBatch
 
     n = len(rays)
@@ -283,7 +285,8 @@ def _pack(rays, cls, device):
     has_q = np.array([r.qo is not None for r in rays])
     q = np.array([complex(r.qo) if r.qo is not None else 0j for r in rays], dtype=np.complex128)
     b = RayBatch.from_arrays(origin, direction,
-                             wavelength=[r.wavelength for r in rays], intensity=[r.intensity for r in rays],
+                             wavelength=[r.wavelength * (getattr(r, "unit", scene_unit) / scene_unit) for r in rays],
+                             intensity=[r.intensity for r in rays],
                              q=q, n_index=[r.n for r in rays], pathlength=[r._pathlength for r in rays],
                              ids=cls, device=device, normalize=False)
     import torch

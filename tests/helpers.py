@@ -26,8 +26,9 @@ def build(name, **kw):
     return table, sc
 
 
-def pack_host(rays):
-    """List[Ray] -> dict of host arrays in the ot_rays layout (+ class ids)."""
+def pack_host(rays, scene_unit=1e-2):
+    """List[Ray] -> dict of host arrays in the ot_rays layout (+ class ids).  Wavelengths are expressed in
+    the scene's length unit (a ray may carry its own `unit`; the reference uses wavelength*ray.unit)."""
     ids = [r._id for r in rays]
     class_of = {}
     cls = np.array([class_of.setdefault(i, len(class_of)) for i in ids], dtype=np.int32)
@@ -37,7 +38,7 @@ def pack_host(rays):
     has_q = np.array([r.qo is not None for r in rays])
     q = np.array([complex(r.qo) if r.qo is not None else 0j for r in rays])
     host = dict(ox=o[:, 0], oy=o[:, 1], oz=o[:, 2], dx=d[:, 0], dy=d[:, 1], dz=d[:, 2],
-                wavelength=np.array([r.wavelength for r in rays], dtype=float), q_re=q.real.copy(), q_im=q.imag.copy(),
+                wavelength=np.array([r.wavelength * (r.unit / scene_unit) for r in rays], dtype=float), q_re=q.real.copy(), q_im=q.imag.copy(),
                 intensity=np.array([r.intensity for r in rays], dtype=float), n=np.array([r.n for r in rays], dtype=float),
                 pathlength=np.array([r._pathlength for r in rays], dtype=float), id=cls,
                 flags=(np.where(has_q, abi.RAY_HAS_Q, 0) | np.where([bool(r.alive) for r in rays], 0, abi.RAY_DEAD)).astype(np.int32))

@@ -248,6 +248,23 @@ def g18_fifo_gate(ns):
     return dict(components=comps, monitors=[], rays=rays, limit={"max_trace_num": 30})
 
 
+def g19_units_and_disorder(ns):
+    """MMADisordered with tilted caps (component_group.py:307-364), MirrorPrism, a dispersive slab hit by
+    rays that carry their OWN length unit (mm instead of the default cm: n(lambda*unit), base.py:31), rays
+    without q and without wavelength."""
+    pts = [[0, 0.25 * (k % 3 - 1), 0.25 * (k // 3 - 1)] for k in range(9)]
+    tilt = [[-1.0, 0.02 * (k % 3 - 1), -0.015 * (k // 3 - 1)] for k in range(9)]
+    comps = [ns.GlassSlab([3, 0, 0], width=3, height=3, thickness=0.6, n1=ns.Vacuum(), n2=ns.Glass_NSF11()).RotZ(0.2),
+             ns.MMADisordered([9, 0, 0], PList=pts, pitch=0.25, roc=6.0, n=1.5, thickness=0.2, nList=tilt, reflectivity=1, transmission=0),
+             ns.MirrorPrism([-4, 0, 0], width=3, height=3, angle=np.pi / 2).RotZ(np.pi)]
+    R = ns.Ray
+    rays = [R([0, 0.05 * k - 0.2, 0.03 * k - 0.1], [1, 0.004 * k, -0.002 * k], wavelength=600e-7 + 40e-7 * k, w0=50e-4, id=k) for k in range(6)]
+    rays += [R([0, 0.1, 0.0], [1, 0, 0.01], wavelength=6000e-7, w0=50e-3, id=10, unit=1e-3),   # millimetres: same 600 nm
+             R([0, -0.1, 0.05], [1, 0.01, 0], id=11),                                           # no wavelength, no q
+             R([0, 0.15, -0.05], [1, -0.01, 0.004], wavelength=450e-7, id=12)]                  # wavelength, no q
+    return dict(components=comps, monitors=[ns.Monitor([1.5, 0, 0], 4, 4)], rays=rays, limit={"max_trace_num": 40})
+
+
 def abcd_4f(ns):
     """4f relay of two bi-convex lenses between two monitors (the system calibrate_symmetric_4f builds,
     optical_table.py:328-340); used for calculate_abcd_matrix parity (optical_table.py:211-297)."""
@@ -267,4 +284,5 @@ SCENES = {
     "g07_spherical_lenses": g07_spherical_lenses, "g08_asphere": g08_asphere, "g09_cfg5": g09_cfg5,
     "g10_cfg3": g10_cfg3, "g11_prism_refl": g11_prism_refl, "g12_dove": g12_dove,
     "g13_count_shadow": g13_count_shadow, "g15_cfg4": g15_cfg4, "g16_misc": g16_misc, "g18_fifo_gate": g18_fifo_gate,
+    "g19_units_and_disorder": g19_units_and_disorder,
 }
