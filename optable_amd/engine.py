@@ -87,28 +87,35 @@ class Engine:
             out_capacity = max(4 * n, 1024)
         out = SegmentBatch(out_capacity, "f64", dev)
         budget = torch.full((n,), int(max_trace_num), dtype=torch.int32, device=dev)
-        cursor = torch.zeros(1, dtype=torch.int64, device=dev)
-        n_next = torch.zeros(1, dtype=torch.int64, device=dev)
+        state = torch.zeros(2, dtype=torch.int64, device=dev)  # [segment cursor, rays in the next generation]
         tree = torch.arange(n, dtype=torch.int32, device=dev)
         n_slots = len(self.scene.limited)
         if n_slots and counts is None:
             counts = torch.zeros((n_slots, n), dtype=torch.int32, device=dev)
         n_classes = 0 if counts is None else counts.shape[1]
-        cur, cur_n = rays, n
+        # two ping-pong generation buffers, grown when a generation outgrows them (no per-generation allocation)
+        cap = max(n * fan, 1024)
+        spare, spare_tree = RayBatch(cap, "f64", dev), torch.empty(cap, dtype=torch.int32, device=dev)
+        other, other_tree = None, None
+        cur, cur_n, written = rays, n, 0
         while cur_n > 0:
-            need = int(cursor.item()) + cur_n
-            if need > out.capacity:
-                out = _grow(out, max(need, 2 * out.capacity), int(cursor.item()))
-            nxt = RayBatch(cur_n * fan, "f64", dev)
-            nxt_tree = torch.empty(cur_n * fan, dtype=torch.int32, device=dev)
-            rs, ss, ns = cur.c_struct(), out.c_struct(), nxt.c_struct()
+            if written + cur_n > out.capacity:
+                out = _grow(out, max(written + cur_n, 2 * out.capacity), written)
+            if cur_n * fan > spare.n:
+                cap = max(cur_n * fan, 2 * spare.n)
+                spare, spare_tree = RayBatch(cap, "f64", dev), torch.empty(cap, dtype=torch.int32, device=dev)
+            rs, ss, ns = cur.c_struct(), out.c_struct(), spare.c_struct()
             abi.check(self.lib.ot_trace_generation_f64(
                 self._ctx, C.byref(rs), tree.data_ptr(), cur_n, budget.data_ptr(), C.byref(ss), out.capacity,
-                cursor.data_ptr(), C.byref(ns), nxt_tree.data_ptr(), cur_n * fan, n_next.data_ptr(),
+                state.data_ptr(), C.byref(ns), spare_tree.data_ptr(), spare.n, state.data_ptr() + 8,
                 None if counts is None else counts.data_ptr(), n_classes), self.lib)
-            cur_n = int(n_next.item())
+            written, cur_n = state.tolist()  # the one host synchronisation per generation
+            nxt, nxt_tree = spare, spare_tree
+            if other is None or other.n < nxt.n:
+                other, other_tree = RayBatch(nxt.n, "f64", dev), torch.empty(nxt.n, dtype=torch.int32, device=dev)
+            spare, spare_tree, other, other_tree = other, other_tree, nxt, nxt_tree
             cur, tree = nxt.slice(0, cur_n), nxt_tree[:cur_n]
-        out.n_valid = int(cursor.item())
+        out.n_valid = int(written)
         out.counts_table = counts
         out.capped = budget <= 0  # cap reached: queued rays were dropped (optical_table.py:138-144)
         return out
