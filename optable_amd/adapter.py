@@ -133,7 +133,6 @@ def lower_interaction(comp):
 def install(optable_module):
     """Patch `optable_module.OpticalTable.ray_tracing` (and `Monitor.record`) to run on the engine.
     Returns a function that undoes the patch."""
-    import copy
 
     from . import table as _table
 
@@ -151,7 +150,7 @@ def install(optable_module):
             if capped:
                 print(f"Ray tracing time exceeds the maximum tracing time after {cap} traces. ({capped} ray tree(s) truncated)")
             self.rays.extend(traced)
-        return copy.deepcopy(self.rays)
+        return _table._clone_rays(self.rays)
 
     def record(self, rays):
         _table.record_monitor_hits(self, rays)
