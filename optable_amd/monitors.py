@@ -147,3 +147,75 @@ class Monitor(OpticalComponent):
     def export_rays_npz(self, filename: str):
         print(f"Exporting {self.ndata} rays to {filename} ...")
         np.savez(filename, xList=self.yList, yList=self.zList, tXList=self.tYList, tYList=self.tZList, IList=self.IList)
+
+
+class MonitorHits:
+    """`Monitor.record` results for a SegmentBatch, kept on the device (no Python objects).
+
+    Mirrors the accessors of `Monitor` (monitor.py:33-156): `yList/zList` are the local hit point
+    projected on the monitor's LAB tangents (as upstream does), `tYList/tZList` the same projections
+    of the segment directions, `IList` the intensities, `tList` the distances.  `sort="YZ"` orders by
+    local y then z (np.lexsort((z, y))), `sort="ID"` by input-ray index, `sort=None` keeps
+    reference order (input-ray-major, then segment order)."""
+
+    def __init__(self, monitor, segs, slot, P, t):
+        import torch
+
+        self.monitor, self.segs = monitor, segs
+        ray = segs.ray[slot].long()
+        if segs.count is not None:  # [k][ray] slots: reference order is ray-major, then k
+            order = torch.argsort(ray * (segs.capacity // max(segs.n_rays, 1)) + slot // max(segs.n_rays, 1))
+        else:
+            order = torch.argsort(ray, stable=True)
+        self.slot, self.P, self.t, self.ray = slot[order], P[order], t[order], ray[order]
+
+    def __len__(self):
+        return int(self.slot.numel())
+
+    def _order(self, sort):
+        import torch
+
+        if sort is None:
+            return torch.arange(len(self), device=self.slot.device)
+        if sort == "ID":
+            return torch.argsort(self.ray, stable=True)
+        if sort == "YZ":
+            by_z = torch.argsort(self.P[:, 2], stable=True)
+            return by_z[torch.argsort(self.P[by_z, 1], stable=True)]
+        raise ValueError(f"unknown sort {sort!r}")
+
+    def _axis(self, which):
+        import torch
+
+        vec = self.monitor.tangent_Y if which == "Y" else self.monitor.tangent_Z
+        return torch.as_tensor(np.asarray(vec, dtype=float), device=self.slot.device)
+
+    def PList(self, sort="YZ"):
+        return self.P[self._order(sort)]
+
+    def yList(self, sort="YZ"):
+        return self.P[self._order(sort)] @ self._axis("Y")
+
+    def zList(self, sort="YZ"):
+        return self.P[self._order(sort)] @ self._axis("Z")
+
+    def tList(self, sort="YZ"):
+        return self.t[self._order(sort)]
+
+    def IList(self, sort="YZ"):
+        return self.segs.intensity[self.slot[self._order(sort)]]
+
+    def ray_index(self, sort="YZ"):
+        return self.ray[self._order(sort)]
+
+    def directionList(self, sort="YZ"):
+        import torch
+
+        s = self.slot[self._order(sort)]
+        return torch.stack([self.segs.dx[s], self.segs.dy[s], self.segs.dz[s]], dim=1)
+
+    def tYList(self, sort="YZ"):
+        return self.directionList(sort) @ self._axis("Y")
+
+    def tZList(self, sort="YZ"):
+        return self.directionList(sort) @ self._axis("Z")

@@ -113,10 +113,12 @@ class OpticalTable:
         return eng.trace_tree(batch, cap, counts=counts)
 
     def record_batch(self, monitor, segs):
-        """Monitor.record over a SegmentBatch without Python objects: returns device tensors
-        (slot index int64 [h], P_local float64 [h,3], t float64 [h]); the hit's intensity, ray index
-        etc. are `segs.<field>[slot]`."""
-        return _engine().monitor_record(monitor_struct(monitor), segs)
+        """Monitor.record over a SegmentBatch without Python objects: a `MonitorHits` (device tensors
+        + the Monitor accessors: yList, tYList, IList, ... with the reference's sort orders)."""
+        from .monitors import MonitorHits
+
+        slot, P, t = _engine().monitor_record(monitor_struct(monitor), segs)
+        return MonitorHits(monitor, segs, slot, P, t)
 
     # -- ABCD extraction (optical_table.py:211-297), a caller of the hot path ----------------------
     def calculate_abcd_matrix(self, mon0, mon1, rays, disp=1e-5, rot=1e-5, debugaxs=None):

@@ -235,12 +235,16 @@ def test_record_batch_matches_object_api():
 
     batch = _pack(sc["rays"], np.arange(len(sc["rays"]), dtype=np.int32), "cuda")
     segs = table.trace_batch(batch, max_segments=16)
-    slot, P, t = table.record_batch(mon, segs)
-    assert len(slot) == mon.ndata
-    ray_of = segs.ray[slot].cpu().numpy()
-    order = np.argsort(ray_of, kind="stable")
-    np.testing.assert_allclose(P.cpu().numpy()[order], np.array([d[0] for d in mon._data_raw]), rtol=1e-12, atol=1e-12)
-    np.testing.assert_allclose(t.cpu().numpy()[order], [d[2] for d in mon._data_raw], rtol=1e-12, atol=1e-12)
+    hits = table.record_batch(mon, segs)
+    assert len(hits) == mon.ndata
+    raw_P = np.array([d[0] for d in mon._data_raw])
+    np.testing.assert_allclose(hits.PList(sort=None).cpu().numpy(), raw_P, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(hits.tList(sort=None).cpu().numpy(), [d[2] for d in mon._data_raw], rtol=1e-12, atol=1e-12)
+    for sort in ("YZ", "ID"):  # the reference's accessor orders (monitor.py:126-134)
+        np.testing.assert_allclose(hits.yList(sort).cpu().numpy(), mon.get_yList(sort=sort), rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(hits.zList(sort).cpu().numpy(), mon.get_zList(sort=sort), rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(hits.tYList(sort).cpu().numpy(), mon.get_tYList(sort=sort), rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(hits.IList(sort).cpu().numpy(), mon.get_IList(sort=sort), rtol=1e-12, atol=1e-12)
 
 
 def test_launch_options_do_not_change_results():
