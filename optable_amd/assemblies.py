@@ -10,10 +10,10 @@ from typing import Callable, Union
 
 import numpy as np
 
-from .geometry import _NO_BOX, pivot_origin
+from .geometry import pivot_origin
 from .components import (OpticalComponent, BaseRefraciveSurface, SquareMirror, SquareRefractive,
                          CircleRefractive, SphereRefractive, Lens)
-from .shapes import Plane, Polygon, ASphere, sag_parametric, sag_exact
+from .shapes import Polygon, ASphere, sag_parametric, sag_exact
 from .slab import solve_normal_to_normal_rotation
 
 _Z = [0, 0, 1]

@@ -5,8 +5,6 @@ every field is a separate contiguous 1-D tensor so a wave of 64 lanes reads/writ
 consecutive elements per field (coalesced 512 B at fp64, 256 B at fp32).  Layouts mirror
 `ot_rays` / `ot_segments` in include/optable_hip.h.
 """
-import ctypes as C
-
 import numpy as np
 import torch
 
@@ -81,6 +79,39 @@ class RayBatch:
         out.id, out.flags = self.id[lo:hi], self.flags[lo:hi]
         out.length = None if self.length is None else self.length[lo:hi]
         return out
+
+    def clone(self):
+        """Deep copy on the device."""
+        out = object.__new__(RayBatch)
+        out.n, out.precision, out.device = self.n, self.precision, self.device
+        for f in abi.RAY_FIELDS:
+            setattr(out, "n_index" if f == "n" else f, self.field(f).clone())
+        out.id, out.flags = self.id.clone(), self.flags.clone()
+        out.length = None if self.length is None else self.length.clone()
+        return out
+
+    def translate_(self, vec):
+        """origin += vec (Vector._Translate, base.py:141-144), in place."""
+        for k, ax in enumerate("xyz"):
+            self.field("o" + ax).add_(float(vec[k]))
+        return self
+
+    def rotate_around_(self, R, points):
+        """Every ray turned by the rotation matrix R about its own lab point `points[i]`
+        (Ray._RotAround -> _RotAroundLocal, ray.py:153-168): direction = R d (renormalised),
+        origin = origin + R(-lp) + lp with lp = point - origin.  In place."""
+        dt = self.ox.dtype
+        R = torch.as_tensor(np.asarray(R, dtype=float), dtype=dt, device=self.device)
+        o = torch.stack([self.ox, self.oy, self.oz], dim=1)
+        d = torch.stack([self.dx, self.dy, self.dz], dim=1)
+        lp = points.to(dt) - o
+        o = o - lp @ R.T + lp
+        d = d @ R.T
+        d = d / torch.linalg.norm(d, dim=1, keepdim=True)
+        for k, ax in enumerate("xyz"):
+            self.field("o" + ax).copy_(o[:, k])
+            self.field("d" + ax).copy_(d[:, k])
+        return self
 
     def c_struct(self):
         s = abi.OtRays()

@@ -8,7 +8,7 @@ scene compiler (scene.py) lowers every leaf through `lower_interaction()` into a
 and the HIP kernel (csrc/trace_core.h) does the arithmetic for all rays at once.
 Rendering and CSV metadata (`render`, `gather_components`) are out of scope.
 """
-from typing import List, Union
+from typing import Union
 
 import numpy as np
 

@@ -6,7 +6,7 @@ A `Ray` is the per-object view of one row of the device's SoA ray stream
 scalable container.  Plot-time helpers of the reference (`render`, beam sampling) are out of
 scope.
 """
-from typing import List, Union
+from typing import List
 
 import numpy as np
 

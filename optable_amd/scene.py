@@ -16,7 +16,7 @@ import ctypes as C
 import numpy as np
 
 from . import abi
-from .components import OpticalComponent, MIRROR, REFRACT, LENS, BLOCK, ROC_INF
+from .components import MIRROR, REFRACT, LENS, ROC_INF
 from .materials import Material
 
 

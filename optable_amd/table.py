@@ -152,6 +152,38 @@ class OpticalTable:
         Ms[:, 0, 1], Ms[:, 1, 1] = (y2 - y0) / rot, (ty2 - ty0) / rot
         return Ms
 
+    def abcd_batch(self, mon0, mon1, batch, disp=1e-5, rot=1e-5, max_segments=64):
+        """`calculate_abcd_matrix` for a RayBatch, entirely on the device: three traces, monitor
+        passes and the finite differences are tensor operations; returns a [N, 2, 2] tensor (ray i of
+        the batch = row i).  Same biasing sequence as the object version (the angular probe acts on
+        the already displaced rays and pivots about mon0's LOCAL hit point used as a lab point,
+        optical_table.py:259-284).  Every ray must cross each monitor exactly once."""
+        import torch
+        from .geometry import rotation_matrix
+
+        def probe(b):
+            segs = self.trace_batch(b, max_segments=max_segments)
+            h0, h1 = self.record_batch(mon0, segs), self.record_batch(mon1, segs)
+            for h, label in ((h0, "mon0"), (h1, "mon1")):
+                if len(h) != b.n or not torch.equal(h.ray_index("ID"), torch.arange(b.n, device=b.device)):
+                    raise AssertionError(f"Rays at {label} do not match the input rays.")
+            return h0, h1
+
+        work = batch.clone()
+        h0, h1 = probe(work)
+        pivots = h0.PList("ID")
+        y0, ty0 = h1.yList("ID"), h1.tYList("ID")
+        work.translate_(np.asarray(mon0.tangent_Y, dtype=float) * disp)
+        _, h1 = probe(work)
+        y1, ty1 = h1.yList("ID"), h1.tYList("ID")
+        work.rotate_around_(rotation_matrix(mon0.tangent_Z, rot), pivots)
+        _, h1 = probe(work)
+        y2, ty2 = h1.yList("ID"), h1.tYList("ID")
+        Ms = torch.empty((batch.n, 2, 2), dtype=y0.dtype, device=batch.device)
+        Ms[:, 0, 0], Ms[:, 1, 0] = (y1 - y0) / disp, (ty1 - ty0) / disp
+        Ms[:, 0, 1], Ms[:, 1, 1] = (y2 - y0) / rot, (ty2 - ty0) / rot
+        return Ms
+
     @staticmethod
     def calibrate_symmetric_4f(lens, rays, F10, F20, criterion="M=-I", debugaxs=None, optimize=True, display_M=False):
         """Tune the distances of mon0 - F1 - lens - 2 F2 - lens(turned) - F1 - mon1 with Nelder-Mead

@@ -224,6 +224,20 @@ def test_calculate_abcd_matrix_matches_reference():
     np.testing.assert_allclose(Ms, gold, rtol=1e-5, atol=1e-5)
 
 
+def test_abcd_batch_matches_reference():
+    """f2, scalable form: the same ABCD matrices from a RayBatch without Python objects."""
+    import optable_amd as oa
+    from optable_amd.table import _pack
+
+    sc = scenes.abcd_4f(oa)
+    table = oa.OpticalTable()
+    table.add_components(sc["components"])
+    rays = sorted(sc["rays"], key=lambda r: r._id)
+    batch = _pack(rays, np.arange(len(rays), dtype=np.int32), "cuda")
+    Ms = table.abcd_batch(sc["monitors"][0], sc["monitors"][1], batch).cpu().numpy()
+    np.testing.assert_allclose(Ms, helpers.golden("g17_abcd")["Ms"], rtol=1e-5, atol=1e-5)
+
+
 def test_record_batch_matches_object_api():
     """f1: Monitor.record on a SegmentBatch (no Python objects) == the List[Ray] path."""
     import optable_amd as oa
