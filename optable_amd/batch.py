@@ -80,6 +80,31 @@ class RayBatch:
         out.length = None if self.length is None else self.length[lo:hi]
         return out
 
+    def sorted_spatially(self, cells=32):
+        """(batch in a spatially coherent order, order) with `sorted.field(f) == self.field(f)[order]`.
+
+        Heavy scenes are latency/VALU-bound and their cost depends on how alike the 64 rays of a wave
+        are (which groups they prune, which grid cells they walk): BASELINE cfg 3 traces 2.3x faster
+        when its rays arrive sorted by origin than in random order.  The trace kernels never reorder
+        rays themselves (their [k][ray] slots are addressed by ray index, and a permuted visit would
+        turn every coalesced stream access into a gather/scatter — measured: 2x SLOWER), so callers
+        with unordered rays sort once here; `order` maps results back (ray j of the sorted batch is
+        ray order[j] of this one).  Key: origin quantised to `cells`^3 over the batch's own bounding
+        box, then direction octant."""
+        o = torch.stack([self.ox, self.oy, self.oz], dim=1).double()
+        lo, hi = o.min(dim=0).values, o.max(dim=0).values
+        q = ((o - lo) / (hi - lo).clamp_min(1e-300) * (cells - 1e-9)).long().clamp_(0, cells - 1)
+        octant = (self.dx < 0).long() + 2 * (self.dy < 0).long() + 4 * (self.dz < 0).long()
+        key = ((q[:, 0] * cells + q[:, 1]) * cells + q[:, 2]) * 8 + octant
+        order = torch.argsort(key, stable=True)
+        out = object.__new__(RayBatch)
+        out.n, out.precision, out.device = self.n, self.precision, self.device
+        for f in abi.RAY_FIELDS:
+            setattr(out, "n_index" if f == "n" else f, self.field(f)[order].contiguous())
+        out.id, out.flags = self.id[order].contiguous(), self.flags[order].contiguous()
+        out.length = None if self.length is None else self.length[order].contiguous()
+        return out, order
+
     def clone(self):
         """Deep copy on the device."""
         out = object.__new__(RayBatch)

@@ -453,3 +453,24 @@ def test_lazy_materialisation_and_csv_export(tmp_path):
     table.export_rays_csv(str(out))
     lines = out.read_text().strip().splitlines()
     assert lines[0].startswith("origin,transform_matrix,intensity") and len(lines) == 1 + len(table.rays)
+
+
+def test_sorted_spatially_is_a_pure_reordering():
+    """RayBatch.sorted_spatially: tracing the sorted batch gives, ray for ray, the bits of tracing the original."""
+    import torch
+    import optable_amd as oa
+
+    comps, gen, n, K, _ = CASES["cfg3"]
+    n = 5000
+    table = _table(comps(oa))
+    o, d = gen(n)
+    batch = _batch(o, d)
+    ordered, order = batch.sorted_spatially()
+    assert torch.equal(torch.sort(order).values, torch.arange(n, device=order.device))
+    a = table.trace_batch(batch, max_segments=K)
+    b = table.trace_batch(ordered, max_segments=K)
+    assert torch.equal(a.count[order], b.count)
+    for f in abi.SEG_FIELDS + ("surface",):
+        x, y = a.field(f).reshape(K, n)[:, order], b.field(f).reshape(K, n)
+        valid = torch.arange(K, device=x.device)[:, None] < b.count[None, :]
+        assert torch.equal(x[valid], y[valid]), f

@@ -19,6 +19,8 @@ import scenes
 eng = get_engine()
 if os.environ.get('LDSKB'):
     eng.set_option(abi.OPT_LDS_LIMIT_KB, int(os.environ['LDSKB']))
+if os.environ.get('SORT'):
+    eng.set_option(abi.OPT_SORT, int(os.environ['SORT']))
 if os.environ.get('MINW'):
     eng.set_option(abi.OPT_MIN_WAVES, int(os.environ['MINW']))
 if os.environ.get('BPC'):
@@ -40,6 +42,8 @@ def _run(name, comps, o, d, wl, K, prec, reps=5):
     eng.upload(scene)
     n = len(o)
     batch = RayBatch.from_arrays(o, d, wavelength=wl, q=Q(wl), precision=prec)
+    if os.environ.get('SORTRAYS'):  # spatially coherent input order (RayBatch.sorted_spatially)
+        batch, _ = batch.sorted_spatially()
     S = scene.n_leaves
     b = 104 if prec == "f64" else 56
     fused = scene.max_children <= 1
