@@ -849,7 +849,8 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
     const int64_t cap = (int64_t)c->n_cus * per_cu;
     const int grid = (int)(blocks_needed < cap ? blocks_needed : cap);
     // smallest instantiation that covers the scene's features, then the launch options
-    constexpr uint32_t FA = F_AABB | F_LENS, FB = F_AABB | F_LENS | F_REFRACT, FC = FB | F_GRID | F_ROOT;
+    constexpr uint32_t FA = F_AABB | F_LENS, FB = F_AABB | F_LENS | F_REFRACT, FC = FB | F_GRID | F_ROOT,
+                       FD = F_AABB | F_REFRACT | F_CURVED | F_GRID;  // spherical / aspheric optics in gridded groups (cfg 5)
     const uint32_t need = c->features;
     // Heavy scenes (many nodes per segment => VALU-bound, uneven path lengths) use the blocked
     // kernel; light ones are HBM-bound and keep one lane per ray with perfectly coalesced streams.
@@ -861,10 +862,12 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
         StateT<T> st;
         for (int k = 0; k < 11; ++k) st.f[k] = (T*)((uint8_t*)c->blocked.p + k * per_field);
         using KernB = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, SegsT<T>, int32_t*, int32_t*, int32_t, StateT<T>);
-        const int fb = (need & ~FC) == 0 ? 0 : 1, ntb = c->opt_nt ? 1 : 0;
-        static const KernB tb[2][2][2] = {
+        const int fb = (need & ~FC) == 0 ? 0 : ((need & ~FD) == 0 ? 1 : 2), ntb = c->opt_nt ? 1 : 0;
+        static const KernB tb[3][2][2] = {
             {{k_trace_blocked<T, FC, false, false, CHUNK>, k_trace_blocked<T, FC, false, true, CHUNK>},
              {k_trace_blocked<T, FC, true, false, CHUNK>, k_trace_blocked<T, FC, true, true, CHUNK>}},
+            {{k_trace_blocked<T, FD, false, false, CHUNK>, k_trace_blocked<T, FD, false, true, CHUNK>},
+             {k_trace_blocked<T, FD, true, false, CHUNK>, k_trace_blocked<T, FD, true, true, CHUNK>}},
             {{k_trace_blocked<T, F_ALL, false, false, CHUNK>, k_trace_blocked<T, F_ALL, false, true, CHUNK>},
              {k_trace_blocked<T, F_ALL, true, false, CHUNK>, k_trace_blocked<T, F_ALL, true, true, CHUNK>}}};
         KernB kb = tb[fb][in_lds ? 1 : 0][ntb];
