@@ -594,7 +594,8 @@ template <class T> static void fill_blob(const ot_scene_desc* s, std::vector<uin
             const double R = h.p[0], ht = h.p[1];
             d.r2 = (T)(ht < R ? R * R - (R - ht) * (R - ht) : 0.0);
         }
-        d.pad0 = d.pad1 = (T)0;
+        d.rad2 = (T)(h.p[0] * h.p[0]);  // sphere / cylinder radius squared
+        d.pad1 = (T)0;
         d.kind = h.kind; d.end = h.end; d.flags = h.flags; d.shape = h.shape; d.inter = h.interaction;
         d.mat1 = h.mat1; d.mat2 = h.mat2; d.roc_kind = h.roc_kind; d.max_count = h.max_interact_count;
         d.slot = h.count_slot; d.aux = h.aux; d.leaf_id = h.leaf_id;

@@ -67,7 +67,7 @@ template <class T> struct DNode {
     T lbox[6];
     T p[8];
     T refl, trans, focal, roc;
-    T inv_focal, r2, pad0, pad1;  // 1/focal_length; p[0]^2 (circle radius squared)
+    T inv_focal, r2, rad2, pad1;  // 1/focal_length; circle radius^2 or cap aperture^2; sphere/cylinder R^2
     int32_t kind, end, flags, shape, inter, mat1, mat2, roc_kind, max_count, slot, aux, leaf_id;
 };
 template <class T> struct DMat {
@@ -203,8 +203,9 @@ template <class T> __device__ __forceinline__ T cached_index(const Scene<T>& sc,
 
 // ---------------------------------------------------------------------------------------------
 // Asphere sag F(r) and the reference's finite differences (surfaces.py:351-369).
-template <class T> __device__ __forceinline__ T sag(const DNode<T>& nd, T r) {
-    const T r2 = r * r;
+// F as a function of r^2 (both sag formulas only contain even powers of r): the root scan needs no
+// square root to get r.
+template <class T> __device__ __forceinline__ T sag_r2(const DNode<T>& nd, T r2) {
     if (nd.shape == OT_SHAPE_ASPHERE_PARAM) {  // component_group.py:1092-1097
         const T R = nd.p[1], k = nd.p[2];
         const T r4 = r2 * r2;
@@ -213,6 +214,17 @@ template <class T> __device__ __forceinline__ T sag(const DNode<T>& nd, T r) {
     }
     const T EFL = nd.p[1], n = nd.p[2];  // component_group.py:1061-1064
     return (EFL / (n + T(1))) * (T(-1) + sqrt_t(T(1) + (n + T(1)) / (n - T(1)) * r2 / (EFL * EFL)));
+}
+template <class T> __device__ __forceinline__ T sag(const DNode<T>& nd, T r) { return sag_r2(nd, r * r); }
+// dF/dr divided by r, analytic, as a function of r^2 (Newton slope of the root polish only: it
+// steers the iteration, the root it converges to does not depend on it)
+template <class T> __device__ __forceinline__ T sag_slope_over_r(const DNode<T>& nd, T r2) {
+    if (nd.shape == OT_SHAPE_ASPHERE_PARAM) {
+        const T R = nd.p[1], sq = sqrt_t(T(1) - (T(1) + nd.p[2]) * r2 / (R * R));
+        return T(1) / (R * sq) + r2 * (T(4) * nd.p[3] + r2 * (T(6) * nd.p[4] + r2 * T(8) * nd.p[5]));
+    }
+    const T E = nd.p[1], n = nd.p[2], A = (n + T(1)) / (n - T(1));
+    return A / ((n + T(1)) * E * sqrt_t(T(1) + A * r2 / (E * E)));
 }
 // fp64: the reference's central differences, h = 1e-4*radius, reproduced term by term.
 // fp32: the differences would lose 4-5 digits to cancellation (F ~ 0.3, h ~ 2.5e-4), far more than
@@ -334,25 +346,23 @@ template <class T>
 __device__ __forceinline__ T surf_g(const Scene<T>& sc, const DNode<T>& nd, T ox, T oy, T oz, T dx, T dy, T dz, T t, T* dg) {
     const T Px = ox + t * dx, Py = oy + t * dy, Pz = oz + t * dz;
     switch (nd.shape) {
-        case OT_SHAPE_SPHERE: {
-            const T r = sqrt_t(Px * Px + Py * Py + Pz * Pz);
-            if (dg) *dg = (Px * dx + Py * dy + Pz * dz) / r;
-            return r - nd.p[0];
+        case OT_SHAPE_SPHERE: {  // |P| - R has the sign and the roots of |P|^2 - R^2: no square root
+            if (dg) *dg = T(2) * (Px * dx + Py * dy + Pz * dz);
+            return Px * Px + Py * Py + Pz * Pz - nd.rad2;
         }
         case OT_SHAPE_CYLINDER: {
-            const T r = sqrt_t(Px * Px + Py * Py);
-            if (dg) *dg = (Px * dx + Py * dy) / r;
-            return r - nd.p[0];
+            if (dg) *dg = T(2) * (Px * dx + Py * dy);
+            return Px * Px + Py * Py - nd.rad2;
         }
         case OT_SHAPE_POLYGON3D: {
             const T* rec = sc.aux + nd.aux;
             if (dg) *dg = rec[1] * dx + rec[2] * dy + rec[3] * dz;
             return rec[1] * (Px - rec[4]) + rec[2] * (Py - rec[5]) + rec[3] * (Pz - rec[6]);
         }
-        default: {  // aspheres: x + F(r)
-            const T r = sqrt_t(Py * Py + Pz * Pz);
-            if (dg) *dg = dx + (r > T(1e-30) ? sag_d1(nd, r) * (Py * dy + Pz * dz) / r : T(0));
-            return Px + sag(nd, r);
+        default: {  // aspheres: x + F(r), F even in r
+            const T r2 = Py * Py + Pz * Pz;
+            if (dg) *dg = dx + sag_slope_over_r(nd, r2) * (Py * dy + Pz * dz);
+            return Px + sag_r2(nd, r2);
         }
     }
 }
