@@ -381,16 +381,17 @@ __device__ __forceinline__ T polish_root(const Scene<T>& sc, const DNode<T>& nd,
         if (g == T(0)) return t;
         if ((g < T(0)) == (ga < T(0))) { a = t; ga = g; } else { b = t; gb = g; }
         T tn = t - g / dg;
+        // converged Newton step: accept BEFORE the bracket safeguard — a converged iterate sits on the
+        // bracket end it has just moved (tn == a), and bisecting there would throw the root away and
+        // spend the remaining iterations halving the interval
+        if (abs_t(tn - t) <= Num<T>::root_tol() * abs_t(t) + Num<T>::tiny()) return (tn >= a && tn <= b) ? tn : t;
         if (!(tn > a && tn < b)) tn = T(0.5) * (a + b);
-        const T step = abs_t(tn - t);
         t = tn;
-        if (step <= Num<T>::root_tol() * abs_t(t) + Num<T>::tiny()) break;
         if (b - a <= Num<T>::root_tol() * abs_t(t)) break;
     }
     return t;
 }
 
-// ---------------------------------------------------------------------------------------------
 // intersect_point_local, non-planar branch (optical_component.py:197-233), ray already in the
 // leaf's frame: local-box slab -> [t1, min(t2, 100)] -> 10-point sign scan -> first root that is
 // far enough, inside the length and inside the shape's boundary.  Planar leaves: test_leaf.
