@@ -216,6 +216,7 @@ def _fanout(kind, refl, trans):
 
 
 ROOT_GRID_MIN_TOP = 12
+ROOT_GRID_CELLS_PER_COMPONENT = 1.0
 
 
 def _root_grid(b, tops):
@@ -239,8 +240,10 @@ def _root_grid(b, tops):
     pad = 4 * margin
     org = [lo[a0] - pad, lo[a1] - pad]
     span = [extent[a0] + 2 * pad, extent[a1] + 2 * pad]
-    # about 4 cells per component, shaped like the scene, at most 64 x 64
-    cells_target = 4.0 * len(tops)
+    # about one cell per component, shaped like the scene, at most 64 x 64.  Measured on cfg 3 (tools/
+    # bench_configs.py): 1 cell per component is 1.45x faster than 4 — every extra cell a ray steps through
+    # is a divergent DDA iteration for its whole wave, which costs more than the few extra candidate tests.
+    cells_target = ROOT_GRID_CELLS_PER_COMPONENT * len(tops)
     g0 = int(np.clip(round(np.sqrt(cells_target * span[0] / span[1])), 1, 64))
     g1 = int(np.clip(round(np.sqrt(cells_target * span[1] / span[0])), 1, 64))
     size = [span[0] / g0, span[1] / g1]
