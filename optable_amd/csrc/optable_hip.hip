@@ -315,7 +315,7 @@ struct ChildStore {  // scratch for up to 2 children per ray, SoA with stride 2n
 };
 
 // PROBE = true: the pre-pass that records geometric hits of count-limited leaves (no outputs).
-template <bool SCENE_IN_LDS, bool PROBE>
+template <uint32_t F, bool SCENE_IN_LDS, bool PROBE>
 __global__ __launch_bounds__(256) void k_gen_trace(SceneBlob blob, double unit, RaysT<double> in, const int32_t* tree, int64_t n,
                                                    const int32_t* proc, const int64_t* seg_off, const int64_t* cursor,
                                                    SegsT<double> out, int64_t out_capacity, ChildStore kids, int32_t* nkids,
@@ -343,10 +343,10 @@ __global__ __launch_bounds__(256) void k_gen_trace(SceneBlob blob, double unit, 
         const bool dead = active && (fl & OT_RAY_DEAD);
         const GateCtx gate = {counts, n_classes, cls, rank, probe, n, i};
         if (PROBE) {
-            (void)nearest_hit<double, F_ALL, GATE_PROBE>(sc, r, active && !dead, gate);
+            (void)nearest_hit<double, F, GATE_PROBE>(sc, r, active && !dead, gate);
             continue;
         }
-        const Hit<double> h = nearest_hit<double, F_ALL, GATE_TABLE>(sc, r, active && !dead, gate);
+        const Hit<double> h = nearest_hit<double, F, GATE_TABLE>(sc, r, active && !dead, gate);
         if (active) {
             const int64_t slot = cur0 + seg_off[i];
             int32_t nk = 0;
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(256) void k_gen_trace(SceneBlob blob, double unit, 
                 else if (h.node < 0) store_segment(out, slot, r, r.len, t, -1);
                 else store_segment(out, slot, r, h.t, t, sc.nodes[h.node].leaf_id);
             }
-            if (!dead && h.node >= 0) nk = interact<double, F_ALL, 2>(sc, r, h, ch, make_matcache(sc, r.wl));
+            if (!dead && h.node >= 0) nk = interact<double, F, 2>(sc, r, h, ch, make_matcache(sc, r.wl));
             for (int c = 0; c < nk; ++c) {
                 const int64_t s = 2 * i + c;
                 const RayState<double>& k = ch[c];
@@ -994,8 +994,13 @@ int ot_trace_generation_f64(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
     const int64_t cap = (int64_t)c->n_cus * 4;
     const int grid = (int)(g1 < cap ? g1 : cap);
     const size_t lds_bytes = in_lds ? c->bytes64 : 0;
-    auto k_probe = in_lds ? k_gen_trace<true, true> : k_gen_trace<false, true>;
-    auto k_main = in_lds ? k_gen_trace<true, false> : k_gen_trace<false, false>;
+    // beam splitters and partially reflecting slabs are planar scenes: they get the small instantiation
+    // (145 instead of 255 VGPRs, 3 waves/SIMD instead of 1); count gates need the full one
+    constexpr uint32_t FG = F_AABB | F_LENS | F_REFRACT;
+    const bool small = (c->features & ~FG) == 0;
+    auto k_probe = in_lds ? k_gen_trace<F_ALL, true, true> : k_gen_trace<F_ALL, false, true>;
+    auto k_main = small ? (in_lds ? k_gen_trace<FG, true, false> : k_gen_trace<FG, false, false>)
+                        : (in_lds ? k_gen_trace<F_ALL, true, false> : k_gen_trace<F_ALL, false, false>);
     if (lds_bytes > 48 * 1024) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         HIP_TRY(hipFuncSetAttribute((const void*)k_main, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
