@@ -189,8 +189,13 @@ template <class T> struct StateT {
     T* f[11];  // ox oy oz dx dy dz qr qi I n pl  (wavelength, id, flags stay in the input arrays)
 };
 
+#ifndef OT_BLOCKED_MINW
+#define OT_BLOCKED_MINW 1
+#endif
+template <class T, uint32_t F> constexpr int blocked_minw() { return (sizeof(T) == 8 && F == 86u) ? OT_BLOCKED_MINW : 1; }
+
 template <class T, uint32_t F, bool SCENE_IN_LDS, bool NT, int CHUNK>
-__global__ __launch_bounds__(256) void k_trace_blocked(SceneBlob blob, T unit, RaysT<T> in, int64_t n, int32_t K, SegsT<T> out,
+__global__ __launch_bounds__(256, (blocked_minw<T, F>())) void k_trace_blocked(SceneBlob blob, T unit, RaysT<T> in, int64_t n, int32_t K, SegsT<T> out,
                                                        int32_t* __restrict__ seg_count, int32_t* counts, int32_t n_classes,
                                                        StateT<T> st) {
     extern __shared__ __align__(16) uint32_t lds[];
@@ -624,7 +629,8 @@ static uint32_t scene_features(const ot_scene_desc* s) {
         if (nd.shape != OT_SHAPE_CIRCLE && nd.shape != OT_SHAPE_RECT && nd.shape != OT_SHAPE_POLYGON2D &&
             nd.shape != OT_SHAPE_CSG)
             f |= F_CURVED;
-        if (nd.shape == OT_SHAPE_POLYGON3D) f |= F_POLY;
+        if (nd.shape == OT_SHAPE_POLYGON3D) f |= F_POLY | F_MISC;
+        if (nd.shape == OT_SHAPE_CYLINDER) f |= F_MISC;
         if (nd.interaction == OT_INT_REFRACT) f |= F_REFRACT;
         if (nd.interaction == OT_INT_LENS) f |= F_LENS;
         if (nd.max_interact_count >= 0) f |= F_LIMIT;

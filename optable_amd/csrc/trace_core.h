@@ -41,7 +41,8 @@ enum : uint32_t {
     F_LIMIT = 32,    // max_interact_count gates
     F_GRID = 64,     // large groups carry a 2-D grid over their children's boxes
     F_ROOT = 128,    // the top-level component list carries a 2-D grid walked cell by cell (DDA)
-    F_ALL = 255
+    F_MISC = 256,    // the rarer curved shapes: cylinder walls, polygons in a tilted plane (needs F_CURVED)
+    F_ALL = 511
 };
 
 template <class T> struct Num;
@@ -322,9 +323,16 @@ __device__ __forceinline__ bool planar_boundary(const Scene<T>& sc, const DNode<
     return false;
 }
 
-template <class T> __device__ __forceinline__ bool curved_boundary(const Scene<T>& sc, const DNode<T>& nd, T Px, T Py, T Pz) {
+template <class T, uint32_t F>
+__device__ __forceinline__ bool curved_boundary(const Scene<T>& sc, const DNode<T>& nd, T Px, T Py, T Pz) {
+    if constexpr (F & F_MISC) {
+        if (nd.shape == OT_SHAPE_POLYGON3D) return poly_inside(sc.aux + nd.aux, Px, Py, Pz);
+        if (nd.shape == OT_SHAPE_CYLINDER) {
+            const T th = atan2(Py, Px);
+            return nd.p[2] <= th && th <= nd.p[3] && -nd.p[1] <= Pz && Pz <= nd.p[1];
+        }
+    }
     switch (nd.shape) {
-        case OT_SHAPE_POLYGON3D: return poly_inside(sc.aux + nd.aux, Px, Py, Pz);
         case OT_SHAPE_SPHERE:
             // surfaces.py:300-303 bounds the cap by x.  For a shallow cap (R >> aperture) that test is
             // ill-conditioned in single precision (dr = dx*R/r), so the fp32 kernel applies the same
@@ -333,31 +341,29 @@ template <class T> __device__ __forceinline__ bool curved_boundary(const Scene<T
             return nd.p[0] - nd.p[1] - T(1e-12) <= Px && Px <= nd.p[0] + T(1e-12);
         case OT_SHAPE_ASPHERE_PARAM:
         case OT_SHAPE_ASPHERE_EXACT: return sqrt_t(Py * Py + Pz * Pz) <= nd.p[0] + T(1e-12);
-        case OT_SHAPE_CYLINDER: {
-            const T th = atan2(Py, Px);
-            return nd.p[2] <= th && th <= nd.p[3] && -nd.p[1] <= Pz && Pz <= nd.p[1];
-        }
         default: return false;
     }
 }
 
 // Implicit function g(t) = f(o + t d) of the non-planar shapes and its derivative.
-template <class T>
+template <class T, uint32_t F>
 __device__ __forceinline__ T surf_g(const Scene<T>& sc, const DNode<T>& nd, T ox, T oy, T oz, T dx, T dy, T dz, T t, T* dg) {
     const T Px = ox + t * dx, Py = oy + t * dy, Pz = oz + t * dz;
+    if constexpr (F & F_MISC) {
+        if (nd.shape == OT_SHAPE_CYLINDER) {
+            if (dg) *dg = T(2) * (Px * dx + Py * dy);
+            return Px * Px + Py * Py - nd.rad2;
+        }
+        if (nd.shape == OT_SHAPE_POLYGON3D) {
+            const T* rec = sc.aux + nd.aux;
+            if (dg) *dg = rec[1] * dx + rec[2] * dy + rec[3] * dz;
+            return rec[1] * (Px - rec[4]) + rec[2] * (Py - rec[5]) + rec[3] * (Pz - rec[6]);
+        }
+    }
     switch (nd.shape) {
         case OT_SHAPE_SPHERE: {  // |P| - R has the sign and the roots of |P|^2 - R^2: no square root
             if (dg) *dg = T(2) * (Px * dx + Py * dy + Pz * dz);
             return Px * Px + Py * Py + Pz * Pz - nd.rad2;
-        }
-        case OT_SHAPE_CYLINDER: {
-            if (dg) *dg = T(2) * (Px * dx + Py * dy);
-            return Px * Px + Py * Py - nd.rad2;
-        }
-        case OT_SHAPE_POLYGON3D: {
-            const T* rec = sc.aux + nd.aux;
-            if (dg) *dg = rec[1] * dx + rec[2] * dy + rec[3] * dz;
-            return rec[1] * (Px - rec[4]) + rec[2] * (Py - rec[5]) + rec[3] * (Pz - rec[6]);
         }
         default: {  // aspheres: x + F(r), F even in r
             const T r2 = Py * Py + Pz * Pz;
@@ -370,14 +376,14 @@ __device__ __forceinline__ T surf_g(const Scene<T>& sc, const DNode<T>& nd, T ox
 // Root of g inside a bracket with a sign change: Newton steps kept inside the shrinking
 // bracket, bisection when a step leaves it (the reference polishes the same bracket with
 // scipy brentq to xtol 2e-12; both converge on the same root).
-template <class T>
+template <class T, uint32_t F>
 __device__ __forceinline__ T polish_root(const Scene<T>& sc, const DNode<T>& nd, T ox, T oy, T oz, T dx, T dy, T dz, T a, T b,
                                          T ga, T gb) {
     T t = a - ga * (b - a) / (gb - ga);  // false-position start
     if (!(t > a && t < b)) t = T(0.5) * (a + b);
     for (int it = 0; it < 48; ++it) {
         T dg;
-        const T g = surf_g(sc, nd, ox, oy, oz, dx, dy, dz, t, &dg);
+        const T g = surf_g<T, F>(sc, nd, ox, oy, oz, dx, dy, dz, t, &dg);
         if (g == T(0)) return t;
         if ((g < T(0)) == (ga < T(0))) { a = t; ga = g; } else { b = t; gb = g; }
         T tn = t - g / dg;
@@ -409,19 +415,19 @@ __device__ __forceinline__ bool hit_leaf(const Scene<T>& sc, const DNode<T>& nd,
         t2 = min_t(t2, T(100));
         // np.linspace(t1 - EPS, t2 + EPS, 10): sign change per sub-interval, roots ascending
         const T a = t1 - EPS, b = t2 + EPS, step = (b - a) / T(9);
-        T tl = a, gl = surf_g(sc, nd, ox, oy, oz, dx, dy, dz, a, (T*)nullptr);
+        T tl = a, gl = surf_g<T, F>(sc, nd, ox, oy, oz, dx, dy, dz, a, (T*)nullptr);
         for (int i = 1; i < 10; ++i) {
             const T tr = (i == 9) ? b : a + T(i) * step;
-            const T gr = surf_g(sc, nd, ox, oy, oz, dx, dy, dz, tr, (T*)nullptr);
+            const T gr = surf_g<T, F>(sc, nd, ox, oy, oz, dx, dy, dz, tr, (T*)nullptr);
             // fp64: the reference's strict product test (optical_component.py:131).  fp32: |P| - R is
             // quantised to ~2e-6 at R ~ 30, so a sample lands on g == 0 exactly for several percent of
             // the rays and the product test would drop those roots; compare signs instead.
             const bool crossing = sizeof(T) == 4 ? ((gl < T(0)) != (gr < T(0))) : (gl * gr < T(0));
             if (crossing) {
-                const T t = polish_root(sc, nd, ox, oy, oz, dx, dy, dz, tl, tr, gl, gr);
+                const T t = polish_root<T, F>(sc, nd, ox, oy, oz, dx, dy, dz, tl, tr, gl, gr);
                 if (t >= T(0) && abs_t(t) >= EPS && t <= len) {
                     const T X = ox + t * dx, Y = oy + t * dy, Z = oz + t * dz;
-                    if (curved_boundary(sc, nd, X, Y, Z)) {
+                    if (curved_boundary<T, F>(sc, nd, X, Y, Z)) {
                         t_out = t; Px = X; Py = Y; Pz = Z;
                         return true;
                     }
@@ -735,12 +741,15 @@ __device__ __forceinline__ void surf_normal(const Scene<T>& sc, const DNode<T>& 
     if constexpr (F & F_CURVED) {
         switch (nd.shape) {
             case OT_SHAPE_SPHERE: nx = Px / nd.p[0]; ny = Py / nd.p[0]; nz = Pz / nd.p[0]; return;
-            case OT_SHAPE_CYLINDER: nx = Px / nd.p[0]; ny = Py / nd.p[0]; nz = T(0); return;
-            case OT_SHAPE_POLYGON3D: {
-                const T* rec = sc.aux + nd.aux;
-                nx = rec[1]; ny = rec[2]; nz = rec[3];
+            case OT_SHAPE_CYLINDER:
+                if constexpr (F & F_MISC) { nx = Px / nd.p[0]; ny = Py / nd.p[0]; nz = T(0); }
                 return;
-            }
+            case OT_SHAPE_POLYGON3D:
+                if constexpr (F & F_MISC) {
+                    const T* rec = sc.aux + nd.aux;
+                    nx = rec[1]; ny = rec[2]; nz = rec[3];
+                }
+                return;
             case OT_SHAPE_ASPHERE_PARAM:
             case OT_SHAPE_ASPHERE_EXACT: {  // surfaces.py:380-388
                 const T r = sqrt_t(Py * Py + Pz * Pz);

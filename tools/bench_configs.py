@@ -16,6 +16,8 @@ from optable_amd.batch import RayBatch, SegmentBatch
 from optable_amd.engine import get_engine
 import scenes
 
+if os.environ.get('OT_LIB'):  # kernel-variant experiments: an alternative build of the library
+    abi.LIB_PATH = os.path.abspath(os.environ['OT_LIB'])
 eng = get_engine()
 if os.environ.get('LDSKB'):
     eng.set_option(abi.OPT_LDS_LIMIT_KB, int(os.environ['LDSKB']))
