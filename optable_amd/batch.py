@@ -105,6 +105,24 @@ class RayBatch:
         out.length = None if self.length is None else self.length[order].contiguous()
         return out, order
 
+    def multiplexed_in_wavelength(self, wavelengths):
+        """Wavelength-major copies of the batch, `multiplex_rays_in_wavelength` (ray.py:428-445) for
+        a device batch: ray j of copy w sits at w*n + j, carries wavelengths[w] and — like the
+        reference's `ray.copy(wavelength=wl)` — shares id, q and every other field with its source."""
+        wl = torch.as_tensor(np.asarray(wavelengths, dtype=np.float64), device=self.device)
+        W = int(wl.numel())
+        out = object.__new__(RayBatch)
+        out.n, out.precision, out.device = self.n * W, self.precision, self.device
+        for f in abi.RAY_FIELDS:
+            name = "n_index" if f == "n" else f
+            if f == "wavelength":
+                setattr(out, name, wl.to(self.wavelength.dtype).repeat_interleave(self.n))
+            else:
+                setattr(out, name, self.field(f).repeat(W))
+        out.id, out.flags = self.id.repeat(W), self.flags.repeat(W)
+        out.length = None if self.length is None else self.length.repeat(W)
+        return out
+
     def clone(self):
         """Deep copy on the device."""
         out = object.__new__(RayBatch)

@@ -1,0 +1,164 @@
+"""BASELINE configs 3-5 at the size ONE GPU sees in the quoted configuration (cfg 3: all 1e7 rays,
+fp32; cfg 4: the 4-GPU shard of 1e7 rays x 64 wavelengths, fp64; cfg 5: the 8-GPU shard of 1e8 rays,
+fp32), checked through properties that need no oracle: segment chains are continuous, directions are
+unit vectors, a shard traced on its own reproduces its part of the whole bit for bit (what
+`bench.py --gpus N` relies on), and cfg 4 has a closed-form answer (Snell through a flat slab).
+Small-size parity against the oracle for the same scenes is in test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+import scenes
+from optable_amd import abi
+
+pytestmark = pytest.mark.gpu
+
+
+def _table(components):
+    import optable_amd as oa
+
+    t = oa.OpticalTable()
+    t.add_components(components)
+    return t
+
+
+def _chain_properties(segs, n, K, tol, unit_tol):
+    """Device-side, one segment index at a time (no [K, n] temporaries)."""
+    import torch
+
+    cnt = segs.count
+    f = {name: segs.field(name).view(K, n) for name in ("ox", "oy", "oz", "dx", "dy", "dz", "length")}
+    surf = segs.surface.view(K, n)
+    worst_gap = worst_norm = 0.0
+    for k in range(K):
+        valid = cnt > k
+        if not bool(valid.any()):
+            break
+        norm = torch.sqrt(f["dx"][k].double() ** 2 + f["dy"][k].double() ** 2 + f["dz"][k].double() ** 2)
+        worst_norm = max(worst_norm, float((norm - 1).abs()[valid].max()))
+        assert bool((f["length"][k][valid] > 0).all())
+        last = cnt == k + 1          # a ray's final segment either escaped (open length) or hit the cap / a block
+        open_end = last & (surf[k] < 0)
+        assert bool(torch.isinf(f["length"][k][open_end]).all())
+        if k + 1 < K:
+            link = cnt > k + 1
+            if bool(link.any()):
+                assert bool((surf[k][link] >= 0).all())
+                for a in "xyz":
+                    end = f["o" + a][k].double() + f["length"][k].double() * f["d" + a][k].double()
+                    worst_gap = max(worst_gap, float((end - f["o" + a][k + 1].double()).abs()[link].max()))
+    assert worst_gap < tol, worst_gap
+    assert worst_norm < unit_tol, worst_norm
+
+
+def _shard_equals_whole(table, batch, segs, lo, hi, K):
+    import torch
+
+    n = batch.n
+    part = table.trace_batch(batch.slice(lo, hi), max_segments=K)
+    assert torch.equal(part.count, segs.count[lo:hi])
+    m = hi - lo
+    keep = torch.arange(K, device=part.count.device).unsqueeze(1) < part.count.unsqueeze(0)
+    for name in abi.SEG_FIELDS + ("surface",):
+        whole = segs.field(name).view(K, n)[:, lo:hi]
+        mine = part.field(name).view(K, m)
+        assert torch.equal(whole[keep], mine[keep]), name
+
+
+def test_cfg3_full_size_fp32():
+    """1e7 rays, 32 mixed components (56 leaves), cap 20, fp32 — BASELINE configs[2] as quoted."""
+    import torch
+    import optable_amd as oa
+    from optable_amd.batch import RayBatch
+
+    n, K = 10_000_000, 20
+    table = _table(scenes.cfg3_components(oa))
+    o, d = scenes.cfg3_rays(n, 2)
+    batch = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=1j * np.pi * scenes.W0**2 / scenes.WL, precision="f32")
+    del o, d
+    segs = table.trace_batch(batch, max_segments=K)
+    cnt = segs.count
+    assert int(cnt.min()) >= 1 and int(cnt.max()) <= K
+    mean = float(cnt.double().mean())
+    assert 4.6 < mean < 5.2, mean        # mean 4.8 segments per ray (oracle-validated)
+    _chain_properties(segs, n, K, tol=6e-3, unit_tol=1e-6)
+    _shard_equals_whole(table, batch, segs, 3_000_000, 4_250_000, K)
+    torch.cuda.empty_cache()
+
+
+def test_cfg4_shard_closed_form_fp64():
+    """The per-GPU shard of configs[3] on 4 GPUs: 2.5e6 rays x 64 wavelengths = 1.6e8 ray-wavelength
+    pairs through an N-BK7 slab, fp64.  Every pair yields exactly 3 segments, the exit ray is parallel
+    to the entry ray, displaced sideways by thickness*sin(ti - tt)/cos(tt) with sin(tt) = sin(ti)/n(wl),
+    and its optical path is the geometric lengths weighted by n — all evaluated here independently
+    from the Sellmeier table on the host (material.py:115-120)."""
+    import torch
+    import optable_amd as oa
+    from optable_amd.batch import RayBatch
+
+    nb, nwl, K = 2_500_000, 64, 3
+    thickness = 0.5
+    rng = np.random.default_rng(4)
+    jit = rng.uniform(-0.3, 0.3, (nb, 2))
+    o = np.stack([np.full(nb, -3.0), 2 + jit[:, 0], jit[:, 1]], 1)
+    d = np.tile([np.cos(np.pi / 6), -np.sin(np.pi / 6), 0.0], (nb, 1))
+    wls = np.linspace(400e-7, 1100e-7, nwl)
+    base = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=1j * np.pi * scenes.W0**2 / scenes.WL)
+    batch = base.multiplexed_in_wavelength(wls)
+    del base, o, d
+    n = nb * nwl
+    glass = oa.Glass_NBK7()
+    table = _table([oa.GlassSlab([0, 0, 0], width=2, height=2, thickness=thickness, n1=oa.Vacuum(), n2=glass, reflectivity=0)])
+    segs = table.trace_batch(batch, max_segments=K)
+    assert int(segs.count.min()) == K and int(segs.count.max()) == K
+    f = {name: segs.field(name).view(K, n) for name in abi.SEG_FIELDS}
+    surf = segs.surface.view(K, n)
+    assert bool((surf[:2] >= 0).all()) and bool((surf[2] == -1).all())
+    # host-side Sellmeier (wavelength in model units x unit 1e-2 m -> micrometres)
+    um = wls * 1e-2 * 1e6
+    B = np.array([1.03961212, 0.231792344, 1.01046945])      # Schott N-BK7 (material.py:123-130)
+    C = np.array([0.00600069867, 0.0200179144, 103.560653])
+    n_glass = np.sqrt(1 + sum(B[i] * um**2 / (um**2 - C[i]) for i in range(3)))
+    n_dev = torch.as_tensor(n_glass, device="cuda").repeat_interleave(nb)
+    assert float((f["n"][1] - n_dev).abs().max()) < 1e-12          # index carried by the inner segment
+    assert float((f["n"][0] - 1).abs().max()) == 0.0 and float((f["n"][2] - 1).abs().max()) == 0.0
+    for a in "xyz":                                                  # exit parallel to entry
+        assert float((f["d" + a][2] - f["d" + a][0]).abs().max()) < 1e-12
+    ti = np.pi / 6
+    tt = torch.arcsin(np.sin(ti) / n_dev)
+    shift = thickness * torch.sin(ti - tt) / torch.cos(tt)
+    # sideways displacement of the exit ray from the entry line (direction d0 through o0)
+    rx, ry, rz = (f["o" + a][2] - f["o" + a][0] for a in "xyz")
+    along = rx * f["dx"][0] + ry * f["dy"][0] + rz * f["dz"][0]
+    perp = torch.sqrt((rx - along * f["dx"][0]) ** 2 + (ry - along * f["dy"][0]) ** 2 + (rz - along * f["dz"][0]) ** 2)
+    assert float((perp - shift).abs().max()) < 1e-10
+    inner = thickness / torch.cos(tt)
+    assert float((f["length"][1] - inner).abs().max()) < 1e-10
+    opl = f["length"][0] + inner * n_dev
+    assert float((f["pathlength"][2] - opl).abs().max()) < 1e-9
+    # transmission 1, reflectivity 0: lossless
+    assert float((f["intensity"] - 1).abs().max()) == 0.0
+    del f, surf, perp, along, rx, ry, rz
+    _shard_equals_whole(table, batch, segs, 40_000_000, 41_000_000, K)
+    torch.cuda.empty_cache()
+
+
+def test_cfg5_shard_fp32():
+    """The per-GPU shard of configs[4] on 8 GPUs: 1.25e7 rays, asphere + MMA 16x16 (260 leaves),
+    cap 50, fp32."""
+    import torch
+    import optable_amd as oa
+    from optable_amd.batch import RayBatch
+
+    n, K = 12_500_000, 50
+    table = _table(scenes.cfg5_components(oa))
+    o, d = scenes.cfg5_rays(n, 3)
+    batch = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=1j * np.pi * scenes.W0**2 / scenes.WL, precision="f32")
+    del o, d
+    segs = table.trace_batch(batch, max_segments=K)
+    cnt = segs.count
+    assert int(cnt.min()) >= 1 and int(cnt.max()) == K      # some rays ring between mirror and MMA to the cap
+    mean = float(cnt.double().mean())
+    assert 20 < mean < 28, mean                              # 24.1 at 4e5 rays (oracle-validated at small n)
+    _chain_properties(segs, n, K, tol=6e-3, unit_tol=1e-6)
+    _shard_equals_whole(table, batch, segs, 5_000_000, 5_400_000, K)
+    torch.cuda.empty_cache()
