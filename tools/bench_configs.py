@@ -83,19 +83,24 @@ n2 = int(os.environ.get("N2", 1_000_000))
 n3 = int(os.environ.get("N3", 2_000_000))
 n4 = int(os.environ.get("N4", 100_000))
 n5 = int(os.environ.get("N5", 200_000))
-for prec in ("f64", "f32"):
-    o, d = scenes.cfg2_rays(n2, 0)
-    run("cfg2 lens+mirrorpair", scenes.cfg2_components(oa), o, d, scenes.WL, 5, prec)
-    o, d = scenes.cfg3_rays(n3, 2)
-    run("cfg3 32 mixed components", scenes.cfg3_components(oa), o, d, scenes.WL, 20, prec)
-    nwl = 64
-    rng = np.random.default_rng(4)
-    jit = rng.uniform(-0.3, 0.3, (n4, 2))
-    ob = np.stack([np.full(n4, -3.0), 2 + jit[:, 0], jit[:, 1]], 1)
-    db = np.tile([np.cos(np.pi / 6), -np.sin(np.pi / 6), 0.0], (n4, 1))
-    wl = np.repeat(np.linspace(400e-7, 1100e-7, nwl), n4)
-    slab = [oa.GlassSlab([0, 0, 0], width=2, height=2, thickness=0.5, n1=oa.Vacuum(), n2=oa.Glass_NBK7(), reflectivity=0)]
-    run("cfg4 NBK7 slab x64 wl", slab, np.tile(ob, (nwl, 1)), np.tile(db, (nwl, 1)), wl, 8, prec)
-    if True:
+only = set(filter(None, os.environ.get("ONLY", "").split(",")))   # e.g. ONLY=cfg3,cfg5
+want = lambda c: not only or c in only
+for prec in filter(None, os.environ.get("PREC", "f64,f32").split(",")):
+    if want("cfg2"):
+        o, d = scenes.cfg2_rays(n2, 0)
+        run("cfg2 lens+mirrorpair", scenes.cfg2_components(oa), o, d, scenes.WL, 5, prec)
+    if want("cfg3"):
+        o, d = scenes.cfg3_rays(n3, 2)
+        run("cfg3 32 mixed components", scenes.cfg3_components(oa), o, d, scenes.WL, 20, prec)
+    if want("cfg4"):
+        nwl = 64
+        rng = np.random.default_rng(4)
+        jit = rng.uniform(-0.3, 0.3, (n4, 2))
+        ob = np.stack([np.full(n4, -3.0), 2 + jit[:, 0], jit[:, 1]], 1)
+        db = np.tile([np.cos(np.pi / 6), -np.sin(np.pi / 6), 0.0], (n4, 1))
+        wl = np.repeat(np.linspace(400e-7, 1100e-7, nwl), n4)
+        slab = [oa.GlassSlab([0, 0, 0], width=2, height=2, thickness=0.5, n1=oa.Vacuum(), n2=oa.Glass_NBK7(), reflectivity=0)]
+        run("cfg4 NBK7 slab x64 wl", slab, np.tile(ob, (nwl, 1)), np.tile(db, (nwl, 1)), wl, int(os.environ.get("K4", 8)), prec)
+    if want("cfg5"):
         o, d = scenes.cfg5_rays(n5, 3)
         run("cfg5 asphere+MMA16x16", scenes.cfg5_components(oa), o, d, scenes.WL, 50, prec)
