@@ -205,7 +205,8 @@ int ot_scene_upload(ot_ctx* ctx, const ot_scene_desc* scene);
  * seg_count[i] = -(k+1) (its first k+1 slots are valid, the tree is incomplete) and must be
  * re-traced with ot_trace_generation_f64.
  * counts: int32 [n_count_slots][n_count_classes] interact-count table indexed by rays.id, or
- * NULL when the scene has no limited surface. */
+ * NULL when the scene has no limited surface.  A ray whose id lies outside [0, n_count_classes)
+ * is not counted (every limited surface stays open to it); nothing is indexed out of range. */
 int ot_trace_f64(ot_ctx* ctx, const ot_rays* rays, int64_t n_rays, int32_t max_segments,
                  const ot_segments* out, int32_t* seg_count, int32_t* counts,
                  int32_t n_count_classes);

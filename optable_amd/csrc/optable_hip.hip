@@ -663,9 +663,54 @@ static int validate_root_grid(const ot_scene_desc* s) {
     return 0;
 }
 
+// polygon record: [nv, plane normal(3), v0(3), e1(3), e2(3) | nv x (x, y)]; returns its length or -1
+static int64_t polygon_record_len(const ot_scene_desc* s, int64_t off) {
+    if (off < 0 || off + 13 > s->n_aux) return -1;
+    const double nv = s->aux[off];
+    if (!(nv >= 3 && nv <= 4096) || nv != (double)(int)nv) return -1;
+    const int64_t len = 13 + 2 * (int64_t)nv;
+    return off + len <= s->n_aux ? len : -1;
+}
+
+// CSG record: [ntok | ntok x (kind, len, body[len])], postfix over a 32-deep bit stack (trace_core.h csg_inside)
+static int validate_csg(const ot_scene_desc* s, int64_t off) {
+    if (off < 0 || off + 1 > s->n_aux) return fail(OT_ERR_INVALID, "CSG program out of range");
+    const double ntok = s->aux[off];
+    if (!(ntok >= 1 && ntok <= 1024) || ntok != (double)(int)ntok) return fail(OT_ERR_INVALID, "bad CSG token count");
+    int64_t t = off + 1;
+    int sp = 0;
+    for (int k = 0; k < (int)ntok; ++k) {
+        if (t + 2 > s->n_aux) return fail(OT_ERR_INVALID, "CSG token out of range");
+        const int kind = (int)s->aux[t];
+        const double len = s->aux[t + 1];
+        if (!(len >= 0 && len <= 16384) || len != (double)(int)len || t + 2 + (int64_t)len > s->n_aux)
+            return fail(OT_ERR_INVALID, "CSG token body out of range");
+        if (kind == 100 || kind == 101) {  // union / subtract
+            if (sp < 2) return fail(OT_ERR_INVALID, "CSG operator without two operands");
+            sp -= 1;
+        } else {
+            if (kind == OT_SHAPE_CIRCLE) { if (len < 1) return fail(OT_ERR_INVALID, "CSG circle needs a radius"); }
+            else if (kind == OT_SHAPE_RECT) { if (len < 2) return fail(OT_ERR_INVALID, "CSG rectangle needs two half sizes"); }
+            else if (kind == OT_SHAPE_POLYGON2D) { if (polygon_record_len(s, t + 2) != (int64_t)len) return fail(OT_ERR_INVALID, "bad CSG polygon record"); }
+            else return fail(OT_ERR_UNSUPPORTED, "unknown CSG primitive");
+            if (++sp > 32) return fail(OT_ERR_UNSUPPORTED, "CSG program deeper than 32");
+        }
+        t += 2 + (int64_t)len;
+    }
+    if (sp != 1) return fail(OT_ERR_INVALID, "CSG program does not reduce to one value");
+    return 0;
+}
+
 static int validate_scene(const ot_scene_desc* s) {
-    if (!s || s->n_nodes < 0 || s->n_materials < 0 || s->n_aux < 0) return fail(OT_ERR_INVALID, "bad scene sizes");
+    if (!s || s->n_nodes < 0 || s->n_materials < 0 || s->n_aux < 0 || s->n_count_slots < 0) return fail(OT_ERR_INVALID, "bad scene sizes");
     if (s->n_nodes && !s->nodes) return fail(OT_ERR_INVALID, "nodes is NULL");
+    if (s->n_materials && !s->materials) return fail(OT_ERR_INVALID, "materials is NULL");
+    if (s->n_aux && !s->aux) return fail(OT_ERR_INVALID, "aux is NULL");
+    if (s->max_children < 0 || s->max_children > 2) return fail(OT_ERR_INVALID, "max_children must be 0, 1 or 2");
+    if (!(s->unit > 0)) return fail(OT_ERR_INVALID, "unit must be positive");
+    for (int i = 0; i < s->n_materials; ++i)
+        if (s->materials[i].kind != OT_MAT_CONST && s->materials[i].kind != OT_MAT_SELLMEIER)
+            return fail(OT_ERR_UNSUPPORTED, "unknown material kind");
     for (int i = 0; i < s->n_nodes; ++i) {
         const ot_node& nd = s->nodes[i];
         if (nd.end <= i || nd.end > s->n_nodes) return fail(OT_ERR_INVALID, "node.end out of range at " + std::to_string(i));
@@ -676,8 +721,12 @@ static int validate_scene(const ot_scene_desc* s) {
             if (nd.interaction == OT_INT_REFRACT &&
                 (nd.mat1 < 0 || nd.mat1 >= s->n_materials || nd.mat2 < 0 || nd.mat2 >= s->n_materials))
                 return fail(OT_ERR_INVALID, "material index out of range");
-            const bool needs_aux = nd.shape == OT_SHAPE_POLYGON2D || nd.shape == OT_SHAPE_POLYGON3D || nd.shape == OT_SHAPE_CSG;
-            if (needs_aux && (nd.aux < 0 || nd.aux >= s->n_aux)) return fail(OT_ERR_INVALID, "aux offset out of range");
+            if ((nd.shape == OT_SHAPE_POLYGON2D || nd.shape == OT_SHAPE_POLYGON3D) && polygon_record_len(s, nd.aux) < 0)
+                return fail(OT_ERR_INVALID, "polygon record out of range at node " + std::to_string(i));
+            if (nd.shape == OT_SHAPE_CSG) {
+                const int rc = validate_csg(s, nd.aux);
+                if (rc) return rc;
+            }
             if (nd.max_interact_count >= 0 && (nd.count_slot < 0 || nd.count_slot >= s->n_count_slots))
                 return fail(OT_ERR_INVALID, "count_slot out of range");
         } else if (nd.kind != OT_NODE_GROUP) {

@@ -477,6 +477,7 @@ struct GateCtx {
     int64_t stride, idx;
 };
 template <int GATE> __device__ __forceinline__ bool count_gate(const GateCtx& g, int32_t slot, int32_t max_count) {
+    if ((uint32_t)g.cls >= (uint32_t)g.n_classes) return true;  // id outside the table: not counted (never indexes out of range)
     int32_t* c = g.counts + (int64_t)slot * g.n_classes + g.cls;
     if (GATE == GATE_TABLE) return *c + g.rank[(int64_t)slot * g.stride + g.idx] < max_count;
     const int32_t v = *c;
