@@ -80,6 +80,22 @@ class RayBatch:
         out.length = None if self.length is None else self.length[lo:hi]
         return out
 
+    def take(self, index):
+        """New batch made of rays `index` (device int64 tensor), in that order."""
+        out = object.__new__(RayBatch)
+        out.n, out.precision, out.device = int(index.numel()), self.precision, self.device
+        for f in abi.RAY_FIELDS:
+            setattr(out, "n_index" if f == "n" else f, self.field(f)[index].contiguous())
+        out.id, out.flags = self.id[index].contiguous(), self.flags[index].contiguous()
+        out.length = None if self.length is None else self.length[index].contiguous()
+        return out
+
+    def with_ids(self, ids):
+        """Same rays (storage shared) under other ids (int32 device tensor)."""
+        out = self.slice(0, self.n)
+        out.id = ids.to(torch.int32).contiguous()
+        return out
+
     def sorted_spatially(self, cells=32):
         """(batch in a spatially coherent order, order) with `sorted.field(f) == self.field(f)[order]`.
 

@@ -103,14 +103,77 @@ class OpticalTable:
         scene = self.compile()
         eng.upload(scene)
         cap = MAX_TRACE_NUM if max_segments is None else int(max_segments)
-        speculate = scene.max_children == 2 and not scene.limited and not scene.always_branches
+        if scene.limited:
+            return self._trace_batch_limited(eng, scene, batch, cap, max_segments is not None, counts)
+        speculate = scene.max_children == 2 and not scene.always_branches
         if max_segments is not None and (scene.max_children <= 1 or speculate):
             # max_children == 2: speculate that no tree actually branches (e.g. mirror-coated
             # interfaces only split on total internal reflection); fall back when one does.
-            segs = eng.trace(batch, cap, counts=counts)
+            segs = eng.trace(batch, cap)
             if scene.max_children <= 1 or not bool((segs.count < 0).any()):
                 return segs
-        return eng.trace_tree(batch, cap, counts=counts)
+        return eng.trace_tree(batch, cap)
+
+    def _trace_batch_limited(self, eng, scene, batch, cap, fused_ok, counts):
+        """`trace_batch` for scenes with `max_interact_count` surfaces.  Their counters are keyed by ray id
+        (optical_component.py:140-149): the device table has one column per DISTINCT id of the batch
+        (`segs.count_ids` names the columns, ascending), and rays that share an id — copies made by
+        `multiplexed_in_wavelength`, explicit duplicates — must see each other's updates in input order,
+        as the reference finishes one input ray before it starts the next (optical_table.py:66-70).  Rays
+        of one id are therefore traced in successive rounds (round r = the r-th ray of every id) over the
+        same table; rays with different ids never interact, so a round is one ordinary launch."""
+        import torch
+        from .batch import SegmentBatch
+
+        n, dev = batch.n, batch.device
+        uniq, inverse = torch.unique(batch.id, return_inverse=True)
+        n_classes, n_slots = int(uniq.numel()), len(scene.limited)
+        if counts is None:
+            counts = torch.zeros((n_slots, max(n_classes, 1)), dtype=torch.int32, device=dev)
+        elif tuple(counts.shape) != (n_slots, n_classes):
+            raise ValueError(f"counts must be [{n_slots}, {n_classes}] (limited surfaces x distinct ray ids)")
+        work = batch.with_ids(inverse)
+        fused = fused_ok and scene.max_children <= 1
+
+        def run(sub):
+            return eng.trace(sub, cap, counts=counts) if fused else eng.trace_tree(sub, cap, counts=counts)
+
+        if n_classes == n:
+            segs = run(work)
+            segs.count_ids = uniq
+            return segs
+        order = torch.argsort(inverse, stable=True)
+        grouped = inverse[order]
+        rounds = torch.empty(n, dtype=torch.int64, device=dev)
+        rounds[order] = torch.arange(n, device=dev) - torch.searchsorted(grouped, grouped)
+        parts = []
+        for r in range(int(rounds.max()) + 1):
+            idx = torch.nonzero(rounds == r).flatten()  # ascending: input order inside a round
+            parts.append((idx, run(work.take(idx))))
+        if fused:  # [k][ray] slots of the whole batch
+            out = SegmentBatch(n * cap, batch.precision, dev)
+            out.count, out.n_rays = torch.empty(n, dtype=torch.int32, device=dev), n
+            for idx, part in parts:
+                m = int(idx.numel())
+                out.count[idx] = part.count
+                for f in abi.SEG_FIELDS + ("surface",):
+                    out.field(f).view(cap, n)[:, idx] = part.field(f).view(cap, m)
+                out.ray.view(cap, n)[:, idx] = idx.to(torch.int32).unsqueeze(0).expand(cap, m)
+        else:  # flat lists: concatenate, tree indices back to positions in `batch`
+            total = sum(part.n_valid for _, part in parts)
+            out = SegmentBatch(total, "f64", dev)
+            out.capped = torch.zeros(n, dtype=torch.bool, device=dev)
+            at = 0
+            for idx, part in parts:
+                v = part.n_valid
+                for f in abi.SEG_FIELDS + ("surface",):
+                    out.field(f)[at:at + v] = part.field(f)[:v]
+                out.ray[at:at + v] = idx[part.ray[:v].long()].to(torch.int32)
+                out.capped[idx] = part.capped
+                at += v
+            out.n_valid = total
+        out.counts_table, out.count_ids = counts, uniq
+        return out
 
     def record_batch(self, monitor, segs):
         """Monitor.record over a SegmentBatch without Python objects: a `MonitorHits` (device tensors

@@ -474,3 +474,45 @@ def test_sorted_spatially_is_a_pure_reordering():
         x, y = a.field(f).reshape(K, n)[:, order], b.field(f).reshape(K, n)
         valid = torch.arange(K, device=x.device)[:, None] < b.count[None, :]
         assert torch.equal(x[valid], y[valid]), f
+
+
+@pytest.mark.parametrize("branching", [False, True])
+def test_batch_limited_scene_with_shared_ids(branching, oracle):
+    """`max_interact_count` surfaces + rays that share an id (three wavelength copies of every ray, as
+    multiplex_rays_in_wavelength makes them, ray.py:441-444): the copies must consume the SAME counters in
+    input order (optical_component.py:140-149).  trace_batch runs them in rounds over one device table; the
+    oracle traces the rays one after the other like the reference."""
+    import optable_amd as oa
+    from optable_amd.batch import RayBatch
+
+    rng = np.random.default_rng(77)
+    comps = [oa.Mirror([-2, 0, 0], radius=3),
+             oa.Mirror([6, 0, 0], radius=3, max_interact_count=2).RotZ(np.pi),      # opens after two hits per id
+             oa.TriangularPrism([10, 0.3, 0], width=1.5, height=2, n1=1, n2=1.5),   # faces 2/3 limited to 5 by default
+             oa.Mirror([14, 0, 0], radius=3, max_interact_count=1).RotZ(np.pi)]
+    if branching:
+        comps.append(oa.BeamSplitter([3, 0, 0], width=4, height=4, eta=0.5).RotZ(0.3))
+    table = _table(comps)
+    scene = table.compile()
+    assert len(scene.limited) >= 3 and scene.max_children == (2 if branching else 1)
+    nb, K = 400, 14
+    o = np.stack([np.zeros(nb), rng.uniform(-1, 1, nb), rng.uniform(-0.2, 0.2, nb)], 1)
+    d = np.stack([np.ones(nb), rng.uniform(-0.05, 0.05, nb), rng.uniform(-0.01, 0.01, nb)], 1)
+    ids = 1000 + 7 * rng.permutation(nb)               # arbitrary, unordered, not 0..n-1
+    base = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=1j * np.pi * scenes.W0**2 / scenes.WL, ids=ids)
+    batch = base.multiplexed_in_wavelength([780e-7, 560e-7, 400e-7])
+    segs = table.trace_batch(batch, max_segments=K)
+    got = segs.to_host(reference_order=True)
+    host = batch.to_host()
+    uniq, inverse = np.unique(host["id"], return_inverse=True)
+    np.testing.assert_array_equal(segs.count_ids.cpu().numpy(), uniq)
+    host["id"] = inverse.astype(np.int32)
+    ref = oracle.trace(scene, host, max_trace_num=K, n_classes=len(uniq))
+    np.testing.assert_array_equal(got["ray"], ref["ray"])
+    np.testing.assert_array_equal(got["surface"], ref["surface"])
+    for f in abi.SEG_FIELDS:
+        np.testing.assert_allclose(got[f], ref[f], rtol=1e-9, atol=1e-9, err_msg=f)
+    np.testing.assert_array_equal(segs.counts_table.cpu().numpy(), ref["counts"])
+    # the gates really acted: the second and third copies of a ray do not repeat the first copy's path
+    first, third = got["surface"][got["ray"] < nb], got["surface"][got["ray"] >= 2 * nb]
+    assert len(first) != len(third) or not np.array_equal(first, third)
