@@ -17,6 +17,17 @@ def shard_range(n, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def shard_indices_by_id(ids, rank, world):
+    """Ray indices (ascending) owned by `rank` when rays that share an id must stay on one GPU — scenes
+    with `max_interact_count` surfaces, whose counters are keyed by id (e.g. the copies made
+    by `multiplexed_in_wavelength` sit n apart and a contiguous split would separate them).  Distinct ids
+    are dealt out in contiguous, equally sized ranges of their sorted order, so shards stay balanced to
+    within one id class; `RayBatch.take(indices)` builds the shard."""
+    uniq, inverse = torch.unique(ids, return_inverse=True)
+    owner = (inverse * world) // max(int(uniq.numel()), 1)
+    return torch.nonzero(owner == rank).flatten()
+
+
 def final_state(segs):
     """[12, n_rays] tensor: each ray's last segment (non-branching [k][ray] layout)."""
     n = segs.n_rays

@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from optable_amd.dist import shard_range, gather_final_state
+from optable_amd.dist import shard_range, gather_final_state, shard_indices_by_id
 
 
 def test_shard_ranges_cover_exactly():
@@ -17,6 +17,24 @@ def test_shard_ranges_cover_exactly():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             assert max(h - l for l, h in spans) - min(h - l for l, h in spans) <= 1
+
+
+def test_id_class_shards_keep_shared_ids_together():
+    """Count-limited scenes: every id lands on exactly one rank, shards cover all rays, stay balanced."""
+    rng = np.random.default_rng(5)
+    base = torch.from_numpy(1000 + 3 * rng.permutation(500)).to(torch.int32)
+    ids = base.repeat(3)                                   # three wavelength copies, n apart
+    for world in (1, 2, 4, 8):
+        shards = [shard_indices_by_id(ids, r, world) for r in range(world)]
+        allidx = torch.cat(shards)
+        assert torch.equal(torch.sort(allidx).values, torch.arange(ids.numel()))
+        owners = {}
+        for r, idx in enumerate(shards):
+            assert bool((idx[1:] > idx[:-1]).all())        # ascending: input order kept inside a shard
+            for i in torch.unique(ids[idx]).tolist():
+                assert owners.setdefault(i, r) == r        # an id never appears on two ranks
+        sizes = [int(s.numel()) for s in shards]
+        assert max(sizes) - min(sizes) <= 3                # one id class (3 copies) at most
 
 
 def _worker(rank, world, port, n, out):
