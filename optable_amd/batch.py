@@ -90,6 +90,19 @@ class RayBatch:
         out.length = None if self.length is None else self.length[index].contiguous()
         return out
 
+    def astype(self, precision):
+        """Copy of the batch with its real fields in another precision ("f64" / "f32")."""
+        if precision == self.precision:
+            return self
+        out = object.__new__(RayBatch)
+        out.n, out.precision, out.device = self.n, precision, self.device
+        dt = _REAL[precision]
+        for f in abi.RAY_FIELDS:
+            setattr(out, "n_index" if f == "n" else f, self.field(f).to(dt))
+        out.id, out.flags = self.id, self.flags
+        out.length = None if self.length is None else self.length.to(dt)
+        return out
+
     def with_ids(self, ids):
         """Same rays (storage shared) under other ids (int32 device tensor)."""
         out = self.slice(0, self.n)

@@ -97,8 +97,8 @@ class OpticalTable:
 
     def trace_batch(self, batch, max_segments=None, counts=None):
         """Scalable entry: `RayBatch` in, `SegmentBatch` out, no Python objects.  Non-branching
-        scenes run as one launch with [segment][ray] output slots; branching scenes run
-        generation by generation."""
+        scenes run as one launch with [segment][ray] output slots, in the batch's precision; branching
+        scenes run generation by generation, always in fp64 (an fp32 batch is widened first)."""
         eng = _engine()
         scene = self.compile()
         eng.upload(scene)
@@ -112,7 +112,7 @@ class OpticalTable:
             segs = eng.trace(batch, cap)
             if scene.max_children <= 1 or not bool((segs.count < 0).any()):
                 return segs
-        return eng.trace_tree(batch, cap)
+        return eng.trace_tree(batch.astype("f64"), cap)  # ray trees are traced in fp64 (the reference's precision)
 
     def _trace_batch_limited(self, eng, scene, batch, cap, fused_ok, counts):
         """`trace_batch` for scenes with `max_interact_count` surfaces.  Their counters are keyed by ray id
@@ -136,7 +136,7 @@ class OpticalTable:
         fused = fused_ok and scene.max_children <= 1
 
         def run(sub):
-            return eng.trace(sub, cap, counts=counts) if fused else eng.trace_tree(sub, cap, counts=counts)
+            return eng.trace(sub, cap, counts=counts) if fused else eng.trace_tree(sub.astype("f64"), cap, counts=counts)
 
         if n_classes == n:
             segs = run(work)

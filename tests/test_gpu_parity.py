@@ -516,3 +516,19 @@ def test_batch_limited_scene_with_shared_ids(branching, oracle):
     # the gates really acted: the second and third copies of a ray do not repeat the first copy's path
     first, third = got["surface"][got["ray"] < nb], got["surface"][got["ray"] >= 2 * nb]
     assert len(first) != len(third) or not np.array_equal(first, third)
+
+
+def test_fp32_batch_on_a_branching_scene_is_widened():
+    """Ray trees are traced in fp64 only; an fp32 batch is converted, not refused."""
+    import optable_amd as oa
+    from optable_amd.batch import RayBatch
+
+    table = _table([oa.BeamSplitter([3, 0, 0], width=3, height=3, eta=0.4).RotZ(0.3), oa.Mirror([6, 0, 0], radius=2).RotZ(np.pi)])
+    o, d = scenes.cfg2_rays(500, 3)
+    q = 1j * np.pi * scenes.W0**2 / scenes.WL
+    s32 = table.trace_batch(RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=q, precision="f32"), max_segments=10)
+    s64 = table.trace_batch(RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=q, precision="f64"), max_segments=10)
+    assert s32.precision == "f64" and s32.n_valid == s64.n_valid
+    a, b = s32.to_host(), s64.to_host()
+    np.testing.assert_array_equal(a["surface"], b["surface"])
+    np.testing.assert_allclose(a["ox"], b["ox"], atol=1e-5)   # inputs were rounded to float once
