@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256, MINW) void k_trace_fused(SceneBlob blob, T uni
 // k_trace_blocked: the same trace for HEAVY scenes (many nodes, long and uneven paths).
 // One lane per ray wastes lanes twice there: rays of a wave end after different numbers of
 // segments, and the segment loop runs as long as its longest ray.  Here every WAVE owns a chunk of
-// CHUNK consecutive rays and advances them generation by generation: after every segment the
+// CHUNK (256 to 1024) consecutive rays and advances them generation by generation: after every segment the
 // surviving rays are compacted (order preserving: ballot + popcount) into a dense index list in
 // LDS, so every pass runs with a full wave until the chunk drains.  The four waves of a workgroup
 // share only the staged scene image; each has its own lists and its own chunks, so there is no
@@ -194,10 +194,10 @@ template <class T> struct StateT {
 #endif
 template <class T, uint32_t F> constexpr int blocked_minw() { return (sizeof(T) == 8 && F == 86u) ? OT_BLOCKED_MINW : 1; }
 
-template <class T, uint32_t F, bool SCENE_IN_LDS, bool NT, int CHUNK>
+template <class T, uint32_t F, bool SCENE_IN_LDS, bool NT>
 __global__ __launch_bounds__(256, (blocked_minw<T, F>())) void k_trace_blocked(SceneBlob blob, T unit, RaysT<T> in, int64_t n, int32_t K, SegsT<T> out,
                                                        int32_t* __restrict__ seg_count, int32_t* counts, int32_t n_classes,
-                                                       StateT<T> st) {
+                                                       StateT<T> st, int32_t CHUNK) {
     extern __shared__ __align__(16) uint32_t lds[];
     const uint32_t* base = blob.words;
     uint32_t* tail = lds;
@@ -914,26 +914,34 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
     // kernel; light ones are HBM-bound and keep one lane per ray with perfectly coalesced streams.
     const bool use_blocked = c->opt_kernel == 2 || (c->opt_kernel == 0 && c->n_nodes >= 24 && K > 2);
     if (use_blocked) {
-        constexpr int CHUNK = 256;  // rays per wave-owned chunk
+        // rays per wave-owned chunk.  Longer chunks keep a wave full for longer (a chunk lives as long as its
+        // longest ray: cfg 5 fp64 84 / 78 / 76 ms at 256 / 512 / 1024 rays) but their index lists take LDS from
+        // the scene image when that is staged too (cfg 3: 8.5 / 8.5 / 10.9 ms), and a small batch needs enough
+        // chunks to give every SIMD a few waves (128-ray chunks lose again: more passes run half empty).
+        int32_t CHUNK = in_lds ? 256 : 1024;
+        while (CHUNK > 256 && n / CHUNK < (int64_t)c->n_cus * 16) CHUNK >>= 1;
         const size_t per_field = align_up(sizeof(T) * (size_t)n);
         if (c->blocked.ensure(11 * per_field)) return fail(OT_ERR_HIP, "hipMalloc of blocked-trace scratch failed");
         StateT<T> st;
         for (int k = 0; k < 11; ++k) st.f[k] = (T*)((uint8_t*)c->blocked.p + k * per_field);
-        using KernB = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, SegsT<T>, int32_t*, int32_t*, int32_t, StateT<T>);
+        using KernB = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, SegsT<T>, int32_t*, int32_t*, int32_t, StateT<T>, int32_t);
         const int fb = (need & ~FC) == 0 ? 0 : ((need & ~FD) == 0 ? 1 : 2), ntb = c->opt_nt ? 1 : 0;
         static const KernB tb[3][2][2] = {
-            {{k_trace_blocked<T, FC, false, false, CHUNK>, k_trace_blocked<T, FC, false, true, CHUNK>},
-             {k_trace_blocked<T, FC, true, false, CHUNK>, k_trace_blocked<T, FC, true, true, CHUNK>}},
-            {{k_trace_blocked<T, FD, false, false, CHUNK>, k_trace_blocked<T, FD, false, true, CHUNK>},
-             {k_trace_blocked<T, FD, true, false, CHUNK>, k_trace_blocked<T, FD, true, true, CHUNK>}},
-            {{k_trace_blocked<T, F_ALL, false, false, CHUNK>, k_trace_blocked<T, F_ALL, false, true, CHUNK>},
-             {k_trace_blocked<T, F_ALL, true, false, CHUNK>, k_trace_blocked<T, F_ALL, true, true, CHUNK>}}};
+            {{k_trace_blocked<T, FC, false, false>, k_trace_blocked<T, FC, false, true>},
+             {k_trace_blocked<T, FC, true, false>, k_trace_blocked<T, FC, true, true>}},
+            {{k_trace_blocked<T, FD, false, false>, k_trace_blocked<T, FD, false, true>},
+             {k_trace_blocked<T, FD, true, false>, k_trace_blocked<T, FD, true, true>}},
+            {{k_trace_blocked<T, F_ALL, false, false>, k_trace_blocked<T, F_ALL, false, true>},
+             {k_trace_blocked<T, F_ALL, true, false>, k_trace_blocked<T, F_ALL, true, true>}}};
         KernB kb = tb[fb][in_lds ? 1 : 0][ntb];
         const size_t lds_b = (in_lds ? ((bytes + 15) / 16) * 16 : 0) + 4 * 2 * CHUNK * sizeof(int32_t);
         if (lds_b > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
-        const int64_t n_chunks = (n + 4 * CHUNK - 1) / (4 * CHUNK);  // workgroups needed: 4 wave-chunks each
-        int fitb = (int)((160 * 1024) / (lds_b + 512));
-        fitb = fitb < 1 ? 1 : (fitb > 8 ? 8 : fitb);
+        const int64_t n_chunks = (n + 4 * (int64_t)CHUNK - 1) / (4 * (int64_t)CHUNK);  // workgroups needed: 4 wave-chunks each
+        // One workgroup per four chunks up to 64 per CU (queued, not resident: LDS and registers decide how
+        // many run at once).  Chunk costs are very uneven — a chunk lives as long as its longest ray — and
+        // short-lived workgroups let the dispatcher balance them: cfg 3 at 1e7 rays 11.0 -> 8.5 ms fp64,
+        // 7.3 -> 6.1 ms fp32 against persistent LDS-fit workgroups; flat from 64 per CU on.
+        int fitb = 64;
         if (c->opt_blocks_per_cu > 0) fitb = c->opt_blocks_per_cu;
         const int64_t capb = (int64_t)c->n_cus * fitb;
         const int gridb = (int)(n_chunks < capb ? n_chunks : capb);
@@ -941,7 +949,7 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
         rc = timing_pair(c, &ev0, &ev1);
         if (rc) return rc;
         hipExtLaunchKernelGGL(kb, dim3(gridb), dim3(block), (uint32_t)lds_b, c->stream, ev0, ev1, 0u, blob, (T)c->unit, view<T>(rays), n, K,
-                              view<T>(out), seg_count, counts, n_classes, st);
+                              view<T>(out), seg_count, counts, n_classes, st, CHUNK);
         HIP_TRY(hipGetLastError());
         return 0;
     }
