@@ -20,9 +20,16 @@ def real_dtype(precision):
 class RayBatch:
     """N rays (reference: N `Ray` objects, ray.py:63-104)."""
 
-    def __init__(self, n, precision="f64", device="cuda"):
+    def __init__(self, n, precision="f64", device="cuda", initialise=True):
         self.n, self.precision, self.device = int(n), precision, torch.device(device)
         dt = _REAL[precision]
+        if not initialise:  # scratch the engine overwrites (generation ping-pong buffers): no fills
+            for f in abi.RAY_FIELDS:
+                setattr(self, "n_index" if f == "n" else f, torch.empty(self.n, dtype=dt, device=self.device))
+            self.id = torch.empty(self.n, dtype=torch.int32, device=self.device)
+            self.flags = torch.empty(self.n, dtype=torch.int32, device=self.device)
+            self.length = None
+            return
         for f in abi.RAY_FIELDS:
             if f != "n":
                 setattr(self, f, torch.zeros(self.n, dtype=dt, device=self.device))

@@ -1056,7 +1056,7 @@ int ot_trace_generation_f64(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
     blob.root = c->root_grid;
     blob.cache_mat = c->cache_mat;
     const bool in_lds = c->bytes64 <= (size_t)c->opt_lds_limit_kb * 1024;
-    const int64_t cap = (int64_t)c->n_cus * 4;
+    const int64_t cap = (int64_t)c->n_cus * (c->opt_blocks_per_cu > 0 ? c->opt_blocks_per_cu : 4);
     const int grid = (int)(g1 < cap ? g1 : cap);
     const size_t lds_bytes = in_lds ? c->bytes64 : 0;
     // beam splitters and partially reflecting slabs are planar scenes: they get the small instantiation

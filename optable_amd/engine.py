@@ -95,7 +95,7 @@ class Engine:
         n_classes = 0 if counts is None else counts.shape[1]
         # two ping-pong generation buffers, grown when a generation outgrows them (no per-generation allocation)
         cap = max(n * fan, 1024)
-        spare, spare_tree = RayBatch(cap, "f64", dev), torch.empty(cap, dtype=torch.int32, device=dev)
+        spare, spare_tree = RayBatch(cap, "f64", dev, initialise=False), torch.empty(cap, dtype=torch.int32, device=dev)
         other, other_tree = None, None
         cur, cur_n, written = rays, n, 0
         while cur_n > 0:
@@ -103,7 +103,7 @@ class Engine:
                 out = _grow(out, max(written + cur_n, 2 * out.capacity), written)
             if cur_n * fan > spare.n:
                 cap = max(cur_n * fan, 2 * spare.n)
-                spare, spare_tree = RayBatch(cap, "f64", dev), torch.empty(cap, dtype=torch.int32, device=dev)
+                spare, spare_tree = RayBatch(cap, "f64", dev, initialise=False), torch.empty(cap, dtype=torch.int32, device=dev)
             rs, ss, ns = cur.c_struct(), out.c_struct(), spare.c_struct()
             abi.check(self.lib.ot_trace_generation_f64(
                 self._ctx, C.byref(rs), tree.data_ptr(), cur_n, budget.data_ptr(), C.byref(ss), out.capacity,
@@ -112,7 +112,7 @@ class Engine:
             written, cur_n = state.tolist()  # the one host synchronisation per generation
             nxt, nxt_tree = spare, spare_tree
             if other is None or other.n < nxt.n:
-                other, other_tree = RayBatch(nxt.n, "f64", dev), torch.empty(nxt.n, dtype=torch.int32, device=dev)
+                other, other_tree = RayBatch(nxt.n, "f64", dev, initialise=False), torch.empty(nxt.n, dtype=torch.int32, device=dev)
             spare, spare_tree, other, other_tree = other, other_tree, nxt, nxt_tree
             cur, tree = nxt.slice(0, cur_n), nxt_tree[:cur_n]
         out.n_valid = int(written)

@@ -84,7 +84,7 @@ n3 = int(os.environ.get("N3", 2_000_000))
 n4 = int(os.environ.get("N4", 100_000))
 n5 = int(os.environ.get("N5", 200_000))
 only = set(filter(None, os.environ.get("ONLY", "").split(",")))   # e.g. ONLY=cfg3,cfg5
-want = lambda c: not only or c in only
+want = lambda c: (not only and c != "cfg4b") or c in only
 for prec in filter(None, os.environ.get("PREC", "f64,f32").split(",")):
     if want("cfg2"):
         o, d = scenes.cfg2_rays(n2, 0)
@@ -101,6 +101,15 @@ for prec in filter(None, os.environ.get("PREC", "f64,f32").split(",")):
         wl = np.repeat(np.linspace(400e-7, 1100e-7, nwl), n4)
         slab = [oa.GlassSlab([0, 0, 0], width=2, height=2, thickness=0.5, n1=oa.Vacuum(), n2=oa.Glass_NBK7(), reflectivity=0)]
         run("cfg4 NBK7 slab x64 wl", slab, np.tile(ob, (nwl, 1)), np.tile(db, (nwl, 1)), wl, int(os.environ.get("K4", 8)), prec)
+    if want("cfg4b") and prec == "f64":   # branching variant of cfg 4: reflectivity 0.2, ray trees
+        nwl, nb = 64, int(os.environ.get("N4B", 20_000))
+        rng = np.random.default_rng(4)
+        jit = rng.uniform(-0.3, 0.3, (nb, 2))
+        ob = np.stack([np.full(nb, -3.0), 2 + jit[:, 0], jit[:, 1]], 1)
+        db = np.tile([np.cos(np.pi / 6), -np.sin(np.pi / 6), 0.0], (nb, 1))
+        wl = np.repeat(np.linspace(400e-7, 1100e-7, nwl), nb)
+        slab = [oa.GlassSlab([0, 0, 0], width=2, height=2, thickness=0.5, n1=oa.Vacuum(), n2=oa.Glass_NBK7(), reflectivity=0.2)]
+        run("cfg4b NBK7 slab R=0.2 trees", slab, np.tile(ob, (nwl, 1)), np.tile(db, (nwl, 1)), wl, 12, prec)
     if want("cfg5"):
         o, d = scenes.cfg5_rays(n5, 3)
         run("cfg5 asphere+MMA16x16", scenes.cfg5_components(oa), o, d, scenes.WL, 50, prec)
