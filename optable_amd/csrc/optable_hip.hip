@@ -193,9 +193,12 @@ template <class T> struct StateT {
 #define OT_BLOCKED_MINW 1
 #endif
 template <class T, uint32_t F> constexpr int blocked_minw() { return (sizeof(T) == 8 && F == 86u) ? OT_BLOCKED_MINW : 1; }
+// largest workgroup an instantiation may be launched with: 512 threads = 2 waves/SIMD = 256 VGPRs, which every
+// instantiation fits except the all-features fp64 one (it would spill 44 bytes per lane)
+template <class T, uint32_t F> constexpr int blocked_threads() { return (sizeof(T) == 8 && F == F_ALL) ? 256 : 512; }
 
 template <class T, uint32_t F, bool SCENE_IN_LDS, bool NT>
-__global__ __launch_bounds__(256, (blocked_minw<T, F>())) void k_trace_blocked(SceneBlob blob, T unit, RaysT<T> in, int64_t n, int32_t K, SegsT<T> out,
+__global__ __launch_bounds__((blocked_threads<T, F>()), (blocked_minw<T, F>())) void k_trace_blocked(SceneBlob blob, T unit, RaysT<T> in, int64_t n, int32_t K, SegsT<T> out,
                                                        int32_t* __restrict__ seg_count, int32_t* counts, int32_t n_classes,
                                                        StateT<T> st, int32_t CHUNK) {
     extern __shared__ __align__(16) uint32_t lds[];
@@ -212,7 +215,8 @@ __global__ __launch_bounds__(256, (blocked_minw<T, F>())) void k_trace_blocked(S
     __syncthreads();  // the only workgroup barrier: the scene image is staged
     const Scene<T> sc = bind_scene<T>(base, blob, unit);
     const int64_t n_chunks = (n + CHUNK - 1) / CHUNK;
-    for (int64_t ch = (int64_t)blockIdx.x * 4 + wave; ch < n_chunks; ch += (int64_t)gridDim.x * 4) {  // wave-uniform
+    const int wpb = blockDim.x >> 6;  // 4 waves per workgroup, 8 when a large scene image fills the CU's LDS
+    for (int64_t ch = (int64_t)blockIdx.x * wpb + wave; ch < n_chunks; ch += (int64_t)gridDim.x * wpb) {  // wave-uniform
         const int64_t first = ch * CHUNK;
         int alive = (int)((n - first) < CHUNK ? (n - first) : CHUNK);
         for (int32_t k = 0; k < K && alive > 0; ++k) {
@@ -914,12 +918,28 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
     // kernel; light ones are HBM-bound and keep one lane per ray with perfectly coalesced streams.
     const bool use_blocked = c->opt_kernel == 2 || (c->opt_kernel == 0 && c->n_nodes >= 24 && K > 2);
     if (use_blocked) {
+        // Where the scene image lives.  Up to 64 KB: LDS, 256-thread workgroups, several per CU.  Up to ~140 KB
+        // (cfg 5: 260 nodes, 96 KB in fp64): still LDS, but ONE 512-thread workgroup per CU so that the CU keeps
+        // 8 waves — the register-limited occupancy of these kernels anyway.  Reading such an image from L2
+        // instead makes every leaf test a 64-lane gather of ~4 cache lines per lane (each ray tests its own
+        // micro-mirror): cfg 5 ran at the L1 line rate, 10.8k cycles per wave-segment per CU.
+        const size_t img = ((bytes + 15) / 16) * 16;
+        int wpb = 4;
+        bool img_lds = in_lds;
+        const bool fits512 = !(f64 && (need & ~FC) != 0 && (need & ~FD) != 0);  // see blocked_threads()
+        if (!in_lds && fits512 && c->opt_lds_limit_kb >= 64 && img + 8 * 2 * 256 * sizeof(int32_t) <= 156 * 1024) {
+            img_lds = true;
+            wpb = 8;
+        }
         // rays per wave-owned chunk.  Longer chunks keep a wave full for longer (a chunk lives as long as its
-        // longest ray: cfg 5 fp64 84 / 78 / 76 ms at 256 / 512 / 1024 rays) but their index lists take LDS from
-        // the scene image when that is staged too (cfg 3: 8.5 / 8.5 / 10.9 ms), and a small batch needs enough
-        // chunks to give every SIMD a few waves (128-ray chunks lose again: more passes run half empty).
+        // longest ray: cfg 5 fp64 84 / 78 / 76 ms at 256 / 512 / 1024 rays with the image in L2) but their index
+        // lists take LDS from the scene image when that is staged too (cfg 3: 8.5 / 8.5 / 10.9 ms), and a small
+        // batch needs enough chunks to give every SIMD a few waves (128-ray chunks lose again: more passes run
+        // half empty).
         int32_t CHUNK = in_lds ? 256 : 1024;
-        while (CHUNK > 256 && n / CHUNK < (int64_t)c->n_cus * 16) CHUNK >>= 1;
+        while (CHUNK > 256 && (n / CHUNK < (int64_t)c->n_cus * 16 ||
+                               (img_lds && img + (size_t)wpb * 2 * CHUNK * sizeof(int32_t) > 156 * 1024)))
+            CHUNK >>= 1;
         const size_t per_field = align_up(sizeof(T) * (size_t)n);
         if (c->blocked.ensure(11 * per_field)) return fail(OT_ERR_HIP, "hipMalloc of blocked-trace scratch failed");
         StateT<T> st;
@@ -933,10 +953,10 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
              {k_trace_blocked<T, FD, true, false>, k_trace_blocked<T, FD, true, true>}},
             {{k_trace_blocked<T, F_ALL, false, false>, k_trace_blocked<T, F_ALL, false, true>},
              {k_trace_blocked<T, F_ALL, true, false>, k_trace_blocked<T, F_ALL, true, true>}}};
-        KernB kb = tb[fb][in_lds ? 1 : 0][ntb];
-        const size_t lds_b = (in_lds ? ((bytes + 15) / 16) * 16 : 0) + 4 * 2 * CHUNK * sizeof(int32_t);
+        KernB kb = tb[fb][img_lds ? 1 : 0][ntb];
+        const size_t lds_b = (img_lds ? img : 0) + (size_t)wpb * 2 * CHUNK * sizeof(int32_t);
         if (lds_b > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
-        const int64_t n_chunks = (n + 4 * (int64_t)CHUNK - 1) / (4 * (int64_t)CHUNK);  // workgroups needed: 4 wave-chunks each
+        const int64_t n_chunks = (n + wpb * (int64_t)CHUNK - 1) / (wpb * (int64_t)CHUNK);  // workgroups needed: one chunk per wave
         // One workgroup per four chunks up to 64 per CU (queued, not resident: LDS and registers decide how
         // many run at once).  Chunk costs are very uneven — a chunk lives as long as its longest ray — and
         // short-lived workgroups let the dispatcher balance them: cfg 3 at 1e7 rays 11.0 -> 8.5 ms fp64,
@@ -948,8 +968,8 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
         hipEvent_t ev0, ev1;
         rc = timing_pair(c, &ev0, &ev1);
         if (rc) return rc;
-        hipExtLaunchKernelGGL(kb, dim3(gridb), dim3(block), (uint32_t)lds_b, c->stream, ev0, ev1, 0u, blob, (T)c->unit, view<T>(rays), n, K,
-                              view<T>(out), seg_count, counts, n_classes, st, CHUNK);
+        hipExtLaunchKernelGGL(kb, dim3(gridb), dim3(64 * wpb), (uint32_t)lds_b, c->stream, ev0, ev1, 0u, blob, (T)c->unit, view<T>(rays), n,
+                              K, view<T>(out), seg_count, counts, n_classes, st, CHUNK);
         HIP_TRY(hipGetLastError());
         return 0;
     }

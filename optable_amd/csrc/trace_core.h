@@ -415,6 +415,38 @@ __device__ __forceinline__ bool hit_leaf(const Scene<T>& sc, const DNode<T>& nd,
         t2 = min_t(t2, T(100));
         // np.linspace(t1 - EPS, t2 + EPS, 10): sign change per sub-interval, roots ascending
         const T a = t1 - EPS, b = t2 + EPS, step = (b - a) / T(9);
+        if (nd.shape == OT_SHAPE_SPHERE) {
+            // Closed form of the same search.  g(t) = |o + t d| - R is negative exactly between the two
+            // intersections r0 < r1 of the line with the sphere, so sample interval i of the scan shows a sign
+            // change iff exactly one of them lies inside it, and brentq would converge to that one.  The
+            // candidates are therefore r0 and r1 (ascending) when they lie inside (a, b) and not both in the
+            // same interval; filters and boundary as below.  Roots through the closest approach to the
+            // centre (no cancellation between |o|^2 and R^2).  ~80 instead of ~380 instructions per test,
+            // and every ray leaving a micro-mirror pays this test for the cap it just left (root at t = 0).
+            const T tca = -(ox * dx + oy * dy + oz * dz);
+            const T cx = ox + tca * dx, cy = oy + tca * dy, cz = oz + tca * dz;
+            const T disc = nd.rad2 - (cx * cx + cy * cy + cz * cz);
+            if (!(disc > T(0))) return false;  // the line stays outside: g never changes sign
+            const T hc = sqrt_t(disc);
+            const T r0 = tca - hc, r1 = tca + hc;
+            const T inv_step = T(9) / (b - a);
+            const bool in0 = r0 > a && r0 < b, in1 = r1 > a && r1 < b;
+            const int i0 = min((int)((r0 - a) * inv_step), 8), i1 = min((int)((r1 - a) * inv_step), 8);
+            if (in0 && in1 && i0 == i1) return false;  // both inside one interval: equal signs at its ends
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const T t = k == 0 ? r0 : r1;
+                if (!(k == 0 ? in0 : in1)) continue;
+                if (t >= T(0) && abs_t(t) >= EPS && t <= len) {
+                    const T X = ox + t * dx, Y = oy + t * dy, Z = oz + t * dz;
+                    if (curved_boundary<T, F>(sc, nd, X, Y, Z)) {
+                        t_out = t; Px = X; Py = Y; Pz = Z;
+                        return true;
+                    }
+                }
+            }
+            return false;
+        }
         T tl = a, gl = surf_g<T, F>(sc, nd, ox, oy, oz, dx, dy, dz, a, (T*)nullptr);
         for (int i = 1; i < 10; ++i) {
             const T tr = (i == 9) ? b : a + T(i) * step;
