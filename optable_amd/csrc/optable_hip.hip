@@ -604,6 +604,13 @@ template <class T> static void fill_blob(const ot_scene_desc* s, std::vector<uin
             d.r2 = (T)(ht < R ? R * R - (R - ht) * (R - ht) : 0.0);
         }
         d.rad2 = (T)(h.p[0] * h.p[0]);  // sphere / cylinder radius squared
+        if (h.shape == OT_SHAPE_ASPHERE_PARAM) {  // folded constants of the root search (trace_core.h sag_search)
+            d.p[6] = (T)((1.0 + h.p[2]) / (h.p[1] * h.p[1]));
+            d.p[7] = (T)(1.0 / h.p[1]);
+        } else if (h.shape == OT_SHAPE_ASPHERE_EXACT) {
+            d.p[6] = (T)((h.p[2] + 1.0) / ((h.p[2] - 1.0) * h.p[1] * h.p[1]));
+            d.p[7] = (T)(h.p[1] / (h.p[2] + 1.0));
+        }
         d.pad1 = (T)0;
         d.kind = h.kind; d.end = h.end; d.flags = h.flags; d.shape = h.shape; d.inter = h.interaction;
         d.mat1 = h.mat1; d.mat2 = h.mat2; d.roc_kind = h.roc_kind; d.max_count = h.max_interact_count;

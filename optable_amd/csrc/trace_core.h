@@ -217,15 +217,34 @@ template <class T> __device__ __forceinline__ T sag_r2(const DNode<T>& nd, T r2)
     return (EFL / (n + T(1))) * (T(-1) + sqrt_t(T(1) + (n + T(1)) / (n - T(1)) * r2 / (EFL * EFL)));
 }
 template <class T> __device__ __forceinline__ T sag(const DNode<T>& nd, T r) { return sag_r2(nd, r * r); }
+// The same F for the root search only (sign scan + Newton polish), with the constant quotients folded on the
+// host (fill_blob): p[6] = (1+k)/R^2, p[7] = 1/R for the parametric form; p[6] = (n+1)/((n-1) EFL^2),
+// p[7] = EFL/(n+1) for the exact one.  One division instead of three, none for the exact form.  The normal
+// and curvature (sag_d1 / sag_d2 below) keep the reference's expression term by term: their finite
+// differences amplify rounding by 1/h^2.
+template <class T> __device__ __forceinline__ T sag_search(const DNode<T>& nd, T r2) {
+    if (nd.shape == OT_SHAPE_ASPHERE_PARAM) {
+        const T r4 = r2 * r2;
+        return div_t(r2 * nd.p[7], T(1) + sqrt_t(T(1) - nd.p[6] * r2)) + nd.p[3] * r4 + nd.p[4] * r4 * r2 + nd.p[5] * r4 * r4;
+    }
+    return nd.p[7] * (sqrt_t(T(1) + nd.p[6] * r2) - T(1));
+}
+// A value with the SIGN of x + F(r) and no division: the 10-point scan only compares signs, and
+// 1 + sqrt(..) > 0.  (A negative radicand gives NaN here as it does in F: no crossing is reported.)
+template <class T> __device__ __forceinline__ T asphere_sign(const DNode<T>& nd, T x, T r2) {
+    if (nd.shape == OT_SHAPE_ASPHERE_PARAM) {
+        const T r4 = r2 * r2;
+        const T poly = nd.p[3] * r4 + nd.p[4] * r4 * r2 + nd.p[5] * r4 * r4;
+        return (x + poly) * (T(1) + sqrt_t(T(1) - nd.p[6] * r2)) + r2 * nd.p[7];
+    }
+    return x + nd.p[7] * (sqrt_t(T(1) + nd.p[6] * r2) - T(1));
+}
 // dF/dr divided by r, analytic, as a function of r^2 (Newton slope of the root polish only: it
 // steers the iteration, the root it converges to does not depend on it)
 template <class T> __device__ __forceinline__ T sag_slope_over_r(const DNode<T>& nd, T r2) {
-    if (nd.shape == OT_SHAPE_ASPHERE_PARAM) {
-        const T R = nd.p[1], sq = sqrt_t(T(1) - (T(1) + nd.p[2]) * r2 / (R * R));
-        return T(1) / (R * sq) + r2 * (T(4) * nd.p[3] + r2 * (T(6) * nd.p[4] + r2 * T(8) * nd.p[5]));
-    }
-    const T E = nd.p[1], n = nd.p[2], A = (n + T(1)) / (n - T(1));
-    return A / ((n + T(1)) * E * sqrt_t(T(1) + A * r2 / (E * E)));
+    if (nd.shape == OT_SHAPE_ASPHERE_PARAM)
+        return div_t(nd.p[7], sqrt_t(T(1) - nd.p[6] * r2)) + r2 * (T(4) * nd.p[3] + r2 * (T(6) * nd.p[4] + r2 * T(8) * nd.p[5]));
+    return div_t(nd.p[6] * nd.p[7], sqrt_t(T(1) + nd.p[6] * r2));
 }
 // fp64: the reference's central differences, h = 1e-4*radius, reproduced term by term.
 // fp32: the differences would lose 4-5 digits to cancellation (F ~ 0.3, h ~ 2.5e-4), far more than
@@ -368,7 +387,7 @@ __device__ __forceinline__ T surf_g(const Scene<T>& sc, const DNode<T>& nd, T ox
         default: {  // aspheres: x + F(r), F even in r
             const T r2 = Py * Py + Pz * Pz;
             if (dg) *dg = dx + sag_slope_over_r(nd, r2) * (Py * dy + Pz * dz);
-            return Px + sag_r2(nd, r2);
+            return Px + sag_search(nd, r2);
         }
     }
 }
@@ -447,10 +466,20 @@ __device__ __forceinline__ bool hit_leaf(const Scene<T>& sc, const DNode<T>& nd,
             }
             return false;
         }
-        T tl = a, gl = surf_g<T, F>(sc, nd, ox, oy, oz, dx, dy, dz, a, (T*)nullptr);
+        // sign samples: aspheres through the division-free form (same sign, and the polish below only uses
+        // the bracket values for its starting guess)
+        const bool asph = nd.shape == OT_SHAPE_ASPHERE_PARAM || nd.shape == OT_SHAPE_ASPHERE_EXACT;
+        auto sample = [&](T t) {
+            if (asph) {
+                const T Y = oy + t * dy, Z = oz + t * dz;
+                return asphere_sign(nd, ox + t * dx, Y * Y + Z * Z);
+            }
+            return surf_g<T, F>(sc, nd, ox, oy, oz, dx, dy, dz, t, (T*)nullptr);
+        };
+        T tl = a, gl = sample(a);
         for (int i = 1; i < 10; ++i) {
             const T tr = (i == 9) ? b : a + T(i) * step;
-            const T gr = surf_g<T, F>(sc, nd, ox, oy, oz, dx, dy, dz, tr, (T*)nullptr);
+            const T gr = sample(tr);
             // fp64: the reference's strict product test (optical_component.py:131).  fp32: |P| - R is
             // quantised to ~2e-6 at R ~ 30, so a sample lands on g == 0 exactly for several percent of
             // the rays and the product test would drop those roots; compare signs instead.

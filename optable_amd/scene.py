@@ -135,8 +135,16 @@ class _Builder:
         typical = np.median(boxes[:, [a0, a1], 1] - boxes[:, [a0, a1], 0], axis=0)
         dims = [int(min(64, max(1, np.floor(extent[a] / max(typical[j] / 2, extent[a] / 64))))) for j, a in enumerate((a0, a1))]
         margin = 1e-7 + 1e-9 * float(extent.max())
-        org = [gbox[a0, 0], gbox[a1, 0]]
-        inv = [dims[0] / extent[a0], dims[1] / extent[a1]]
+        # The children of a lattice end exactly on cell borders, and binning them with a margin would put each
+        # one into the neighbouring cells as well (MMA 16x16: 4 caps per cell instead of 1-2).  Start the grid a
+        # quarter cell early (one more cell per axis) so that child borders fall inside cells.
+        size = [extent[a0] / dims[0], extent[a1] / dims[1]]
+        org = [gbox[a0, 0] - 0.25 * size[0], gbox[a1, 0] - 0.25 * size[1]]
+        dims = [min(dims[0] + 1, 64), min(dims[1] + 1, 64)]
+        inv = [1.0 / size[0], 1.0 / size[1]]
+        if org[0] + dims[0] * size[0] < gbox[a0, 1] + margin or org[1] + dims[1] * size[1] < gbox[a1, 1] + margin:
+            size = [(gbox[a0, 1] + 2 * margin - org[0]) / dims[0], (gbox[a1, 1] + 2 * margin - org[1]) / dims[1]]  # 64-cell cap: stretch
+            inv = [1.0 / size[0], 1.0 / size[1]]
         cells = [[] for _ in range(dims[0] * dims[1])]
         for k, bx in zip(kids, boxes):
             lo0 = int(np.clip(np.floor((bx[a0, 0] - margin - org[0]) * inv[0]), 0, dims[0] - 1))
