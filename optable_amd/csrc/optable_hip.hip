@@ -318,18 +318,31 @@ __global__ void k_gen_mark(const int32_t* tree, const int64_t* head, const int32
     if (i < n) proc[i] = (i - head[i]) < (int64_t)budget[tree[i]] ? 1 : 0;
 }
 
-struct ChildStore {  // scratch for up to 2 children per ray, SoA with stride 2n
-    double* f[12];
-    int32_t* flags;
+// Ordered single-pass allocation of child slots (decoupled look-back): tiles of 256 rays are handed out by an
+// atomic ticket, so a tile with a smaller index is always held by a workgroup that is already running.  A tile
+// publishes its child count as an AGGREGATE, then walks back over its predecessors (one wave, 64 tiles per read)
+// adding aggregates until it meets an inclusive PREFIX, and publishes its own prefix.  Flag and value share one
+// 64-bit word, so a reader never sees one without the other and RELAXED device-scope atomics suffice
+// (acquire/release at device scope invalidate / write back the XCD's L2 around every access: 3.5x slower here).
+// The next generation is therefore written once, in parent order then child order, straight from the registers
+// of the trace (an earlier version parked both children of every ray in scratch, scanned the counts and
+// compacted in a second kernel: 40 % of the generation's bytes).
+struct LookBack {
+    unsigned long long* state;   // [n_tiles] (flag << 62) | value, zeroed before the launch
+    unsigned long long* ticket;  // next tile to hand out, zeroed before the launch
 };
+static constexpr unsigned long long LB_AGG = 1ull << 62, LB_PREFIX = 2ull << 62, LB_MASK = (1ull << 62) - 1ull;
 
 // PROBE = true: the pre-pass that records geometric hits of count-limited leaves (no outputs).
 template <uint32_t F, bool SCENE_IN_LDS, bool PROBE>
 __global__ __launch_bounds__(256) void k_gen_trace(SceneBlob blob, double unit, RaysT<double> in, const int32_t* tree, int64_t n,
                                                    const int32_t* proc, const int64_t* seg_off, const int64_t* cursor,
-                                                   SegsT<double> out, int64_t out_capacity, ChildStore kids, int32_t* nkids,
+                                                   SegsT<double> out, int64_t out_capacity, LookBack lb, RaysOutT<double> next,
+                                                   int32_t* next_tree, int64_t next_capacity, int64_t* n_next,
                                                    int32_t* counts, int32_t n_classes, const int32_t* rank, int32_t* probe) {
     extern __shared__ __align__(16) uint32_t lds[];
+    __shared__ long long s_tile, s_base;
+    __shared__ int s_wave_total[4];
     const uint32_t* base = blob.words;
     if (SCENE_IN_LDS) {
         for (int w = threadIdx.x; w < blob.n_words; w += blockDim.x) lds[w] = blob.words[w];
@@ -338,9 +351,14 @@ __global__ __launch_bounds__(256) void k_gen_trace(SceneBlob blob, double unit, 
     }
     const Scene<double> sc = bind_scene<double>(base, blob, unit);
     const int64_t cur0 = *cursor;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < n; i0 += stride) {
-        const int64_t i = i0 + threadIdx.x;
+    const int64_t n_tiles = (n + 255) / 256;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (;;) {
+        if (threadIdx.x == 0) s_tile = (long long)atomicAdd(lb.ticket, 1ull);
+        __syncthreads();
+        const int64_t tile = s_tile;
+        if (tile >= n_tiles) break;  // workgroup-uniform
+        const int64_t i = tile * 256 + threadIdx.x;
         bool active = i < n && proc[i];
         RayState<double> r = {};
         int32_t cls = 0, fl = 0;
@@ -353,33 +371,77 @@ __global__ __launch_bounds__(256) void k_gen_trace(SceneBlob blob, double unit, 
         const GateCtx gate = {counts, n_classes, cls, rank, probe, n, i};
         if (PROBE) {
             (void)nearest_hit<double, F, GATE_PROBE>(sc, r, active && !dead, gate);
+            __syncthreads();  // s_tile is rewritten at the top of the loop
             continue;
         }
         const Hit<double> h = nearest_hit<double, F, GATE_TABLE>(sc, r, active && !dead, gate);
+        int32_t nk = 0, t = 0;
+        RayState<double> ch[2];
         if (active) {
             const int64_t slot = cur0 + seg_off[i];
-            int32_t nk = 0;
-            RayState<double> ch[2];
-            const int32_t t = tree[i];
+            t = tree[i];
             if (slot < out_capacity) {
                 if (dead) store_segment(out, slot, r, r.len, t, -2);
                 else if (h.node < 0) store_segment(out, slot, r, r.len, t, -1);
                 else store_segment(out, slot, r, h.t, t, sc.nodes[h.node].leaf_id);
             }
             if (!dead && h.node >= 0) nk = interact<double, F, 2>(sc, r, h, ch, make_matcache(sc, r.wl));
-            for (int c = 0; c < nk; ++c) {
-                const int64_t s = 2 * i + c;
-                const RayState<double>& k = ch[c];
-                kids.f[0][s] = k.ox; kids.f[1][s] = k.oy; kids.f[2][s] = k.oz;
-                kids.f[3][s] = k.dx; kids.f[4][s] = k.dy; kids.f[5][s] = k.dz;
-                kids.f[6][s] = k.wl; kids.f[7][s] = k.qr; kids.f[8][s] = k.qi;
-                kids.f[9][s] = k.I; kids.f[10][s] = k.n; kids.f[11][s] = k.pl;
-                kids.flags[s] = fl & OT_RAY_HAS_Q;
-            }
-            nkids[i] = nk;
-        } else if (i < n) {
-            nkids[i] = 0;
         }
+        // child slots: inclusive scan inside the wave, wave totals through LDS, tile prefix by look-back
+        int incl = nk;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += up;
+        }
+        if (lane == 63) s_wave_total[wave] = incl;
+        __syncthreads();
+        if (wave == 0) {  // look-back by a whole wave: 64 predecessors per read
+            const unsigned long long total = (unsigned long long)(s_wave_total[0] + s_wave_total[1] + s_wave_total[2] + s_wave_total[3]);
+            unsigned long long before = 0;
+            if (tile > 0) {
+                if (lane == 0) __hip_atomic_store(&lb.state[tile], LB_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int64_t wbase = tile - 1;;) {
+                    const int64_t idx = wbase - lane;  // lane 0 = nearest predecessor
+                    unsigned long long v = LB_PREFIX;  // before tile 0: an inclusive prefix of zero
+                    if (idx >= 0) v = __hip_atomic_load(&lb.state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned flag = (unsigned)(v >> 62);
+                    const unsigned long long m_prefix = __ballot(flag == 2u), m_empty = __ballot(flag == 0u);
+                    unsigned long long need = ~0ull;   // the lanes up to and including the nearest prefix
+                    if (m_prefix) {
+                        const int pl = __ffsll((long long)m_prefix) - 1;
+                        need = pl == 63 ? ~0ull : ((1ull << (pl + 1)) - 1ull);
+                    }
+                    if (m_empty & need) { __builtin_amdgcn_s_sleep(2); continue; }  // one of them is still tracing: read again
+                    long long part = ((need >> lane) & 1ull) ? (long long)(v & LB_MASK) : 0ll;
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+                    before += (unsigned long long)part;
+                    if (m_prefix) break;
+                    wbase -= 64;
+                }
+            }
+            if (lane == 0) {
+                __hip_atomic_store(&lb.state[tile], LB_PREFIX | (before + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_base = (long long)before;
+                if (tile == n_tiles - 1) *n_next = (int64_t)(before + total);
+            }
+        }
+        __syncthreads();
+        int64_t d = s_base + (incl - nk);
+        for (int w = 0; w < wave; ++w) d += s_wave_total[w];
+        for (int c = 0; c < nk; ++c, ++d) {
+            if (d >= next_capacity) break;
+            const RayState<double>& k = ch[c];
+            next.ox[d] = k.ox; next.oy[d] = k.oy; next.oz[d] = k.oz;
+            next.dx[d] = k.dx; next.dy[d] = k.dy; next.dz[d] = k.dz;
+            next.wl[d] = k.wl; next.qr[d] = k.qr; next.qi[d] = k.qi;
+            next.I[d] = k.I; next.n[d] = k.n; next.pl[d] = k.pl;
+            next.flags[d] = fl & OT_RAY_HAS_Q;
+            next.id[d] = cls;
+            next_tree[d] = t;
+        }
+        __syncthreads();  // s_tile / s_base / s_wave_total are rewritten by the next tile
     }
 }
 
@@ -403,27 +465,8 @@ __global__ void k_gen_counts(const int32_t* tree, const int32_t* ids, int64_t n,
     }
 }
 
-__global__ void k_gen_compact(const int32_t* tree, const int32_t* ids, int64_t n, ChildStore kids, const int32_t* nkids,
-                              const int64_t* child_off, RaysOutT<double> next, int32_t* next_tree, int64_t next_capacity) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int32_t nk = nkids[i];
-    for (int c = 0; c < nk; ++c) {
-        const int64_t s = 2 * i + c, d = child_off[i] + c;
-        if (d >= next_capacity) return;
-        next.ox[d] = kids.f[0][s]; next.oy[d] = kids.f[1][s]; next.oz[d] = kids.f[2][s];
-        next.dx[d] = kids.f[3][s]; next.dy[d] = kids.f[4][s]; next.dz[d] = kids.f[5][s];
-        next.wl[d] = kids.f[6][s]; next.qr[d] = kids.f[7][s]; next.qi[d] = kids.f[8][s];
-        next.I[d] = kids.f[9][s]; next.n[d] = kids.f[10][s]; next.pl[d] = kids.f[11][s];
-        next.flags[d] = kids.flags[s];
-        next.id[d] = ids[i];
-        next_tree[d] = tree[i];
-    }
-}
-
 __global__ void k_gen_finish(const int32_t* tree, const int64_t* head, int64_t n, int32_t* budget, const int32_t* proc,
-                             const int64_t* seg_off, const int32_t* nkids, const int64_t* child_off, int64_t* cursor,
-                             int64_t* n_next) {
+                             const int64_t* seg_off, int64_t* cursor) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (i == n - 1 || tree[i + 1] != tree[i]) {  // last ray of its tree in this generation
@@ -431,10 +474,7 @@ __global__ void k_gen_finish(const int32_t* tree, const int64_t* head, int64_t n
         const int32_t b = budget[tree[i]];
         budget[tree[i]] = b - (int32_t)(in_gen < b ? in_gen : b);
     }
-    if (i == n - 1) {
-        *cursor += seg_off[i] + proc[i];
-        *n_next = child_off[i] + nkids[i];
-    }
+    if (i == n - 1) *cursor += seg_off[i] + proc[i];  // (*n_next was written by the trace: its last tile's prefix)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1037,31 +1077,29 @@ int ot_trace_generation_f64(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
     HIP_TRY(hipSetDevice(c->device));
     // scratch carve-up
     const size_t sz_i64 = align_up(sizeof(int64_t) * n), sz_i32 = align_up(sizeof(int32_t) * n);
-    const size_t sz_kid = align_up(sizeof(double) * 2 * n), sz_kfl = align_up(sizeof(int32_t) * 2 * n);
     const int ns = c->n_slots;
     const size_t sz_slot = align_up(sizeof(int32_t) * n * (ns > 0 ? ns : 1));
-    const size_t total = 4 * sz_i64 + 2 * sz_i32 + 12 * sz_kid + sz_kfl + 3 * sz_slot;
+    const int64_t n_tiles = (n + 255) / 256;
+    const size_t sz_lb = align_up(sizeof(unsigned long long) * (n_tiles + 1));  // tile states + the ticket
+    const size_t total = 3 * sz_i64 + sz_i32 + sz_lb + 3 * sz_slot;
     if (c->gen.ensure(total)) return fail(OT_ERR_HIP, "hipMalloc of generation scratch failed");
     uint8_t* p = (uint8_t*)c->gen.p;
     int64_t* head = (int64_t*)p; p += sz_i64;
     int64_t* head_scan = (int64_t*)p; p += sz_i64;
     int64_t* seg_off = (int64_t*)p; p += sz_i64;
-    int64_t* child_off = (int64_t*)p; p += sz_i64;
     int32_t* proc = (int32_t*)p; p += sz_i32;
-    int32_t* nkids = (int32_t*)p; p += sz_i32;
-    ChildStore kids;
-    for (int k = 0; k < 12; ++k) { kids.f[k] = (double*)p; p += sz_kid; }
-    kids.flags = (int32_t*)p; p += sz_kfl;
+    LookBack lb;
+    lb.state = (unsigned long long*)p;
+    lb.ticket = lb.state + n_tiles;
+    p += sz_lb;
     int32_t* probe = (int32_t*)p; p += sz_slot;
     int32_t* probe_ex = (int32_t*)p; p += sz_slot;
     int32_t* rank = (int32_t*)p;
     // scan temp
-    size_t tmp_a = 0, tmp_b = 0, tmp_c = 0;
+    size_t tmp_a = 0, tmp_b = 0;
     hipcub::DeviceScan::InclusiveScan((void*)nullptr, tmp_a, head, head_scan, hipcub::Max(), (int)n, c->stream);
     hipcub::DeviceScan::ExclusiveSum((void*)nullptr, tmp_b, proc, seg_off, (int)n, c->stream);
-    hipcub::DeviceScan::ExclusiveSum((void*)nullptr, tmp_c, nkids, child_off, (int)n, c->stream);
     size_t tmp = tmp_a > tmp_b ? tmp_a : tmp_b, tmp_d = 0;
-    tmp = tmp > tmp_c ? tmp : tmp_c;
     if (ns > 0) {
         hipcub::DeviceScan::ExclusiveSum((void*)nullptr, tmp_d, probe, probe_ex, (int)n, c->stream);
         tmp = tmp > tmp_d ? tmp : tmp_d;
@@ -1099,24 +1137,22 @@ int ot_trace_generation_f64(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
     }
     if (ns > 0) {  // FIFO-exact interact-count gating: probe -> per-slot scan -> rank within the tree
         HIP_TRY(hipMemsetAsync(probe, 0, sizeof(int32_t) * n * ns, c->stream));
+        HIP_TRY(hipMemsetAsync(lb.ticket, 0, sizeof(unsigned long long), c->stream));
         hipLaunchKernelGGL(k_probe, dim3(grid), dim3(block), lds_bytes, c->stream, blob, c->unit, view<double>(rays), tree, n, proc,
-                           seg_off, seg_cursor, view<double>(out), out_capacity, kids, nkids, counts, n_classes,
-                           (const int32_t*)nullptr, probe);
+                           seg_off, seg_cursor, view<double>(out), out_capacity, lb, view_out<double>(next), next_tree, next_capacity,
+                           n_next, counts, n_classes, (const int32_t*)nullptr, probe);
         for (int s = 0; s < ns; ++s)
             HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->scan_tmp.p, tmp, probe + (int64_t)s * n, probe_ex + (int64_t)s * n, (int)n, c->stream));
         hipLaunchKernelGGL(k_gen_rank, dim3(g1), dim3(block), 0, c->stream, head_scan, n, ns, probe_ex, rank);
     }
+    HIP_TRY(hipMemsetAsync(lb.state, 0, sizeof(unsigned long long) * (n_tiles + 1), c->stream));  // tile states and the ticket
     hipLaunchKernelGGL(k_main, dim3(grid), dim3(block), lds_bytes, c->stream, blob, c->unit, view<double>(rays), tree, n, proc, seg_off,
-                       seg_cursor, view<double>(out), out_capacity, kids, nkids, counts, n_classes, (const int32_t*)rank,
-                       (int32_t*)nullptr);
+                       seg_cursor, view<double>(out), out_capacity, lb, view_out<double>(next), next_tree, next_capacity, n_next,
+                       counts, n_classes, (const int32_t*)rank, (int32_t*)nullptr);
     if (ns > 0)
         hipLaunchKernelGGL(k_gen_counts, dim3(g1), dim3(block), 0, c->stream, tree, rays->id, n, ns, rank, probe, c->slot_max, counts,
                            n_classes);
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->scan_tmp.p, tmp, nkids, child_off, (int)n, c->stream));
-    hipLaunchKernelGGL(k_gen_compact, dim3(g1), dim3(block), 0, c->stream, tree, rays->id, n, kids, nkids, child_off,
-                       view_out<double>(next), next_tree, next_capacity);
-    hipLaunchKernelGGL(k_gen_finish, dim3(g1), dim3(block), 0, c->stream, tree, head_scan, n, budget, proc, seg_off, nkids,
-                       child_off, seg_cursor, n_next);
+    hipLaunchKernelGGL(k_gen_finish, dim3(g1), dim3(block), 0, c->stream, tree, head_scan, n, budget, proc, seg_off, seg_cursor);
     HIP_TRY(hipGetLastError());
     return timing_end(c);
 }
