@@ -223,6 +223,42 @@ def _fanout(kind, refl, trans):
     return 1 if kind == LENS else 0
 
 
+def _flattenable_leaves(b, top):
+    """Leaf node indices below `top` if the subtree can be replaced by them in the top-level grid, else None."""
+    nd = b.nodes[top]
+    if nd.kind == abi.NODE_LEAF:
+        return [top]
+    out = []
+    stack = [(top, None)]
+    j = top
+    end = nd.end
+    # depth-first list: the enclosing groups of node j are those opened before it whose `end` lies beyond it
+    open_groups = []
+    while j < end:
+        node = b.nodes[j]
+        while open_groups and b.nodes[open_groups[-1]].end <= j:
+            open_groups.pop()
+        box = np.array(node.aabb[:], dtype=float).reshape(3, 2)
+        if not np.all(np.isfinite(box)):
+            return None
+        for g in open_groups:
+            gbox = np.array(b.nodes[g].aabb[:], dtype=float).reshape(3, 2)
+            if np.any(box[:, 0] < gbox[:, 0]) or np.any(box[:, 1] > gbox[:, 1]):
+                return None  # a stale cached bbox: the group's own test is not implied, keep the subtree
+        if node.kind == abi.NODE_GROUP:
+            if node.flags & abi.NODE_GRID:
+                return None
+            if not (node.flags & abi.NODE_CHECK_AABB) and j != top:
+                return None
+            open_groups.append(j)
+        else:
+            if not (node.flags & abi.NODE_CHECK_AABB):
+                return None  # every child of a group is AABB-tested (component_group.py:104-107)
+            out.append(j)
+        j += 1
+    return out
+
+
 ROOT_GRID_MIN_TOP = 12
 ROOT_GRID_CELLS_PER_COMPONENT = 1.0
 
@@ -257,7 +293,19 @@ def _root_grid(b, tops):
     size = [span[0] / g0, span[1] / g1]
     inv = [1.0 / size[0], 1.0 / size[1]]
     cells = [[] for _ in range(g0 * g1)]
-    for idx, bx in zip(tops, boxes):
+    # What goes into the cells: the LEAVES of a group instead of the group when every box on the way down
+    # contains the boxes below it (always true unless a cached bbox went stale, optical_component.py:62-67) and
+    # no group below has a grid of its own.  A ray that passes a leaf's AABB test then passes its ancestors' too
+    # (bigger box: wider slab interval, laxer parallel-axis rule), so testing the leaf alone is the same test —
+    # and all lanes of a wave run one flat loop over leaves instead of nested walks of different depth.
+    entries = []
+    for top in tops:
+        leaves = _flattenable_leaves(b, top)
+        entries.extend(leaves if leaves is not None else [top])
+    entry_boxes = np.array([b.nodes[i].aabb[:] for i in entries], dtype=float).reshape(-1, 3, 2)
+    if not np.all(np.isfinite(entry_boxes)):
+        entries, entry_boxes = list(tops), boxes
+    for idx, bx in zip(entries, entry_boxes):
         lo0 = int(np.clip(np.floor((bx[a0, 0] - margin - org[0]) * inv[0]), 0, g0 - 1))
         hi0 = int(np.clip(np.floor((bx[a0, 1] + margin - org[0]) * inv[0]), 0, g0 - 1))
         lo1 = int(np.clip(np.floor((bx[a1, 0] - margin - org[1]) * inv[1]), 0, g1 - 1))

@@ -85,12 +85,11 @@ def test_root_grid_lists_every_component_in_the_cells_it_overlaps():
     cells = g0 * g1
     start = g[11:11 + cells + 1].astype(int)
     items = g[11 + cells + 1: 11 + cells + 1 + start[-1]].astype(int)
-    tops, i = [], 0
-    while i < scene.n_nodes:
-        tops.append(i)
-        i = int(nodes["end"][i])
-    assert sorted(set(items.tolist())) == tops
-    for t in tops:
+    listed = sorted(set(items.tolist()))
+    # cfg 3's groups (GlassSlab, Prism) contain their children's boxes: the grid lists their LEAVES
+    assert all(nodes["kind"][t] == 1 for t in listed)
+    assert listed == [i for i in range(scene.n_nodes) if nodes["kind"][i] == 1]
+    for t in listed:
         box = nodes["aabb"][t].reshape(3, 2)
         for c1 in range(g1):
             for c0 in range(g0):
@@ -98,6 +97,31 @@ def test_root_grid_lists_every_component_in_the_cells_it_overlaps():
                 overlaps = (box[a0, 0] <= lo0 + g[9] and box[a0, 1] >= lo0 and box[a1, 0] <= lo1 + g[10] and box[a1, 1] >= lo1)
                 if overlaps:
                     assert t in items[start[c1 * g0 + c0]:start[c1 * g0 + c0 + 1]]
+
+
+def test_root_grid_keeps_a_group_whose_cached_box_went_stale():
+    """A group moved after its bbox was cached (optical_component.py:62-67: never invalidated) no longer
+    contains its children's boxes; its own AABB test then prunes hits and cannot be skipped, so the grid must
+    list the group, not its leaves."""
+    comps = scenes.cfg3_components(oa)
+    slab = next(c for c in comps if type(c).__name__ == "GlassSlab")
+    from optable_amd.geometry import _NO_BOX
+
+    _ = slab.bbox                      # cache the group box (and the children's) ...
+    for child in slab.components:      # ... then move the children and let only THEIR boxes be recomputed
+        child._Translate([0.0, 0.7, 0.0])
+        child._bbox = _NO_BOX
+    scene = oa.compile_scene(comps)
+    nodes = scene.node_table()
+    aux = np.ctypeslib.as_array(scene.aux)[: scene.n_aux]
+    g = aux[scene.root_grid:]
+    cells = int(g[2]) * int(g[3])
+    start = g[11:11 + cells + 1].astype(int)
+    items = set(g[11 + cells + 1: 11 + cells + 1 + start[-1]].astype(int).tolist())
+    groups = [i for i in items if nodes["kind"][i] == 0]
+    assert len(groups) == 1
+    gi = groups[0]
+    assert not any(gi < i < nodes["end"][gi] for i in items)   # its leaves are reached through it only
 
 
 def test_no_grids_when_a_leaf_is_count_limited():
