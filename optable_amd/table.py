@@ -375,10 +375,13 @@ def _clone_rays(rays):
     walking every object graph: the arrays are copied, scalars and the (immutable) material are
     shared.  ~20x cheaper than deepcopy, which is the reference's own bottleneck here."""
     out = []
+    new = object.__new__
     for r in rays:
-        c = copy.copy(r)
-        c.origin = r.origin.copy()
-        c._direction = r._direction.copy()
+        c = new(type(r))
+        d = c.__dict__
+        d.update(r.__dict__)
+        d["origin"] = r.origin.copy()
+        d["_direction"] = r._direction.copy()
         out.append(c)
     return out
 
@@ -417,25 +420,45 @@ def _fused_capped(host_segs, cap):
 
 
 def _scatter_segments(host_segs, sources, pick, per_ray):
-    """Rebuild Ray objects, grouped by input ray, in the reference's order."""
-    tree = host_segs["ray"]
-    for local, k in enumerate(pick):
+    """Rebuild Ray objects, grouped by input ray, in the reference's order.  Every segment starts as a
+    shallow clone of its input ray (it inherits _id, wavelength, unit and any user attribute, like the copy
+    chain upstream) with the traced fields replaced.  Columns are converted to Python lists once and the
+    clone is `__new__` + a dict update: ~2 us per segment instead of ~10 with copy.copy and per-field numpy
+    scalars."""
+    from .materials import Material
+
+    tree = host_segs["ray"].tolist()
+    surface = host_segs["surface"].tolist()
+    length = host_segs["length"].tolist()
+    intensity = host_segs["intensity"].tolist()
+    q_re, q_im = host_segs["q_re"].tolist(), host_segs["q_im"].tolist()
+    index, path = host_segs["n"].tolist(), host_segs["pathlength"].tolist()
+    origin = np.stack([host_segs["ox"], host_segs["oy"], host_segs["oz"]], axis=1)
+    direction = np.stack([host_segs["dx"], host_segs["dy"], host_segs["dz"]], axis=1)
+    inf = float("inf")
+    constants = {}  # one shared constant Material per distinct index value (Materials are immutable)
+    for k in pick:
         per_ray[k] = []
-    for s in range(len(tree)):
-        src = sources[int(tree[s])]
-        surface = int(host_segs["surface"][s])
-        length = float(host_segs["length"][s])
-        seg = copy.copy(src)  # inherits _id, wavelength, unit and any user attribute, like the copy chain upstream
-        seg.origin = np.array([host_segs["ox"][s], host_segs["oy"][s], host_segs["oz"][s]])
-        seg._direction = np.array([host_segs["dx"][s], host_segs["dy"][s], host_segs["dz"][s]])
-        seg.intensity = float(host_segs["intensity"][s])
-        seg.length = None if np.isinf(length) else length
-        seg.alive = surface == -1
-        if src.qo is not None:
-            seg.qo = complex(host_segs["q_re"][s], host_segs["q_im"][s])
-        seg._n = float(host_segs["n"][s])
-        seg._pathlength = float(host_segs["pathlength"][s])
-        per_ray[pick[int(tree[s])]].append(seg)
+    new = object.__new__
+    for s, t in enumerate(tree):
+        src = sources[t]
+        seg = new(type(src))
+        d = seg.__dict__
+        d.update(src.__dict__)
+        d["origin"] = origin[s].copy()
+        d["_direction"] = direction[s].copy()
+        d["intensity"] = intensity[s]
+        d["length"] = None if length[s] == inf else length[s]
+        d["alive"] = surface[s] == -1
+        if d.get("qo") is not None:
+            d["qo"] = complex(q_re[s], q_im[s])
+        n = index[s]
+        mat = constants.get(n)
+        if mat is None:
+            mat = constants[n] = Material("Constant", n=n)
+        d["_n"] = mat  # what the RefractiveIndex descriptor would store for a float
+        d["_pathlength"] = path[s]
+        per_ray[pick[t]].append(seg)
 
 
 def monitor_struct(monitor):
