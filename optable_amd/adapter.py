@@ -66,13 +66,83 @@ _SURFACES = {
 }
 
 
+def _closure_operands(surf):
+    """(left, right) of a reference `Plane.union` / `Plane.subtract` result, or None.  Upstream builds those as
+    a fresh Plane whose `within_boundary` is a closure over `self` and `other` (surfaces.py:100-136)."""
+    fn = getattr(surf, "__dict__", {}).get("within_boundary")
+    code = getattr(fn, "__code__", None)
+    if code is None or not fn.__closure__ or set(code.co_freevars) != {"self", "other"}:
+        return None
+    cells = dict(zip(code.co_freevars, (c.cell_contents for c in fn.__closure__)))
+    return cells["self"], cells["other"]
+
+
+def _probe_points(box, n=9):
+    _, _, y0, y1, z0, z1 = (float(v) for v in box)
+    ys, zs = np.linspace(y0, y1, n), np.linspace(z0, z1, n)
+    return [np.array([0.0, y, z]) for y in ys for z in zs]
+
+
+def _boolean_postfix(surf, out):
+    """Postfix program (shapes.BooleanPlane layout) of a closure-built aperture.  The operator is not
+    readable from the closure, so it is MEASURED: at a point inside `other` a union is true and a subtraction
+    false."""
+    pair = _closure_operands(surf)
+    if pair is None:
+        low = lower_surface(surf)
+        if low.kind not in (shapes.CIRCLE, shapes.RECT, shapes.POLYGON2D):
+            raise AdapterError(f"boolean aperture operand {type(surf).__name__} has no device form")
+        body = low.aux if low.kind == shapes.POLYGON2D else low.params
+        out.extend([float(low.kind), float(len(body))] + list(body))
+        return
+    left, right = pair
+    inside_right = next((P for P in _probe_points(right.get_bbox_local()) if right.within_boundary(P)), None)
+    if inside_right is None:
+        raise AdapterError("boolean aperture: no probe point inside the second operand")
+    op = shapes.CSG_OR if surf.within_boundary(inside_right) else shapes.CSG_ANDNOT
+    _boolean_postfix(left, out)
+    _boolean_postfix(right, out)
+    out.extend([float(op), 0.0])
+
+
+def _boolean_plane(surf):
+    prog = []
+    _boolean_postfix(surf, prog)
+    n_tokens = sum(1 for _ in shapes._walk_tokens(prog))
+    low = Lowered(shapes.CSG, aux=[float(n_tokens)] + prog)
+    # check the recovered program against the closure on a grid over the aperture's box
+    def run(P):
+        stack, i = [], 0
+        while i < len(prog):
+            kind, ln = int(prog[i]), int(prog[i + 1])
+            body = prog[i + 2:i + 2 + ln]
+            if kind == shapes.CSG_OR:
+                b, a = stack.pop(), stack.pop(); stack.append(a or b)
+            elif kind == shapes.CSG_ANDNOT:
+                b, a = stack.pop(), stack.pop(); stack.append(a and not b)
+            elif kind == shapes.CIRCLE:
+                stack.append(float(np.linalg.norm(P)) <= body[0])
+            elif kind == shapes.RECT:
+                stack.append(abs(P[1]) <= body[0] and abs(P[2]) <= body[1])
+            else:
+                return None  # polygons are checked through their own lowering
+            i += 2 + ln
+        return stack[0]
+    for P in _probe_points(surf.get_bbox_local(), 13):
+        mine = run(P)
+        if mine is not None and bool(mine) != bool(surf.within_boundary(P)):
+            raise AdapterError("boolean aperture: recovered program disagrees with the closure")
+    return low
+
+
 def lower_surface(surf):
     if hasattr(surf, "lower"):
         return surf.lower()
     fn = _SURFACES.get(type(surf).__name__)
-    if fn is None:  # a bare Plane (unbounded) or the closure-based Plane.union / subtract of the reference
-        raise AdapterError(f"surface {type(surf).__name__} has no device form (boolean apertures of the reference are "
-                           "closures; build them with optable_amd.Plane.union/subtract)")
+    if fn is None:
+        if _closure_operands(surf) is not None:  # the closure-based Plane.union / subtract of the reference
+            return _boolean_plane(surf)
+        raise AdapterError(f"surface {type(surf).__name__} has no device form")
     return fn(surf)
 
 

@@ -29,7 +29,7 @@ def ref():
     return optable
 
 
-ADAPTABLE = [n for n in sorted(scenes.SCENES) if n != "g16_misc"]  # g16 has a Plane.subtract closure (Block with a hole)
+ADAPTABLE = sorted(scenes.SCENES)  # incl. g16: Block with a hole = the reference's closure-based Plane.subtract
 
 
 @pytest.mark.parametrize("name", ADAPTABLE)
@@ -54,8 +54,29 @@ def test_reference_objects_compile_to_the_same_tables(name, ref):
     assert (theirs.max_children, theirs.root_grid, len(theirs.limited)) == (mine.max_children, mine.root_grid, len(mine.limited))
 
 
-def test_reference_boolean_aperture_is_rejected_loudly(ref):
-    blk = ref.Block([4, 0, 0], hole=ref.Circle(0.3), width=2, height=2)
+def test_reference_boolean_apertures_are_recovered_from_their_closures(ref):
+    """The reference builds Plane.union / subtract as closures (surfaces.py:100-136); the adapter reads the
+    operands from the closure cells, MEASURES the operator and checks the recovered program on a grid."""
+    from optable_amd import shapes
+
+    hole = ref.Block([4, 0, 0], hole=ref.Circle(0.3), width=2, height=2)
+    mine = oa.Block([4, 0, 0], hole=oa.Circle(0.3), width=2, height=2)
+    a, b = oa.compile_scene([hole]), oa.compile_scene([mine])
+    np.testing.assert_array_equal(np.ctypeslib.as_array(a.aux)[: a.n_aux], np.ctypeslib.as_array(b.aux)[: b.n_aux])
+    assert a.node_table()["shape"][0] == shapes.CSG
+    # nested: (rectangle - circle) | small rectangle
+    nested_ref = ref.Rectangle(2, 2).subtract(ref.Circle(0.5)).union(ref.Rectangle(0.2, 3.0))
+    nested_mine = oa.Rectangle(2, 2).subtract(oa.Circle(0.5)).union(oa.Rectangle(0.2, 3.0))
+    from optable_amd import adapter
+    assert adapter.lower_surface(nested_ref).aux == nested_mine.lower().aux
+
+
+def test_unrecognisable_surface_is_rejected_loudly(ref):
+    class Blob(ref.Plane):          # a user subclass with its own boundary: no device form
+        def within_boundary(self, P):
+            return P[1] ** 2 + 3 * P[2] ** 2 < 1
+    blk = ref.Block([4, 0, 0], width=2, height=2)
+    blk.surface = Blob()
     with pytest.raises(oa.SceneError):
         oa.compile_scene([blk])
 
