@@ -37,6 +37,8 @@ class Engine:
 
     # -- scene -----------------------------------------------------------------------------
     def upload(self, scene):
+        if scene is self.scene:  # the very object already on the device (a CompiledScene is immutable)
+            return
         desc = scene.desc()
         abi.check(self.lib.ot_scene_upload(self._ctx, C.byref(desc)), self.lib)
         self.scene = scene

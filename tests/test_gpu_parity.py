@@ -532,3 +532,28 @@ def test_fp32_batch_on_a_branching_scene_is_widened():
     a, b = s32.to_host(), s64.to_host()
     np.testing.assert_array_equal(a["surface"], b["surface"])
     np.testing.assert_allclose(a["ox"], b["ox"], atol=1e-5)   # inputs were rounded to float once
+
+
+def test_compiled_scene_can_be_reused_and_is_not_uploaded_twice():
+    """trace_batch(scene=...) skips the Python flattening; the engine skips the upload of the scene it already
+    holds; a component moved afterwards needs a fresh compile (poses are read at compile time)."""
+    import torch
+    import optable_amd as oa
+    from optable_amd.engine import get_engine
+
+    comps = scenes.cfg2_components(oa)
+    table = _table(comps)
+    o, d = scenes.cfg2_rays(2000, 1)
+    batch = _batch(o, d)
+    scene = table.compile()
+    a = table.trace_batch(batch, max_segments=5, scene=scene)
+    assert get_engine().scene is scene
+    b = table.trace_batch(batch, max_segments=5, scene=scene)
+    fresh = table.trace_batch(batch, max_segments=5)
+    for f in abi.SEG_FIELDS:
+        assert torch.equal(a.field(f), b.field(f)) and torch.equal(a.field(f), fresh.field(f))
+    comps[0]._Translate([0.5, 0, 0])                       # move the lens
+    stale = table.trace_batch(batch, max_segments=5, scene=scene)
+    moved = table.trace_batch(batch, max_segments=5)
+    assert torch.equal(stale.field("length"), a.field("length"))
+    assert not torch.equal(moved.field("length"), a.field("length"))
