@@ -253,11 +253,15 @@ class SegmentBatch:
         if self.count is not None:
             K = self.capacity // self.n_rays
             cnt = np.abs(self.count.cpu().numpy())  # a negative count marks a tree that branched (its slots are still valid)
-            keep = np.arange(K)[:, None] < cnt[None, :]            # [K, N]
+            full = bool(cnt.min() == K)                            # every slot valid: no masking needed
+            keep = None if full else np.arange(K)[:, None] < cnt[None, :]            # [K, N]
             out = {}
             for f in abi.SEG_FIELDS + ("ray", "surface"):
-                a = self.field(f).cpu().numpy().reshape(K, self.n_rays)
-                out[f] = a.T[keep.T] if reference_order else a[keep]
+                a = self.field(f)[: K * self.n_rays].cpu().numpy().reshape(K, self.n_rays)
+                if full:
+                    out[f] = np.ascontiguousarray(a.T).reshape(-1) if reference_order else a.reshape(-1)
+                else:
+                    out[f] = a.T[keep.T] if reference_order else a[keep]
             out["count"] = cnt
             return out
         out = {f: self.field(f)[: self.n_valid].cpu().numpy() for f in abi.SEG_FIELDS + ("ray", "surface")}

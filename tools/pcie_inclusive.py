@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of BASELINE cfg 2 (for DESIGN.md §7; never the bench.py `value`): host numpy arrays in
+(RayBatch.from_arrays = H2D), trace, full segment history back to host numpy (SegmentBatch.to_host = D2H)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(1, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import optable_amd as oa
+from optable_amd.batch import RayBatch
+from optable_amd import dist as odist
+import scenes
+
+n, K = 1_000_000, 5
+table = oa.OpticalTable(); table.add_components(scenes.cfg2_components(oa))
+o, d = scenes.cfg2_rays(n, 0)
+q = 1j * np.pi * scenes.W0**2 / scenes.WL
+scene = table.compile()
+for rep in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    batch = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=q)
+    torch.cuda.synchronize(); t1 = time.perf_counter()
+    segs = table.trace_batch(batch, max_segments=K, scene=scene)
+    torch.cuda.synchronize(); t2 = time.perf_counter()
+    final = odist.final_state(segs).cpu()
+    torch.cuda.synchronize(); t3 = time.perf_counter()
+    host = segs.to_host(reference_order=False)
+    t4 = time.perf_counter()
+    print(f"rep {rep}: H2D+pack {1e3*(t1-t0):7.2f} ms | trace {1e3*(t2-t1):6.2f} ms | final state D2H (96 MB) {1e3*(t3-t2):7.2f} ms | "
+          f"full history D2H (520 MB) {1e3*(t4-t3):7.2f} ms")
+    segs_n = int(np.sum(host["count"]))
+    print(f"   intersections/s incl. H2D + final-state D2H: {segs_n*3/(t3-t0):.3e};  incl. full history D2H: {segs_n*3/((t2-t0)+(t4-t3)):.3e}")
