@@ -1218,7 +1218,7 @@ int ot_bench_stream_f64(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, co
     if (n < 1 || K < 1 || !seg_count || n >= (int64_t)1 << 31) return fail(OT_ERR_INVALID, "bad n / K / seg_count");
     HIP_TRY(hipSetDevice(c->device));
     const int block = 256;
-    const int64_t need = (n + block - 1) / block, cap = (int64_t)c->n_cus * (c->opt_blocks_per_cu > 0 ? c->opt_blocks_per_cu : 8);
+    const int64_t need = (n + block - 1) / block, cap = (int64_t)c->n_cus * (c->opt_blocks_per_cu > 0 ? c->opt_blocks_per_cu : 256);  // the fused kernel's grid rule
     const int grid = (int)(need < cap ? need : cap);
     rc = timing_begin(c);
     if (rc) return rc;
