@@ -229,7 +229,6 @@ def _flattenable_leaves(b, top):
     if nd.kind == abi.NODE_LEAF:
         return [top]
     out = []
-    stack = [(top, None)]
     j = top
     end = nd.end
     # depth-first list: the enclosing groups of node j are those opened before it whose `end` lies beyond it

@@ -7,7 +7,6 @@ import sys
 import numpy as np
 import pytest
 
-import helpers
 import scenes
 import optable_amd as oa
 from optable_amd import abi

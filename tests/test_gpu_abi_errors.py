@@ -4,7 +4,6 @@ tables are indices into each other (node.end, aux offsets, grid records, polygon
 ot_scene_upload checks every one of them before a ray can follow them on the device."""
 import ctypes as C
 
-import numpy as np
 import pytest
 
 import scenes

@@ -243,7 +243,7 @@ def test_record_batch_matches_object_api():
     import optable_amd as oa
 
     table, sc = helpers.build("g07_spherical_lenses")
-    out = table.ray_tracing(sc["rays"])
+    table.ray_tracing(sc["rays"])   # fills the monitors through the object path
     mon = table.monitors[0]
     from optable_amd.table import _pack
 

@@ -11,7 +11,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(1, os.path.join(ROOT, "tests"))
 import numpy as np
-import torch
 import optable_amd as oa
 from optable_amd import abi
 from optable_amd.batch import RayBatch, SegmentBatch
