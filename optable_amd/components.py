@@ -65,6 +65,30 @@ class OpticalComponent(Vector):
     def point_to_lab_coordinates(self, point_local):
         return self.transform_matrix @ point_local + self.origin
 
+    def ray_to_local_coordinates(self, ray):
+        """The ray seen from this component's frame (optical_component.py:106-111); M is a rotation."""
+        R = self.transform_matrix.T
+        return ray.copy(origin=R @ (ray.origin - self.origin), direction=R @ ray.direction)
+
+    def ray_to_lab_coordinates(self, ray):
+        """A local-frame ray back in the lab frame (optical_component.py:119-124)."""
+        R = self.transform_matrix
+        return ray.copy(origin=R @ ray.origin + self.origin, direction=R @ ray.direction)
+
+    # -- the per-object form of the hot path: one ray against this component, on the device ------------
+    def interact(self, ray):
+        """`(t, [truncated, *children])` or `(None, None)` (optical_component.py:337-378)."""
+        from .table import interact_component
+
+        return interact_component(self, ray)
+
+    def intersect_point_local(self, ray_local):
+        """`(P_local, t)` of the first valid hit of a LOCAL-frame ray, or `(None, None)`
+        (optical_component.py:151-233)."""
+        from .table import intersect_leaf_local
+
+        return intersect_leaf_local(self, ray_local)
+
     # -- bounding boxes (cached on first use and never invalidated, as upstream :62-67) -----
     def get_bbox_local(self):
         return self.surface.get_bbox_local()

@@ -122,6 +122,39 @@ class Engine:
         out.capped = budget <= 0  # cap reached: queued rays were dropped (optical_table.py:138-144)
         return out
 
+    def generation_step(self, rays: RayBatch, counts=None):
+        """ONE generation of the breadth-first trace: every input ray is processed once (nearest hit,
+        interaction).  Returns (segments, children, parent): a SegmentBatch with one record per input ray
+        (slot i = ray i), the emitted rays as a RayBatch in parent order then child order, and for each of them
+        the index of its parent.  This is `component.interact(ray)` for a batch (optical_component.py:337-378)."""
+        if self.scene is None:
+            raise RuntimeError("upload a scene first")
+        if rays.precision != "f64":
+            raise NotImplementedError("generation steps are fp64 only")
+        dev, n = rays.device, rays.n
+        out = SegmentBatch(n, "f64", dev)
+        out.n_valid = 0
+        if n == 0:
+            return out, RayBatch(0, "f64", dev), torch.zeros(0, dtype=torch.int32, device=dev)
+        fan = max(self.scene.max_children, 1)
+        budget = torch.ones(n, dtype=torch.int32, device=dev)
+        state = torch.zeros(2, dtype=torch.int64, device=dev)
+        tree = torch.arange(n, dtype=torch.int32, device=dev)
+        nxt = RayBatch(n * fan, "f64", dev, initialise=False)
+        nxt_tree = torch.empty(n * fan, dtype=torch.int32, device=dev)
+        n_slots = len(self.scene.limited)
+        if n_slots and counts is None:
+            counts = torch.zeros((n_slots, n), dtype=torch.int32, device=dev)
+        n_classes = 0 if counts is None else counts.shape[1]
+        rs, ss, ns = rays.c_struct(), out.c_struct(), nxt.c_struct()
+        abi.check(self.lib.ot_trace_generation_f64(
+            self._ctx, C.byref(rs), tree.data_ptr(), n, budget.data_ptr(), C.byref(ss), out.capacity,
+            state.data_ptr(), C.byref(ns), nxt_tree.data_ptr(), nxt.n, state.data_ptr() + 8,
+            None if counts is None else counts.data_ptr(), n_classes), self.lib)
+        written, n_next = state.tolist()
+        out.n_valid, out.counts_table = int(written), counts
+        return out, nxt.slice(0, int(n_next)), nxt_tree[: int(n_next)]
+
     # -- monitors -------------------------------------------------------------------------------
     def monitor_record(self, monitor_struct, segs: SegmentBatch, n_segments=None):
         """Device pass of Monitor.record over a SegmentBatch.  Returns (slot index, P_local [h,3], t)

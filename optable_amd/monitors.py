@@ -136,6 +136,29 @@ class Monitor(OpticalComponent):
             out.append(-z if np.dot(r.direction, self.normal) > 0 else z)
         return np.array(out)
 
+    def get_beam_waist(self):
+        """Gaussian waist of every recorded ray at the monitor (monitor.py:218-225; upstream reads an undefined
+        `self.rList` there — `self.rays` is what the loop needs)."""
+        return np.array([r.waist(r.q_at_z(t)) for r, t in zip(self.rays, self.tList)])
+
+    def get_delta_pos(self):
+        """Spacings of the hits sorted by y (monitor.py:227-238)."""
+        y, z = self.yList, self.zList
+        if len(y) == 0 or len(z) == 0:
+            return np.array([0.0]), np.array([0.0])
+        order = np.argsort(y)
+        return np.diff(y[order]), np.diff(z[order])
+
+    def _get_hist_y(self):
+        return np.histogram(self.yList, bins=30, range=(-self.width / 2, self.width / 2))
+
+    @property
+    def std_histy(self):
+        """Standard deviation of the 30-bin y histogram (monitor.py:248-253)."""
+        counts, bins = self._get_hist_y()
+        mean = np.sum(counts * bins[:-1]) / np.sum(counts)
+        return np.sqrt(np.sum(counts * bins[:-1] ** 2) / np.sum(counts) - mean**2)
+
     @property
     def sum_intensity(self):
         return np.sum([d[1] for d in self.get_data()])

@@ -467,6 +467,67 @@ def _scatter_segments(host_segs, sources, pick, per_ray):
         per_ray[pick[t]].append(seg)
 
 
+def interact_component(comp, ray):
+    """`component.interact(ray)` (optical_component.py:337-378; component_group.py:93-122 for groups) through
+    the engine: one generation step over a scene made of this component alone.  Returns `(t, [truncated,
+    *children])` or `(None, None)`; interact counters of the component (and of a group's children: every
+    geometric hit consumes one) are read from and written back to the objects."""
+    from .scene import compile_scene as _compile
+
+    if not ray.alive:
+        return None, None
+    import torch
+
+    eng = _engine()
+    scene = _compile([comp])
+    eng.upload(scene)
+    batch = _pack([ray], np.zeros(1, dtype=np.int32), eng.device, scene.unit)
+    counts = None
+    if scene.limited:
+        host = np.array([[c._interact_count.get(ray._id, 0)] for c in scene.limited], dtype=np.int32)
+        counts = torch.from_numpy(host).to(eng.device)
+    segs, kids, _ = eng.generation_step(batch, counts)
+    if scene.limited:
+        after = counts.cpu().numpy()
+        for s, c in enumerate(scene.limited):
+            if after[s, 0] or ray._id in c._interact_count:
+                c._interact_count[ray._id] = int(after[s, 0])
+    if int(segs.surface[0].item()) < 0:
+        return None, None
+    t = float(segs.length[0].item())
+    truncated = _clone_rays([ray])[0]
+    truncated.length, truncated.alive = t, False
+    out = [truncated]
+    if kids.n:
+        k = {f: kids.field(f).cpu().numpy() for f in abi.RAY_FIELDS}
+        for j in range(kids.n):
+            child = _clone_rays([ray])[0]
+            child.origin = np.array([k["ox"][j], k["oy"][j], k["oz"][j]])
+            child._direction = np.array([k["dx"][j], k["dy"][j], k["dz"][j]])
+            child.intensity = float(k["intensity"][j])
+            child.length, child.alive = None, True
+            if ray.qo is not None:
+                child.qo = complex(k["q_re"][j], k["q_im"][j])
+            child._n = float(k["n"][j])
+            child._pathlength = float(k["pathlength"][j])
+            out.append(child)
+    return t, out
+
+
+def intersect_leaf_local(comp, ray_local):
+    """`leaf.intersect_point_local(ray_local)` (optical_component.py:151-233): the ray is already in the
+    leaf's frame, so the leaf is traced with an identity pose; count gates do not apply here."""
+    if hasattr(comp, "components"):
+        raise NotImplementedError("intersect_point_local is defined for leaf components")
+    probe = copy.copy(comp)
+    probe.origin, probe.transform_matrix = np.zeros(3), np.identity(3)
+    probe._bbox, probe.max_interact_count, probe._interact_count = _NO_BOX, None, {}
+    t, rays = interact_component(probe, ray_local)
+    if t is None:
+        return None, None
+    return np.asarray(ray_local.origin, dtype=float) + t * np.asarray(ray_local.direction, dtype=float), t
+
+
 def monitor_struct(monitor):
     """ot_monitor for a Monitor's current pose."""
     mon = abi.OtMonitor()

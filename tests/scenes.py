@@ -286,3 +286,27 @@ SCENES = {
     "g13_count_shadow": g13_count_shadow, "g15_cfg4": g15_cfg4, "g16_misc": g16_misc, "g18_fifo_gate": g18_fifo_gate,
     "g19_units_and_disorder": g19_units_and_disorder,
 }
+
+
+def interact_cases(ns):
+    """Single-call API of the hot path: `component.interact(ray)` and, for leaves,
+    `intersect_point_local(ray_to_local_coordinates(ray))`.  Returns [(name, component, [rays])]."""
+    R = ns.Ray
+    wl, w0 = 780e-7, 50e-4
+    fan = lambda x0: [R([x0, y, z], [1, dy, 0.01], wavelength=wl, w0=w0) for y, z, dy in
+                      ((0.0, 0.0, 0.0), (0.3, -0.1, 0.02), (-0.4, 0.2, -0.05), (2.5, 0.0, 0.0))]  # the last one misses
+    dead = R([-3, 0, 0], [1, 0, 0], wavelength=wl, w0=w0, alive=False)
+    inside = [R([0.0, 0.1, 0.0], [np.cos(a), np.sin(a), 0.0], wavelength=wl, w0=w0) for a in (0.2, 0.75, 1.2)]
+    for r in inside:
+        r._n = 1.5   # travelling in glass towards the interface: the steep one is totally reflected
+    return [
+        ("mirror", ns.Mirror([2, 0, 0], radius=1.0).RotZ(0.3), fan(-3) + [dead]),
+        ("partial_mirror", ns.Mirror([2, 0, 0], radius=1.0, reflectivity=0.7, transmission=0.3).RotZ(-0.2), fan(-3)),
+        ("lens", ns.Lens([2, 0, 0], focal_length=6.0, radius=1.0).RotY(0.1), fan(-3)),
+        ("block", ns.Block([2, 0, 0], width=2, height=2), fan(-3)),
+        ("interface", ns.SquareRefractive([1, 0, 0], width=4, height=4, n1=1.0, n2=1.5, reflectivity=0.1).RotZ(np.pi), inside),
+        ("sphere", ns.SphereRefractive([2, 0, 0], radius=6.0, height=0.5, n1=1.5, n2=1.0).RotZ(np.pi), fan(-8)),
+        ("slab_group", ns.GlassSlab([2, 0, 0], width=2, height=2, thickness=0.5, n1=1.0, n2=ns.Glass_NBK7()).RotZ(0.2), fan(-3)),
+        ("asphere_group", ns.ASphericParametricLens([2, 0, 0], CT=0.6, diameter=2.4, n=1.5, R=8.0, kappa=-1, a4=1e-4), fan(-3)),
+        ("prism_limited", ns.TriangularPrism([2, 0, 0], width=1.5, height=2, n1=1, n2=1.5), fan(-3)),
+    ]

@@ -66,3 +66,21 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle|oracle/|libot_oracle", src, flags=re.M), f
 
+
+
+def test_frame_transforms_are_host_logic():
+    """ray_to_local_coordinates / ray_to_lab_coordinates (optical_component.py:106-124): plain rotations of a
+    single Ray object, round trip exact to rounding; no GPU involved."""
+    import numpy as np
+    import optable_amd as oa
+
+    comp = oa.Mirror([2.0, -1.0, 0.5], radius=1.0).RotZ(0.7).RotY(-0.3)
+    ray = oa.Ray([0.3, 0.2, -0.1], [1.0, 0.2, -0.05], wavelength=780e-7, w0=50e-4)
+    local = comp.ray_to_local_coordinates(ray)
+    M = comp.transform_matrix
+    np.testing.assert_allclose(local.origin, M.T @ (ray.origin - comp.origin), atol=1e-15)
+    np.testing.assert_allclose(local.direction, M.T @ ray.direction, atol=1e-15)
+    back = comp.ray_to_lab_coordinates(local)
+    np.testing.assert_allclose(back.origin, ray.origin, atol=1e-14)
+    np.testing.assert_allclose(back.direction, ray.direction, atol=1e-14)
+    assert back._id == ray._id and back.qo == ray.qo and local is not ray

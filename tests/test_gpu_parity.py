@@ -2,6 +2,8 @@
 from the reference and (b) the CPU oracle on the same seeded inputs, plus size-independent
 properties at BASELINE's full cfg-2 size.  Tolerance: 1e-6 relative (north_star) against the
 reference fixtures; 1e-9 against the oracle (both fp64, same formulas, different root polish)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -557,3 +559,68 @@ def test_compiled_scene_can_be_reused_and_is_not_uploaded_twice():
     moved = table.trace_batch(batch, max_segments=5)
     assert torch.equal(stale.field("length"), a.field("length"))
     assert not torch.equal(moved.field("length"), a.field("length"))
+
+
+def _g20():
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "g20_interact.npz"))
+
+
+def test_single_call_api_matches_reference_fixture():
+    """`component.interact(ray)` and `leaf.intersect_point_local(...)` — the per-object form of the hot path
+     — against outputs of the reference's own methods (tools/make_golden.py g20)."""
+    import optable_amd as oa
+
+    g = _g20()
+    for name, comp, rays in scenes.interact_cases(oa):
+        t_ref = g[f"{name}_t"]
+        owner = g[f"{name}_out_owner"]
+        rows = 0
+        for k, ray in enumerate(rays):
+            t, out = comp.interact(ray)
+            if np.isnan(t_ref[k]):
+                assert t is None and out is None, (name, k)
+                continue
+            assert t == pytest.approx(t_ref[k], rel=1e-9, abs=1e-9), (name, k)
+            sel = np.nonzero(owner == k)[0]
+            assert len(out) == len(sel), (name, k, len(out), len(sel))
+            for r, j in zip(out, sel):
+                np.testing.assert_allclose(r.origin, g[f"{name}_out_origin"][j], atol=1e-9, err_msg=f"{name} {k}")
+                np.testing.assert_allclose(r.direction, g[f"{name}_out_direction"][j], atol=1e-9, err_msg=f"{name} {k}")
+                assert r.intensity == pytest.approx(g[f"{name}_out_intensity"][j], rel=1e-12, abs=1e-15)
+                assert bool(r.alive) == bool(g[f"{name}_out_alive"][j])
+                ref_len = g[f"{name}_out_length"][j]
+                assert (r.length is None) == bool(np.isinf(ref_len))
+                if r.length is not None:
+                    assert r.length == pytest.approx(ref_len, rel=1e-9)
+                assert r.n == pytest.approx(g[f"{name}_out_n"][j], rel=1e-12)
+                assert r._pathlength == pytest.approx(g[f"{name}_out_pathlength"][j], rel=1e-9, abs=1e-9)
+                qtol = 2e-3 if "asphere" in name else 1e-9
+                assert complex(r.qo) == pytest.approx(complex(g[f"{name}_out_q"][j]), rel=qtol, abs=1e-9)
+                rows += 1
+            if f"{name}_local_t" in g.files:
+                P, tl = comp.intersect_point_local(comp.ray_to_local_coordinates(ray))
+                assert tl == pytest.approx(g[f"{name}_local_t"][k], rel=1e-9, abs=1e-9)
+                np.testing.assert_allclose(P, g[f"{name}_local_P"][k], atol=1e-9)
+        assert rows > 0, name
+    # a miss in the local API, and the counters of the limited prism faces
+    leaf = oa.Mirror([2, 0, 0], radius=1.0)
+    assert leaf.intersect_point_local(oa.Ray([-3, 5, 0], [1, 0, 0])) == (None, None)
+
+
+def test_monitor_analysis_helpers():
+    """get_delta_pos / std_histy / get_beam_waist (monitor.py:218-253) on hits recorded by the device pass."""
+    table, sc = helpers.build("g06_mirror_pair")
+    table.ray_tracing(sc["rays"])
+    mon = table.monitors[0]
+    assert mon.ndata >= 1
+    dy, dz = mon.get_delta_pos()
+    assert len(dy) == max(mon.ndata - 1, 0) or (mon.ndata == 0 and len(dy) == 1)
+    assert np.isfinite(mon.std_histy)
+    import optable_amd as oa
+    t = oa.OpticalTable()
+    m = oa.Monitor([3, 0, 0], 2, 2)
+    t.add_monitors(m)
+    t.ray_tracing([oa.Ray([0, 0.1 * k, 0], [1, 0, 0], wavelength=780e-7, w0=50e-4) for k in range(4)])
+    w = m.get_beam_waist()
+    assert w.shape == (4,) and np.allclose(w, 50e-4)       # free propagation keeps the waist
+    assert np.allclose(np.sort(m.get_delta_pos()[0]), 0.1)

@@ -140,10 +140,42 @@ def slab_vectors():
     print("g14_slab: 64 rays x 4 boxes")
 
 
+def interact_fixture():
+    """g20: the single-call API (`component.interact(ray)`, `intersect_point_local`) on single components."""
+    out = {}
+    names = []
+    for name, comp, rays in scenes.interact_cases(ref):
+        names.append(name)
+        for key, val in ray_rows(rays).items():
+            out[f"{name}_in_{key}"] = val
+        t_all, rows, owner = [], [], []
+        P_loc, t_loc = [], []
+        for k, ray in enumerate(rays):
+            t, rays_out = comp.interact(ray)
+            t_all.append(np.nan if t is None else t)
+            for r in (rays_out or []):
+                rows.append(r)
+                owner.append(k)
+            if not hasattr(comp, "components"):
+                P, tl = comp.intersect_point_local(comp.ray_to_local_coordinates(ray))
+                P_loc.append([np.nan] * 3 if P is None else list(P))
+                t_loc.append(np.nan if tl is None else tl)
+        out[f"{name}_t"] = np.array(t_all, dtype=float)
+        for key, val in ray_rows(rows).items():
+            out[f"{name}_out_{key}"] = val
+        out[f"{name}_out_owner"] = np.array(owner, dtype=np.int32)
+        if P_loc:
+            out[f"{name}_local_P"] = np.array(P_loc, dtype=float).reshape(-1, 3)
+            out[f"{name}_local_t"] = np.array(t_loc, dtype=float)
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "g20_interact.npz"), **out)
+    print("g20_interact:", names)
+
+
 if __name__ == "__main__":
     names = sys.argv[1:] or list(scenes.SCENES)
     for nm in names:
-        if nm in ("g14_slab", "g17_abcd"):
+        if nm in ("g14_slab", "g17_abcd", "g20_interact"):
             continue
         np.random.seed(12345)
         run(nm)
@@ -151,3 +183,6 @@ if __name__ == "__main__":
         slab_vectors()
     if not sys.argv[1:] or "g17_abcd" in sys.argv[1:]:
         abcd_fixture()
+    if not sys.argv[1:] or "g20_interact" in sys.argv[1:]:
+        np.random.seed(12345)
+        interact_fixture()
