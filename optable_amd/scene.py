@@ -146,11 +146,10 @@ class _Builder:
             size = [(gbox[a0, 1] + 2 * margin - org[0]) / dims[0], (gbox[a1, 1] + 2 * margin - org[1]) / dims[1]]  # 64-cell cap: stretch
             inv = [1.0 / size[0], 1.0 / size[1]]
         cells = [[] for _ in range(dims[0] * dims[1])]
-        for k, bx in zip(kids, boxes):
-            lo0 = int(np.clip(np.floor((bx[a0, 0] - margin - org[0]) * inv[0]), 0, dims[0] - 1))
-            hi0 = int(np.clip(np.floor((bx[a0, 1] + margin - org[0]) * inv[0]), 0, dims[0] - 1))
-            lo1 = int(np.clip(np.floor((bx[a1, 0] - margin - org[1]) * inv[1]), 0, dims[1] - 1))
-            hi1 = int(np.clip(np.floor((bx[a1, 1] + margin - org[1]) * inv[1]), 0, dims[1] - 1))
+        span = lambda col, pad, o, i, n: np.clip(np.floor((col + pad - o) * i), 0, n - 1).astype(int).tolist()
+        lo0s, hi0s = span(boxes[:, a0, 0], -margin, org[0], inv[0], dims[0]), span(boxes[:, a0, 1], margin, org[0], inv[0], dims[0])
+        lo1s, hi1s = span(boxes[:, a1, 0], -margin, org[1], inv[1], dims[1]), span(boxes[:, a1, 1], margin, org[1], inv[1], dims[1])
+        for k, lo0, hi0, lo1, hi1 in zip(kids, lo0s, hi0s, lo1s, hi1s):
             for c1 in range(lo1, hi1 + 1):
                 for c0 in range(lo0, hi0 + 1):
                     cells[c1 * dims[0] + c0].append(k)
