@@ -726,7 +726,14 @@ __device__ __forceinline__ void root_grid_hit(const Scene<T>& sc, const RayState
     for (int guard = 0; guard < g0 + g1 + 2; ++guard) {
         const int cidx = c1 * g0 + c0;
         const int kb = (int)start[cidx], ke = (int)start[cidx + 1];
-        for (int k = kb; k < ke; ++k) walk_subtree<T, F, GATE>(sc, (int)items[k], r, ri, best, gate);
+        for (int k = kb; k < ke; ++k) {
+            const int item = (int)items[k];
+            const DNode<T>& nd = sc.nodes[item];
+            // the compiler lists leaves directly wherever it can (scene.py:_root_grid): cheap planar rejections
+            // first, the leaf's own AABB test last; subtrees (stale boxes, gridded groups) take the general walk
+            if (nd.kind == OT_NODE_LEAF) test_leaf<T, F, GATE, false, true>(sc, nd, item, r, best, gate, &ri);
+            else walk_subtree<T, F, GATE>(sc, item, r, ri, best, gate);
+        }
         const T texit = min_t(tmax0, tmax1);
         if (best.t + slack < texit) return;  // nothing in later cells can be nearer (or tie)
         if (tmax0 < tmax1) { c0 += s0; tmax0 += dt0; if (c0 < 0 || c0 >= g0) return; }
