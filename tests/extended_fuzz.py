@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Extended differential fuzzing on the GPU box (HIP path vs the C oracle): 90 more seeds of the three scene
+"""Not collected by pytest (run by hand: python tests/extended_fuzz.py).  Extended differential fuzzing on the GPU box (HIP path vs the C oracle): 90 more seeds of the three scene
 families of tests/test_gpu_fuzz.py (small, large with grids/arrays/dispersion, branching).  Prints the fraction
 of rays whose surface sequence differs and the worst relative field error per seed; flags anything beyond
 0.2 % / 1e-7.  Last run: 90 seeds, no path differences, worst error 4e-9."""
 import os, sys
-ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(1, os.path.join(ROOT, "tests"))
 import numpy as np
 import optable_amd as oa
