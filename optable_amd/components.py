@@ -82,6 +82,13 @@ class OpticalComponent(Vector):
 
         return interact_component(self, ray)
 
+    def interact_local(self, ray_local):
+        """The rays a hit emits, in this leaf's frame (the per-class physics upstream: mirror :536-570,
+        interface :617-717, thin lens :930-948; a base OpticalComponent has none and raises, as :240 does)."""
+        from .table import interact_leaf_local
+
+        return interact_leaf_local(self, ray_local)
+
     def intersect_point_local(self, ray_local):
         """`(P_local, t)` of the first valid hit of a LOCAL-frame ray, or `(None, None)`
         (optical_component.py:151-233)."""

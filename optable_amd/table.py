@@ -514,14 +514,26 @@ def interact_component(comp, ray):
     return t, out
 
 
-def intersect_leaf_local(comp, ray_local):
-    """`leaf.intersect_point_local(ray_local)` (optical_component.py:151-233): the ray is already in the
-    leaf's frame, so the leaf is traced with an identity pose; count gates do not apply here."""
+def _pose_free_copy(comp):
     if hasattr(comp, "components"):
-        raise NotImplementedError("intersect_point_local is defined for leaf components")
+        raise NotImplementedError("local-frame calls are defined for leaf components")
     probe = copy.copy(comp)
     probe.origin, probe.transform_matrix = np.zeros(3), np.identity(3)
     probe._bbox, probe.max_interact_count, probe._interact_count = _NO_BOX, None, {}
+    return probe
+
+
+def interact_leaf_local(comp, ray_local):
+    """`leaf.interact_local(ray_local)` (optical_component.py:536-570, 617-717, 930-948): the rays a hit emits,
+    in the leaf's frame; an empty list when the local ray misses (upstream would fail on `P is None` there)."""
+    _, rays = interact_component(_pose_free_copy(comp), ray_local)
+    return [] if rays is None else rays[1:]
+
+
+def intersect_leaf_local(comp, ray_local):
+    """`leaf.intersect_point_local(ray_local)` (optical_component.py:151-233): the ray is already in the
+    leaf's frame, so the leaf is traced with an identity pose; count gates do not apply here."""
+    probe = _pose_free_copy(comp)
     t, rays = interact_component(probe, ray_local)
     if t is None:
         return None, None

@@ -624,3 +624,28 @@ def test_monitor_analysis_helpers():
     w = m.get_beam_waist()
     assert w.shape == (4,) and np.allclose(w, 50e-4)       # free propagation keeps the waist
     assert np.allclose(np.sort(m.get_delta_pos()[0]), 0.1)
+
+
+def test_interact_local_is_the_lab_interaction_seen_from_the_leaf():
+    """leaf.interact_local(ray_local) == children of leaf.interact(ray) mapped into the leaf's frame."""
+    import optable_amd as oa
+
+    for name, comp, rays in scenes.interact_cases(oa):
+        if hasattr(comp, "components"):
+            with pytest.raises(NotImplementedError):
+                comp.interact_local(rays[0])
+            continue
+        for ray in rays[:3]:
+            t, out = comp.interact(ray)
+            local = comp.interact_local(comp.ray_to_local_coordinates(ray))
+            if t is None:
+                assert local == []
+                continue
+            assert len(local) == len(out) - 1
+            for a, b in zip(local, out[1:]):
+                back = comp.ray_to_lab_coordinates(a)
+                np.testing.assert_allclose(back.origin, b.origin, atol=1e-9)
+                np.testing.assert_allclose(back.direction, b.direction, atol=1e-9)
+                assert a.intensity == pytest.approx(b.intensity)
+    with pytest.raises(NotImplementedError):
+        oa.OpticalComponent([0, 0, 0]).interact_local(oa.Ray([-1, 0, 0], [1, 0, 0]))

@@ -19,6 +19,9 @@ import scenes
 if os.environ.get('OT_LIB'):  # kernel-variant experiments: an alternative build of the library
     abi.LIB_PATH = os.path.abspath(os.environ['OT_LIB'])
 eng = get_engine()
+if os.environ.get('RGC'):  # experiment: top-level grid resolution (cells per component)
+    import optable_amd.scene as _scene
+    _scene.ROOT_GRID_CELLS_PER_COMPONENT = float(os.environ['RGC'])
 if os.environ.get('LDSKB'):
     eng.set_option(abi.OPT_LDS_LIMIT_KB, int(os.environ['LDSKB']))
 if os.environ.get('SORT'):
