@@ -226,6 +226,11 @@ int ot_trace_generation_f64(ot_ctx* ctx, const ot_rays* rays, const int32_t* ray
                             int64_t out_capacity, int64_t* seg_cursor, const ot_rays* next,
                             int32_t* next_tree, int64_t next_capacity, int64_t* n_next,
                             int32_t* counts, int32_t n_count_classes);
+int ot_trace_generation_f32(ot_ctx* ctx, const ot_rays* rays, const int32_t* rays_tree,
+                            int64_t n_rays, int32_t* budget, const ot_segments* out,
+                            int64_t out_capacity, int64_t* seg_cursor, const ot_rays* next,
+                            int32_t* next_tree, int64_t next_capacity, int64_t* n_next,
+                            int32_t* counts, int32_t n_count_classes);
 
 /* Monitor.record (monitor.py:183-193): intersect finished segments with a rectangular
  * monitor plane, honouring segment length.  hit_index receives the slot indices of the segments

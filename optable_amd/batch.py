@@ -234,6 +234,22 @@ class SegmentBatch:
         s.ray, s.surface = self.ray.data_ptr(), self.surface.data_ptr()
         return s
 
+    def astype(self, precision):
+        """The same segments with their real fields in another precision (a copy unless already there)."""
+        if precision == self.precision:
+            return self
+        out = object.__new__(SegmentBatch)
+        out.capacity, out.precision, out.device = self.capacity, precision, self.device
+        dt = _REAL[precision]
+        for f in abi.SEG_FIELDS:
+            setattr(out, "n_index" if f == "n" else f, self.field(f).to(dt))
+        out.ray, out.surface = self.ray, self.surface
+        out.count, out.n_rays, out.n_valid = self.count, self.n_rays, self.n_valid
+        for extra in ("capped", "counts_table", "count_ids"):
+            if hasattr(self, extra):
+                setattr(out, extra, getattr(self, extra))
+        return out
+
     def valid_mask(self):
         """Boolean mask over slots (device)."""
         if self.count is not None:

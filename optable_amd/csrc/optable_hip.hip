@@ -334,10 +334,10 @@ struct LookBack {
 static constexpr unsigned long long LB_AGG = 1ull << 62, LB_PREFIX = 2ull << 62, LB_MASK = (1ull << 62) - 1ull;
 
 // PROBE = true: the pre-pass that records geometric hits of count-limited leaves (no outputs).
-template <uint32_t F, bool SCENE_IN_LDS, bool PROBE>
-__global__ __launch_bounds__(256) void k_gen_trace(SceneBlob blob, double unit, RaysT<double> in, const int32_t* tree, int64_t n,
+template <class T, uint32_t F, bool SCENE_IN_LDS, bool PROBE>
+__global__ __launch_bounds__(256) void k_gen_trace(SceneBlob blob, T unit, RaysT<T> in, const int32_t* tree, int64_t n,
                                                    const int32_t* proc, const int64_t* seg_off, const int64_t* cursor,
-                                                   SegsT<double> out, int64_t out_capacity, LookBack lb, RaysOutT<double> next,
+                                                   SegsT<T> out, int64_t out_capacity, LookBack lb, RaysOutT<T> next,
                                                    int32_t* next_tree, int64_t next_capacity, int64_t* n_next,
                                                    int32_t* counts, int32_t n_classes, const int32_t* rank, int32_t* probe) {
     extern __shared__ __align__(16) uint32_t lds[];
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void k_gen_trace(SceneBlob blob, double unit, 
         __syncthreads();
         base = lds;
     }
-    const Scene<double> sc = bind_scene<double>(base, blob, unit);
+    const Scene<T> sc = bind_scene<T>(base, blob, unit);
     const int64_t cur0 = *cursor;
     const int64_t n_tiles = (n + 255) / 256;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void k_gen_trace(SceneBlob blob, double unit, 
         if (tile >= n_tiles) break;  // workgroup-uniform
         const int64_t i = tile * 256 + threadIdx.x;
         bool active = i < n && proc[i];
-        RayState<double> r = {};
+        RayState<T> r = {};
         int32_t cls = 0, fl = 0;
         if (active) {
             fl = in.flags[i];
@@ -370,13 +370,13 @@ __global__ __launch_bounds__(256) void k_gen_trace(SceneBlob blob, double unit, 
         const bool dead = active && (fl & OT_RAY_DEAD);
         const GateCtx gate = {counts, n_classes, cls, rank, probe, n, i};
         if (PROBE) {
-            (void)nearest_hit<double, F, GATE_PROBE>(sc, r, active && !dead, gate);
+            (void)nearest_hit<T, F, GATE_PROBE>(sc, r, active && !dead, gate);
             __syncthreads();  // s_tile is rewritten at the top of the loop
             continue;
         }
-        const Hit<double> h = nearest_hit<double, F, GATE_TABLE>(sc, r, active && !dead, gate);
+        const Hit<T> h = nearest_hit<T, F, GATE_TABLE>(sc, r, active && !dead, gate);
         int32_t nk = 0, t = 0;
-        RayState<double> ch[2];
+        RayState<T> ch[2];
         if (active) {
             const int64_t slot = cur0 + seg_off[i];
             t = tree[i];
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void k_gen_trace(SceneBlob blob, double unit, 
                 else if (h.node < 0) store_segment(out, slot, r, r.len, t, -1);
                 else store_segment(out, slot, r, h.t, t, sc.nodes[h.node].leaf_id);
             }
-            if (!dead && h.node >= 0) nk = interact<double, F, 2>(sc, r, h, ch, make_matcache(sc, r.wl));
+            if (!dead && h.node >= 0) nk = interact<T, F, 2>(sc, r, h, ch, make_matcache(sc, r.wl));
         }
         // child slots: inclusive scan inside the wave, wave totals through LDS, tile prefix by look-back
         int incl = nk;
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256) void k_gen_trace(SceneBlob blob, double unit, 
         for (int w = 0; w < wave; ++w) d += s_wave_total[w];
         for (int c = 0; c < nk; ++c, ++d) {
             if (d >= next_capacity) break;
-            const RayState<double>& k = ch[c];
+            const RayState<T>& k = ch[c];
             next.ox[d] = k.ox; next.oy[d] = k.oy; next.oz[d] = k.oz;
             next.dx[d] = k.dx; next.dy[d] = k.dy; next.dz[d] = k.dz;
             next.wl[d] = k.wl; next.qr[d] = k.qr; next.qi[d] = k.qi;
@@ -1056,7 +1056,10 @@ int ot_trace_f32(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, const ot_
     return trace_fused<float>(c, rays, n, K, out, seg_count, counts, n_classes);
 }
 
-int ot_trace_generation_f64(ot_ctx* c, const ot_rays* rays, const int32_t* tree, int64_t n, int32_t* budget,
+}  // extern "C"
+
+template <class T>
+static int trace_generation(ot_ctx* c, const ot_rays* rays, const int32_t* tree, int64_t n, int32_t* budget,
                             const ot_segments* out, int64_t out_capacity, int64_t* seg_cursor, const ot_rays* next,
                             int32_t* next_tree, int64_t next_capacity, int64_t* n_next, int32_t* counts,
                             int32_t n_classes) {
@@ -1114,23 +1117,25 @@ int ot_trace_generation_f64(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
     hipLaunchKernelGGL(k_gen_mark, dim3(g1), dim3(block), 0, c->stream, tree, head_scan, budget, n, proc);
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->scan_tmp.p, tmp, proc, seg_off, (int)n, c->stream));
     SceneBlob blob;
-    blob.words = (const uint32_t*)c->blob64;
-    blob.n_words = (int32_t)(c->bytes64 / 4);
+    constexpr bool f64 = sizeof(T) == 8;
+    const size_t bytes = f64 ? c->bytes64 : c->bytes32;
+    blob.words = (const uint32_t*)(f64 ? c->blob64 : c->blob32);
+    blob.n_words = (int32_t)(bytes / 4);
     blob.n_nodes = c->n_nodes;
     blob.n_mats = c->n_mats;
     blob.root = c->root_grid;
     blob.cache_mat = c->cache_mat;
-    const bool in_lds = c->bytes64 <= (size_t)c->opt_lds_limit_kb * 1024;
+    const bool in_lds = bytes <= (size_t)c->opt_lds_limit_kb * 1024;
     const int64_t cap = (int64_t)c->n_cus * (c->opt_blocks_per_cu > 0 ? c->opt_blocks_per_cu : 4);
     const int grid = (int)(g1 < cap ? g1 : cap);
-    const size_t lds_bytes = in_lds ? c->bytes64 : 0;
+    const size_t lds_bytes = in_lds ? bytes : 0;
     // beam splitters and partially reflecting slabs are planar scenes: they get the small instantiation
     // (145 instead of 255 VGPRs, 3 waves/SIMD instead of 1); count gates need the full one
     constexpr uint32_t FG = F_AABB | F_LENS | F_REFRACT;
     const bool small = (c->features & ~FG) == 0;
-    auto k_probe = in_lds ? k_gen_trace<F_ALL, true, true> : k_gen_trace<F_ALL, false, true>;
-    auto k_main = small ? (in_lds ? k_gen_trace<FG, true, false> : k_gen_trace<FG, false, false>)
-                        : (in_lds ? k_gen_trace<F_ALL, true, false> : k_gen_trace<F_ALL, false, false>);
+    auto k_probe = in_lds ? k_gen_trace<T, F_ALL, true, true> : k_gen_trace<T, F_ALL, false, true>;
+    auto k_main = small ? (in_lds ? k_gen_trace<T, FG, true, false> : k_gen_trace<T, FG, false, false>)
+                        : (in_lds ? k_gen_trace<T, F_ALL, true, false> : k_gen_trace<T, F_ALL, false, false>);
     if (lds_bytes > 48 * 1024) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         HIP_TRY(hipFuncSetAttribute((const void*)k_main, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -1138,16 +1143,16 @@ int ot_trace_generation_f64(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
     if (ns > 0) {  // FIFO-exact interact-count gating: probe -> per-slot scan -> rank within the tree
         HIP_TRY(hipMemsetAsync(probe, 0, sizeof(int32_t) * n * ns, c->stream));
         HIP_TRY(hipMemsetAsync(lb.ticket, 0, sizeof(unsigned long long), c->stream));
-        hipLaunchKernelGGL(k_probe, dim3(grid), dim3(block), lds_bytes, c->stream, blob, c->unit, view<double>(rays), tree, n, proc,
-                           seg_off, seg_cursor, view<double>(out), out_capacity, lb, view_out<double>(next), next_tree, next_capacity,
+        hipLaunchKernelGGL(k_probe, dim3(grid), dim3(block), lds_bytes, c->stream, blob, (T)c->unit, view<T>(rays), tree, n, proc,
+                           seg_off, seg_cursor, view<T>(out), out_capacity, lb, view_out<T>(next), next_tree, next_capacity,
                            n_next, counts, n_classes, (const int32_t*)nullptr, probe);
         for (int s = 0; s < ns; ++s)
             HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->scan_tmp.p, tmp, probe + (int64_t)s * n, probe_ex + (int64_t)s * n, (int)n, c->stream));
         hipLaunchKernelGGL(k_gen_rank, dim3(g1), dim3(block), 0, c->stream, head_scan, n, ns, probe_ex, rank);
     }
     HIP_TRY(hipMemsetAsync(lb.state, 0, sizeof(unsigned long long) * (n_tiles + 1), c->stream));  // tile states and the ticket
-    hipLaunchKernelGGL(k_main, dim3(grid), dim3(block), lds_bytes, c->stream, blob, c->unit, view<double>(rays), tree, n, proc, seg_off,
-                       seg_cursor, view<double>(out), out_capacity, lb, view_out<double>(next), next_tree, next_capacity, n_next,
+    hipLaunchKernelGGL(k_main, dim3(grid), dim3(block), lds_bytes, c->stream, blob, (T)c->unit, view<T>(rays), tree, n, proc, seg_off,
+                       seg_cursor, view<T>(out), out_capacity, lb, view_out<T>(next), next_tree, next_capacity, n_next,
                        counts, n_classes, (const int32_t*)rank, (int32_t*)nullptr);
     if (ns > 0)
         hipLaunchKernelGGL(k_gen_counts, dim3(g1), dim3(block), 0, c->stream, tree, rays->id, n, ns, rank, probe, c->slot_max, counts,
@@ -1155,6 +1160,23 @@ int ot_trace_generation_f64(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
     hipLaunchKernelGGL(k_gen_finish, dim3(g1), dim3(block), 0, c->stream, tree, head_scan, n, budget, proc, seg_off, seg_cursor);
     HIP_TRY(hipGetLastError());
     return timing_end(c);
+}
+
+extern "C" {
+
+int ot_trace_generation_f64(ot_ctx* c, const ot_rays* rays, const int32_t* tree, int64_t n, int32_t* budget,
+                            const ot_segments* out, int64_t out_capacity, int64_t* seg_cursor, const ot_rays* next,
+                            int32_t* next_tree, int64_t next_capacity, int64_t* n_next, int32_t* counts,
+                            int32_t n_classes) {
+    return trace_generation<double>(c, rays, tree, n, budget, out, out_capacity, seg_cursor, next, next_tree, next_capacity, n_next,
+                                    counts, n_classes);
+}
+int ot_trace_generation_f32(ot_ctx* c, const ot_rays* rays, const int32_t* tree, int64_t n, int32_t* budget,
+                            const ot_segments* out, int64_t out_capacity, int64_t* seg_cursor, const ot_rays* next,
+                            int32_t* next_tree, int64_t next_capacity, int64_t* n_next, int32_t* counts,
+                            int32_t n_classes) {
+    return trace_generation<float>(c, rays, tree, n, budget, out, out_capacity, seg_cursor, next, next_tree, next_capacity, n_next,
+                                   counts, n_classes);
 }
 
 int ot_monitor_record_f64(ot_ctx* c, const ot_monitor* mon, const ot_segments* segs, int64_t n, const int32_t* seg_count,

@@ -76,18 +76,18 @@ class Engine:
         SegmentBatch in generation order plus, per tree, whether the cap cut it short."""
         if self.scene is None:
             raise RuntimeError("upload a scene first")
-        if rays.precision != "f64":
-            raise NotImplementedError("branching trace is fp64 only")
+        prec = rays.precision
+        gen_fn = self.lib.ot_trace_generation_f64 if prec == "f64" else self.lib.ot_trace_generation_f32
         dev, n = rays.device, rays.n
         if n == 0:
-            out = SegmentBatch(0, "f64", dev)
+            out = SegmentBatch(0, prec, dev)
             out.n_valid, out.counts_table = 0, counts
             out.capped = torch.zeros(0, dtype=torch.bool, device=dev)
             return out
         fan = max(self.scene.max_children, 1)
         if out_capacity is None:
             out_capacity = max(4 * n, 1024)
-        out = SegmentBatch(out_capacity, "f64", dev)
+        out = SegmentBatch(out_capacity, prec, dev)
         budget = torch.full((n,), int(max_trace_num), dtype=torch.int32, device=dev)
         state = torch.zeros(2, dtype=torch.int64, device=dev)  # [segment cursor, rays in the next generation]
         tree = torch.arange(n, dtype=torch.int32, device=dev)
@@ -97,7 +97,7 @@ class Engine:
         n_classes = 0 if counts is None else counts.shape[1]
         # two ping-pong generation buffers, grown when a generation outgrows them (no per-generation allocation)
         cap = max(n * fan, 1024)
-        spare, spare_tree = RayBatch(cap, "f64", dev, initialise=False), torch.empty(cap, dtype=torch.int32, device=dev)
+        spare, spare_tree = RayBatch(cap, prec, dev, initialise=False), torch.empty(cap, dtype=torch.int32, device=dev)
         other, other_tree = None, None
         cur, cur_n, written = rays, n, 0
         while cur_n > 0:
@@ -105,16 +105,16 @@ class Engine:
                 out = _grow(out, max(written + cur_n, 2 * out.capacity), written)
             if cur_n * fan > spare.n:
                 cap = max(cur_n * fan, 2 * spare.n)
-                spare, spare_tree = RayBatch(cap, "f64", dev, initialise=False), torch.empty(cap, dtype=torch.int32, device=dev)
+                spare, spare_tree = RayBatch(cap, prec, dev, initialise=False), torch.empty(cap, dtype=torch.int32, device=dev)
             rs, ss, ns = cur.c_struct(), out.c_struct(), spare.c_struct()
-            abi.check(self.lib.ot_trace_generation_f64(
+            abi.check(gen_fn(
                 self._ctx, C.byref(rs), tree.data_ptr(), cur_n, budget.data_ptr(), C.byref(ss), out.capacity,
                 state.data_ptr(), C.byref(ns), spare_tree.data_ptr(), spare.n, state.data_ptr() + 8,
                 None if counts is None else counts.data_ptr(), n_classes), self.lib)
             written, cur_n = state.tolist()  # the one host synchronisation per generation
             nxt, nxt_tree = spare, spare_tree
             if other is None or other.n < nxt.n:
-                other, other_tree = RayBatch(nxt.n, "f64", dev, initialise=False), torch.empty(nxt.n, dtype=torch.int32, device=dev)
+                other, other_tree = RayBatch(nxt.n, prec, dev, initialise=False), torch.empty(nxt.n, dtype=torch.int32, device=dev)
             spare, spare_tree, other, other_tree = other, other_tree, nxt, nxt_tree
             cur, tree = nxt.slice(0, cur_n), nxt_tree[:cur_n]
         out.n_valid = int(written)
@@ -129,25 +129,25 @@ class Engine:
         the index of its parent.  This is `component.interact(ray)` for a batch (optical_component.py:337-378)."""
         if self.scene is None:
             raise RuntimeError("upload a scene first")
-        if rays.precision != "f64":
-            raise NotImplementedError("generation steps are fp64 only")
+        prec = rays.precision
+        gen_fn = self.lib.ot_trace_generation_f64 if prec == "f64" else self.lib.ot_trace_generation_f32
         dev, n = rays.device, rays.n
-        out = SegmentBatch(n, "f64", dev)
+        out = SegmentBatch(n, prec, dev)
         out.n_valid = 0
         if n == 0:
-            return out, RayBatch(0, "f64", dev), torch.zeros(0, dtype=torch.int32, device=dev)
+            return out, RayBatch(0, prec, dev), torch.zeros(0, dtype=torch.int32, device=dev)
         fan = max(self.scene.max_children, 1)
         budget = torch.ones(n, dtype=torch.int32, device=dev)
         state = torch.zeros(2, dtype=torch.int64, device=dev)
         tree = torch.arange(n, dtype=torch.int32, device=dev)
-        nxt = RayBatch(n * fan, "f64", dev, initialise=False)
+        nxt = RayBatch(n * fan, prec, dev, initialise=False)
         nxt_tree = torch.empty(n * fan, dtype=torch.int32, device=dev)
         n_slots = len(self.scene.limited)
         if n_slots and counts is None:
             counts = torch.zeros((n_slots, n), dtype=torch.int32, device=dev)
         n_classes = 0 if counts is None else counts.shape[1]
         rs, ss, ns = rays.c_struct(), out.c_struct(), nxt.c_struct()
-        abi.check(self.lib.ot_trace_generation_f64(
+        abi.check(gen_fn(
             self._ctx, C.byref(rs), tree.data_ptr(), n, budget.data_ptr(), C.byref(ss), out.capacity,
             state.data_ptr(), C.byref(ns), nxt_tree.data_ptr(), nxt.n, state.data_ptr() + 8,
             None if counts is None else counts.data_ptr(), n_classes), self.lib)
@@ -161,6 +161,8 @@ class Engine:
         in ascending slot order.  For the [k][ray] layout every slot is scanned and unused ones
         are skipped on the device."""
         dev = segs.device
+        if segs.precision != "f64":  # the monitor pass is fp64: widen an fp32 history once
+            segs = segs.astype("f64")
         if segs.count is not None:
             n_segments, count_ptr, n_rays = segs.capacity // segs.n_rays * segs.n_rays, segs.count.data_ptr(), segs.n_rays
         else:

@@ -97,8 +97,8 @@ class OpticalTable:
 
     def trace_batch(self, batch, max_segments=None, counts=None, scene=None):
         """Scalable entry: `RayBatch` in, `SegmentBatch` out, no Python objects.  Non-branching
-        scenes run as one launch with [segment][ray] output slots, in the batch's precision; branching
-        scenes run generation by generation, always in fp64 (an fp32 batch is widened first).
+        scenes run as one launch with [segment][ray] output slots; branching scenes run generation by
+        generation; both in the batch's precision.
         `scene`: a `table.compile()` result to reuse when the components have not changed since (flattening
         a few hundred components in Python costs milliseconds — 10 ms for cfg 5 — and the engine skips the
         upload when it already holds that very scene); default: compile now, poses are read at call time."""
@@ -116,7 +116,7 @@ class OpticalTable:
             segs = eng.trace(batch, cap)
             if scene.max_children <= 1 or not bool((segs.count < 0).any()):
                 return segs
-        return eng.trace_tree(batch.astype("f64"), cap)  # ray trees are traced in fp64 (the reference's precision)
+        return eng.trace_tree(batch, cap)
 
     def _trace_batch_limited(self, eng, scene, batch, cap, fused_ok, counts):
         """`trace_batch` for scenes with `max_interact_count` surfaces.  Their counters are keyed by ray id
@@ -140,7 +140,7 @@ class OpticalTable:
         fused = fused_ok and scene.max_children <= 1
 
         def run(sub):
-            return eng.trace(sub, cap, counts=counts) if fused else eng.trace_tree(sub.astype("f64"), cap, counts=counts)
+            return eng.trace(sub, cap, counts=counts) if fused else eng.trace_tree(sub, cap, counts=counts)
 
         if n_classes == n:
             segs = run(work)
@@ -165,7 +165,7 @@ class OpticalTable:
                 out.ray.view(cap, n)[:, idx] = idx.to(torch.int32).unsqueeze(0).expand(cap, m)
         else:  # flat lists: concatenate, tree indices back to positions in `batch`
             total = sum(part.n_valid for _, part in parts)
-            out = SegmentBatch(total, "f64", dev)
+            out = SegmentBatch(total, batch.precision, dev)
             out.capped = torch.zeros(n, dtype=torch.bool, device=dev)
             at = 0
             for idx, part in parts:

@@ -520,20 +520,30 @@ def test_batch_limited_scene_with_shared_ids(branching, oracle):
     assert len(first) != len(third) or not np.array_equal(first, third)
 
 
-def test_fp32_batch_on_a_branching_scene_is_widened():
-    """Ray trees are traced in fp64 only; an fp32 batch is converted, not refused."""
+def test_fp32_ray_trees_track_fp64():
+    """The generational path in single precision (`ot_trace_generation_f32`): same trees, same order; positions
+    within 2e-4 of the fp64 trace over ten generations (float epsilon x path length x a few bounces)."""
     import optable_amd as oa
     from optable_amd.batch import RayBatch
 
-    table = _table([oa.BeamSplitter([3, 0, 0], width=3, height=3, eta=0.4).RotZ(0.3), oa.Mirror([6, 0, 0], radius=2).RotZ(np.pi)])
-    o, d = scenes.cfg2_rays(500, 3)
+    table = _table([oa.BeamSplitter([3, 0, 0], width=3, height=3, eta=0.4).RotZ(0.3), oa.Mirror([6, 0, 0], radius=2).RotZ(np.pi),
+                    oa.GlassSlab([-2, 0, 0], width=3, height=3, thickness=0.4, n1=1, n2=1.5, reflectivity=0.2).RotZ(0.1)])
+    o, d = scenes.cfg2_rays(2000, 3)
     q = 1j * np.pi * scenes.W0**2 / scenes.WL
     s32 = table.trace_batch(RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=q, precision="f32"), max_segments=10)
     s64 = table.trace_batch(RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=q, precision="f64"), max_segments=10)
-    assert s32.precision == "f64" and s32.n_valid == s64.n_valid
+    assert s32.precision == "f32" and s64.precision == "f64"
     a, b = s32.to_host(), s64.to_host()
-    np.testing.assert_array_equal(a["surface"], b["surface"])
-    np.testing.assert_allclose(a["ox"], b["ox"], atol=1e-5)   # inputs were rounded to float once
+    n = 2000
+    seq = lambda x: [tuple(x["surface"][x["ray"] == i].tolist()) for i in range(n)]
+    same = np.array([u == v for u, v in zip(seq(a), seq(b))])
+    assert same.mean() > 0.995, same.mean()            # a ray grazing an edge may fall on the other side in float
+    ka, kb = same[a["ray"]], same[b["ray"]]
+    for f in ("ox", "oy", "oz", "dx", "dy", "dz", "intensity"):
+        assert np.abs(a[f][ka].astype(np.float64) - b[f][kb]).max() < 2e-4, f
+    mon = oa.Monitor([1, 0, 0], 6, 6)
+    h32, h64 = table.record_batch(mon, s32), table.record_batch(mon, s64)     # monitor pass widens fp32 segments
+    assert abs(len(h32) - len(h64)) <= 0.005 * len(h64) + 2
 
 
 def test_compiled_scene_can_be_reused_and_is_not_uploaded_twice():
