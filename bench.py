@@ -6,7 +6,8 @@ focus of Lens([5,0,0], f=5, r=1) followed by MirrorPair([10,0,0], 4, 4); S = 3 l
 cap 5 segments (every ray uses exactly 5); fp64; inputs resident in HBM before the timed region.
 A "step" is one trace of the whole batch (one launch of k_trace_fused<double>).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4|cfg5]
+(`--workload`: the other BASELINE configs at their per-GPU size, same JSON line; the default is the bench line.)
 For N > 1 it is launched by torch.distributed.run, one rank per GPU; every rank traces its own
 1e6-ray shard (weak scaling, no collective in the data path); the single end-of-job gather of the
 per-ray final state over RCCL is timed separately and reported as `gather_ms`.
@@ -27,33 +28,59 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 N_RAYS = 1_000_000
-MAX_SEG = 5
-S_LEAVES = 3
 BYTES_RAY = 104  # fp64: 12 reals + id + flags   
 BYTES_SEG = 104  # fp64: 12 reals + ray + surface
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(table, batch_host, budget_s=10.0):
+def workloads(scenes, oa):
+    """name -> (components, rays(n, seed) -> (origins, directions, wavelengths), segment cap, precision, rays per
+    GPU, description).  `cfg2` is the bench line (BASELINE.json configs[1]); the others are the remaining BASELINE
+    configs at the size ONE GPU sees in the quoted configuration (`--workload`) — not the driver's
+    default."""
+    def cfg4_rays(n, seed):
+        nwl = 64
+        nb = max(n // nwl, 1)
+        rng = np.random.default_rng(4 + seed)
+        jit = rng.uniform(-0.3, 0.3, (nb, 2))
+        o = np.stack([np.full(nb, -3.0), 2 + jit[:, 0], jit[:, 1]], 1)
+        d = np.tile([np.cos(np.pi / 6), -np.sin(np.pi / 6), 0.0], (nb, 1))
+        return np.tile(o, (nwl, 1)), np.tile(d, (nwl, 1)), np.repeat(np.linspace(400e-7, 1100e-7, nwl), nb)
+
+    plain = lambda gen, base: (lambda n, seed: gen(n, base + seed) + (scenes.WL,))
+    slab = lambda: [oa.GlassSlab([0, 0, 0], width=2, height=2, thickness=0.5, n1=oa.Vacuum(), n2=oa.Glass_NBK7(), reflectivity=0)]
+    return {
+        "cfg2": (lambda: scenes.cfg2_components(oa), plain(scenes.cfg2_rays, 0), 5, "f64", N_RAYS,
+                 "cfg2: 1e6 point-source rays -> Lens + MirrorPair (S=3 leaves), 5-segment cap"),
+        "cfg3": (lambda: scenes.cfg3_components(oa), plain(scenes.cfg3_rays, 2), 20, "f32", 10_000_000,
+                 "cfg3: 1e7 rays, 32 mixed components (S=56 leaves), 20-segment cap, fp32"),
+        "cfg4": (slab, cfg4_rays, 3, "f64", 160_000_000,
+                 "cfg4: 2.5e6 rays x 64 wavelengths per GPU (the 4-GPU shard of 1e7 x 64) through an N-BK7 slab, fp64"),
+        "cfg5": (lambda: scenes.cfg5_components(oa), plain(scenes.cfg5_rays, 3), 50, "f32", 12_500_000,
+                 "cfg5: 1.25e7 rays per GPU (the 8-GPU shard of 1e8), asphere + MMA 16x16 (S=260 leaves), 50-segment cap, fp32"),
+    }
+
+
+def cpu_baseline(table, batch_host, max_seg, n_leaves, label, budget_s=10.0):
     """The oracle (CPU restatement, single thread) on the same workload, timed on this box's host."""
     from oracle import oracle as orc
 
     orc.build()
     scene = table.compile()
     n = len(batch_host["ox"])
-    sample = {k: v[: min(n, 200_000)] for k, v in batch_host.items()}
+    sample = {k: v[: min(n, 200_000 if max_seg <= 8 else 20_000)] for k, v in batch_host.items()}
     t0 = time.perf_counter()
     segs = 0
     rays = 0
     while True:
-        out = orc.trace(scene, sample, max_trace_num=MAX_SEG)
+        out = orc.trace(scene, sample, max_trace_num=max_seg)
         segs += len(out["ray"])
         rays += len(sample["ox"])
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
-    return {"value": segs * S_LEAVES / dt, "unit": "ray-surface intersections/s", "cores": 1, "kind": "port",
-            "sample": f"{rays} rays of the same cfg-2 batch ({segs} segments) in {dt:.2f} s, C oracle, 1 thread; "
+    return {"value": segs * n_leaves / dt, "unit": "ray-surface intersections/s", "cores": 1, "kind": "port",
+            "sample": f"{rays} rays of the same {label} batch ({segs} segments) in {dt:.2f} s, C oracle, 1 thread; "
                       f"host has {os.cpu_count()} cores",
             "segments_per_s": segs / dt}
 
@@ -63,7 +90,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--rays", type=int, default=N_RAYS)
+    ap.add_argument("--rays", type=int, default=None, help="rays per GPU (default: the workload's own size)")
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
+                    help="cfg2 = the bench line; the others are the remaining BASELINE configs at their per-GPU size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the real thing) or gloo (rehearsal on a 1-GPU box)")
     args = ap.parse_args()
@@ -90,22 +119,33 @@ def main():
     from optable_amd import dist as odist
     import scenes
 
-    n = args.rays
+    comps, gen_rays, MAX_SEG, prec, n_default, label = workloads(scenes, oa)[args.workload]
+    n = args.rays if args.rays else n_default
+    bytes_rec = BYTES_RAY if prec == "f64" else 56  # 12 reals + two int32 per record
     table = oa.OpticalTable()
-    table.add_components(scenes.cfg2_components(oa))
-    o, d = scenes.cfg2_rays(n, seed=rank)  # every rank its own shard of the job
-    q = 1j * np.pi * scenes.W0**2 / scenes.WL
-    batch = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=q, device=f"cuda:{local_rank}")
+    table.add_components(comps())
+    o, d, wl = gen_rays(n, rank)  # every rank its own shard of the job
+    n = len(o)
+    batch = RayBatch.from_arrays(o, d, wavelength=wl, q=1j * np.pi * scenes.W0**2 / wl, precision=prec,
+                                 device=f"cuda:{local_rank}")
+    del o, d
     eng = get_engine(local_rank)
     scene = table.compile()
+    S_LEAVES_W = scene.n_leaves
     eng.upload(scene)
-    out = SegmentBatch(n * MAX_SEG, "f64", batch.device)
+    out = SegmentBatch(n * MAX_SEG, prec, batch.device)
 
     # The chip takes tens of milliseconds of sustained load to reach its steady clocks (kernel time
     # 122 -> 109 us between 5 and 300 launches of pre-load on the same device), so load it for
     # ~60 ms first; then the contract's W untimed warmup steps.
-    for _ in range(500):
-        eng.trace(batch, MAX_SEG, out=out)
+    if args.workload == "cfg2":
+        for _ in range(500):
+            eng.trace(batch, MAX_SEG, out=out)
+    else:  # millisecond-scale launches: load the chip for the same ~60 ms
+        t_load = time.perf_counter()
+        while time.perf_counter() - t_load < 0.06:
+            eng.trace(batch, MAX_SEG, out=out)
+            torch.cuda.synchronize()
     torch.cuda.synchronize()
     for _ in range(args.warmup):
         eng.trace(batch, MAX_SEG, out=out)
@@ -125,9 +165,11 @@ def main():
     kernel_ms, launches = eng.timing_read()
     # roofline companion: the same streams with no tracing (what this access pattern can reach)
     eng.timing_reset()
-    for _ in range(10):
-        eng.stream_ceiling(batch, MAX_SEG, out)
-    ceil_ms, ceil_n = eng.timing_read()
+    ceil_ms, ceil_n = 0.0, 0
+    if prec == "f64":  # the companion kernel exists for the fp64 streams
+        for _ in range(10 if args.workload == "cfg2" else 3):
+            eng.stream_ceiling(batch, MAX_SEG, out)
+        ceil_ms, ceil_n = eng.timing_read()
     eng.timing(False)
     eng.trace(batch, MAX_SEG, out=out)  # leave real results in `out`
 
@@ -159,35 +201,41 @@ def main():
         segs_total_step = segs_step
 
     if rank == 0:
-        value = segs_total_step * S_LEAVES * args.steps / dt
+        is_cfg2 = args.workload == "cfg2"
+        value = segs_total_step * S_LEAVES_W * args.steps / dt
         avg_kernel_s = kernel_ms / max(launches, 1) / 1e3
-        alg_bytes = n * BYTES_RAY + segs_step * BYTES_SEG  # per launch, this rank
+        alg_bytes = n * bytes_rec + segs_step * bytes_rec  # per launch, this rank
         achieved = alg_bytes / avg_kernel_s / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_cfg2_f64.json")
-        if os.path.exists(tpath):
+        if is_cfg2 and os.path.exists(tpath):  # PMC-measured HBM bytes exist for the bench workload only
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        heavy = args.workload in ("cfg3", "cfg5")
+        kernel = ("k_trace_blocked" if heavy else "k_trace_fused") + ("<double>" if prec == "f64" else "<float>")
         line = {
             "metric": "ray-surface intersections/sec", "value": value, "unit": "intersections/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "cfg2: 1e6 point-source rays -> Lens + MirrorPair (S=3 leaves), 5-segment cap",
-                       "rays_per_gpu": n, "segments_per_ray": segs_step / n, "leaf_surfaces": S_LEAVES,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": prec, "data": "synthetic",
+            "config": {"workload": label,
+                       "rays_per_gpu": n, "segments_per_ray": segs_step / n, "leaf_surfaces": S_LEAVES_W,
                        "parallelism": f"ray-shard x{world}, scene replicated"},
             "segments_per_s": segs_total_step * args.steps / dt,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_trace_fused<double>", "kernel_us": avg_kernel_s * 1e6,
+                         "kernel": kernel, "kernel_us": avg_kernel_s * 1e6,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "stream_ceiling_gbs": alg_bytes / (ceil_ms / max(ceil_n, 1) / 1e3) / 1e9},
+                         "stream_ceiling_gbs": (alg_bytes / (ceil_ms / ceil_n / 1e3) / 1e9) if ceil_n else None},
         }
+        if heavy:
+            line["roofline"]["note"] = ("this workload is VALU/latency-bound (S >= 24, SURVEY.md §8d): the HBM fraction is "
+                                        "reported for comparison, not as its roof")
         if gather_error is not None:
             line["gather_error"] = gather_error
         elif gather_ms is not None:
             line["gather_ms"] = gather_ms
-            line["value_incl_gather"] = segs_total_step * S_LEAVES * args.steps / (dt + gather_ms / 1e3)
+            line["value_incl_gather"] = segs_total_step * S_LEAVES_W * args.steps / (dt + gather_ms / 1e3)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(table, batch.to_host())
+            line["cpu_baseline"] = cpu_baseline(table, batch.slice(0, min(n, 200_000)).to_host(), MAX_SEG, S_LEAVES_W, args.workload)
         print(json.dumps(line), flush=True)
     if distributed:
         dist.destroy_process_group()
