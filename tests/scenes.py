@@ -278,13 +278,28 @@ def abcd_4f(ns):
     return dict(components=[l0, l1], monitors=[mon0, mon1], rays=rays, limit=None)
 
 
+def g21_ties(ns):
+    """Exact ties: two mirrors in the same plane (the first in list order must win: strict `t < t_min`,
+    optical_table.py:119-123) and a group whose two children coincide (np.argmin keeps the first,
+    component_group.py:118-120)."""
+    near_a = ns.Mirror([3, 0, 0], radius=1.0, reflectivity=0.25)
+    near_b = ns.Mirror([3, 0, 0], radius=1.0, reflectivity=0.75)
+    pair = ns.ComponentGroup([6, 0, 0])
+    pair.add_component(ns.Lens([6, 0, 0], focal_length=4.0, radius=1.0))
+    pair.add_component(ns.Mirror([6, 0, 0], radius=1.0))
+    back = ns.Mirror([-2, 0, 0], radius=2.0).RotZ(np.pi)
+    rays = [ns.Ray([0, y, 0], [1, 0, 0], wavelength=WL, w0=W0) for y in (-0.3, 0.0, 0.2)]
+    rays += [ns.Ray([4.5, y, 0], [1, 0.01, 0], wavelength=WL, w0=W0) for y in (-0.1, 0.25)]   # start beyond the mirrors
+    return dict(components=[back, near_a, near_b, pair], monitors=[], rays=rays, limit={"max_trace_num": 6})
+
+
 SCENES = {
     "g01_gaussian_beam": g01_gaussian_beam, "g02_cfg2": g02_cfg2, "g03_chromatic": g03_chromatic,
     "g04_glass_slab": g04_glass_slab, "g05_cavity": g05_cavity, "g06_mirror_pair": g06_mirror_pair,
     "g07_spherical_lenses": g07_spherical_lenses, "g08_asphere": g08_asphere, "g09_cfg5": g09_cfg5,
     "g10_cfg3": g10_cfg3, "g11_prism_refl": g11_prism_refl, "g12_dove": g12_dove,
     "g13_count_shadow": g13_count_shadow, "g15_cfg4": g15_cfg4, "g16_misc": g16_misc, "g18_fifo_gate": g18_fifo_gate,
-    "g19_units_and_disorder": g19_units_and_disorder,
+    "g19_units_and_disorder": g19_units_and_disorder, "g21_ties": g21_ties,
 }
 
 

@@ -659,3 +659,50 @@ def test_interact_local_is_the_lab_interaction_seen_from_the_leaf():
                 assert a.intensity == pytest.approx(b.intensity)
     with pytest.raises(NotImplementedError):
         oa.OpticalComponent([0, 0, 0]).interact_local(oa.Ray([-1, 0, 0], [1, 0, 0]))
+
+
+@pytest.mark.parametrize("many", [False, True])
+def test_exact_ties_go_to_the_first_component(many, oracle):
+    """Two surfaces at exactly the same distance: OpticalTable keeps the first in list order (strict `t < t_min`,
+    optical_table.py:119-123) and a ComponentGroup the first minimum (np.argmin, component_group.py:118-120).
+    Checked on the plain pass and, with 14 more components, on the top-level grid (ties go to the lower node
+    index there too), against the oracle and against the explicit expectation."""
+    import optable_amd as oa
+
+    near_a = oa.Mirror([3, 0, 0], radius=1.0, reflectivity=0.25)          # same plane x = 3, same aperture
+    near_b = oa.Mirror([3, 0, 0], radius=1.0, reflectivity=0.75)
+    pair = oa.ComponentGroup([6, 0, 0])                                    # a group whose two children coincide
+    pair.add_component(oa.Lens([6, 0, 0], focal_length=4.0, radius=1.0))
+    pair.add_component(oa.Mirror([6, 0, 0], radius=1.0))
+    comps = [oa.Mirror([-2, 0, 0], radius=2.0).RotZ(np.pi), near_a, near_b, pair]
+    if many:
+        comps += [oa.Block([10 + k, 5 + (k % 3), 0], width=0.5, height=0.5) for k in range(14)]
+    table = _table(comps)
+    scene = table.compile()
+    assert (scene.root_grid >= 0) == many
+    o = np.tile([[0.0, 0.0, 0.0]], (64, 1)) + np.linspace(-0.3, 0.3, 64)[:, None] * np.array([[0, 1, 0]])
+    d = np.tile([[1.0, 0.0, 0.0]], (64, 1))
+    batch = _batch(o, d)
+    got = table.trace_batch(batch, max_segments=4).to_host(reference_order=True)
+    ref = oracle.trace(scene, batch.to_host(), max_trace_num=4)
+    np.testing.assert_array_equal(got["surface"], ref["surface"])
+    for f in abi.SEG_FIELDS:
+        np.testing.assert_allclose(got[f], ref[f], rtol=1e-12, atol=1e-12, err_msg=f)
+    first = got["surface"].reshape(64, -1)[:, 0]
+    assert (first == 1).all()                                               # near_a (leaf 1), never near_b (leaf 2)
+    second_intensity = got["intensity"].reshape(64, -1)[:, 1]
+    np.testing.assert_allclose(second_intensity, 0.25)                      # reflected by near_a
+
+
+def test_group_tie_keeps_the_first_child(oracle):
+    import optable_amd as oa
+
+    pair = oa.ComponentGroup([6, 0, 0])
+    pair.add_component(oa.Lens([6, 0, 0], focal_length=4.0, radius=1.0))
+    pair.add_component(oa.Mirror([6, 0, 0], radius=1.0))
+    table = _table([pair])
+    o, d = np.array([[0.0, 0.2, 0.0]]), np.array([[1.0, 0.0, 0.0]])
+    got = table.trace_batch(_batch(o, d), max_segments=3).to_host()
+    ref = oracle.trace(table.compile(), _batch(o, d).to_host(), max_trace_num=3)
+    np.testing.assert_array_equal(got["surface"], ref["surface"])
+    assert got["surface"][0] == 0 and got["dx"][1] > 0                      # the lens won: the ray goes on, bent
