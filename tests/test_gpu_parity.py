@@ -706,3 +706,41 @@ def test_group_tie_keeps_the_first_child(oracle):
     ref = oracle.trace(table.compile(), _batch(o, d).to_host(), max_trace_num=3)
     np.testing.assert_array_equal(got["surface"], ref["surface"])
     assert got["surface"][0] == 0 and got["dx"][1] > 0                      # the lens won: the ray goes on, bent
+
+
+def test_axis_parallel_rays_and_flat_boxes_match_oracle(oracle):
+    """The slab test's special cases on the device (solver.py:27-33, :46): direction components that are exactly
+    zero or below np.isclose's 1e-8 (axis treated as parallel: miss iff the origin lies outside the slab), rays
+    that start ON a box face, and the zero-thickness AABBs every axis-aligned planar leaf of a group has."""
+    import optable_amd as oa
+    from optable_amd.batch import RayBatch
+
+    comps = [oa.GlassSlab([4, 0, 0], width=2, height=2, thickness=0.5, n1=1, n2=1.5),             # axis-aligned: flat child boxes
+             oa.MirrorPair([9, 0, 0], 4, 4),
+             oa.GlassSlab([4, 3, 0], width=2, height=2, thickness=0.5, n1=1, n2=1.5).RotZ(np.pi / 2),  # faces normal to y
+             oa.Prism([-4, 0, 0], width=1.5, height=2, n1=1, n2=1.5).RotZ(np.pi)]
+    table = _table(comps)
+    rng = np.random.default_rng(8)
+    n = 4000
+    o = np.stack([rng.uniform(-6, 12, n), rng.uniform(-2, 5, n), rng.uniform(-1.2, 1.2, n)], 1)
+    d = rng.normal(size=(n, 3))
+    d[0::5] = [1.0, 0.0, 0.0]                  # exactly along x
+    d[1::5, 2] = 0.0                            # in the z = const plane
+    d[2::10] = [0.0, 1.0, 0.0]                  # exactly along y: parallel to the first slab's faces
+    d[3::10, 1] = 1e-9                          # below isclose's threshold: treated as parallel
+    d[4::10, 2] = -5e-9
+    o[0::20, 0] = 3.75                          # start exactly on the slab's front face plane
+    o[5::20, 1] = 1.0                           # ... on its side plane (y = +1 edge of the 2 x 2 aperture)
+    o[10::20, 2] = 1.0                          # ... on the top edge plane
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    batch = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=1j * np.pi * scenes.W0**2 / scenes.WL, normalize=False)
+    got = table.trace_batch(batch, max_segments=10).to_host(reference_order=True)
+    ref = oracle.trace(table.compile(), batch.to_host(), max_trace_num=10)
+    seq = lambda x: [tuple(x["surface"][x["ray"] == i].tolist()) for i in range(n)]
+    same = np.array([a == b for a, b in zip(seq(got), seq(ref))])
+    assert (~same).sum() <= 2, f"{(~same).sum()} rays took a different path"   # edge-grazing rounding only
+    kg, kr = same[got["ray"]], same[ref["ray"]]
+    for f in abi.SEG_FIELDS:
+        np.testing.assert_allclose(got[f][kg], ref[f][kr], rtol=1e-9, atol=1e-9, err_msg=f)
+    hit_any = np.array([len(s) > 1 for s in seq(ref)])
+    assert hit_any[0::5].sum() > 50 and hit_any[2::10].sum() > 10              # the special rays do reach things
