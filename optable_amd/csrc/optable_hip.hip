@@ -309,13 +309,19 @@ __global__ __launch_bounds__(256) void k_stream_ceiling(RaysT<T> in, int64_t n, 
 
 // ------------------------------------------------------------------------------------------
 // breadth-first generation step
-__global__ void k_gen_heads(const int32_t* tree, int64_t n, int64_t* head) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) head[i] = (i == 0 || tree[i - 1] != tree[i]) ? i : 0;
-}
-__global__ void k_gen_mark(const int32_t* tree, const int64_t* head, const int32_t* budget, int64_t n, int32_t* proc) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) proc[i] = (i - head[i]) < (int64_t)budget[tree[i]] ? 1 : 0;
+// A generation lists its rays tree by tree (parent order), so `tree[]` is non-decreasing and the first ray of
+// ray i's tree is a lower bound: rank within the tree = i - tree_head(i).  ~log2(n) L2-resident loads per ray
+// replace the head-flag kernel, the max-scan and the mark kernel of the first version.
+__device__ __forceinline__ int64_t tree_head(const int32_t* __restrict__ tree, int64_t i) {
+    const int32_t t = tree[i];
+    for (int k = 1; k <= 3; ++k)  // most trees have a handful of rays per generation: look at the neighbours first
+        if (i - k < 0 || tree[i - k] != t) return i - k + 1;
+    int64_t lo = 0, hi = i - 3;  // tree[hi] == t
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (tree[mid] < t) lo = mid + 1; else hi = mid;
+    }
+    return lo;
 }
 
 // Ordered single-pass allocation of child slots (decoupled look-back): tiles of 256 rays are handed out by an
@@ -332,17 +338,19 @@ struct LookBack {
     unsigned long long* ticket;  // next tile to hand out, zeroed before the launch
 };
 static constexpr unsigned long long LB_AGG = 1ull << 62, LB_PREFIX = 2ull << 62, LB_MASK = (1ull << 62) - 1ull;
+// the 62-bit value carries two counts: processed rays = segment slots (bits 32..61, n < 2^30) and children (bits 0..31)
+static constexpr int LB_SEG_SHIFT = 32;
 
 // PROBE = true: the pre-pass that records geometric hits of count-limited leaves (no outputs).
 template <class T, uint32_t F, bool SCENE_IN_LDS, bool PROBE>
 __global__ __launch_bounds__(256) void k_gen_trace(SceneBlob blob, T unit, RaysT<T> in, const int32_t* tree, int64_t n,
-                                                   const int32_t* proc, const int64_t* seg_off, const int64_t* cursor,
+                                                   const int32_t* budget, const int64_t* cursor,
                                                    SegsT<T> out, int64_t out_capacity, LookBack lb, RaysOutT<T> next,
-                                                   int32_t* next_tree, int64_t next_capacity, int64_t* n_next,
+                                                   int32_t* next_tree, int64_t next_capacity, int64_t* totals,
                                                    int32_t* counts, int32_t n_classes, const int32_t* rank, int32_t* probe) {
     extern __shared__ __align__(16) uint32_t lds[];
     __shared__ long long s_tile, s_base;
-    __shared__ int s_wave_total[4];
+    __shared__ unsigned long long s_wave_total[4];
     const uint32_t* base = blob.words;
     if (SCENE_IN_LDS) {
         for (int w = threadIdx.x; w < blob.n_words; w += blockDim.x) lds[w] = blob.words[w];
@@ -359,7 +367,24 @@ __global__ __launch_bounds__(256) void k_gen_trace(SceneBlob blob, T unit, RaysT
         const int64_t tile = s_tile;
         if (tile >= n_tiles) break;  // workgroup-uniform
         const int64_t i = tile * 256 + threadIdx.x;
-        bool active = i < n && proc[i];
+        // Rank of the ray inside its tree (rays beyond the tree's remaining max_trace_num budget are dropped,
+        // optical_table.py:138-144).  The head of the tree is the nearest earlier ray of this WAVE that starts a
+        // tree (max-scan of start flags) unless the tree began before the wave: those lanes all look up the head
+        // of the wave's first ray — the same addresses for all of them, one cache line per step.
+        int32_t my_tree = -1;
+        long long start = -1;
+        if (i < n) {
+            my_tree = tree[i];
+            if (lane == 0 || tree[i - 1] != my_tree) start = i;
+        }
+        long long head = start;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const long long up = __shfl_up(head, off, 64);
+            if (lane >= off && up > head) head = up;
+        }
+        if (i < n && head == i - lane) head = tree_head(tree, i - lane);  // the run reaches back to the wave's first ray
+        bool active = i < n && (i - head) < (int64_t)budget[my_tree];
         RayState<T> r = {};
         int32_t cls = 0, fl = 0;
         if (active) {
@@ -378,26 +403,22 @@ __global__ __launch_bounds__(256) void k_gen_trace(SceneBlob blob, T unit, RaysT
         int32_t nk = 0, t = 0;
         RayState<T> ch[2];
         if (active) {
-            const int64_t slot = cur0 + seg_off[i];
             t = tree[i];
-            if (slot < out_capacity) {
-                if (dead) store_segment(out, slot, r, r.len, t, -2);
-                else if (h.node < 0) store_segment(out, slot, r, r.len, t, -1);
-                else store_segment(out, slot, r, h.t, t, sc.nodes[h.node].leaf_id);
-            }
             if (!dead && h.node >= 0) nk = interact<T, F, 2>(sc, r, h, ch, make_matcache(sc, r.wl));
         }
-        // child slots: inclusive scan inside the wave, wave totals through LDS, tile prefix by look-back
-        int incl = nk;
+        // segment and child slots: inclusive scan of both counts inside the wave (packed: segments high, children
+        // low), wave totals through LDS, tile prefix by look-back
+        const unsigned long long mine = ((unsigned long long)(active ? 1 : 0) << LB_SEG_SHIFT) | (unsigned long long)nk;
+        unsigned long long incl = mine;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
-            const int up = __shfl_up(incl, off, 64);
+            const unsigned long long up = (unsigned long long)__shfl_up((long long)incl, off, 64);
             if (lane >= off) incl += up;
         }
         if (lane == 63) s_wave_total[wave] = incl;
         __syncthreads();
         if (wave == 0) {  // look-back by a whole wave: 64 predecessors per read
-            const unsigned long long total = (unsigned long long)(s_wave_total[0] + s_wave_total[1] + s_wave_total[2] + s_wave_total[3]);
+            const unsigned long long total = s_wave_total[0] + s_wave_total[1] + s_wave_total[2] + s_wave_total[3];
             unsigned long long before = 0;
             if (tile > 0) {
                 if (lane == 0) __hip_atomic_store(&lb.state[tile], LB_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -412,7 +433,7 @@ __global__ __launch_bounds__(256) void k_gen_trace(SceneBlob blob, T unit, RaysT
                         const int pl = __ffsll((long long)m_prefix) - 1;
                         need = pl == 63 ? ~0ull : ((1ull << (pl + 1)) - 1ull);
                     }
-                    if (m_empty & need) { __builtin_amdgcn_s_sleep(2); continue; }  // one of them is still tracing: read again
+                    if (m_empty & need) { __builtin_amdgcn_s_sleep(24); continue; }  // one of them is still tracing: wait ~0.6 us, read again
                     long long part = ((need >> lane) & 1ull) ? (long long)(v & LB_MASK) : 0ll;
 #pragma unroll
                     for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
@@ -424,12 +445,25 @@ __global__ __launch_bounds__(256) void k_gen_trace(SceneBlob blob, T unit, RaysT
             if (lane == 0) {
                 __hip_atomic_store(&lb.state[tile], LB_PREFIX | (before + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 s_base = (long long)before;
-                if (tile == n_tiles - 1) *n_next = (int64_t)(before + total);
+                if (tile == n_tiles - 1) {  // generation totals for k_gen_finish and the host
+                    const unsigned long long all = before + total;
+                    totals[0] = (int64_t)(all >> LB_SEG_SHIFT);          // segments written
+                    totals[1] = (int64_t)(all & 0xffffffffull);          // rays in the next generation
+                }
             }
         }
         __syncthreads();
-        int64_t d = s_base + (incl - nk);
-        for (int w = 0; w < wave; ++w) d += s_wave_total[w];
+        unsigned long long before_me = (unsigned long long)s_base + (incl - mine);
+        for (int w = 0; w < wave; ++w) before_me += s_wave_total[w];
+        if (active) {
+            const int64_t slot = cur0 + (int64_t)(before_me >> LB_SEG_SHIFT);
+            if (slot < out_capacity) {
+                if (dead) store_segment(out, slot, r, r.len, t, -2);
+                else if (h.node < 0) store_segment(out, slot, r, r.len, t, -1);
+                else store_segment(out, slot, r, h.t, t, sc.nodes[h.node].leaf_id);
+            }
+        }
+        int64_t d = (int64_t)(before_me & 0xffffffffull);
         for (int c = 0; c < nk; ++c, ++d) {
             if (d >= next_capacity) break;
             const RayState<T>& k = ch[c];
@@ -446,10 +480,11 @@ __global__ __launch_bounds__(256) void k_gen_trace(SceneBlob blob, T unit, RaysT
 }
 
 // rank[slot][i] = how many earlier rays of i's tree (this generation) hit limited leaf `slot`
-__global__ void k_gen_rank(const int64_t* head, int64_t n, int32_t n_slots, const int32_t* ex, int32_t* rank) {
+__global__ void k_gen_rank(const int32_t* tree, int64_t n, int32_t n_slots, const int32_t* ex, int32_t* rank) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    for (int s = 0; s < n_slots; ++s) rank[(int64_t)s * n + i] = ex[(int64_t)s * n + i] - ex[(int64_t)s * n + head[i]];
+    const int64_t head = tree_head(tree, i);
+    for (int s = 0; s < n_slots; ++s) rank[(int64_t)s * n + i] = ex[(int64_t)s * n + i] - ex[(int64_t)s * n + head];
 }
 // after the trace: each tree's last ray of the generation folds the generation's hits into the table
 __global__ void k_gen_counts(const int32_t* tree, const int32_t* ids, int64_t n, int32_t n_slots, const int32_t* rank,
@@ -465,16 +500,19 @@ __global__ void k_gen_counts(const int32_t* tree, const int32_t* ids, int64_t n,
     }
 }
 
-__global__ void k_gen_finish(const int32_t* tree, const int64_t* head, int64_t n, int32_t* budget, const int32_t* proc,
-                             const int64_t* seg_off, int64_t* cursor) {
+__global__ void k_gen_finish(const int32_t* tree, int64_t n, int32_t* budget, const int64_t* totals, int64_t* cursor,
+                             int64_t* n_next) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (i == n - 1 || tree[i + 1] != tree[i]) {  // last ray of its tree in this generation
-        const int64_t in_gen = i - head[i] + 1;
+        const int64_t in_gen = i - tree_head(tree, i) + 1;
         const int32_t b = budget[tree[i]];
         budget[tree[i]] = b - (int32_t)(in_gen < b ? in_gen : b);
     }
-    if (i == n - 1) *cursor += seg_off[i] + proc[i];  // (*n_next was written by the trace: its last tile's prefix)
+    if (i == n - 1) {  // the trace kernel read *cursor at its start, so it is advanced here, after it
+        *cursor += totals[0];
+        *n_next = totals[1];
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1079,43 +1117,31 @@ static int trace_generation(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
     if (c->n_slots > 0 && (!counts || n_classes < 1)) return fail(OT_ERR_INVALID, "scene has limited surfaces: counts table required");
     HIP_TRY(hipSetDevice(c->device));
     // scratch carve-up
-    const size_t sz_i64 = align_up(sizeof(int64_t) * n), sz_i32 = align_up(sizeof(int32_t) * n);
     const int ns = c->n_slots;
     const size_t sz_slot = align_up(sizeof(int32_t) * n * (ns > 0 ? ns : 1));
     const int64_t n_tiles = (n + 255) / 256;
     const size_t sz_lb = align_up(sizeof(unsigned long long) * (n_tiles + 1));  // tile states + the ticket
-    const size_t total = 3 * sz_i64 + sz_i32 + sz_lb + 3 * sz_slot;
+    const size_t sz_tot = align_up(sizeof(int64_t) * 2);
+    const size_t total = sz_lb + sz_tot + (ns > 0 ? 3 * sz_slot : 0);
     if (c->gen.ensure(total)) return fail(OT_ERR_HIP, "hipMalloc of generation scratch failed");
     uint8_t* p = (uint8_t*)c->gen.p;
-    int64_t* head = (int64_t*)p; p += sz_i64;
-    int64_t* head_scan = (int64_t*)p; p += sz_i64;
-    int64_t* seg_off = (int64_t*)p; p += sz_i64;
-    int32_t* proc = (int32_t*)p; p += sz_i32;
     LookBack lb;
     lb.state = (unsigned long long*)p;
     lb.ticket = lb.state + n_tiles;
     p += sz_lb;
+    int64_t* totals = (int64_t*)p; p += sz_tot;
     int32_t* probe = (int32_t*)p; p += sz_slot;
     int32_t* probe_ex = (int32_t*)p; p += sz_slot;
     int32_t* rank = (int32_t*)p;
-    // scan temp
-    size_t tmp_a = 0, tmp_b = 0;
-    hipcub::DeviceScan::InclusiveScan((void*)nullptr, tmp_a, head, head_scan, hipcub::Max(), (int)n, c->stream);
-    hipcub::DeviceScan::ExclusiveSum((void*)nullptr, tmp_b, proc, seg_off, (int)n, c->stream);
-    size_t tmp = tmp_a > tmp_b ? tmp_a : tmp_b, tmp_d = 0;
+    size_t tmp = 0;
     if (ns > 0) {
-        hipcub::DeviceScan::ExclusiveSum((void*)nullptr, tmp_d, probe, probe_ex, (int)n, c->stream);
-        tmp = tmp > tmp_d ? tmp : tmp_d;
+        hipcub::DeviceScan::ExclusiveSum((void*)nullptr, tmp, probe, probe_ex, (int)n, c->stream);
+        if (c->scan_tmp.ensure(tmp + 256)) return fail(OT_ERR_HIP, "hipMalloc of scan scratch failed");
     }
-    if (c->scan_tmp.ensure(tmp + 256)) return fail(OT_ERR_HIP, "hipMalloc of scan scratch failed");
     const int block = 256;
     const int g1 = (int)((n + block - 1) / block);
     rc = timing_begin(c);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_gen_heads, dim3(g1), dim3(block), 0, c->stream, tree, n, head);
-    HIP_TRY(hipcub::DeviceScan::InclusiveScan(c->scan_tmp.p, tmp, head, head_scan, hipcub::Max(), (int)n, c->stream));
-    hipLaunchKernelGGL(k_gen_mark, dim3(g1), dim3(block), 0, c->stream, tree, head_scan, budget, n, proc);
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->scan_tmp.p, tmp, proc, seg_off, (int)n, c->stream));
     SceneBlob blob;
     constexpr bool f64 = sizeof(T) == 8;
     const size_t bytes = f64 ? c->bytes64 : c->bytes32;
@@ -1143,21 +1169,21 @@ static int trace_generation(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
     if (ns > 0) {  // FIFO-exact interact-count gating: probe -> per-slot scan -> rank within the tree
         HIP_TRY(hipMemsetAsync(probe, 0, sizeof(int32_t) * n * ns, c->stream));
         HIP_TRY(hipMemsetAsync(lb.ticket, 0, sizeof(unsigned long long), c->stream));
-        hipLaunchKernelGGL(k_probe, dim3(grid), dim3(block), lds_bytes, c->stream, blob, (T)c->unit, view<T>(rays), tree, n, proc,
-                           seg_off, seg_cursor, view<T>(out), out_capacity, lb, view_out<T>(next), next_tree, next_capacity,
-                           n_next, counts, n_classes, (const int32_t*)nullptr, probe);
+        hipLaunchKernelGGL(k_probe, dim3(grid), dim3(block), lds_bytes, c->stream, blob, (T)c->unit, view<T>(rays), tree, n, budget,
+                           seg_cursor, view<T>(out), out_capacity, lb, view_out<T>(next), next_tree, next_capacity, totals,
+                           counts, n_classes, (const int32_t*)nullptr, probe);
         for (int s = 0; s < ns; ++s)
             HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->scan_tmp.p, tmp, probe + (int64_t)s * n, probe_ex + (int64_t)s * n, (int)n, c->stream));
-        hipLaunchKernelGGL(k_gen_rank, dim3(g1), dim3(block), 0, c->stream, head_scan, n, ns, probe_ex, rank);
+        hipLaunchKernelGGL(k_gen_rank, dim3(g1), dim3(block), 0, c->stream, tree, n, ns, probe_ex, rank);
     }
     HIP_TRY(hipMemsetAsync(lb.state, 0, sizeof(unsigned long long) * (n_tiles + 1), c->stream));  // tile states and the ticket
-    hipLaunchKernelGGL(k_main, dim3(grid), dim3(block), lds_bytes, c->stream, blob, (T)c->unit, view<T>(rays), tree, n, proc, seg_off,
-                       seg_cursor, view<T>(out), out_capacity, lb, view_out<T>(next), next_tree, next_capacity, n_next,
-                       counts, n_classes, (const int32_t*)rank, (int32_t*)nullptr);
+    hipLaunchKernelGGL(k_main, dim3(grid), dim3(block), lds_bytes, c->stream, blob, (T)c->unit, view<T>(rays), tree, n, budget,
+                       seg_cursor, view<T>(out), out_capacity, lb, view_out<T>(next), next_tree, next_capacity, totals, counts,
+                       n_classes, (const int32_t*)rank, (int32_t*)nullptr);
     if (ns > 0)
         hipLaunchKernelGGL(k_gen_counts, dim3(g1), dim3(block), 0, c->stream, tree, rays->id, n, ns, rank, probe, c->slot_max, counts,
                            n_classes);
-    hipLaunchKernelGGL(k_gen_finish, dim3(g1), dim3(block), 0, c->stream, tree, head_scan, n, budget, proc, seg_off, seg_cursor);
+    hipLaunchKernelGGL(k_gen_finish, dim3(g1), dim3(block), 0, c->stream, tree, n, budget, totals, seg_cursor, n_next);
     HIP_TRY(hipGetLastError());
     return timing_end(c);
 }

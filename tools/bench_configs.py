@@ -78,13 +78,17 @@ def _run(name, comps, o, d, wl, K, prec, reps=5):
                   f"(trace moves {(n * b + segs * b) / 1e9:.2f} GB in {t * 1e3:.3f} ms)", flush=True)
             eng.trace(batch, K, out=out)
     else:
+        eng.timing(True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         out = eng.trace_tree(batch, K)
         torch.cuda.synchronize()
         t = time.perf_counter() - t0
+        kms, kcnt = eng.timing_read()
+        eng.timing(False)
         segs = out.n_valid
         mode = "generations"
+        print(f"   generations: {kcnt} launches sequences, device time {kms:.2f} ms of {t * 1e3:.2f} ms wall", flush=True)
     gbs = (n * b + segs * b) / t / 1e9
     print(f"{name:28s} {prec} {mode:11s} n={n:9d} S={S:3d} K={K:2d} segs/ray={segs / n:5.2f} time={t * 1e3:9.3f} ms "
           f"{segs / t:10.3e} seg/s {segs * S / t:10.3e} isect/s  {gbs:7.1f} GB/s ({gbs / 80:4.1f}% of 8 TB/s)", flush=True)
