@@ -4,6 +4,7 @@ Everything that touches rays goes through liboptable_hip.so; this module only mo
 pointers.  If the library or a GPU is missing the constructor raises — there is no CPU path.
 """
 import ctypes as C
+import threading
 
 import torch
 
@@ -24,6 +25,10 @@ class Engine:
         stream = torch.cuda.current_stream(self.device).cuda_stream
         abi.check(self.lib.ot_ctx_create(device, C.c_void_p(stream), C.byref(self._ctx)), self.lib)
         self.scene = None
+        # An ot_ctx holds one scene and one set of scratch buffers: calls on it are serialised (include/
+        # optable_hip.h).  The table-level entry points hold this lock across their upload + trace sequence so that
+        # Python threads sharing the engine cannot interleave them (ctypes releases the GIL during a call).
+        self.lock = threading.RLock()
 
     def use_stream(self, stream=None):
         """Launch on `stream` (a torch.cuda.Stream; default: torch's current stream) from now on."""
@@ -160,6 +165,10 @@ class Engine:
         """Device pass of Monitor.record over a SegmentBatch.  Returns (slot index, P_local [h,3], t)
         in ascending slot order.  For the [k][ray] layout every slot is scanned and unused ones
         are skipped on the device."""
+        with self.lock:
+            return self._monitor_record(monitor_struct, segs, n_segments)
+
+    def _monitor_record(self, monitor_struct, segs, n_segments):
         dev = segs.device
         if segs.precision != "f64":  # the monitor pass is fp64: widen an fp32 history once
             segs = segs.astype("f64")

@@ -105,18 +105,19 @@ class OpticalTable:
         eng = _engine()
         if scene is None:
             scene = self.compile()
-        eng.upload(scene)
-        cap = MAX_TRACE_NUM if max_segments is None else int(max_segments)
-        if scene.limited:
-            return self._trace_batch_limited(eng, scene, batch, cap, max_segments is not None, counts)
-        speculate = scene.max_children == 2 and not scene.always_branches
-        if max_segments is not None and (scene.max_children <= 1 or speculate):
-            # max_children == 2: speculate that no tree actually branches (e.g. mirror-coated
-            # interfaces only split on total internal reflection); fall back when one does.
-            segs = eng.trace(batch, cap)
-            if scene.max_children <= 1 or not bool((segs.count < 0).any()):
-                return segs
-        return eng.trace_tree(batch, cap)
+        with eng.lock:
+            eng.upload(scene)
+            cap = MAX_TRACE_NUM if max_segments is None else int(max_segments)
+            if scene.limited:
+                return self._trace_batch_limited(eng, scene, batch, cap, max_segments is not None, counts)
+            speculate = scene.max_children == 2 and not scene.always_branches
+            if max_segments is not None and (scene.max_children <= 1 or speculate):
+                # max_children == 2: speculate that no tree actually branches (e.g. mirror-coated
+                # interfaces only split on total internal reflection); fall back when one does.
+                segs = eng.trace(batch, cap)
+                if scene.max_children <= 1 or not bool((segs.count < 0).any()):
+                    return segs
+            return eng.trace_tree(batch, cap)
 
     def _trace_batch_limited(self, eng, scene, batch, cap, fused_ok, counts):
         """`trace_batch` for scenes with `max_interact_count` surfaces.  Their counters are keyed by ray id
@@ -323,6 +324,10 @@ class OpticalTable:
 
     # -- List[Ray] plumbing ------------------------------------------------------------------------
     def _trace_objects(self, rays, cap):
+        with _engine().lock:  # upload + every trace of this call as one unit (see Engine.lock)
+            return self._trace_objects_locked(rays, cap)
+
+    def _trace_objects_locked(self, rays, cap):
         import torch
 
         eng = _engine()
@@ -480,13 +485,14 @@ def interact_component(comp, ray):
 
     eng = _engine()
     scene = _compile([comp])
-    eng.upload(scene)
     batch = _pack([ray], np.zeros(1, dtype=np.int32), eng.device, scene.unit)
     counts = None
     if scene.limited:
         host = np.array([[c._interact_count.get(ray._id, 0)] for c in scene.limited], dtype=np.int32)
         counts = torch.from_numpy(host).to(eng.device)
-    segs, kids, _ = eng.generation_step(batch, counts)
+    with eng.lock:
+        eng.upload(scene)
+        segs, kids, _ = eng.generation_step(batch, counts)
     if scene.limited:
         after = counts.cpu().numpy()
         for s, c in enumerate(scene.limited):

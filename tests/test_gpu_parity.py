@@ -744,3 +744,33 @@ def test_axis_parallel_rays_and_flat_boxes_match_oracle(oracle):
         np.testing.assert_allclose(got[f][kg], ref[f][kr], rtol=1e-9, atol=1e-9, err_msg=f)
     hit_any = np.array([len(s) > 1 for s in seq(ref)])
     assert hit_any[0::5].sum() > 50 and hit_any[2::10].sum() > 10              # the special rays do reach things
+
+
+def test_two_threads_sharing_the_engine_do_not_interleave():
+    """An ot_ctx holds ONE scene: two Python threads tracing different tables through the shared engine must each
+    get the result of their own scene (the table entry points hold the engine lock over upload + trace)."""
+    import threading
+    import torch
+    import optable_amd as oa
+
+    o, d = scenes.cfg2_rays(20000, 4)
+    tables = [_table(scenes.cfg2_components(oa)), _table([oa.Mirror([3, 0, 0], radius=2.0).RotZ(np.pi)])]
+    expect = [t.trace_batch(_batch(o, d), max_segments=5).count.clone() for t in tables]
+    assert not torch.equal(expect[0], expect[1])
+    errors = []
+
+    def work(k):
+        try:
+            for _ in range(30):
+                got = tables[k].trace_batch(_batch(o, d), max_segments=5).count
+                if not torch.equal(got, expect[k]):
+                    errors.append(k)
+        except Exception as exc:  # noqa: BLE001
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in (0, 1)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
