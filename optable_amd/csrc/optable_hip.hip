@@ -988,7 +988,7 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
     // balances better than 16 long-lived blocks per CU (cfg 4, 1.6e8 rays: 12.7 -> 11.8 ms fp64; flat from
     // 64 per CU on).  Scenes with a large LDS image run persistent, as many blocks per CU as the image allows.
     int per_cu = 256;
-    if (in_lds && bytes > 8 * 1024) {
+    if (in_lds && bytes > 16 * 1024) {  // beyond 64 B of staging per ray a short-lived workgroup no longer pays
         const int fit = (int)((160 * 1024) / (bytes + 512));
         per_cu = fit < 1 ? 1 : (fit > 8 ? 8 : fit);
     }
