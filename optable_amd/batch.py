@@ -53,27 +53,35 @@ class RayBatch:
         if normalize:  # Ray.direction setter normalises (ray.py:115-119)
             direction = direction / np.linalg.norm(direction, axis=1, keepdims=True)
         nrays = origin.shape[0]
-        b = cls(nrays, precision, device)
         dt = _REAL[precision]
-
-        def put(name, values):
-            arr = np.array(np.broadcast_to(np.asarray(values, dtype=np.float64), (nrays,)))  # writable copy
-            b.field(name).copy_(torch.from_numpy(arr).to(dt))
-
-        for k, ax in enumerate("xyz"):
-            put("o" + ax, origin[:, k])
-            put("d" + ax, direction[:, k])
-        put("wavelength", wavelength)
-        put("intensity", intensity)
-        put("n", n_index)
-        put("pathlength", pathlength)
+        # one staging block [12, stride] -> ONE host-to-device copy; the fields are its rows (contiguous 1-D views,
+        # each starting on a 256-byte boundary)
+        stride = (nrays + 31) // 32 * 32
+        host = np.zeros((len(abi.RAY_FIELDS), stride), dtype=np.float64)[:, :nrays]
+        row = {f: k for k, f in enumerate(abi.RAY_FIELDS)}
+        host[row["ox"]], host[row["oy"]], host[row["oz"]] = origin[:, 0], origin[:, 1], origin[:, 2]
+        host[row["dx"]], host[row["dy"]], host[row["dz"]] = direction[:, 0], direction[:, 1], direction[:, 2]
+        host[row["wavelength"]] = wavelength
+        host[row["intensity"]] = intensity
+        host[row["n"]] = n_index
+        host[row["pathlength"]] = pathlength
         if q is not None:
-            q = np.broadcast_to(np.asarray(q, dtype=np.complex128), (nrays,))
-            put("q_re", q.real)
-            put("q_im", q.imag)
-            b.flags.fill_(abi.RAY_HAS_Q)
+            qc = np.broadcast_to(np.asarray(q, dtype=np.complex128), (nrays,))
+            host[row["q_re"]], host[row["q_im"]] = qc.real, qc.imag
+        else:
+            host[row["q_re"]] = host[row["q_im"]] = 0.0
+        dev = torch.device(device)
+        block = torch.from_numpy(host.base if host.base is not None else host).to(dt).to(dev)[:, :nrays]
+        b = object.__new__(cls)
+        b.n, b.precision, b.device = int(nrays), precision, dev
+        for f, k in row.items():
+            setattr(b, "n_index" if f == "n" else f, block[k])
+        b.flags = torch.full((nrays,), abi.RAY_HAS_Q if q is not None else 0, dtype=torch.int32, device=dev)
         if ids is not None:
-            b.id.copy_(torch.from_numpy(np.asarray(ids, dtype=np.int32)))
+            b.id = torch.from_numpy(np.ascontiguousarray(ids, dtype=np.int32)).to(dev)
+        else:
+            b.id = torch.arange(nrays, dtype=torch.int32, device=dev)
+        b.length = None
         return b
 
     def slice(self, lo, hi):
@@ -259,6 +267,18 @@ class SegmentBatch:
         m[: self.n_valid] = True
         return m
 
+    def _columns_to_host(self, m):
+        """The first m slots of every field as numpy arrays.  Small histories (the object API) go through one
+        stacked device tensor = one device-to-host copy instead of fourteen."""
+        names = abi.SEG_FIELDS + ("ray", "surface")
+        if m > 1_000_000:
+            return {f: self.field(f)[:m].cpu().numpy() for f in names}
+        reals = torch.stack([self.field(f)[:m] for f in abi.SEG_FIELDS]).cpu().numpy()
+        ints = torch.stack([self.ray[:m], self.surface[:m]]).cpu().numpy()
+        out = {f: reals[k] for k, f in enumerate(abi.SEG_FIELDS)}
+        out["ray"], out["surface"] = ints[0], ints[1]
+        return out
+
     def to_host(self, reference_order=True):
         """Valid segments as numpy arrays.  reference_order: input-ray-major, then segment
         order within the ray (the order OpticalTable.ray_tracing returns, optical_table.py:66-70)."""
@@ -272,15 +292,16 @@ class SegmentBatch:
             full = bool(cnt.min() == K)                            # every slot valid: no masking needed
             keep = None if full else np.arange(K)[:, None] < cnt[None, :]            # [K, N]
             out = {}
+            cols = self._columns_to_host(K * self.n_rays)
             for f in abi.SEG_FIELDS + ("ray", "surface"):
-                a = self.field(f)[: K * self.n_rays].cpu().numpy().reshape(K, self.n_rays)
+                a = cols[f].reshape(K, self.n_rays)
                 if full:
                     out[f] = np.ascontiguousarray(a.T).reshape(-1) if reference_order else a.reshape(-1)
                 else:
                     out[f] = a.T[keep.T] if reference_order else a[keep]
             out["count"] = cnt
             return out
-        out = {f: self.field(f)[: self.n_valid].cpu().numpy() for f in abi.SEG_FIELDS + ("ray", "surface")}
+        out = self._columns_to_host(self.n_valid)
         if reference_order:  # generation order -> tree-major; within a tree generation order IS FIFO order
             order = np.argsort(out["ray"], kind="stable")
             out = {k: v[order] for k, v in out.items()}
