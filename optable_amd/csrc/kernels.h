@@ -1,0 +1,539 @@
+// kernels.h — the gfx950 __global__ kernels of liboptable_hip.so and the typed views they take.
+// Device math (nearest hit, shapes, interactions) is in trace_core.h; the C-ABI, validation and launch logic in
+// optable_hip.hip.
+//   k_trace_fused<T>     one lane per ray, every segment of the ray in one launch (non-branching scenes, light
+//                        scene tables).  HBM-bound: SoA streams, 64 consecutive elements per wave instruction.
+//   k_trace_blocked<T>   the same trace for heavy scenes: wave-owned chunks, survivors compacted every segment.
+//   k_stream_ceiling<T>  the fused kernel's streams with no tracing (roofline companion).
+//   k_gen_trace<T>       one breadth-first generation of branching ray trees (optical_table.py:115-134):
+//                        rank within the tree, trace, ordered slot allocation by decoupled look-back;
+//                        k_gen_rank / k_gen_counts keep interact-count gates FIFO-exact, k_gen_finish closes it.
+//   k_mon_*              Monitor.record over a segment stream (monitor.py:183-193).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "trace_core.h"
+
+using namespace ot;
+
+// ------------------------------------------------------------------------------------------
+// typed views of the C structs
+template <class T> struct RaysT {
+    const T *ox, *oy, *oz, *dx, *dy, *dz, *wl, *qr, *qi, *I, *n, *pl;
+    const int32_t *id, *flags;
+    const T* len;
+};
+template <class T> struct RaysOutT {
+    T *ox, *oy, *oz, *dx, *dy, *dz, *wl, *qr, *qi, *I, *n, *pl;
+    int32_t *id, *flags;
+};
+template <class T> struct SegsT {
+    T *ox, *oy, *oz, *dx, *dy, *dz, *len, *I, *qr, *qi, *n, *pl;
+    int32_t *ray, *surface;
+};
+template <class T> static RaysT<T> view(const ot_rays* r) {
+    return {(const T*)r->ox, (const T*)r->oy, (const T*)r->oz, (const T*)r->dx, (const T*)r->dy, (const T*)r->dz,
+            (const T*)r->wavelength, (const T*)r->q_re, (const T*)r->q_im, (const T*)r->intensity, (const T*)r->n,
+            (const T*)r->pathlength, r->id, r->flags, (const T*)r->length};
+}
+template <class T> static RaysOutT<T> view_out(const ot_rays* r) {
+    return {(T*)r->ox, (T*)r->oy, (T*)r->oz, (T*)r->dx, (T*)r->dy, (T*)r->dz, (T*)r->wavelength, (T*)r->q_re,
+            (T*)r->q_im, (T*)r->intensity, (T*)r->n, (T*)r->pathlength, r->id, r->flags};
+}
+template <class T> static SegsT<T> view(const ot_segments* s) {
+    return {(T*)s->ox, (T*)s->oy, (T*)s->oz, (T*)s->dx, (T*)s->dy, (T*)s->dz, (T*)s->length, (T*)s->intensity,
+            (T*)s->q_re, (T*)s->q_im, (T*)s->n, (T*)s->pathlength, s->ray, s->surface};
+}
+
+// ------------------------------------------------------------------------------------------
+// scene blob: [DNode<T> x n_nodes][DMat<T> x n_mats][T x n_aux], staged into LDS word by word
+struct SceneBlob {
+    const uint32_t* words;
+    int32_t n_words, n_nodes, n_mats, root, cache_mat;
+};
+
+template <class T> __device__ __forceinline__ Scene<T> bind_scene(const uint32_t* base, const SceneBlob& b, T unit) {
+    Scene<T> sc;
+    sc.nodes = reinterpret_cast<const DNode<T>*>(base);
+    sc.mats = reinterpret_cast<const DMat<T>*>(sc.nodes + b.n_nodes);
+    sc.aux = reinterpret_cast<const T*>(sc.mats + b.n_mats);
+    sc.n_nodes = b.n_nodes;
+    sc.n_mats = b.n_mats;
+    sc.cache_mat = b.cache_mat;
+    sc.root = b.root;
+    sc.unit = unit;
+    return sc;
+}
+
+// Segment records are written once and never re-read by the trace: NT = true marks the stores
+// non-temporal so they stream past L2 / Infinity Cache instead of evicting the scene and inputs.
+template <bool NT, class V> __device__ __forceinline__ void st(V* p, V v) {
+    if (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+template <class T, bool NT = false>
+__device__ __forceinline__ void store_segment(const SegsT<T>& out, int64_t slot, const RayState<T>& r, T len, int32_t tree,
+                                              int32_t surface) {
+    st<NT>(out.ox + slot, r.ox); st<NT>(out.oy + slot, r.oy); st<NT>(out.oz + slot, r.oz);
+    st<NT>(out.dx + slot, r.dx); st<NT>(out.dy + slot, r.dy); st<NT>(out.dz + slot, r.dz);
+    st<NT>(out.len + slot, len); st<NT>(out.I + slot, r.I);
+    st<NT>(out.qr + slot, r.qr); st<NT>(out.qi + slot, r.qi);
+    st<NT>(out.n + slot, r.n); st<NT>(out.pl + slot, r.pl);
+    st<NT>(out.ray + slot, tree); st<NT>(out.surface + slot, surface);
+}
+
+template <class T> __device__ __forceinline__ RayState<T> load_ray(const RaysT<T>& in, int64_t i, int32_t flags) {
+    RayState<T> r;
+    r.ox = in.ox[i]; r.oy = in.oy[i]; r.oz = in.oz[i];
+    r.dx = in.dx[i]; r.dy = in.dy[i]; r.dz = in.dz[i];
+    r.wl = in.wl[i]; r.qr = in.qr[i]; r.qi = in.qi[i];
+    r.I = in.I[i]; r.n = in.n[i]; r.pl = in.pl[i];
+    r.len = in.len ? in.len[i] : Num<T>::inf();
+    r.has_q = (flags & OT_RAY_HAS_Q) != 0;
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_trace_fused: the hot kernel
+template <class T, uint32_t F, bool SCENE_IN_LDS, int MINW, bool NT>
+__global__ __launch_bounds__(256, MINW) void k_trace_fused(SceneBlob blob, T unit, RaysT<T> in, int64_t n, int32_t K, SegsT<T> out,
+                                                     int32_t* __restrict__ seg_count, int32_t* counts, int32_t n_classes) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    const uint32_t* base = blob.words;
+    if (SCENE_IN_LDS) {
+        for (int w = threadIdx.x; w < blob.n_words; w += blockDim.x) lds[w] = blob.words[w];
+        __syncthreads();
+        base = lds;
+    }
+    const Scene<T> sc = bind_scene<T>(base, blob, unit);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < n; i0 += stride) {
+        const int64_t i = i0 + threadIdx.x;
+        bool active = i < n;
+        RayState<T> r = {};
+        int32_t cls = 0, used = 0;
+        MatCache<T> mc = {T(1)};
+        if (active) {
+            const int32_t fl = in.flags[i];
+            r = load_ray(in, i, fl);
+            if constexpr (F & F_REFRACT) mc = make_matcache(sc, r.wl);
+            cls = in.id[i];
+            if (fl & OT_RAY_DEAD) {  // optical_component.py:349: a dead ray hits nothing and is returned as is
+                store_segment<T, NT>(out, i, r, r.len, (int32_t)i, -2);
+                used = 1;
+                active = false;
+            }
+        }
+        for (int32_t k = 0; k < K; ++k) {  // wave-uniform trip count: lanes never leave the loop alone
+            if (!__any(active)) break;
+            const GateCtx gate = {counts, n_classes, cls, nullptr, nullptr, 0, 0};
+            const Hit<T> h = nearest_hit<T, F, GATE_PLAIN>(sc, r, active, gate);
+            if (active) {
+                const int64_t slot = (int64_t)k * n + i;
+                used = k + 1;
+                if (h.node < 0) {  // escaped: archived unchanged (optical_table.py:132-134)
+                    store_segment<T, NT>(out, slot, r, r.len, (int32_t)i, -1);
+                    active = false;
+                } else {
+                    store_segment<T, NT>(out, slot, r, h.t, (int32_t)i, sc.nodes[h.node].leaf_id);
+                    RayState<T> child;
+                    const int nk = interact<T, F, 1>(sc, r, h, &child, mc);
+                    if (nk == 1) r = child;
+                    else {
+                        active = false;
+                        if (nk > 1) used = -(k + 1);  // the tree branches here: not representable in [k][ray] slots
+                    }
+                }
+            }
+        }
+        if (i < n) seg_count[i] = used;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_trace_blocked: the same trace for HEAVY scenes (many nodes, long and uneven paths).
+// One lane per ray wastes lanes twice there: rays of a wave end after different numbers of
+// segments, and the segment loop runs as long as its longest ray.  Here every WAVE owns a chunk of
+// CHUNK (256 to 1024) consecutive rays and advances them generation by generation: after every segment the
+// surviving rays are compacted (order preserving: ballot + popcount) into a dense index list in
+// LDS, so every pass runs with a full wave until the chunk drains.  The four waves of a workgroup
+// share only the staged scene image; each has its own lists and its own chunks, so there is no
+// workgroup barrier inside the loop (a first version with one 1024-ray chunk per workgroup spent
+// 57 % of its wave-cycles waiting, mostly at the two barriers per pass: profiles/).
+// The state of a live ray travels through a per-ray scratch record in global memory (L2/MALL
+// resident); segment records go to the same [k][ray] slots as k_trace_fused, so the two kernels
+// are interchangeable bit for bit.
+template <class T> struct StateT {
+    T* f[11];  // ox oy oz dx dy dz qr qi I n pl  (wavelength, id, flags stay in the input arrays)
+};
+
+#ifndef OT_BLOCKED_MINW
+#define OT_BLOCKED_MINW 1
+#endif
+template <class T, uint32_t F> constexpr int blocked_minw() { return (sizeof(T) == 8 && F == 86u) ? OT_BLOCKED_MINW : 1; }
+// largest workgroup an instantiation may be launched with: 512 threads = 2 waves/SIMD = 256 VGPRs, which every
+// instantiation fits except the all-features fp64 one (it would spill 44 bytes per lane)
+template <class T, uint32_t F> constexpr int blocked_threads() { return (sizeof(T) == 8 && F == F_ALL) ? 256 : 512; }
+
+template <class T, uint32_t F, bool SCENE_IN_LDS, bool NT>
+__global__ __launch_bounds__((blocked_threads<T, F>()), (blocked_minw<T, F>())) void k_trace_blocked(SceneBlob blob, T unit, RaysT<T> in, int64_t n, int32_t K, SegsT<T> out,
+                                                       int32_t* __restrict__ seg_count, int32_t* counts, int32_t n_classes,
+                                                       StateT<T> st, int32_t CHUNK) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    const uint32_t* base = blob.words;
+    uint32_t* tail = lds;
+    if (SCENE_IN_LDS) {
+        for (int w = threadIdx.x; w < blob.n_words; w += blockDim.x) lds[w] = blob.words[w];
+        base = lds;
+        tail = lds + ((blob.n_words + 3) & ~3);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int32_t* cur = reinterpret_cast<int32_t*>(tail) + wave * 2 * CHUNK;  // wave-private lists
+    int32_t* nxt = cur + CHUNK;
+    __syncthreads();  // the only workgroup barrier: the scene image is staged
+    const Scene<T> sc = bind_scene<T>(base, blob, unit);
+    const int64_t n_chunks = (n + CHUNK - 1) / CHUNK;
+    const int wpb = blockDim.x >> 6;  // 4 waves per workgroup, 8 when a large scene image fills the CU's LDS
+    for (int64_t ch = (int64_t)blockIdx.x * wpb + wave; ch < n_chunks; ch += (int64_t)gridDim.x * wpb) {  // wave-uniform
+        const int64_t first = ch * CHUNK;
+        int alive = (int)((n - first) < CHUNK ? (n - first) : CHUNK);
+        for (int32_t k = 0; k < K && alive > 0; ++k) {
+            int next_alive = 0;
+            for (int p0 = 0; p0 < alive; p0 += 64) {
+                const int p = p0 + lane;
+                bool active = p < alive;
+                const int j = active ? (k == 0 ? p : cur[p]) : 0;
+                const int64_t i = first + j;
+                RayState<T> r = {};
+                int32_t cls = 0;
+                bool survive = false;
+                if (active) {
+                    const int32_t fl = in.flags[i];
+                    cls = in.id[i];
+                    if (k == 0) {
+                        r = load_ray(in, i, fl);
+                        if (fl & OT_RAY_DEAD) {
+                            store_segment<T, NT>(out, i, r, r.len, (int32_t)i, -2);
+                            seg_count[i] = 1;
+                            active = false;
+                        }
+                    } else {
+                        r.ox = st.f[0][i]; r.oy = st.f[1][i]; r.oz = st.f[2][i];
+                        r.dx = st.f[3][i]; r.dy = st.f[4][i]; r.dz = st.f[5][i];
+                        r.qr = st.f[6][i]; r.qi = st.f[7][i]; r.I = st.f[8][i]; r.n = st.f[9][i]; r.pl = st.f[10][i];
+                        r.wl = in.wl[i];
+                        r.len = Num<T>::inf();
+                        r.has_q = (fl & OT_RAY_HAS_Q) != 0;
+                    }
+                }
+                const GateCtx gate = {counts, n_classes, cls, nullptr, nullptr, 0, 0};
+                const Hit<T> h = nearest_hit<T, F, GATE_PLAIN>(sc, r, active, gate);
+                if (active) {
+                    const int64_t slot = (int64_t)k * n + i;
+                    int32_t used = k + 1;
+                    if (h.node < 0) {
+                        store_segment<T, NT>(out, slot, r, r.len, (int32_t)i, -1);
+                    } else {
+                        store_segment<T, NT>(out, slot, r, h.t, (int32_t)i, sc.nodes[h.node].leaf_id);
+                        RayState<T> child;
+                        MatCache<T> mc = {T(1)};
+                        if constexpr (F & F_REFRACT) mc = make_matcache(sc, r.wl);
+                        const int nk = interact<T, F, 1>(sc, r, h, &child, mc);
+                        if (nk == 1) {
+                            survive = k + 1 < K;
+                            if (survive) {
+                                st.f[0][i] = child.ox; st.f[1][i] = child.oy; st.f[2][i] = child.oz;
+                                st.f[3][i] = child.dx; st.f[4][i] = child.dy; st.f[5][i] = child.dz;
+                                st.f[6][i] = child.qr; st.f[7][i] = child.qi; st.f[8][i] = child.I;
+                                st.f[9][i] = child.n; st.f[10][i] = child.pl;
+                            }
+                        } else if (nk > 1) {
+                            used = -(k + 1);
+                        }
+                    }
+                    if (!survive) seg_count[i] = used;
+                }
+                // order-preserving append of this pass's survivors (wave-private list: no barrier)
+                const unsigned long long mask = __ballot(survive);
+                if (survive) nxt[next_alive + __popcll(mask & ((1ull << lane) - 1ull))] = j;
+                next_alive += __popcll(mask);
+            }
+            // the list written above is read by other lanes of this wave in the next generation, and
+            // so is the scratch state: LDS and global accesses of one wave complete in issue order,
+            // the fence only stops the compiler from moving them
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            int32_t* t = cur; cur = nxt; nxt = t;
+            alive = next_alive;
+        }
+    }
+}
+
+// k_stream_ceiling: the fused kernel's memory traffic with no tracing — reads one ray record,
+// writes K segment records per ray through the same SoA streams.  What this access pattern can
+// reach on the device; reported next to the trace kernel (bench.py).
+template <class T, bool NT>
+__global__ __launch_bounds__(256) void k_stream_ceiling(RaysT<T> in, int64_t n, int32_t K, SegsT<T> out, int32_t* seg_count) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        RayState<T> r = load_ray(in, i, in.flags[i]);
+        const int32_t cls = in.id[i];
+        for (int32_t k = 0; k < K; ++k) {
+            store_segment<T, NT>(out, (int64_t)k * n + i, r, r.len, (int32_t)i, cls);
+            r.ox += T(1);  // keep the K records distinct so the stores cannot be merged
+        }
+        seg_count[i] = K;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// breadth-first generation step
+// A generation lists its rays tree by tree (parent order), so `tree[]` is non-decreasing and the first ray of
+// ray i's tree is a lower bound: rank within the tree = i - tree_head(i).  ~log2(n) L2-resident loads per ray
+// replace the head-flag kernel, the max-scan and the mark kernel of the first version.
+__device__ __forceinline__ int64_t tree_head(const int32_t* __restrict__ tree, int64_t i) {
+    const int32_t t = tree[i];
+    for (int k = 1; k <= 3; ++k)  // most trees have a handful of rays per generation: look at the neighbours first
+        if (i - k < 0 || tree[i - k] != t) return i - k + 1;
+    int64_t lo = 0, hi = i - 3;  // tree[hi] == t
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (tree[mid] < t) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// Ordered single-pass allocation of child slots (decoupled look-back): tiles of 256 rays are handed out by an
+// atomic ticket, so a tile with a smaller index is always held by a workgroup that is already running.  A tile
+// publishes its child count as an AGGREGATE, then walks back over its predecessors (one wave, 64 tiles per read)
+// adding aggregates until it meets an inclusive PREFIX, and publishes its own prefix.  Flag and value share one
+// 64-bit word, so a reader never sees one without the other and RELAXED device-scope atomics suffice
+// (acquire/release at device scope invalidate / write back the XCD's L2 around every access: 3.5x slower here).
+// The next generation is therefore written once, in parent order then child order, straight from the registers
+// of the trace (an earlier version parked both children of every ray in scratch, scanned the counts and
+// compacted in a second kernel: 40 % of the generation's bytes).
+struct LookBack {
+    unsigned long long* state;   // [n_tiles] (flag << 62) | value, zeroed before the launch
+    unsigned long long* ticket;  // next tile to hand out, zeroed before the launch
+};
+static constexpr unsigned long long LB_AGG = 1ull << 62, LB_PREFIX = 2ull << 62, LB_MASK = (1ull << 62) - 1ull;
+// the 62-bit value carries two counts: processed rays = segment slots (bits 32..61, n < 2^30) and children (bits 0..31)
+static constexpr int LB_SEG_SHIFT = 32;
+
+// PROBE = true: the pre-pass that records geometric hits of count-limited leaves (no outputs).
+template <class T, uint32_t F, bool SCENE_IN_LDS, bool PROBE>
+__global__ __launch_bounds__(256) void k_gen_trace(SceneBlob blob, T unit, RaysT<T> in, const int32_t* tree, int64_t n,
+                                                   const int32_t* budget, const int64_t* cursor,
+                                                   SegsT<T> out, int64_t out_capacity, LookBack lb, RaysOutT<T> next,
+                                                   int32_t* next_tree, int64_t next_capacity, int64_t* totals,
+                                                   int32_t* counts, int32_t n_classes, const int32_t* rank, int32_t* probe) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    __shared__ long long s_tile, s_base;
+    __shared__ unsigned long long s_wave_total[4];
+    const uint32_t* base = blob.words;
+    if (SCENE_IN_LDS) {
+        for (int w = threadIdx.x; w < blob.n_words; w += blockDim.x) lds[w] = blob.words[w];
+        __syncthreads();
+        base = lds;
+    }
+    const Scene<T> sc = bind_scene<T>(base, blob, unit);
+    const int64_t cur0 = *cursor;
+    const int64_t n_tiles = (n + 255) / 256;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (;;) {
+        if (threadIdx.x == 0) s_tile = (long long)atomicAdd(lb.ticket, 1ull);
+        __syncthreads();
+        const int64_t tile = s_tile;
+        if (tile >= n_tiles) break;  // workgroup-uniform
+        const int64_t i = tile * 256 + threadIdx.x;
+        // Rank of the ray inside its tree (rays beyond the tree's remaining max_trace_num budget are dropped,
+        // optical_table.py:138-144).  The head of the tree is the nearest earlier ray of this WAVE that starts a
+        // tree (max-scan of start flags) unless the tree began before the wave: those lanes all look up the head
+        // of the wave's first ray — the same addresses for all of them, one cache line per step.
+        int32_t my_tree = -1;
+        long long start = -1;
+        if (i < n) {
+            my_tree = tree[i];
+            if (lane == 0 || tree[i - 1] != my_tree) start = i;
+        }
+        long long head = start;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const long long up = __shfl_up(head, off, 64);
+            if (lane >= off && up > head) head = up;
+        }
+        if (i < n && head == i - lane) head = tree_head(tree, i - lane);  // the run reaches back to the wave's first ray
+        bool active = i < n && (i - head) < (int64_t)budget[my_tree];
+        RayState<T> r = {};
+        int32_t cls = 0, fl = 0;
+        if (active) {
+            fl = in.flags[i];
+            r = load_ray(in, i, fl);
+            cls = in.id[i];
+        }
+        const bool dead = active && (fl & OT_RAY_DEAD);
+        const GateCtx gate = {counts, n_classes, cls, rank, probe, n, i};
+        if (PROBE) {
+            (void)nearest_hit<T, F, GATE_PROBE>(sc, r, active && !dead, gate);
+            __syncthreads();  // s_tile is rewritten at the top of the loop
+            continue;
+        }
+        const Hit<T> h = nearest_hit<T, F, GATE_TABLE>(sc, r, active && !dead, gate);
+        int32_t nk = 0, t = 0;
+        RayState<T> ch[2];
+        if (active) {
+            t = tree[i];
+            if (!dead && h.node >= 0) nk = interact<T, F, 2>(sc, r, h, ch, make_matcache(sc, r.wl));
+        }
+        // segment and child slots: inclusive scan of both counts inside the wave (packed: segments high, children
+        // low), wave totals through LDS, tile prefix by look-back
+        const unsigned long long mine = ((unsigned long long)(active ? 1 : 0) << LB_SEG_SHIFT) | (unsigned long long)nk;
+        unsigned long long incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long up = (unsigned long long)__shfl_up((long long)incl, off, 64);
+            if (lane >= off) incl += up;
+        }
+        if (lane == 63) s_wave_total[wave] = incl;
+        __syncthreads();
+        if (wave == 0) {  // look-back by a whole wave: 64 predecessors per read
+            const unsigned long long total = s_wave_total[0] + s_wave_total[1] + s_wave_total[2] + s_wave_total[3];
+            unsigned long long before = 0;
+            if (tile > 0) {
+                if (lane == 0) __hip_atomic_store(&lb.state[tile], LB_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int64_t wbase = tile - 1;;) {
+                    const int64_t idx = wbase - lane;  // lane 0 = nearest predecessor
+                    unsigned long long v = LB_PREFIX;  // before tile 0: an inclusive prefix of zero
+                    if (idx >= 0) v = __hip_atomic_load(&lb.state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned flag = (unsigned)(v >> 62);
+                    const unsigned long long m_prefix = __ballot(flag == 2u), m_empty = __ballot(flag == 0u);
+                    unsigned long long need = ~0ull;   // the lanes up to and including the nearest prefix
+                    if (m_prefix) {
+                        const int pl = __ffsll((long long)m_prefix) - 1;
+                        need = pl == 63 ? ~0ull : ((1ull << (pl + 1)) - 1ull);
+                    }
+                    if (m_empty & need) { __builtin_amdgcn_s_sleep(24); continue; }  // one of them is still tracing: wait ~0.6 us, read again
+                    long long part = ((need >> lane) & 1ull) ? (long long)(v & LB_MASK) : 0ll;
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+                    before += (unsigned long long)part;
+                    if (m_prefix) break;
+                    wbase -= 64;
+                }
+            }
+            if (lane == 0) {
+                __hip_atomic_store(&lb.state[tile], LB_PREFIX | (before + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_base = (long long)before;
+                if (tile == n_tiles - 1) {  // generation totals for k_gen_finish and the host
+                    const unsigned long long all = before + total;
+                    totals[0] = (int64_t)(all >> LB_SEG_SHIFT);          // segments written
+                    totals[1] = (int64_t)(all & 0xffffffffull);          // rays in the next generation
+                }
+            }
+        }
+        __syncthreads();
+        unsigned long long before_me = (unsigned long long)s_base + (incl - mine);
+        for (int w = 0; w < wave; ++w) before_me += s_wave_total[w];
+        if (active) {
+            const int64_t slot = cur0 + (int64_t)(before_me >> LB_SEG_SHIFT);
+            if (slot < out_capacity) {
+                if (dead) store_segment(out, slot, r, r.len, t, -2);
+                else if (h.node < 0) store_segment(out, slot, r, r.len, t, -1);
+                else store_segment(out, slot, r, h.t, t, sc.nodes[h.node].leaf_id);
+            }
+        }
+        int64_t d = (int64_t)(before_me & 0xffffffffull);
+        for (int c = 0; c < nk; ++c, ++d) {
+            if (d >= next_capacity) break;
+            const RayState<T>& k = ch[c];
+            next.ox[d] = k.ox; next.oy[d] = k.oy; next.oz[d] = k.oz;
+            next.dx[d] = k.dx; next.dy[d] = k.dy; next.dz[d] = k.dz;
+            next.wl[d] = k.wl; next.qr[d] = k.qr; next.qi[d] = k.qi;
+            next.I[d] = k.I; next.n[d] = k.n; next.pl[d] = k.pl;
+            next.flags[d] = fl & OT_RAY_HAS_Q;
+            next.id[d] = cls;
+            next_tree[d] = t;
+        }
+        __syncthreads();  // s_tile / s_base / s_wave_total are rewritten by the next tile
+    }
+}
+
+// rank[slot][i] = how many earlier rays of i's tree (this generation) hit limited leaf `slot`
+__global__ void k_gen_rank(const int32_t* tree, int64_t n, int32_t n_slots, const int32_t* ex, int32_t* rank) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t head = tree_head(tree, i);
+    for (int s = 0; s < n_slots; ++s) rank[(int64_t)s * n + i] = ex[(int64_t)s * n + i] - ex[(int64_t)s * n + head];
+}
+// after the trace: each tree's last ray of the generation folds the generation's hits into the table
+__global__ void k_gen_counts(const int32_t* tree, const int32_t* ids, int64_t n, int32_t n_slots, const int32_t* rank,
+                             const int32_t* probe, const int32_t* slot_max, int32_t* counts, int32_t n_classes) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (i == n - 1 || tree[i + 1] != tree[i]) {
+        for (int s = 0; s < n_slots; ++s) {
+            int32_t* c = counts + (int64_t)s * n_classes + ids[i];
+            const int32_t total = *c + rank[(int64_t)s * n + i] + probe[(int64_t)s * n + i];
+            *c = total < slot_max[s] ? total : (*c > slot_max[s] ? *c : slot_max[s]);
+        }
+    }
+}
+
+__global__ void k_gen_finish(const int32_t* tree, int64_t n, int32_t* budget, const int64_t* totals, int64_t* cursor,
+                             int64_t* n_next) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (i == n - 1 || tree[i + 1] != tree[i]) {  // last ray of its tree in this generation
+        const int64_t in_gen = i - tree_head(tree, i) + 1;
+        const int32_t b = budget[tree[i]];
+        budget[tree[i]] = b - (int32_t)(in_gen < b ? in_gen : b);
+    }
+    if (i == n - 1) {  // the trace kernel read *cursor at its start, so it is advanced here, after it
+        *cursor += totals[0];
+        *n_next = totals[1];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Monitor.record
+__global__ void k_mon_test(ot_monitor mon, SegsT<double> s, int64_t n, const int32_t* seg_count, int64_t n_rays, int32_t* hit,
+                           double* P, double* tt) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (seg_count) {  // [k][ray] layout of ot_trace_*: slot i is valid iff k < |seg_count[ray]|
+        const int32_t c = seg_count[i % n_rays];
+        if (i / n_rays >= (c < 0 ? -c : c)) { hit[i] = 0; return; }
+    }
+    const double rx = s.ox[i] - mon.origin[0], ry = s.oy[i] - mon.origin[1], rz = s.oz[i] - mon.origin[2];
+    const double* M = mon.M;
+    const double ox = M[0] * rx + M[3] * ry + M[6] * rz, oy = M[1] * rx + M[4] * ry + M[7] * rz,
+                 oz = M[2] * rx + M[5] * ry + M[8] * rz;
+    double dx = M[0] * s.dx[i] + M[3] * s.dy[i] + M[6] * s.dz[i], dy = M[1] * s.dx[i] + M[4] * s.dy[i] + M[7] * s.dz[i],
+           dz = M[2] * s.dx[i] + M[5] * s.dy[i] + M[8] * s.dz[i];
+    const double inv = 1.0 / sqrt(dx * dx + dy * dy + dz * dz);  // ray_to_local_coordinates renormalises
+    dx *= inv; dy *= inv; dz *= inv;
+    int32_t ok = 0;
+    if (dx != 0.0) {
+        const double t = -ox / dx;
+        if (!(fabs(t) < 1e-9 || t < 0.0 || t > s.len[i])) {
+            const double Px = ox + t * dx, Py = oy + t * dy, Pz = oz + t * dz;
+            if (fabs(Py) <= mon.half_width && fabs(Pz) <= mon.half_height) {
+                ok = 1;
+                P[3 * i] = Px; P[3 * i + 1] = Py; P[3 * i + 2] = Pz;
+                tt[i] = t;
+            }
+        }
+    }
+    hit[i] = ok;
+}
+__global__ void k_mon_compact(const int32_t* hit, const int64_t* off, const double* P, const double* tt, int64_t n,
+                              int64_t* hit_index, double* Px, double* Py, double* Pz, double* t, int64_t* n_hits) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (hit[i]) {
+        const int64_t d = off[i];
+        hit_index[d] = i; Px[d] = P[3 * i]; Py[d] = P[3 * i + 1]; Pz[d] = P[3 * i + 2]; t[d] = tt[i];
+    }
+    if (i == n - 1) *n_hits = off[i] + hit[i];
+}
+
