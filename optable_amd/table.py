@@ -180,6 +180,12 @@ class OpticalTable:
         out.counts_table, out.count_ids = counts, uniq
         return out
 
+    def trace_host(self, origin, direction, **kwargs):
+        """Host numpy rays in, host numpy results out, PCIe copies overlapped with the trace (stream.py)."""
+        from .stream import trace_host
+
+        return trace_host(self, origin, direction, **kwargs)
+
     def record_batch(self, monitor, segs):
         """Monitor.record over a SegmentBatch without Python objects: a `MonitorHits` (device tensors
         + the Monitor accessors: yList, tYList, IList, ... with the reference's sort orders)."""

@@ -29,3 +29,13 @@ for rep in range(3):
           f"full history D2H (520 MB) {1e3*(t4-t3):7.2f} ms")
     segs_n = int(np.sum(host["count"]))
     print(f"   intersections/s incl. H2D + final-state D2H: {segs_n*3/(t3-t0):.3e};  incl. full history D2H: {segs_n*3/((t2-t0)+(t4-t3)):.3e}")
+
+# the same job through the streamed API: chunks on two HIP streams, copies overlapped with the trace, pinned results
+for chunk in (1 << 18, 1 << 20):
+    for hist in (False, True):
+        res = table.trace_host(o, d, wavelength=scenes.WL, q=q, max_segments=K, chunk=chunk, history=hist)  # warm: pinned pools, engines
+        del res
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        res = table.trace_host(o, d, wavelength=scenes.WL, q=q, max_segments=K, chunk=chunk, history=hist)
+        dt = time.perf_counter() - t0
+        print(f"trace_host chunk={chunk} history={hist}: {dt*1e3:7.2f} ms -> {int(res['count'].sum())*3/dt:.3e} intersections/s")
