@@ -31,15 +31,17 @@ for row in csv.DictReader(open(stats)):
         summary["min_ns"] = float(row["MinNs"])
         summary["max_ns"] = float(row["MaxNs"])
         break
-# bench.py launches 500 pre-load + W warmup + K timed + 1 final trace: report the timed region separately
+# bench.py launches 500 pre-load + W warmup + K timed + K with per-launch events + 1 final trace (tools/profile.sh:
+# W = 3, K = 20): report the timed region separately
 traces = glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))
 if traces:
     durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(traces[0])) if kernel in r["Kernel_Name"]]
-    if len(durs) > 121:
+    if len(durs) == 544:
         summary["avg_ns_first_100_launches_clock_ramp"] = sum(durs[:100]) / 100
-        summary["avg_ns_timed_region_20_steps"] = sum(durs[-21:-1]) / 20
-        summary["note"] = (f"{len(durs)} launches = 500 pre-load + 3 warmup + 20 timed + 1 final; `avg_ns` is over all of them, "
-                           "the timed region of bench.py is the 20 launches before the last")
+        summary["avg_ns_timed_region_20_steps"] = sum(durs[503:523]) / 20
+        summary["avg_ns_companion_loop_per_launch_events"] = sum(durs[523:543]) / 20
+        summary["note"] = ("544 launches = 500 pre-load + 3 warmup + 20 timed + 20 with per-launch events + 1 final; `avg_ns` is over "
+                           "all of them, `avg_ns_timed_region_20_steps` is the region bench.py times")
 counters = collections.defaultdict(list)
 for part in ("fetch", "write", "sq"):
     files = glob.glob(os.path.join(src, part, "*", "*_counter_collection.csv"))
