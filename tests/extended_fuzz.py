@@ -2,7 +2,7 @@
 """Not collected by pytest (run by hand: python tests/extended_fuzz.py).  Extended differential fuzzing on the GPU box (HIP path vs the C oracle): 90 more seeds of the three scene
 families of tests/test_gpu_fuzz.py (small, large with grids/arrays/dispersion, branching).  Prints the fraction
 of rays whose surface sequence differs and the worst relative field error per seed; flags anything beyond
-0.2 % / 1e-7.  Last run: 90 seeds, no path differences, worst error 4e-9."""
+0.2 % / 1e-7.  Last runs: 90 seeds and `SEEDS=600` (1800 scenes, 5.5e6 rays): see DESIGN.md §5."""
 import os, sys
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(1, os.path.join(ROOT, "tests"))
@@ -36,17 +36,18 @@ def compare(table, batch, K, n, tag):
     flag = "" if (frac <= 0.002 and worst < 1e-7) else "   <<<<<<"
     if flag: bad += 1
     print(f"{tag}: paths differ {frac*100:.3f}%  worst rel err {worst:.2e}{flag}", flush=True)
-for seed in range(100, 140):
+N_SEEDS = int(os.environ.get('SEEDS', 0))  # SEEDS=n: n seeds per family instead of the default 40 / 30 / 20
+for seed in range(100, 100 + (N_SEEDS or 40)):
     rng = np.random.default_rng(1000 + seed)
     t = oa.OpticalTable(); t.add_components(F.random_scene(oa, rng))
     n, K = 3000, 12
     o = np.stack([np.zeros(n), rng.uniform(-4, 4, n), rng.uniform(-0.4, 0.4, n)], 1)
     d = np.stack([np.ones(n), rng.uniform(-0.15, 0.15, n), rng.uniform(-0.03, 0.03, n)], 1)
     compare(t, RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=1j*np.pi*scenes.W0**2/scenes.WL), K, n, f"small {seed}")
-for seed in range(100, 130):
+for seed in range(100, 100 + (N_SEEDS or 30)):
     table, o, d, wl = F._large_case(oa, seed)
     compare(table, RayBatch.from_arrays(o, d, wavelength=wl, q=1j*np.pi*scenes.W0**2/wl), 16, len(o), f"large {seed}")
-for seed in range(100, 120):
+for seed in range(100, 100 + (N_SEEDS or 20)):
     rng = np.random.default_rng(2000 + seed)
     t = oa.OpticalTable(); t.add_components(F.random_branching_scene(oa, rng))
     n, cap = 1500, 14
