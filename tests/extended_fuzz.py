@@ -54,4 +54,33 @@ for seed in range(100, 100 + (N_SEEDS or 20)):
     o = np.stack([np.zeros(n), rng.uniform(-3, 3, n), rng.uniform(-0.3, 0.3, n)], 1)
     d = np.stack([np.ones(n), rng.uniform(-0.12, 0.12, n), rng.uniform(-0.02, 0.02, n)], 1)
     compare(t, RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=1j*np.pi*scenes.W0**2/scenes.WL), cap, n, f"branch {seed}")
+# fourth family: interact-count limits (optical_component.py:140-149) with unique and with shared ray ids
+for seed in range(100, 100 + (N_SEEDS or 20)):
+    rng = np.random.default_rng(4000 + seed)
+    comps = F.random_scene(oa, rng)
+    for c in comps:
+        if not hasattr(c, "components") and rng.uniform() < 0.5:
+            c.max_interact_count = int(rng.integers(1, 4))
+    comps.append(oa.TriangularPrism([rng.uniform(4, 20), rng.uniform(-3, 3), 0], width=1.5, height=2, n1=1, n2=1.5).RotZ(rng.uniform(-3, 3)))
+    comps.append(oa.Mirror([-1, 0, 0], radius=6).RotZ(np.pi))      # sends rays back for second encounters
+    t = oa.OpticalTable(); t.add_components(comps)
+    scene = t.compile()
+    n, K = 2000, 14
+    o = np.stack([np.zeros(n), rng.uniform(-4, 4, n), rng.uniform(-0.4, 0.4, n)], 1)
+    d = np.stack([np.ones(n), rng.uniform(-0.15, 0.15, n), rng.uniform(-0.03, 0.03, n)], 1)
+    ids = np.arange(n) if seed % 2 else rng.integers(0, n // 3, n)  # odd seeds: unique ids; even: about three rays per id
+    batch = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=1j*np.pi*scenes.W0**2/scenes.WL, ids=ids)
+    segs = t.trace_batch(batch, max_segments=K)
+    got = segs.to_host(reference_order=True)
+    host = batch.to_host()
+    uniq, inverse = np.unique(host["id"], return_inverse=True)
+    host["id"] = inverse.astype(np.int32)
+    ref = orc.trace(scene, host, max_trace_num=K, n_classes=len(uniq))
+    a, b = F._sequences(got, n), F._sequences(ref, n)
+    same = np.array([x == y for x, y in zip(a, b)])
+    counts_equal = np.array_equal(segs.counts_table.cpu().numpy(), ref["counts"]) if scene.limited else True
+    frac = (~same).mean()
+    flag = "" if (frac <= 0.002 and (counts_equal or frac > 0)) else "   <<<<<<"
+    if flag: bad += 1
+    print(f"limited {seed} ({'unique' if seed % 2 else 'shared'} ids, {len(scene.limited)} limited leaves): paths differ {frac*100:.3f}%  counts equal {counts_equal}{flag}", flush=True)
 print("FLAGGED:", bad)
