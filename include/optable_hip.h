@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define OT_ABI_VERSION 2
+#define OT_ABI_VERSION 3  /* 3: ot_trace_generation_f32 */
 
 /* ---- status codes ------------------------------------------------------------------- */
 enum ot_status {
