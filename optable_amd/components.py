@@ -12,7 +12,7 @@ from typing import Union
 
 import numpy as np
 
-from .geometry import Vector, Color, _NO_BOX, pivot_origin
+from .geometry import Vector, Color, _NO_BOX, pivot_origin, out_of_scope
 from .materials import Material, RefractiveIndex
 from .shapes import Surface, Plane, Point, Circle, Rectangle, Sphere, Cylinder
 
@@ -26,6 +26,9 @@ _BOX_CORNER_PICK = np.array([[i & 1, 2 + ((i >> 1) & 1), 4 + ((i >> 2) & 1)] for
 
 class OpticalComponent(Vector):
     """Pose + surface + bookkeeping common to every element (optical_component.py:8-149)."""
+    render = out_of_scope("render")
+    gather_components = out_of_scope("gather_components")
+
 
     def __init__(self, origin, **kwargs):
         super().__init__(origin, **kwargs)

@@ -13,6 +13,17 @@ import numpy as np
 _NO_BOX = (None,) * 6
 
 
+def out_of_scope(name):
+    """A method of the reference that lives outside the accelerated path (rendering, component metadata):
+    calling it says so instead of failing with a bare AttributeError."""
+    def method(self, *args, **kwargs):
+        raise NotImplementedError(
+            f"{type(self).__name__}.{name} is outside optable_amd's scope (it rebuilds only the ray-tracing path); "
+            "keep the original package for it and route its hot path here with optable_amd.install(optable)")
+    method.__name__ = name
+    return method
+
+
 class Base:
     """Attribute bag with an identity that survives `copy()` (base.py:8-22)."""
 

@@ -10,7 +10,7 @@ from typing import List
 
 import numpy as np
 
-from .geometry import Vector, pivot_origin
+from .geometry import Vector, pivot_origin, out_of_scope
 from .materials import RefractiveIndex
 
 _RAY_NONE_LENGTH = 100
@@ -51,6 +51,8 @@ class GaussianBeam:
 
 class Ray(Vector):
     """Geometric ray with optional Gaussian q (ray.py:58-200)."""
+    render = out_of_scope("render")
+
 
     _n = RefractiveIndex("_n")
 

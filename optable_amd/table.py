@@ -20,7 +20,7 @@ from . import abi
 from .assemblies import *  # noqa: F401,F403  (reference re-exports, optical_table.py:1-3)
 from .components import *  # noqa: F401,F403
 from .components import OpticalComponent
-from .geometry import base_merge_bboxs, _NO_BOX, to_mathematical_str, get_attr_str
+from .geometry import base_merge_bboxs, _NO_BOX, to_mathematical_str, get_attr_str, out_of_scope
 from .monitors import Monitor
 from .rays import Ray
 from .scene import compile_scene
@@ -36,6 +36,11 @@ def _engine():
 
 
 class OpticalTable:
+    render = out_of_scope("render")
+    gather_components = out_of_scope("gather_components")
+    export_components_csv = out_of_scope("export_components_csv")
+    add_wavelength_legend = out_of_scope("add_wavelength_legend")
+
     def __init__(self, **kwargs):
         self.components = []
         self.rays = []

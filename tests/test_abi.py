@@ -84,3 +84,16 @@ def test_frame_transforms_are_host_logic():
     np.testing.assert_allclose(back.origin, ray.origin, atol=1e-14)
     np.testing.assert_allclose(back.direction, ray.direction, atol=1e-14)
     assert back._id == ray._id and back.qo == ray.qo and local is not ray
+
+
+def test_out_of_scope_methods_say_so():
+    """Rendering and component-metadata methods of the reference are not rebuilt; calling one raises a
+    NotImplementedError that names the way out (keep the original package + install())."""
+    import pytest
+    import optable_amd as oa
+
+    table = oa.OpticalTable()
+    for obj, name in ((table, "render"), (table, "gather_components"), (table, "export_components_csv"),
+                      (oa.Mirror([0, 0, 0]), "render"), (oa.Ray([0, 0, 0], [1, 0, 0]), "render"), (oa.Monitor([0, 0, 0], 1, 1), "render")):
+        with pytest.raises(NotImplementedError, match="install"):
+            getattr(obj, name)()
