@@ -21,7 +21,7 @@ for f in glob.glob(out + "/*/*/*_counter_collection.csv"):
         acc[k]["_vgpr"] = [float(r["VGPR_Count"])]
         acc[k]["_grid"] = [float(r["Grid_Size"])]
 for k, c in acc.items():
-    if "k_trace" not in k:
+    if "k_trace" not in k and "k_gen" not in k:
         continue
     print(k)
     for name, v in sorted(c.items()):
