@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
                     help="cfg2 = the bench line; the others are the remaining BASELINE configs at their per-GPU size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU time spent on the oracle baseline (bounded sample)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the real thing) or gloo (rehearsal on a 1-GPU box)")
     args = ap.parse_args()
 
@@ -248,7 +249,8 @@ def main():
             line["gather_ms"] = gather_ms
             line["value_incl_gather"] = segs_total_step * S_LEAVES_W * args.steps / (dt + gather_ms / 1e3)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(table, batch.slice(0, min(n, 200_000)).to_host(), MAX_SEG, S_LEAVES_W, args.workload)
+            line["cpu_baseline"] = cpu_baseline(table, batch.slice(0, min(n, 200_000)).to_host(), MAX_SEG, S_LEAVES_W, args.workload,
+                                                budget_s=args.cpu_seconds)
         print(json.dumps(line), flush=True)
     if distributed:
         dist.destroy_process_group()

@@ -1,0 +1,42 @@
+"""bench.py as the driver runs it (a subprocess printing ONE JSON line), at reduced ray counts so that the test
+takes seconds: the line parses, carries every contract field, and its numbers are self-consistent."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*extra):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--cpu-seconds", "1", *extra],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("workload,rays", [("cfg2", 200_000), ("cfg5", 60_000)])
+def test_bench_line_contract(workload, rays):
+    line = _run("--workload", workload, "--rays", str(rays))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["warmup"] == 1 and line["vs_baseline"] is None
+    assert line["scaling"] == "weak" and line["higher_is_better"] is True and line["data"] == "synthetic"
+    assert line["config"]["rays_per_gpu"] == rays and "model" not in line["config"]
+    roof = line["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+    assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"])
+    # value = segments x leaves x steps / wall time: consistent with ms_per_step
+    segs = line["config"]["segments_per_ray"] * rays
+    assert line["value"] == pytest.approx(segs * line["config"]["leaf_surfaces"] / (line["ms_per_step"] / 1e3), rel=1e-6)
+    # the event-timed launch cannot be longer than the wall-clock step
+    assert roof["kernel_us"] <= line["ms_per_step"] * 1e3 * 1.02
+    cpu = line["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["value"] > 0 and "sample" in cpu
+    assert line["value"] > 50 * cpu["value"]          # a GPU against one host core, even at this size
