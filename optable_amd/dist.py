@@ -30,8 +30,10 @@ def shard_indices_by_id(ids, rank, world):
 
 def final_state(segs):
     """[12, n_rays] tensor: each ray's last segment (non-branching [k][ray] layout)."""
+    if segs.count is None:
+        raise ValueError("final_state needs the [segment][ray] layout of a non-branching trace; a ray tree has no single last segment")
     n = segs.n_rays
-    last = (segs.count.long() - 1).clamp_(min=0) * n + torch.arange(n, device=segs.device)
+    last = (segs.count.long().abs() - 1).clamp_(min=0) * n + torch.arange(n, device=segs.device)
     return torch.stack([segs.field(f)[last] for f in FINAL_FIELDS])
 
 
