@@ -97,3 +97,23 @@ def test_out_of_scope_methods_say_so():
                       (oa.Mirror([0, 0, 0]), "render"), (oa.Ray([0, 0, 0], [1, 0, 0]), "render"), (oa.Monitor([0, 0, 0], 1, 1), "render")):
         with pytest.raises(NotImplementedError, match="install"):
             getattr(obj, name)()
+
+
+def test_product_never_touches_the_oracle_or_the_reference():
+    """The oracle is test infrastructure and the reference cannot travel: nothing under optable_amd/ (Python or
+    HIP sources), nor the build recipe, may import, link or mention either as a code path."""
+    import os
+    import re
+
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "optable_amd")
+    offenders = []
+    for folder, _, files in os.walk(root):
+        for name in files:
+            if not name.endswith((".py", ".h", ".hip", "Makefile")) and name != "Makefile":
+                continue
+            text = open(os.path.join(folder, name), errors="ignore").read()
+            if re.search(r"^\s*(from|import)\s+oracle\b", text, re.M) or "ot_oracle" in text or "libot_oracle" in text:
+                offenders.append(name + ": oracle")
+            if re.search(r"sys\.path\.(insert|append)\([^)]*reference", text) or re.search(r"^\s*import\s+optable\s*$", text, re.M):
+                offenders.append(name + ": reference import")
+    assert not offenders, offenders
