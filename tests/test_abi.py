@@ -117,3 +117,11 @@ def test_product_never_touches_the_oracle_or_the_reference():
             if re.search(r"sys\.path\.(insert|append)\([^)]*reference", text) or re.search(r"^\s*import\s+optable\s*$", text, re.M):
                 offenders.append(name + ": reference import")
     assert not offenders, offenders
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    """Without the built .so there is nothing to run: load() names the missing file and the build command."""
+    monkeypatch.setattr(abi, "LIB_PATH", str(tmp_path / "liboptable_hip.so"))
+    monkeypatch.setattr(abi, "_lib", None)
+    with pytest.raises(abi.EngineUnavailable, match="no CPU fallback"):
+        abi.load()
