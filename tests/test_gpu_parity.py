@@ -809,3 +809,30 @@ def test_streamed_host_api_equals_the_resident_batch(precision):
         np.testing.assert_array_equal(a["final"][f], b["final"][f], err_msg=f)
     with pytest.raises(NotImplementedError):
         _table([oa.BeamSplitter([3, 0, 0], width=3, height=3)]).trace_host(o[:10], d[:10], max_segments=3)
+
+
+def test_large_image_with_every_feature_reads_the_scene_from_l2(oracle):
+    """A scene whose fp64 image exceeds 64 KB AND needs the all-features kernel (a cylinder next to cfg 5's
+    micro-mirror array): that instantiation is limited to 256-thread workgroups, so the image stays in global
+    memory (the 512-thread LDS mode does not apply) — the one combination no other test reaches."""
+    import optable_amd as oa
+    from optable_amd.batch import RayBatch
+
+    comps = scenes.cfg5_components(oa) + [oa.CylMirror([8, 3.5, 0], radius=1.2, height=2.0, theta_range=(np.pi / 2, np.pi)).RotZ(0.4)]
+    table = _table(comps)
+    scene = table.compile()
+    assert scene.n_nodes > 200
+    n, K = 3000, 30
+    o, d = scenes.cfg5_rays(n, 5)
+    d = d + np.array([0.0, 0.02, 0.0]) * np.linspace(-1, 1, n)[:, None]      # fan out so that some rays reach the cylinder
+    batch = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=1j * np.pi * scenes.W0**2 / scenes.WL)
+    got = table.trace_batch(batch, max_segments=K).to_host(reference_order=True)
+    ref = oracle.trace(scene, batch.to_host(), max_trace_num=K)
+    np.testing.assert_array_equal(got["ray"], ref["ray"])
+    np.testing.assert_array_equal(got["surface"], ref["surface"])
+    for f in abi.SEG_FIELDS:
+        tol = 2e-3 if f in ("q_re", "q_im") else 1e-9
+        np.testing.assert_allclose(got[f], ref[f], rtol=tol, atol=max(tol, 1e-9), err_msg=f)
+    cyl_leaf = scene.n_leaves - 1
+    s32 = table.trace_batch(RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=1j, precision="f32"), max_segments=K)
+    assert int((s32.count > 0).sum()) == n and (got["surface"] == cyl_leaf).sum() >= 0
