@@ -282,8 +282,12 @@ def main():
             line["gather_ms"] = gather_ms
             line["value_incl_gather"] = segs_total_step * S_LEAVES_W * args.steps / (dt + gather_ms / 1e3)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(table, batch.slice(0, min(n, 200_000)).to_host(), MAX_SEG, S_LEAVES_W, args.workload,
-                                                budget_s=args.cpu_seconds)
+            try:
+                line["cpu_baseline"] = cpu_baseline(table, batch.slice(0, min(n, 200_000)).to_host(), MAX_SEG, S_LEAVES_W,
+                                                    args.workload, budget_s=args.cpu_seconds)
+            except Exception as exc:  # noqa: BLE001 — the GPU numbers above are still worth printing
+                line["cpu_baseline"] = {"value": None, "unit": "ray-surface intersections/s", "cores": 0, "kind": "port",
+                                        "sample": f"failed: {type(exc).__name__}: {exc}"}
         print(json.dumps(line), flush=True)
     if distributed:
         dist.destroy_process_group()
