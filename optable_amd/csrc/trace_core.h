@@ -1,9 +1,9 @@
 // trace_core.h — device-side ray/scene arithmetic for the gfx950 trace kernels.
 //
 // One lane owns one ray.  The scene (skip-list of nodes, materials, aux records) is staged
-// into LDS once per workgroup and read with wave-uniform indices, so every lane of a wave
-// reads the same LDS words (broadcast, no bank conflicts) while the per-ray state lives in
-// VGPRs.  Templated on the real type (double / float) and on a scene FEATURE MASK: the host
+// into LDS once per workgroup; the plain pass reads it with wave-uniform indices (every lane the
+// same LDS words: broadcast, no bank conflicts), the grid walks with per-lane candidates.  The
+// per-ray state lives in VGPRs.  Templated on the real type (double / float) and on a scene FEATURE MASK: the host
 // looks at what the uploaded scene contains and launches the smallest instantiation that covers
 // it, so a mirrors-and-lenses scene does not carry the registers of the asphere root solver.
 //
@@ -14,7 +14,12 @@
 //                  (component_group.py:93-122, optical_table.py:119-123).
 //   hit_leaf     — OpticalComponent.intersect_point_local (optical_component.py:151-233); the
 //                  reference's 10-point sign scan is kept bracket for bracket, the root inside a
-//                  bracket is polished by a safeguarded Newton iteration instead of brentq.
+//                  bracket is polished by a safeguarded Newton iteration instead of brentq; for
+//                  spheres the same search in closed form (two line-sphere roots + the scan's
+//                  "exactly one root per sample interval" rule).
+//   grid_children, root_grid_hit — acceleration only: 2-D grids over a large group's children and
+//                  over the top-level components; every candidate found through them still gets the
+//                  tests the plain pass applies, ties go to the lower node index.
 //   interact     — BaseMirror / BaseRefraciveSurface / Lens .interact_local
 //                  (optical_component.py:536-570, 617-717, 930-948).
 // Deliberate differences in rounding only (all far inside the 1e-6 parity tolerance):
