@@ -278,6 +278,14 @@ def abcd_4f(ns):
     return dict(components=[l0, l1], monitors=[mon0, mon1], rays=rays, limit=None)
 
 
+def calibrate_case(ns):
+    """Inputs of calibrate_symmetric_4f (optical_table.py:299-422): one bi-convex lens, the 7-ray fan with ids."""
+    lens = ns.BiConvexLens([0, 0, 0], CT=0.6, R1=20.0, R2=-20.0, diameter=5.08, EFL=20.0)
+    rays = [ns.Ray([-10, i * 0.3, 0], [1, 0, 0], wavelength=780e-7, w0=61e-4, id=int(i + 3)).Propagate(-10)
+            for i in np.arange(-3, 4)]
+    return dict(lens=lens, rays=rays, F10=19.7, F20=20.4)
+
+
 def g21_ties(ns):
     """Exact ties: two mirrors in the same plane (the first in list order must win: strict `t < t_min`,
     optical_table.py:119-123) and a group whose two children coincide (np.argmin keeps the first,

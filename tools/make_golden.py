@@ -172,10 +172,26 @@ def interact_fixture():
     print("g20_interact:", names)
 
 
+def calibrate_fixture():
+    """g22: OpticalTable.calibrate_symmetric_4f (optical_table.py:299-422), a caller of the hot path: the cost
+    terms at a fixed (F1, F2) and the Nelder-Mead result for two criteria."""
+    import contextlib
+    import io
+
+    sc = scenes.calibrate_case(ref)
+    out = {}  # (optimize=False renders upstream, :346-359 — plotting, out of scope; the fixed-point matrices are g17)
+    for crit in ("M=-I", "min_stdtY"):
+        with contextlib.redirect_stdout(io.StringIO()):
+            F1, F2 = ref.OpticalTable.calibrate_symmetric_4f(sc["lens"], sc["rays"], sc["F10"], sc["F20"], criterion=crit)
+        out["opt_" + crit.replace("=", "").replace("-", "m")] = np.array([F1, F2])
+    np.savez_compressed(os.path.join(OUT, "g22_calibrate.npz"), **out)
+    print("g22_calibrate:", {k: np.round(v, 5).tolist() if v.size <= 4 else v.shape for k, v in out.items()})
+
+
 if __name__ == "__main__":
     names = sys.argv[1:] or list(scenes.SCENES)
     for nm in names:
-        if nm in ("g14_slab", "g17_abcd", "g20_interact"):
+        if nm in ("g14_slab", "g17_abcd", "g20_interact", "g22_calibrate"):
             continue
         np.random.seed(12345)
         run(nm)
@@ -183,6 +199,9 @@ if __name__ == "__main__":
         slab_vectors()
     if not sys.argv[1:] or "g17_abcd" in sys.argv[1:]:
         abcd_fixture()
+    if not sys.argv[1:] or "g22_calibrate" in sys.argv[1:]:
+        np.random.seed(12345)
+        calibrate_fixture()
     if not sys.argv[1:] or "g20_interact" in sys.argv[1:]:
         np.random.seed(12345)
         interact_fixture()
