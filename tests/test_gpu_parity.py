@@ -893,3 +893,19 @@ def test_calibrate_symmetric_4f_reaches_the_reference_optimum(criterion, key, ca
     assert mine <= theirs * 1.05 + 1e-9, (mine, theirs, (F1, F2), ref_opt.tolist())
     if criterion == "min_stdtY":
         assert F2 == pytest.approx(ref_opt[1], abs=2e-3)       # the direction the cost does depend on
+
+
+def test_monitor_export_rays_npz(tmp_path, capsys):
+    """f4: Monitor.export_rays_npz (monitor.py:255-269) writes the sorted hit lists under the reference's key names."""
+    table, sc = helpers.build("g06_mirror_pair")
+    table.ray_tracing(sc["rays"])
+    mon = next(m for m in table.monitors if m.ndata)
+    path = tmp_path / "hits.npz"
+    mon.export_rays_npz(str(path))
+    capsys.readouterr()
+    data = np.load(path)
+    assert sorted(data.files) == ["IList", "tXList", "tYList", "xList", "yList"]
+    np.testing.assert_array_equal(data["xList"], mon.yList)      # upstream names the monitor's Y axis "x" in the file
+    np.testing.assert_array_equal(data["yList"], mon.zList)
+    np.testing.assert_array_equal(data["tXList"], mon.tYList)
+    np.testing.assert_array_equal(data["IList"], mon.IList)
