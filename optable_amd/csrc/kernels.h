@@ -320,6 +320,36 @@ static constexpr unsigned long long LB_AGG = 1ull << 62, LB_PREFIX = 2ull << 62,
 // the 62-bit value carries two counts: processed rays = segment slots (bits 32..61, n < 2^30) and children (bits 0..31)
 static constexpr int LB_SEG_SHIFT = 32;
 
+// Exclusive prefix of `total` over the tiles before `tile`; publishes this tile's aggregate and inclusive prefix.
+// Called by ONE full wave (all 64 lanes); every lane returns the same value.
+__device__ __forceinline__ unsigned long long lookback_exclusive(const LookBack& lb, int64_t tile, unsigned long long total, int lane) {
+    unsigned long long before = 0;
+    if (tile > 0) {
+        if (lane == 0) __hip_atomic_store(&lb.state[tile], LB_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int64_t wbase = tile - 1;;) {
+            const int64_t idx = wbase - lane;  // lane 0 = nearest predecessor
+            unsigned long long v = LB_PREFIX;  // before tile 0: an inclusive prefix of zero
+            if (idx >= 0) v = __hip_atomic_load(&lb.state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned flag = (unsigned)(v >> 62);
+            const unsigned long long m_prefix = __ballot(flag == 2u), m_empty = __ballot(flag == 0u);
+            unsigned long long need = ~0ull;   // the lanes up to and including the nearest prefix
+            if (m_prefix) {
+                const int pl = __ffsll((long long)m_prefix) - 1;
+                need = pl == 63 ? ~0ull : ((1ull << (pl + 1)) - 1ull);
+            }
+            if (m_empty & need) { __builtin_amdgcn_s_sleep(24); continue; }  // one of them is still working: wait ~0.6 us, read again
+            long long part = ((need >> lane) & 1ull) ? (long long)(v & LB_MASK) : 0ll;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+            before += (unsigned long long)part;
+            if (m_prefix) break;
+            wbase -= 64;
+        }
+    }
+    if (lane == 0) __hip_atomic_store(&lb.state[tile], LB_PREFIX | (before + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return before;
+}
+
 // PROBE = true: the pre-pass that records geometric hits of count-limited leaves (no outputs).
 template <class T, uint32_t F, bool SCENE_IN_LDS, bool PROBE>
 __global__ __launch_bounds__(256) void k_gen_trace(SceneBlob blob, T unit, RaysT<T> in, const int32_t* tree, int64_t n,
@@ -398,31 +428,8 @@ __global__ __launch_bounds__(256) void k_gen_trace(SceneBlob blob, T unit, RaysT
         __syncthreads();
         if (wave == 0) {  // look-back by a whole wave: 64 predecessors per read
             const unsigned long long total = s_wave_total[0] + s_wave_total[1] + s_wave_total[2] + s_wave_total[3];
-            unsigned long long before = 0;
-            if (tile > 0) {
-                if (lane == 0) __hip_atomic_store(&lb.state[tile], LB_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                for (int64_t wbase = tile - 1;;) {
-                    const int64_t idx = wbase - lane;  // lane 0 = nearest predecessor
-                    unsigned long long v = LB_PREFIX;  // before tile 0: an inclusive prefix of zero
-                    if (idx >= 0) v = __hip_atomic_load(&lb.state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const unsigned flag = (unsigned)(v >> 62);
-                    const unsigned long long m_prefix = __ballot(flag == 2u), m_empty = __ballot(flag == 0u);
-                    unsigned long long need = ~0ull;   // the lanes up to and including the nearest prefix
-                    if (m_prefix) {
-                        const int pl = __ffsll((long long)m_prefix) - 1;
-                        need = pl == 63 ? ~0ull : ((1ull << (pl + 1)) - 1ull);
-                    }
-                    if (m_empty & need) { __builtin_amdgcn_s_sleep(24); continue; }  // one of them is still tracing: wait ~0.6 us, read again
-                    long long part = ((need >> lane) & 1ull) ? (long long)(v & LB_MASK) : 0ll;
-#pragma unroll
-                    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-                    before += (unsigned long long)part;
-                    if (m_prefix) break;
-                    wbase -= 64;
-                }
-            }
+            const unsigned long long before = lookback_exclusive(lb, tile, total, lane);
             if (lane == 0) {
-                __hip_atomic_store(&lb.state[tile], LB_PREFIX | (before + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 s_base = (long long)before;
                 if (tile == n_tiles - 1) {  // generation totals for k_gen_finish and the host
                     const unsigned long long all = before + total;
