@@ -89,3 +89,38 @@ def test_install_patches_and_restores(ref):
     assert table.compile().n_leaves == 3
     undo()
     assert ref.OpticalTable.ray_tracing is before and not hasattr(ref.OpticalTable, "compile")
+
+
+def test_reference_ray_objects_round_trip_through_pack_and_scatter(ref):
+    """install() hands the ORIGINAL Ray objects to this package's packing / unpacking code.  Without a GPU the
+    trace in between cannot run here, but both ends can: pack reference rays into a (CPU) RayBatch, then rebuild
+    reference Ray objects from a fabricated segment table and use them through the reference's own methods."""
+    from optable_amd.table import _pack, _scatter_segments, _clone_rays
+
+    rays = [ref.Ray([0, 0.1 * k, 0], [1, 0.01 * k, 0], wavelength=780e-7, w0=50e-4, id=7 + k) for k in range(3)]
+    rays.append(ref.Ray([1, 2, 3], [0, 1, 0], alive=False, length=2.5))          # no wavelength, no q, dead, finite
+    batch = _pack(rays, np.arange(4, dtype=np.int32), "cpu")
+    np.testing.assert_allclose(batch.oy.numpy(), [0.0, 0.1, 0.2, 2.0])
+    np.testing.assert_allclose(batch.dx.numpy()[:3], [r.direction[0] for r in rays[:3]])
+    assert batch.flags.tolist() == [abi.RAY_HAS_Q] * 3 + [abi.RAY_DEAD]
+    assert batch.length is not None and batch.length.tolist()[3] == 2.5 and np.isinf(batch.length.tolist()[0])
+    np.testing.assert_allclose(batch.q_im.numpy()[:3], [complex(r.qo).imag for r in rays[:3]])
+    segs = {"ray": np.array([0, 0, 2], dtype=np.int32), "surface": np.array([4, -1, -1], dtype=np.int32),
+            "ox": np.array([0.0, 5.0, 0.0]), "oy": np.array([0.0, 0.05, 0.2]), "oz": np.zeros(3),
+            "dx": np.array([1.0, -1.0, 1.0]), "dy": np.zeros(3), "dz": np.zeros(3),
+            "length": np.array([5.0, np.inf, np.inf]), "intensity": np.array([1.0, 0.5, 1.0]),
+            "q_re": np.array([0.0, 5.0, 0.0]), "q_im": np.array([1.0, 1.0, 1.0]),
+            "n": np.array([1.0, 1.5, 1.0]), "pathlength": np.array([0.0, 5.0, 0.0])}
+    per_ray = [None] * 4
+    _scatter_segments(segs, rays, np.arange(4), per_ray)
+    assert [len(p) for p in per_ray] == [2, 0, 1, 0]
+    first, second = per_ray[0]
+    assert type(first) is type(rays[0]) and first._id == rays[0]._id == 7
+    assert first.length == 5.0 and first.alive is False and second.length is None and second.alive is True
+    assert second.n == 1.5 and second.intensity == 0.5                          # the reference's own `n` property
+    assert second.pathlength(2.0) == pytest.approx(5.0 + 2.0 * 1.5)             # and its pathlength(t)
+    assert complex(second.q_at_z(1.0)) == pytest.approx(6 + 1j)
+    np.testing.assert_allclose(second.direction, [-1, 0, 0])
+    clones = _clone_rays(per_ray[0])
+    clones[0].origin[0] = 99.0
+    assert per_ray[0][0].origin[0] == 0.0                                        # the returned list is independent
