@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define OT_ABI_VERSION 3  /* 3: ot_trace_generation_f32 */
+#define OT_ABI_VERSION 4  /* 3: ot_trace_generation_f32; 4: ot_bench_stream_f32 */
 
 /* ---- status codes ------------------------------------------------------------------- */
 enum ot_status {
@@ -266,6 +266,8 @@ int ot_set_option(ot_ctx* ctx, int32_t option, int32_t value);
 /* Roofline companion of ot_trace_f64: the same streams (one ray record in, max_segments segment
  * records out per ray) with no tracing in between — the ceiling of this access pattern. */
 int ot_bench_stream_f64(ot_ctx* ctx, const ot_rays* rays, int64_t n_rays, int32_t max_segments,
+                        const ot_segments* out, int32_t* seg_count);
+int ot_bench_stream_f32(ot_ctx* ctx, const ot_rays* rays, int64_t n_rays, int32_t max_segments,
                         const ot_segments* out, int32_t* seg_count);
 
 #ifdef __cplusplus

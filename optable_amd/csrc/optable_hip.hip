@@ -726,7 +726,10 @@ int ot_set_option(ot_ctx* c, int32_t option, int32_t value) {
     }
 }
 
-int ot_bench_stream_f64(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, const ot_segments* out, int32_t* seg_count) {
+}  // extern "C"
+
+template <class T>
+static int bench_stream(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, const ot_segments* out, int32_t* seg_count) {
     if (!c) return fail(OT_ERR_INVALID, "ctx is NULL");
     int rc = check_rays(rays, "rays");
     if (rc) return rc;
@@ -740,11 +743,20 @@ int ot_bench_stream_f64(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, co
     rc = timing_begin(c);
     if (rc) return rc;
     if (c->opt_nt)
-        hipLaunchKernelGGL((k_stream_ceiling<double, true>), dim3(grid), dim3(block), 0, c->stream, view<double>(rays), n, K, view<double>(out), seg_count);
+        hipLaunchKernelGGL((k_stream_ceiling<T, true>), dim3(grid), dim3(block), 0, c->stream, view<T>(rays), n, K, view<T>(out), seg_count);
     else
-        hipLaunchKernelGGL((k_stream_ceiling<double, false>), dim3(grid), dim3(block), 0, c->stream, view<double>(rays), n, K, view<double>(out), seg_count);
+        hipLaunchKernelGGL((k_stream_ceiling<T, false>), dim3(grid), dim3(block), 0, c->stream, view<T>(rays), n, K, view<T>(out), seg_count);
     HIP_TRY(hipGetLastError());
     return timing_end(c);
+}
+
+extern "C" {
+
+int ot_bench_stream_f64(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, const ot_segments* out, int32_t* seg_count) {
+    return bench_stream<double>(c, rays, n, K, out, seg_count);
+}
+int ot_bench_stream_f32(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, const ot_segments* out, int32_t* seg_count) {
+    return bench_stream<float>(c, rays, n, K, out, seg_count);
 }
 
 int ot_timing_enable(ot_ctx* c, int enabled) {

@@ -209,7 +209,8 @@ class Engine:
         if out.count is None or out.count.numel() != rays.n:
             out.count = torch.empty(rays.n, dtype=torch.int32, device=rays.device)
         rs, ss = rays.c_struct(), out.c_struct()
-        abi.check(self.lib.ot_bench_stream_f64(self._ctx, C.byref(rs), rays.n, int(max_segments), C.byref(ss),
+        fn = self.lib.ot_bench_stream_f64 if rays.precision == "f64" else self.lib.ot_bench_stream_f32
+        abi.check(fn(self._ctx, C.byref(rs), rays.n, int(max_segments), C.byref(ss),
                                                out.count.data_ptr()), self.lib)
 
     def synchronize(self):

@@ -67,13 +67,13 @@ def _run(name, comps, o, d, wl, K, prec, reps=5):
         segs = int(out.count.sum().item())
         t = ms / cnt / 1e3
         mode = "fused"
-        if prec == "f64" and os.environ.get("CEILING"):  # the same streams with no tracing (fixed K records per ray)
+        if os.environ.get("CEILING"):  # the same streams with no tracing (fixed K records per ray)
             eng.timing(True)
             for _ in range(reps):
                 eng.stream_ceiling(batch, K, out)
             cms, ccnt = eng.timing_read()
             eng.timing(False)
-            cb = n * 104 + n * K * 104
+            cb = n * b + n * K * b
             print(f"   stream ceiling for n={n} K={K}: {cms / ccnt:.3f} ms = {cb / (cms / ccnt / 1e3) / 1e9:.0f} GB/s "
                   f"(trace moves {(n * b + segs * b) / 1e9:.2f} GB in {t * 1e3:.3f} ms)", flush=True)
             eng.trace(batch, K, out=out)
