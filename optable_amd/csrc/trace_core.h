@@ -141,8 +141,11 @@ __device__ __forceinline__ double div_t(double a, double b) {
     const double q = a * r;
     return fma(fma(-b, q, a), r, q);
 }
-__device__ __forceinline__ float rcp_t(float b) { return 1.0f / b; }
-__device__ __forceinline__ float div_t(float a, float b) { return a / b; }
+// fp32: the hardware reciprocal (v_rcp_f32, 1 ulp) instead of the ~10-instruction IEEE division sequence.  The
+// single-precision kernels are VALU-bound where the double-precision ones are HBM-bound (cfg 2: 80 % of the fp32
+// stream ceiling), and their contract is a tolerance against fp64, not correctly rounded quotients.
+__device__ __forceinline__ float rcp_t(float b) { return __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ float div_t(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 
 // ---------------------------------------------------------------------------------------------
 // solver.py:5-48 with the per-axis reciprocal hoisted out (RayInv is built once per segment).
