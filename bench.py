@@ -1,68 +1,83 @@
 #!/usr/bin/env python3
 """bench.py — ray-surface intersections/s of the OpticalTable.ray_tracing hot path on MI355X.
 
-Workload (BASELINE.json configs[1], SURVEY.md §8d cfg 2): 1e6 rays from a point source at the
-focus of Lens([5,0,0], f=5, r=1) followed by MirrorPair([10,0,0], 4, 4); S = 3 leaf surfaces;
-cap 5 segments (every ray uses exactly 5); fp64; inputs resident in HBM before the timed region.
-A "step" is one trace of the whole batch (one launch of k_trace_fused<double>).
+Headline workload (BASELINE.json configs[1], SURVEY.md §8d cfg 2): 1e6 rays from a point source at the focus of
+Lens([5,0,0], f=5, r=1) followed by MirrorPair([10,0,0], 4, 4); S = 3 leaf surfaces; cap 5 segments (every ray
+uses exactly 5); fp64; inputs resident in HBM before the timed region.  A "step" is one trace of one whole batch
+(one launch of k_trace_fused<double>); consecutive steps rotate through several distinct input / output batches
+(> 256 MiB of inputs in total) so that no step can be served from the Infinity Cache.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4|cfg5]
-(`--workload`: the other BASELINE configs at their per-GPU size, same JSON line; the default is the bench line.)
-For N > 1 it is launched by torch.distributed.run, one rank per GPU; every rank traces its own
-1e6-ray shard (weak scaling, no collective in the data path); the single end-of-job gather of the
-per-ray final state over RCCL is timed separately and reported as `gather_ms`.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4|cfg5] [--rays R]
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (a child
+`python -m torch.distributed.run`, before this process has touched the GPU); under a launcher (WORLD_SIZE set) the
+process is one rank.  cfg 2 / cfg 3 scale weakly (every rank traces the config's full size); cfg 4 / cfg 5 name a
+TOTAL (6.4e8 ray-wavelength pairs, 1e8 rays) that is sharded over the ranks (`"scaling": "strong"`).  No
+collective in the data path; the single end-of-job gather of the per-ray final state over RCCL is timed
+separately (`gather_ms`).  The default N = 1 run also measures the other BASELINE configs at the size one GPU sees
+(`configs`), a >= 1 s sustained loop (`sustained`), the cold-start figure (`cold`) and the CPU baseline.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(1, os.path.join(ROOT, "tests"))
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
-N_RAYS = 1_000_000
-BYTES_RAY = 104  # fp64: 12 reals + id + flags   
-BYTES_SEG = 104  # fp64: 12 reals + ray + surface
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BYTES = {"f64": 104, "f32": 56}  # 12 reals + two int32 per ray record and per segment record
+PRELOAD_LAUNCHES = 500  # cfg 2 only: ~60 ms of load so the chip reaches its steady clocks before the W warmup steps
+# size ONE GPU sees in the configuration BASELINE.json quotes (cfg 4: the 4-GPU shard; cfg 5: the 8-GPU shard)
+QUOTED_SHARD = {"cfg3": 10_000_000, "cfg4": 160_000_000, "cfg5": 12_500_000}
+# most rays one rank takes (HBM: rays + the full [k][ray] history must fit 288 GB with headroom)
+MAX_PER_RANK = {"cfg2": 50_000_000, "cfg3": 50_000_000, "cfg4": 320_000_000, "cfg5": 25_000_000}
+# the reference itself (pure Python), single thread, measured by importing /root/reference in the build container
+# (it cannot travel to the GPU box): segments/s per config
+REFERENCE_PYTHON_SEG_S = {"cfg2": 3.0e3, "cfg3": 434.0, "cfg4": 2.7e3, "cfg5": 593.0}
 
 
-def workloads(scenes, oa):
-    """name -> (components, rays(n, seed) -> (origins, directions, wavelengths), segment cap, precision, rays per
-    GPU, description).  `cfg2` is the bench line (BASELINE.json configs[1]); the others are the remaining BASELINE
-    configs at the size ONE GPU sees in the quoted configuration (`--workload`) — not the driver's
-    default."""
-    def cfg4_rays(n, seed):
-        nwl = 64
-        nb = max(n // nwl, 1)
-        rng = np.random.default_rng(4 + seed)
-        jit = rng.uniform(-0.3, 0.3, (nb, 2))
-        o = np.stack([np.full(nb, -3.0), 2 + jit[:, 0], jit[:, 1]], 1)
-        d = np.tile([np.cos(np.pi / 6), -np.sin(np.pi / 6), 0.0], (nb, 1))
-        return np.tile(o, (nwl, 1)), np.tile(d, (nwl, 1)), np.repeat(np.linspace(400e-7, 1100e-7, nwl), nb)
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rays", type=int, default=None, help="rays per GPU (default: from the workload and the world size)")
+    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
+                    help="cfg2 = the bench line; the others are the remaining BASELINE configs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the cfg3/cfg4/cfg5 survey of the default run")
+    ap.add_argument("--no-sustained", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU time spent on the oracle baseline (bounded sample)")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the real thing) or gloo (rehearsal: ranks may share a card)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / sharding / gather rehearsal without a GPU: no trace, fabricated per-ray state (tests)")
+    return ap.parse_args(argv)
 
-    plain = lambda gen, base: (lambda n, seed: gen(n, base + seed) + (scenes.WL,))
-    slab = lambda: [oa.GlassSlab([0, 0, 0], width=2, height=2, thickness=0.5, n1=oa.Vacuum(), n2=oa.Glass_NBK7(), reflectivity=0)]
-    return {
-        "cfg2": (lambda: scenes.cfg2_components(oa), plain(scenes.cfg2_rays, 0), 5, "f64", N_RAYS,
-                 "cfg2: 1e6 point-source rays -> Lens + MirrorPair (S=3 leaves), 5-segment cap"),
-        "cfg3": (lambda: scenes.cfg3_components(oa), plain(scenes.cfg3_rays, 2), 20, "f32", 10_000_000,
-                 "cfg3: 1e7 rays, 32 mixed components (S=56 leaves), 20-segment cap, fp32"),
-        "cfg4": (slab, cfg4_rays, 3, "f64", 160_000_000,
-                 "cfg4: 2.5e6 rays x 64 wavelengths per GPU (the 4-GPU shard of 1e7 x 64) through an N-BK7 slab, fp64"),
-        "cfg5": (lambda: scenes.cfg5_components(oa), plain(scenes.cfg5_rays, 3), 50, "f32", 12_500_000,
-                 "cfg5: 1.25e7 rays per GPU (the 8-GPU shard of 1e8), asphere + MMA 16x16 (S=260 leaves), 50-segment cap, fp32"),
-    }
+
+def launch_ranks(args, argv):
+    """Start `args.gpus` ranks of this script and wait for them.  Runs before anything here has initialised HIP
+    (importing torch does not), as a CHILD process: a process that touched the GPU must never exec another."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(table, batch_host, max_seg, n_leaves, label, budget_s=10.0):
     """The oracle (CPU restatement, single thread) on the same workload, timed on this box's host."""
+    from concurrent.futures import ThreadPoolExecutor
+
     from oracle import oracle as orc
 
     orc.build()
@@ -83,13 +98,9 @@ def cpu_baseline(table, batch_host, max_seg, n_leaves, label, budget_s=10.0):
             "sample": f"{rays} rays of the same {label} batch ({segs} segments) in {dt:.2f} s, C oracle, 1 thread; "
                       f"host has {os.cpu_count()} cores",
             "segments_per_s": segs / dt}
-    # the same restatement on several host cores (rays are independent: every thread traces its own slice of the sample; the
-    # oracle is stateless C and ctypes releases the GIL) — BASELINE.md §4 asks for both figures
-    from concurrent.futures import ThreadPoolExecutor
-
+    # the same restatement on several host cores (rays are independent: every thread traces its own slice of the
+    # sample; the oracle is stateless C and ctypes releases the GIL) — BASELINE.md §4 asks for both figures
     threads = max(1, min(16, (os.cpu_count() or 1)))
-    # ~25k rays per call and thread: long enough to amortise the GIL hand-offs around each call, small enough that the
-    # threads do not serialise in the kernel on page faults of freshly allocated 100-MB output arrays
     m = len(sample["ox"])
     per = max(1, min(25_000, m))
     shards = [{k: v[(i * per) % max(m - per + 1, 1):(i * per) % max(m - per + 1, 1) + per] for k, v in sample.items()}
@@ -104,9 +115,8 @@ def cpu_baseline(table, batch_host, max_seg, n_leaves, label, budget_s=10.0):
                 return done
 
     with ThreadPoolExecutor(threads) as pool:
-        # untimed warm-up: the first multi-threaded seconds of a process run nearly serialised (every call mmaps and
-        # page-faults fresh output arrays until glibc's dynamic mmap threshold has grown and the arenas exist);
-        # measured 5.6 -> 47 M segments/s on 8 threads between the first and the second second
+        # untimed warm-up: the first multi-threaded seconds of a process run nearly serialised (page faults of
+        # fresh output arrays until glibc's mmap threshold has grown)
         deadline[0] = time.perf_counter() + min(2.0, budget_s / 4)
         list(pool.map(work, shards))
         deadline[0] = time.perf_counter() + budget_s / 3
@@ -115,176 +125,329 @@ def cpu_baseline(table, batch_host, max_seg, n_leaves, label, budget_s=10.0):
         dt_mt = time.perf_counter() - t1
     base["multithread"] = {"value": total * n_leaves / dt_mt, "cores": threads, "segments_per_s": total / dt_mt,
                            "sample": f"{total} segments in {dt_mt:.2f} s on {threads} threads"}
+    ref = REFERENCE_PYTHON_SEG_S.get(label)
+    if ref:
+        base["reference_python"] = {
+            "value": ref * n_leaves, "segments_per_s": ref, "cores": 1, "kind": "reference",
+            "provenance": "the reference package itself (pure Python), imported from /root/reference in the build "
+                          "container (8 host cores, Python 3.10, numpy 2.2), single thread, same scene and generator at "
+                          "400-3200 rays; BASELINE.md §2 / SURVEY.md §6.  Not measured on this box: the reference does "
+                          "not travel to it."}
     return base
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--rays", type=int, default=None, help="rays per GPU (default: the workload's own size)")
-    ap.add_argument("--workload", default="cfg2", choices=["cfg2", "cfg3", "cfg4", "cfg5"],
-                    help="cfg2 = the bench line; the others are the remaining BASELINE configs at their per-GPU size")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU time spent on the oracle baseline (bounded sample)")
-    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the real thing) or gloo (rehearsal on a 1-GPU box)")
-    args = ap.parse_args()
+def make_batch(oa, wl, n, rank, device, seed_shift=0):
+    """This rank's rays of workload `wl` as a device-resident RayBatch."""
+    import numpy as np
+    from optable_amd import workloads as W
+    from optable_amd.batch import RayBatch
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if wl.name == "cfg4":  # base rays on the host, the 64 wavelength copies made on the device (ray.py:428-445)
+        nb = max(n // W.CFG4_WAVELENGTHS, 1)
+        o, d, _ = W.cfg4_rays(nb, 4 + rank + seed_shift, n_wavelengths=1)
+        base = RayBatch.from_arrays(o, d, wavelength=W.WL, q=1j * np.pi * W.W0**2 / W.WL, precision=wl.precision, device=device)
+        return base.multiplexed_in_wavelength(np.linspace(400e-7, 1100e-7, W.CFG4_WAVELENGTHS))
+    o, d, lam = wl.rays(n, rank + seed_shift)
+    return RayBatch.from_arrays(o, d, wavelength=lam, q=1j * np.pi * W.W0**2 / lam, precision=wl.precision, device=device)
+
+
+def kernel_name(scene, wl):
+    heavy = scene.n_nodes >= 24
+    return ("k_trace_blocked" if heavy else "k_trace_fused") + ("<double>" if wl.precision == "f64" else "<float>")
+
+
+def committed_counters(name):
+    """SQ-counter summary of this workload committed under profiles/ (tools/profile_configs.sh), or None."""
+    path = os.path.join(ROOT, "profiles", f"r02_{name}_counters.json")
+    if os.path.exists(path):
+        rec = json.load(open(path))
+        rec["source"] = os.path.relpath(path, ROOT)
+        return rec
+    return None
+
+
+def survey_config(oa, eng, name, device):
+    """One of the other BASELINE configs at the size one GPU sees in the quoted configuration: device time per
+    trace (library HIP events around every launch), segments/s, algorithmic GB/s."""
+    import torch
+    from optable_amd import workloads as W
+    from optable_amd.batch import SegmentBatch
+
+    wl = W.baseline_workloads(oa)[name]
+    n = QUOTED_SHARD[name]
+    table = oa.OpticalTable()
+    table.add_components(wl.components())
+    scene = table.compile()
+    eng.upload(scene)
+    batch = make_batch(oa, wl, n, 0, device)
+    n = batch.n
+    out = SegmentBatch(n * wl.max_segments, wl.precision, batch.device)
+    t_load = time.perf_counter()
+    while time.perf_counter() - t_load < 0.06:  # clocks up
+        eng.trace(batch, wl.max_segments, out=out)
+        torch.cuda.synchronize()
+    reps = 5 if name == "cfg3" else 3
+    eng.timing(True)
+    for _ in range(reps):
+        eng.trace(batch, wl.max_segments, out=out)
+    ms, cnt = eng.timing_read()
+    eng.timing(False)
+    segs = int(out.count.abs().sum().item())
+    t = ms / cnt / 1e3
+    b = BYTES[wl.precision]
+    alg = n * b + segs * b
+    rec = {"workload": wl.label, "rays": n, "dtype": wl.precision, "kernel": kernel_name(scene, wl), "leaf_surfaces": scene.n_leaves,
+           "launches": cnt, "ms_per_trace": t * 1e3, "segments_per_ray": segs / n, "segments_per_s": segs / t,
+           "intersections_per_s": segs * scene.n_leaves / t, "algorithmic_gbs": alg / t / 1e9,
+           "hbm_frac": alg / t / 1e9 / HBM_PEAK_GBS,
+           "bound": "hbm" if scene.n_nodes < 24 else "valu/latency (S >= 24, SURVEY.md §8d): the HBM fraction is for comparison"}
+    counters = committed_counters(name)
+    if counters:
+        rec["sq_counters"] = counters
+    del out, batch
+    torch.cuda.empty_cache()
+    return rec
+
+
+def main():
+    args = parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
+    world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                 f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
     distributed = world > 1
-    if args.backend == "gloo":  # rehearsal: several ranks may share one card
-        local_rank %= torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
+
+    import numpy as np
+    import torch
+
+    if not args.dry_run:
+        if args.backend == "gloo":  # rehearsal: several ranks may share one card
+            local_rank %= max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(local_rank)
     if distributed:
         import torch.distributed as dist
 
-        if args.backend == "nccl":
+        if args.backend == "nccl" and not args.dry_run:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo")
-    comm_dev = torch.device("cuda", local_rank) if args.backend == "nccl" else torch.device("cpu")
+    use_nccl = args.backend == "nccl" and not args.dry_run
+    comm_dev = torch.device("cuda", local_rank) if use_nccl else torch.device("cpu")
 
     import optable_amd as oa
-    from optable_amd.batch import RayBatch, SegmentBatch
-    from optable_amd.engine import get_engine
     from optable_amd import dist as odist
-    import scenes
+    from optable_amd import workloads as W
 
-    comps, gen_rays, MAX_SEG, prec, n_default, label = workloads(scenes, oa)[args.workload]
-    n = args.rays if args.rays else n_default
-    bytes_rec = BYTES_RAY if prec == "f64" else 56  # 12 reals + two int32 per record
+    wl = W.baseline_workloads(oa)[args.workload]
+    n = min(wl.rays_per_rank(world, args.rays), MAX_PER_RANK[wl.name])
+    if wl.name == "cfg4":
+        n = max(n // W.CFG4_WAVELENGTHS, 1) * W.CFG4_WAVELENGTHS
+    MAX_SEG, prec, bytes_rec = wl.max_segments, wl.precision, BYTES[wl.precision]
     table = oa.OpticalTable()
-    table.add_components(comps())
-    o, d, wl = gen_rays(n, rank)  # every rank its own shard of the job
-    n = len(o)
-    batch = RayBatch.from_arrays(o, d, wavelength=wl, q=1j * np.pi * scenes.W0**2 / wl, precision=prec,
-                                 device=f"cuda:{local_rank}")
-    del o, d
-    eng = get_engine(local_rank)
+    table.add_components(wl.components())
     scene = table.compile()
-    S_LEAVES_W = scene.n_leaves
-    eng.upload(scene)
-    out = SegmentBatch(n * MAX_SEG, prec, batch.device)
+    S_LEAVES = scene.n_leaves
+    extra = {}
 
-    # The chip takes tens of milliseconds of sustained load to reach its steady clocks (kernel time
-    # 122 -> 109 us between 5 and 300 launches of pre-load on the same device), so load it for
-    # ~60 ms first; then the contract's W untimed warmup steps.
-    if args.workload == "cfg2":
-        for _ in range(500):
-            eng.trace(batch, MAX_SEG, out=out)
-    else:  # millisecond-scale launches: load the chip for the same ~60 ms
-        t_load = time.perf_counter()
-        while time.perf_counter() - t_load < 0.06:
-            eng.trace(batch, MAX_SEG, out=out)
-            torch.cuda.synchronize()
-    torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        eng.trace(batch, MAX_SEG, out=out)
-    # Timed region: K launches back to back, bracketed by barrier + synchronize (wall clock -> `value`) and by one
-    # pair of HIP events on the launch stream (the engine launches on torch's current stream, so torch.cuda.Event
-    # records there) -> average launch duration for the roofline.  Per-launch event pairs are NOT attached here:
-    # they cost ~5 us between consecutive 100-us kernels (measured: 105.7 vs 100.5 us per step).
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        eng.trace(batch, MAX_SEG, out=out)
-    ev1.record()
-    torch.cuda.synchronize()
-    if distributed:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    region_ms = ev0.elapsed_time(ev1)
-    # the same K launches again with a HIP event pair around every launch (library timing): the pure kernel
-    # duration, the number rocprofv3 reports
-    eng.timing(True)
-    for _ in range(args.steps):
-        eng.trace(batch, MAX_SEG, out=out)
-    kernel_ms, launches = eng.timing_read()
-    # roofline companion: the same streams with no tracing (what this access pattern can reach)
-    eng.timing_reset()
-    ceil_ms, ceil_n = 0.0, 0
-    if args.workload in ("cfg2", "cfg4"):  # the HBM-bound workloads: every ray fills its K slots, like the companion kernel
-        for _ in range(10 if args.workload == "cfg2" else 3):
-            eng.stream_ceiling(batch, MAX_SEG, out)
-        ceil_ms, ceil_n = eng.timing_read()
-    eng.timing(False)
-    eng.trace(batch, MAX_SEG, out=out)  # leave real results in `out`
+    if args.dry_run:
+        # no device: pretend every ray used its whole budget, keep the launcher, the shard sizes and the collective real
+        t0 = time.perf_counter()
+        time.sleep(0.01)
+        dt = time.perf_counter() - t0
+        segs_step, region_ms, kernel_ms, launches, ceil_ms, ceil_n = n * MAX_SEG, dt * 1e3, dt * 1e3, args.steps, 0.0, 0
+        local_final = torch.full((12, min(n, 50_000)), float(rank), dtype=torch.float64)  # a bounded stand-in block
+        n_inputs = 1
+    else:
+        from optable_amd.batch import SegmentBatch
+        from optable_amd.engine import get_engine
 
-    segs_step = int(out.count.sum().item())
+        device = f"cuda:{local_rank}"
+        eng = get_engine(local_rank)
+        eng.upload(scene)
+        # distinct batches to rotate through: > 256 MiB of inputs in total, so a step's reads cannot come from the
+        # Infinity Cache (cfg 2: 104 MB each -> 4; the larger workloads exceed it with one)
+        n_inputs = max(1, min(4, -(-300_000_000 // (n * bytes_rec))))
+        batches = [make_batch(oa, wl, n, rank, device, seed_shift=1000 * k) for k in range(n_inputs)]
+        n = batches[0].n
+        outs = [SegmentBatch(n * MAX_SEG, prec, batches[0].device) for _ in range(n_inputs)]
+
+        def step(s):
+            eng.trace(batches[s % n_inputs], MAX_SEG, out=outs[s % n_inputs])
+
+        # cold: what a caller sees right after the upload — one launch to load the code object, then the next 20
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        step(0)
+        torch.cuda.synchronize()
+        ev0.record()
+        for s in range(20):
+            step(s)
+        ev1.record()
+        torch.cuda.synchronize()
+        extra["cold"] = {"us_per_step": ev0.elapsed_time(ev1) / 20 * 1e3, "steps": 20,
+                         "note": "first 20 launches after one code-object-loading launch, no pre-load: the chip is still "
+                                 "below its steady clocks"}
+        # The chip takes tens of milliseconds of sustained load to reach its steady clocks (kernel time 122 -> 109 us
+        # between 5 and 300 launches of pre-load on the same device): load it for ~60 ms, then the W warmup steps.
+        preload = 0
+        if wl.name == "cfg2":
+            for s in range(PRELOAD_LAUNCHES):
+                step(s)
+            preload = PRELOAD_LAUNCHES
+        else:
+            t_load = time.perf_counter()
+            while time.perf_counter() - t_load < 0.06:
+                step(preload)
+                preload += 1
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        extra["preload_launches"] = preload
+        for s in range(args.warmup):
+            step(s)
+        # Timed region: K launches back to back, bracketed by barrier + synchronize (wall clock -> `value`) and by ONE
+        # pair of HIP events on the launch stream (the engine launches on torch's current stream, so
+        # torch.cuda.Event records there) -> average launch duration for the roofline.
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev0.record()
+        for s in range(args.steps):
+            step(s)
+        ev1.record()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        region_ms = ev0.elapsed_time(ev1)
+        # the same K launches again with a HIP event pair around every launch (library timing): the pure kernel
+        # duration, the number rocprofv3 reports
+        eng.timing(True)
+        for s in range(args.steps):
+            step(s)
+        kernel_ms, launches = eng.timing_read()
+        eng.timing_reset()
+        ceil_ms, ceil_n = 0.0, 0
+        if scene.n_nodes < 24:  # the HBM-bound workloads: the same streams with no tracing (every ray fills its K slots)
+            for s in range(10 if wl.name == "cfg2" else 3):
+                eng.stream_ceiling(batches[s % n_inputs], MAX_SEG, outs[s % n_inputs])
+            ceil_ms, ceil_n = eng.timing_read()
+        eng.timing(False)
+        if world == 1 and not args.no_sustained:
+            # >= 1 s of back-to-back launches: long enough for any outside sampler to see the GPU busy, and the
+            # figure a long job gets
+            t_s = time.perf_counter()
+            done = 0
+            chunk = max(1, int(0.02 / max(dt / args.steps, 1e-6)))  # ~20 ms of launches between host syncs
+            while time.perf_counter() - t_s < 1.0:
+                for s in range(chunk):
+                    step(done + s)
+                done += chunk
+                torch.cuda.synchronize()
+            dt_s = time.perf_counter() - t_s
+            extra["sustained"] = {"seconds": dt_s, "steps": done, "ms_per_step": dt_s / done * 1e3}
+        step(0)  # leave real results in outs[0]
+        torch.cuda.synchronize()
+        segs_step = int(outs[0].count.abs().sum().item())
+        local_final = None
+
     gather_ms = gather_error = None
     if distributed:
         tmax = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        tot = torch.tensor([segs_step], dtype=torch.int64, device=comm_dev)
+        n_gather = n if local_final is None else local_final.shape[1]
+        tot = torch.tensor([segs_step, n, n_gather], dtype=torch.int64, device=comm_dev)
         dist.all_reduce(tot)
-        segs_total_step = int(tot.item())
-        # the one collective of the job: per-ray final state to rank 0 (outside the timed steps).  It is
-        # not part of `value`; if it fails the trace numbers are still reported, with the error beside them.
+        segs_total_step, rays_total, gather_total = (int(x) for x in tot.tolist())
+        # the one collective of the job: per-ray final state to rank 0 (outside the timed steps).  It is not part
+        # of `value`; if it fails the trace numbers are still reported, with the error beside them.
         try:
-            local = odist.final_state(out)
-            torch.cuda.synchronize()
+            local = local_final if local_final is not None else odist.final_state(outs[0])
+            if not args.dry_run:
+                torch.cuda.synchronize()
             dist.barrier()
             g0 = time.perf_counter()
             gathered = odist.gather_final_state(local, dst=0)
-            torch.cuda.synchronize()
+            if not args.dry_run:
+                torch.cuda.synchronize()
             dist.barrier()
             gather_ms = (time.perf_counter() - g0) * 1e3
-            if rank == 0 and tuple(gathered.shape) != (12, n * world):
-                gather_error = f"gathered shape {tuple(gathered.shape)} != {(12, n * world)}"
+            if rank == 0:
+                extra["gathered_shape"] = list(gathered.shape)
+                if tuple(gathered.shape) != (12, gather_total):
+                    gather_error = f"gathered shape {tuple(gathered.shape)} != {(12, gather_total)}"
         except Exception as exc:  # noqa: BLE001 — reported in the JSON line
             gather_error = f"{type(exc).__name__}: {exc}"
     else:
-        segs_total_step = segs_step
+        segs_total_step, rays_total = segs_step, n
 
     if rank == 0:
-        is_cfg2 = args.workload == "cfg2"
-        value = segs_total_step * S_LEAVES_W * args.steps / dt
+        value = segs_total_step * S_LEAVES * args.steps / dt
         avg_kernel_s = region_ms / args.steps / 1e3             # HIP events over the timed region, incl. launch gaps
         per_launch_us = kernel_ms / max(launches, 1) * 1e3      # event pair per launch, companion loop
-        alg_bytes = n * bytes_rec + segs_step * bytes_rec  # per launch, this rank
+        alg_bytes = n * bytes_rec + segs_step * bytes_rec       # per launch, this rank
         achieved = alg_bytes / avg_kernel_s / 1e9
-        traffic = None
+        traffic = traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "traffic_cfg2_f64.json")
-        if is_cfg2 and os.path.exists(tpath):  # PMC-measured HBM bytes exist for the bench workload only
+        if wl.name == "cfg2" and os.path.exists(tpath):  # PMC-measured HBM bytes exist for the bench workload only
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        heavy = args.workload in ("cfg3", "cfg5")
-        kernel = ("k_trace_blocked" if heavy else "k_trace_fused") + ("<double>" if prec == "f64" else "<float>")
+            traffic_source = ("profiles/traffic_cfg2_f64.json: rocprofv3 --pmc passes of this workload (FETCH_SIZE x 2 + "
+                              "WRITE_SIZE, calibrated on k_stream_ceiling), committed — not re-measured by this run")
+        heavy = scene.n_nodes >= 24
         line = {
             "metric": "ray-surface intersections/sec", "value": value, "unit": "intersections/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": prec, "data": "synthetic",
-            "config": {"workload": label,
-                       "rays_per_gpu": n, "segments_per_ray": segs_step / n, "leaf_surfaces": S_LEAVES_W,
+            "higher_is_better": True, "scaling": wl.scaling, "vs_baseline": None, "dtype": prec, "data": "synthetic",
+            "config": {"workload": wl.label, "rays_per_gpu": n, "rays_total": rays_total,
+                       "segments_per_ray": segs_step / n, "leaf_surfaces": S_LEAVES, "input_batches_rotated": n_inputs,
                        "parallelism": f"ray-shard x{world}, scene replicated"},
             "segments_per_s": segs_total_step * args.steps / dt,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": kernel, "kernel_us": avg_kernel_s * 1e6, "kernel_us_per_launch_events": per_launch_us,
-                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": kernel_name(scene, wl), "kernel_us": avg_kernel_s * 1e6,
+                         "kernel_us_per_launch_events": per_launch_us, "algorithmic_bytes_per_launch": alg_bytes,
                          "stream_ceiling_gbs": (alg_bytes / (ceil_ms / ceil_n / 1e3) / 1e9) if ceil_n else None},
         }
         if heavy:
             line["roofline"]["note"] = ("this workload is VALU/latency-bound (S >= 24, SURVEY.md §8d): the HBM fraction is "
                                         "reported for comparison, not as its roof")
+        if args.dry_run:
+            line["dry_run"] = True
+        if "sustained" in extra:
+            sus = extra["sustained"]
+            sus["value"] = segs_step * S_LEAVES / (sus["ms_per_step"] / 1e3)
+            sus["hbm_frac"] = alg_bytes / (sus["ms_per_step"] / 1e3) / 1e9 / HBM_PEAK_GBS
+        if "cold" in extra:
+            extra["cold"]["hbm_frac"] = alg_bytes / (extra["cold"]["us_per_step"] / 1e6) / 1e9 / HBM_PEAK_GBS
+        line.update(extra)
         if gather_error is not None:
             line["gather_error"] = gather_error
         elif gather_ms is not None:
             line["gather_ms"] = gather_ms
-            line["value_incl_gather"] = segs_total_step * S_LEAVES_W * args.steps / (dt + gather_ms / 1e3)
-        if world == 1 and not args.no_cpu_baseline:
+            line["value_incl_gather"] = segs_total_step * S_LEAVES * args.steps / (dt + gather_ms / 1e3)
+        if world == 1 and not args.dry_run and wl.name == "cfg2" and not args.no_configs and args.rays is None:
+            # the other BASELINE configs, at the size one GPU sees in the configuration they are quoted on
+            del batches, outs
+            torch.cuda.empty_cache()
+            line["configs"] = []
+            for name in ("cfg3", "cfg4", "cfg5"):
+                try:
+                    line["configs"].append(survey_config(oa, eng, name, device))
+                except Exception as exc:  # noqa: BLE001 — the headline is still worth printing
+                    line["configs"].append({"workload": name, "error": f"{type(exc).__name__}: {exc}"})
+            batches = [make_batch(oa, wl, min(n, 200_000), rank, device)]
+            eng.upload(scene)
+        if world == 1 and not args.no_cpu_baseline and not args.dry_run:
             try:
-                line["cpu_baseline"] = cpu_baseline(table, batch.slice(0, min(n, 200_000)).to_host(), MAX_SEG, S_LEAVES_W,
-                                                    args.workload, budget_s=args.cpu_seconds)
+                line["cpu_baseline"] = cpu_baseline(table, batches[0].slice(0, min(n, 200_000)).to_host(), MAX_SEG, S_LEAVES,
+                                                    wl.name, budget_s=args.cpu_seconds)
             except Exception as exc:  # noqa: BLE001 — the GPU numbers above are still worth printing
                 line["cpu_baseline"] = {"value": None, "unit": "ray-surface intersections/s", "cores": 0, "kind": "port",
                                         "sample": f"failed: {type(exc).__name__}: {exc}"}

@@ -206,7 +206,14 @@ int ot_scene_upload(ot_ctx* ctx, const ot_scene_desc* scene);
  * re-traced with ot_trace_generation_f64.
  * counts: int32 [n_count_slots][n_count_classes] interact-count table indexed by rays.id, or
  * NULL when the scene has no limited surface.  A ray whose id lies outside [0, n_count_classes)
- * is not counted (every limited surface stays open to it); nothing is indexed out of range. */
+ * is not counted (every limited surface stays open to it); nothing is indexed out of range.
+ * Precondition for the reference's order (optical_table.py:66-70 finishes one input ray before the
+ * next): at most ONE ray per id in a launch — callers with rays that share an id trace them in
+ * successive launches over the same table (round r = the r-th ray of every id), as table.py does.
+ * If the precondition is broken nothing is corrupted: the gate is an atomic increment-below-cap,
+ * a counter never passes its cap; only WHICH of the sharing rays get the remaining counts is then
+ * unspecified (ot_trace_generation_*: the trees of one generation all see the table as it stood
+ * before the generation, and the table is closed at the cap afterwards). */
 int ot_trace_f64(ot_ctx* ctx, const ot_rays* rays, int64_t n_rays, int32_t max_segments,
                  const ot_segments* out, int32_t* seg_count, int32_t* counts,
                  int32_t n_count_classes);

@@ -161,7 +161,7 @@ def lower_material(mat):
         return mat
     if hasattr(mat, "Bs") and hasattr(mat, "Cs") and len(mat.Bs) == len(mat.Cs) <= 3:
         pad = 3 - len(mat.Bs)
-        return _Spec(("sellmeier", list(mat.Bs) + [0.0] * pad, list(mat.Cs) + [1.0] * pad), getattr(mat, "name", "?"))
+        return _Spec(("sellmeier", list(mat.Bs) + [0.0] * pad, list(mat.Cs) + [-1.0] * pad), getattr(mat, "name", "?"))
     if hasattr(mat, "n_func"):
         vals = [float(mat.n_func(w)) for w in (0.0, 4e-7, 7.8e-7, 1.55e-6)]
         if max(vals) == min(vals):

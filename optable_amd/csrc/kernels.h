@@ -322,37 +322,60 @@ static constexpr int LB_SEG_SHIFT = 32;
 
 // Exclusive prefix of `total` over the tiles before `tile`; publishes this tile's aggregate and inclusive prefix.
 // Called by ONE full wave (all 64 lanes); every lane returns the same value.
+// The walk reads LB_WINDOWS windows of 64 predecessors per round trip, all loads in flight together: with ~800
+// workgroups resident, a tile that finishes its trace typically finds the nearest inclusive prefix a few hundred
+// tiles back (everything nearer has only published an aggregate), and walking there one window per L2/fabric
+// round trip (the first version) was the longest link of the load -> trace -> look-back -> store chain.
+static constexpr int LB_WINDOWS = 4;
 __device__ __forceinline__ unsigned long long lookback_exclusive(const LookBack& lb, int64_t tile, unsigned long long total, int lane) {
     unsigned long long before = 0;
     if (tile > 0) {
         if (lane == 0) __hip_atomic_store(&lb.state[tile], LB_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        long long part = 0;  // per-lane partial sum, reduced once at the end
         for (int64_t wbase = tile - 1;;) {
-            const int64_t idx = wbase - lane;  // lane 0 = nearest predecessor
-            unsigned long long v = LB_PREFIX;  // before tile 0: an inclusive prefix of zero
-            if (idx >= 0) v = __hip_atomic_load(&lb.state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned flag = (unsigned)(v >> 62);
-            const unsigned long long m_prefix = __ballot(flag == 2u), m_empty = __ballot(flag == 0u);
-            unsigned long long need = ~0ull;   // the lanes up to and including the nearest prefix
-            if (m_prefix) {
-                const int pl = __ffsll((long long)m_prefix) - 1;
-                need = pl == 63 ? ~0ull : ((1ull << (pl + 1)) - 1ull);
-            }
-            if (m_empty & need) { __builtin_amdgcn_s_sleep(24); continue; }  // one of them is still working: wait ~0.6 us, read again
-            long long part = ((need >> lane) & 1ull) ? (long long)(v & LB_MASK) : 0ll;
+            unsigned long long v[LB_WINDOWS];
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-            before += (unsigned long long)part;
-            if (m_prefix) break;
-            wbase -= 64;
+            for (int j = 0; j < LB_WINDOWS; ++j) {
+                const int64_t idx = wbase - 64 * j - lane;  // lane 0 = nearest predecessor of window j
+                v[j] = LB_PREFIX;                           // before tile 0: an inclusive prefix of zero
+                if (idx >= 0) v[j] = __hip_atomic_load(&lb.state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            bool found = false;
+            int consumed = LB_WINDOWS;  // windows fully accounted for in this round
+#pragma unroll
+            for (int j = 0; j < LB_WINDOWS; ++j) {
+                if (found || consumed < LB_WINDOWS) continue;  // wave-uniform
+                const unsigned flag = (unsigned)(v[j] >> 62);
+                const unsigned long long m_prefix = __ballot(flag == 2u), m_empty = __ballot(flag == 0u);
+                unsigned long long need = ~0ull;  // the lanes up to and including the nearest prefix
+                if (m_prefix) {
+                    const int pl = __ffsll((long long)m_prefix) - 1;
+                    need = pl == 63 ? ~0ull : ((1ull << (pl + 1)) - 1ull);
+                }
+                if (m_empty & need) { consumed = j; continue; }  // one of them is still working: read again from here
+                if ((need >> lane) & 1ull) part += (long long)(v[j] & LB_MASK);
+                if (m_prefix) found = true;
+            }
+            if (found) break;
+            wbase -= 64 * consumed;
+            if (consumed < LB_WINDOWS) __builtin_amdgcn_s_sleep(24);  // ~0.6 us
         }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
+        before = (unsigned long long)part;
     }
     if (lane == 0) __hip_atomic_store(&lb.state[tile], LB_PREFIX | (before + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return before;
 }
 
 // PROBE = true: the pre-pass that records geometric hits of count-limited leaves (no outputs).
+// Registers: both children of every ray stay live across the look-back (they are stored afterwards, straight from
+// registers).  The planar fp64 instantiation wants 176 VGPRs, 8 more than three waves per SIMD allow: it is capped there
+// (no spill with the scene image in LDS; the L2-image variant would spill 4 registers and keeps the compiler's choice).
+template <class T, uint32_t F, bool L> constexpr int gen_minw() { return (L && sizeof(T) == 8 && F == (F_AABB | F_LENS | F_REFRACT)) ? 3 : 1; }
+
 template <class T, uint32_t F, bool SCENE_IN_LDS, bool PROBE>
-__global__ __launch_bounds__(256) void k_gen_trace(SceneBlob blob, T unit, RaysT<T> in, const int32_t* tree, int64_t n,
+__global__ __launch_bounds__(256, (gen_minw<T, F, SCENE_IN_LDS>())) void k_gen_trace(SceneBlob blob, T unit, RaysT<T> in, const int32_t* tree, int64_t n,
                                                    const int32_t* budget, const int64_t* cursor,
                                                    SegsT<T> out, int64_t out_capacity, LookBack lb, RaysOutT<T> next,
                                                    int32_t* next_tree, int64_t next_capacity, int64_t* totals,
@@ -410,7 +433,7 @@ __global__ __launch_bounds__(256) void k_gen_trace(SceneBlob blob, T unit, RaysT
         }
         const Hit<T> h = nearest_hit<T, F, GATE_TABLE>(sc, r, active && !dead, gate);
         int32_t nk = 0, t = 0;
-        RayState<T> ch[2];
+        RayState<T> ch[2];  // only ever indexed by constants: both children stay in registers
         if (active) {
             t = tree[i];
             if (!dead && h.node >= 0) nk = interact<T, F, 2>(sc, r, h, ch, make_matcache(sc, r.wl));
@@ -449,10 +472,9 @@ __global__ __launch_bounds__(256) void k_gen_trace(SceneBlob blob, T unit, RaysT
                 else store_segment(out, slot, r, h.t, t, sc.nodes[h.node].leaf_id);
             }
         }
-        int64_t d = (int64_t)(before_me & 0xffffffffull);
-        for (int c = 0; c < nk; ++c, ++d) {
-            if (d >= next_capacity) break;
-            const RayState<T>& k = ch[c];
+        const int64_t d0 = (int64_t)(before_me & 0xffffffffull);
+        auto put = [&](const RayState<T>& k, int64_t d) {
+            if (d >= next_capacity) return;
             next.ox[d] = k.ox; next.oy[d] = k.oy; next.oz[d] = k.oz;
             next.dx[d] = k.dx; next.dy[d] = k.dy; next.dz[d] = k.dz;
             next.wl[d] = k.wl; next.qr[d] = k.qr; next.qi[d] = k.qi;
@@ -460,7 +482,9 @@ __global__ __launch_bounds__(256) void k_gen_trace(SceneBlob blob, T unit, RaysT
             next.flags[d] = fl & OT_RAY_HAS_Q;
             next.id[d] = cls;
             next_tree[d] = t;
-        }
+        };
+        if (nk > 0) put(ch[0], d0);
+        if (nk > 1) put(ch[1], d0 + 1);
         __syncthreads();  // s_tile / s_base / s_wave_total are rewritten by the next tile
     }
 }
@@ -479,6 +503,7 @@ __global__ void k_gen_counts(const int32_t* tree, const int32_t* ids, int64_t n,
     if (i >= n) return;
     if (i == n - 1 || tree[i + 1] != tree[i]) {
         for (int s = 0; s < n_slots; ++s) {
+            if ((uint32_t)ids[i] >= (uint32_t)n_classes) break;  // id outside the table: not counted (count_gate's rule)
             int32_t* c = counts + (int64_t)s * n_classes + ids[i];
             const int32_t total = *c + rank[(int64_t)s * n + i] + probe[(int64_t)s * n + i];
             *c = total < slot_max[s] ? total : (*c > slot_max[s] ? *c : slot_max[s]);

@@ -425,6 +425,15 @@ static int check_segs(const ot_segments* s) {
 
 static size_t align_up(size_t x) { return (x + 255) / 256 * 256; }
 
+// Address of one k_trace_fused instantiation, or nullptr for the combinations the launch logic never selects: the
+// 128-register cap (MINW = 4) on the fp64 Snell kernel would spill (145 VGPRs wanted), so it is not even compiled.
+template <class T, uint32_t FM, bool L, int W, bool N>
+static auto fused_ptr() {
+    using Kern = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, SegsT<T>, int32_t*, int32_t*, int32_t);
+    if constexpr (sizeof(T) == 8 && W == 4 && (FM & F_REFRACT) != 0) return (Kern) nullptr;
+    else return (Kern)k_trace_fused<T, FM, L, W, N>;
+}
+
 template <class T>
 static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, const ot_segments* out, int32_t* seg_count,
                        int32_t* counts, int32_t n_classes) {
@@ -534,7 +543,7 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
     const int fi = (need & ~FA) == 0 ? 0 : ((need & ~FB) == 0 ? 1 : 2);
     // the 128-register cap pays for the mirror/lens kernel only; the Snell kernel would spill (fp64: 145 VGPRs)
     const int mw = (c->opt_minw == 4 && (fi == 0 || (fi == 1 && !f64))) ? 1 : 0, nt = c->opt_nt ? 1 : 0;
-#define OT_K(FM, L, W, N) k_trace_fused<T, FM, L, W, N>
+#define OT_K(FM, L, W, N) fused_ptr<T, FM, L, W, N>()
 #define OT_ROW(FM) {{{OT_K(FM, false, 1, false), OT_K(FM, false, 1, true)}, {OT_K(FM, false, 4, false), OT_K(FM, false, 4, true)}}, \
                     {{OT_K(FM, true, 1, false), OT_K(FM, true, 1, true)}, {OT_K(FM, true, 4, false), OT_K(FM, true, 4, true)}}}
     static const Kern table[3][2][2][2] = {OT_ROW(FA), OT_ROW(FB),
@@ -543,6 +552,7 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
 #undef OT_ROW
 #undef OT_K
     Kern kern = table[fi][in_lds ? 1 : 0][mw][nt];
+    if (!kern) return fail(OT_ERR_UNSUPPORTED, "no kernel instantiation for this scene / option combination");
     const size_t lds_bytes = in_lds ? bytes : 0;
     if (lds_bytes > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), (uint32_t)lds_bytes, c->stream, ev0, ev1, 0u, blob, (T)c->unit, view<T>(rays), n, K,

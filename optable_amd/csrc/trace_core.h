@@ -531,7 +531,8 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 
 // Interact-count gate (optical_component.py:140-149, 359-362): a limited leaf that is
 // geometrically hit consumes one count while count < max, otherwise it is transparent.
-//   GATE_PLAIN  one ray per class in the launch (fused kernel): read-modify-write.
+//   GATE_PLAIN  fused / blocked kernels: atomic increment-below-cap (exact for one ray per class per launch, the
+//               host API's rounds; memory-safe and cap-exact for any sharing).
 //   GATE_PROBE  pre-pass of a branching generation: only record which limited leaves the ray
 //               hits geometrically (probe[slot*stride + idx] = 1); nothing else is evaluated.
 //   GATE_TABLE  branching generation proper: pass iff counts + (number of EARLIER rays of this
@@ -549,8 +550,13 @@ template <int GATE> __device__ __forceinline__ bool count_gate(const GateCtx& g,
     if ((uint32_t)g.cls >= (uint32_t)g.n_classes) return true;  // id outside the table: not counted (never indexes out of range)
     int32_t* c = g.counts + (int64_t)slot * g.n_classes + g.cls;
     if (GATE == GATE_TABLE) return *c + g.rank[(int64_t)slot * g.stride + g.idx] < max_count;
-    const int32_t v = *c;
-    if (v < max_count) { *c = v + 1; return true; }
+    // "increment while below the cap" as one atomic step: rays of one class that meet in a launch (a direct C-ABI
+    // caller that did not split them into rounds) can never push a counter past its cap or lose an update; WHICH
+    // of them gets the remaining counts is then unspecified (the reference's order is the caller's rounds).
+    int32_t v = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (v < max_count) {
+        if (__hip_atomic_compare_exchange_strong(c, &v, v + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return true;
+    }
     return false;
 }
 
@@ -861,12 +867,16 @@ __device__ __forceinline__ int interact(const Scene<T>& sc, const RayState<T>& r
     int nk = 0;
     auto emit = [&](T lx, T ly, T lz, T I, T qr, T qi, T n, T pl) {
         if (nk < MAXK) {
-            RayState<T>& k = kids[MAXK == 1 ? 0 : nk];  // static index keeps the child in registers
+            RayState<T> k;
             const T inv = rsqrt_t(lx * lx + ly * ly + lz * lz);
             to_lab(nd, lx * inv, ly * inv, lz * inv, k.dx, k.dy, k.dz);
             k.ox = Ox; k.oy = Oy; k.oz = Oz;
             k.wl = r.wl; k.has_q = r.has_q; k.len = Num<T>::inf();
             k.I = I; k.qr = qr; k.qi = qi; k.n = n; k.pl = pl;
+            // constant indices only: kids[nk] with a run-time nk would put both children into private scratch
+            // (240 B per lane in the fp64 generation kernel of round 1)
+            if (MAXK == 1 || nk == 0) kids[0] = k;
+            else kids[MAXK > 1 ? 1 : 0] = k;
         }
         ++nk;
     };

@@ -76,9 +76,16 @@ class Engine:
         return out
 
     # -- branching trace: breadth-first, one generation per launch ------------------------------
-    def trace_tree(self, rays: RayBatch, max_trace_num, counts=None, out_capacity=None):
+    def trace_tree(self, rays: RayBatch, max_trace_num, counts=None, out_capacity=None, max_trace_time=None):
         """Full ray trees (beam splitters, partial reflections, any cap).  Returns a flat
-        SegmentBatch in generation order plus, per tree, whether the cap cut it short."""
+        SegmentBatch in generation order plus, per tree, whether a cap cut it short.
+        `max_trace_time` (seconds): the reference's wall-clock cap (optical_table.py:84-97, `perfomance_limit
+        ["max_trace_time"]`), honoured at generation granularity — the clock is read after every generation of
+        the whole batch, and once it has run out the rays still queued are dropped, as the reference drops a
+        tree's queue (`:138-144`); the trees they belonged to are reported in `capped` (`timed_out` says why)."""
+        import time
+
+        t_start = time.time()
         if self.scene is None:
             raise RuntimeError("upload a scene first")
         prec = rays.precision
@@ -122,9 +129,18 @@ class Engine:
                 other, other_tree = RayBatch(nxt.n, prec, dev, initialise=False), torch.empty(nxt.n, dtype=torch.int32, device=dev)
             spare, spare_tree, other, other_tree = other, other_tree, nxt, nxt_tree
             cur, tree = nxt.slice(0, cur_n), nxt_tree[:cur_n]
+            if max_trace_time is not None and cur_n > 0 and time.time() - t_start >= max_trace_time:
+                timed_out = torch.zeros(n, dtype=torch.bool, device=dev)
+                timed_out[tree.long()] = True  # trees with rays still queued
+                break
+        else:
+            timed_out = None
         out.n_valid = int(written)
         out.counts_table = counts
         out.capped = budget <= 0  # cap reached: queued rays were dropped (optical_table.py:138-144)
+        out.timed_out = timed_out is not None
+        if timed_out is not None:
+            out.capped = out.capped | timed_out
         return out
 
     def generation_step(self, rays: RayBatch, counts=None):

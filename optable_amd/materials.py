@@ -89,8 +89,10 @@ class SellmeierMaterial(Material):
     def device_spec(self):
         if len(self.Bs) > 3 or len(self.Bs) != len(self.Cs):
             return None
+        # missing terms: B = 0 over a denominator that cannot vanish (lam^2 - C with C = -1 is > 0 for every wavelength;
+        # the device forms one common denominator of the three terms, so a padded C = 1 would give 0/0 at exactly 1 um)
         pad = 3 - len(self.Bs)
-        return ("sellmeier", list(self.Bs) + [0.0] * pad, list(self.Cs) + [1.0] * pad)
+        return ("sellmeier", list(self.Bs) + [0.0] * pad, list(self.Cs) + [-1.0] * pad)
 
 
 # Glass catalogue: coefficient tables are data (material.py:123-168).

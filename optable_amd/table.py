@@ -7,8 +7,10 @@ tables (scene.py), the rays are packed structure-of-arrays into HBM (batch.py) a
 liboptable_hip.so traces every ray tree; `Ray` objects are rebuilt from the segment stream
 only at the end.  `trace_batch` is the same path without Python objects, for 1e6+ rays.
 
-Not modelled: the 600 s wall-clock cap (`max_trace_time`) — a device trace is bounded by
-`max_trace_num` alone; the per-second progress print.  Render / CSV / GUI are out of scope.
+The wall-clock cap (`perfomance_limit["max_trace_time"]`, 600 s by default, optical_table.py:84-97) is honoured
+where a trace takes more than one launch: ray trees advance generation by generation and the clock is read
+after each (engine.trace_tree).  A non-branching scene is ONE launch bounded by `max_trace_num`; nothing can
+be cut inside it.  Not modelled: the per-second progress print.  Render / GUI are out of scope.
 """
 import copy
 import csv
@@ -26,6 +28,7 @@ from .rays import Ray
 from .scene import compile_scene
 
 MAX_TRACE_NUM = 2000  # optical_table.py:87
+MAX_TRACE_TIME = 600.0  # seconds, optical_table.py:86
 _FUSED_MAX_SEGMENTS = 64
 
 
@@ -89,11 +92,13 @@ class OpticalTable:
         everything accumulated so far (optical_table.py:57-72)."""
         if isinstance(rays, Ray):
             rays = [rays]
-        cap = MAX_TRACE_NUM
+        cap, max_time = MAX_TRACE_NUM, MAX_TRACE_TIME
         if perfomance_limit is not None and "max_trace_num" in perfomance_limit:
             cap = int(perfomance_limit["max_trace_num"])
-        if len(rays) and cap > 0:
-            traced, capped = self._trace_objects(list(rays), cap)
+        if perfomance_limit is not None and "max_trace_time" in perfomance_limit:
+            max_time = float(perfomance_limit["max_trace_time"])
+        if len(rays) and cap > 0 and max_time > 0:  # the reference's loop does not start on an exhausted limit
+            traced, capped = self._trace_objects(list(rays), cap, max_time)
             if capped:
                 print(f"Ray tracing time exceeds the maximum tracing time after {cap} traces. "
                       f"({capped} ray tree(s) truncated)")
@@ -334,11 +339,11 @@ class OpticalTable:
         return [seg for chunk in per_ray if chunk for seg in chunk]
 
     # -- List[Ray] plumbing ------------------------------------------------------------------------
-    def _trace_objects(self, rays, cap):
+    def _trace_objects(self, rays, cap, max_time=MAX_TRACE_TIME):
         with _engine().lock:  # upload + every trace of this call as one unit (see Engine.lock)
-            return self._trace_objects_locked(rays, cap)
+            return self._trace_objects_locked(rays, cap, max_time)
 
-    def _trace_objects_locked(self, rays, cap):
+    def _trace_objects_locked(self, rays, cap, max_time=MAX_TRACE_TIME):
         import torch
 
         eng = _engine()
@@ -375,7 +380,7 @@ class OpticalTable:
                 host_segs = segs.to_host(reference_order=True)
                 capped = _fused_capped(host_segs, cap)
             else:
-                segs = eng.trace_tree(batch, cap, counts=counts)
+                segs = eng.trace_tree(batch, cap, counts=counts, max_trace_time=max_time)
                 host_segs = segs.to_host(reference_order=True)
                 capped = int(segs.capped.sum().item())
             total_capped += capped

@@ -7,7 +7,9 @@ follow SURVEY.md §8(d) verbatim (seeds, draw order).
 """
 import numpy as np
 
-WL, W0 = 780e-7, 61e-4  # every synthetic ray carries a Gaussian q
+# the BASELINE configs (scene + ray generators) live in the package, where bench.py and the tools find them too
+from optable_amd.workloads import (WL, W0, cfg2_rays, cfg2_components, cfg3_rays, cfg3_components,  # noqa: F401
+                                   cfg4_rays, cfg4_components, cfg5_rays, cfg5_components)
 
 
 def g01_gaussian_beam(ns):
@@ -20,20 +22,6 @@ def g01_gaussian_beam(ns):
              ns.Lens([0, 4, 0], radius=0.8, focal_length=10), ns.Lens([0, 6.5, 0], radius=0.8, focal_length=10),
              ns.GlassSlab([0, 9, 0], n1=1, n2=2, thickness=5), ns.Mirror([0, 11, 0]).RotZ(-np.pi / 2)]
     return dict(components=comps, monitors=[], rays=rays, limit=None)
-
-
-def cfg2_rays(n, seed=0):
-    """Point source at the lens focus, cone half-angle 0.15*sqrt(u) (SURVEY.md §8d cfg 2)."""
-    rng = np.random.default_rng(seed)
-    u = rng.uniform(0, 1, n)
-    phi = rng.uniform(0, 2 * np.pi, n)
-    theta = 0.15 * np.sqrt(u)
-    d = np.stack([np.cos(theta), np.sin(theta) * np.cos(phi), np.sin(theta) * np.sin(phi)], axis=1)
-    return np.zeros((n, 3)), d
-
-
-def cfg2_components(ns):
-    return [ns.Lens([5, 0, 0], focal_length=5, radius=1.0), ns.MirrorPair([10, 0, 0], 4, 4)]
 
 
 def g02_cfg2(ns, n=1000):
@@ -103,56 +91,10 @@ def g08_asphere(ns):
     return dict(components=[lens, exact], monitors=[mon], rays=_fan(ns, D=0.55), limit=None)
 
 
-def cfg5_components(ns, N=(16, 16)):
-    return [ns.SquareMirror([-1, 0, 0], 6, 6),
-            ns.ASphericParametricLens([5, 0, 0], CT=0.8, diameter=5, n=1.5, R=10, kappa=-1, a4=1e-5),
-            ns.MMA(origin=[15, 0, 0], N=N, pitch=0.2, roc=28, n=1.5, thickness=0.1, reflectivity=1, transmission=0)]
-
-
-def cfg5_rays(n, seed=3):
-    rng = np.random.default_rng(seed)
-    yz = rng.uniform(-1.4, 1.4, (n, 2))  # y then z per ray
-    o = np.concatenate([np.zeros((n, 1)), yz], axis=1)
-    d = np.tile([1.0, 0.0, 0.0], (n, 1))
-    return o, d
-
-
 def g09_cfg5(ns, n=40):
     o, d = cfg5_rays(n, 3)
     rays = [ns.Ray(o[i], d[i], wavelength=WL, w0=W0, id=i) for i in range(n)]
     return dict(components=cfg5_components(ns), monitors=[], rays=rays, limit={"max_trace_num": 50})
-
-
-def cfg3_components(ns):
-    rng = np.random.default_rng(1)
-    comps = []
-    for ix in range(8):
-        for iy in range(4):
-            origin = [4 * (ix + 1), 3 * (iy - 1.5), 0]
-            kind = ["Mirror", "Lens", "GlassSlab", "Prism"][(ix + iy) % 4]
-            a = rng.uniform(-np.pi, np.pi)
-            if kind == "Mirror":
-                comps.append(ns.Mirror(origin, radius=1).RotZ(a))
-            elif kind == "Lens":
-                f = rng.uniform(4, 12)
-                comps.append(ns.Lens(origin, focal_length=f, radius=1).RotZ(0.2 * a))
-            elif kind == "GlassSlab":
-                comps.append(ns.GlassSlab(origin, width=2, height=2, thickness=0.5, n1=1, n2=1.5).RotZ(0.3 * a))
-            else:
-                comps.append(ns.Prism(origin, width=1.5, height=2, n1=1, n2=1.5).RotZ(a))
-    return comps
-
-
-def cfg3_rays(n, seed=2):
-    rng = np.random.default_rng(seed)
-    draws = rng.uniform(0, 1, (n, 4))
-    y0 = -5.5 + 11.0 * draws[:, 0]
-    z0 = -0.5 + 1.0 * draws[:, 1]
-    dy = -0.05 + 0.10 * draws[:, 2]
-    dz = -0.02 + 0.04 * draws[:, 3]
-    o = np.stack([np.zeros(n), y0, z0], axis=1)
-    d = np.stack([np.ones(n), dy, dz], axis=1)
-    return o, d / np.linalg.norm(d, axis=1, keepdims=True)
 
 
 def g10_cfg3(ns, n=400):

@@ -40,3 +40,21 @@ def test_bench_line_contract(workload, rays):
     cpu = line["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["value"] > 0 and "sample" in cpu
     assert line["value"] > 50 * cpu["value"]          # a GPU against one host core, even at this size
+    assert cpu["reference_python"]["kind"] == "reference" and "provenance" in cpu["reference_python"]
+    # measurement hygiene: what ran before the warmup is reported, rotated inputs exceed the Infinity
+    # Cache, a cold and a sustained figure stand beside the steady one, the PMC traffic names its source
+    assert line["preload_launches"] > 0 and line["cold"]["us_per_step"] > 0
+    assert line["sustained"]["seconds"] >= 1.0 and line["sustained"]["steps"] > 0
+    nb, rec = line["config"]["input_batches_rotated"], 104 if line["dtype"] == "f64" else 56
+    assert nb * rays * rec >= 256 * 2**20 or nb == 4
+    if roof["traffic"] is not None:
+        assert "profiles/" in roof["traffic_source"]
+
+
+def test_two_ranks_on_one_card_gloo_rehearsal():
+    """`bench.py --gpus 2` must start its two ranks itself (the driver runs exactly this command for N > 1, with RCCL);
+    here both ranks share the one card and the collective runs over gloo."""
+    line = _run("--gpus", "2", "--backend", "gloo", "--rays", "20000", "--no-cpu-baseline")
+    assert line["n_gpus"] == 2 and line["config"]["rays_per_gpu"] == 20000 and line["config"]["rays_total"] == 40000
+    assert line["gathered_shape"] == [12, 40000] and line["gather_ms"] > 0 and "gather_error" not in line
+    assert line["config"]["segments_per_ray"] == 5.0

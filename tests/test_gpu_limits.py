@@ -1,0 +1,123 @@
+"""Limits and guards around the trace (round-2 correctness debts):
+  * `perfomance_limit["max_trace_time"]` (optical_table.py:84-97) cuts a branching trace between generations;
+  * count tables: ids outside the table and ids shared inside one launch never corrupt memory or a counter
+    (optical_component.py:140-149 keeps one counter per ray id);
+  * Sellmeier materials with fewer than three terms (material.py:106-120 sums only the terms given)."""
+import numpy as np
+import pytest
+import torch
+
+import optable_amd as oa
+import scenes
+from optable_amd.batch import RayBatch
+from optable_amd.engine import get_engine
+from optable_amd.materials import SellmeierMaterial
+
+pytestmark = pytest.mark.gpu
+
+
+def _cavity_table():
+    sc = scenes.g05_cavity(oa)
+    table = oa.OpticalTable()
+    table.add_components(sc["components"])
+    return table, sc
+
+
+def test_max_trace_time_cuts_between_generations(capsys):
+    table, sc = _cavity_table()
+    full = table.ray_tracing(sc["rays"], perfomance_limit={"max_trace_num": 300})
+    assert len(full) == 300
+    table2, sc2 = _cavity_table()
+    cut = table2.ray_tracing(sc2["rays"], perfomance_limit={"max_trace_num": 300, "max_trace_time": 1e-9})
+    out = capsys.readouterr().out
+    assert 1 <= len(cut) < 10  # the clock had run out after the first generation: only it was archived
+    assert "exceeds the maximum tracing time" in out
+    # what was traced before the cut is the same prefix of the same tree
+    for a, b in zip(cut, full):
+        np.testing.assert_allclose(a.origin, b.origin, atol=1e-12)
+    # engine level: the cut is reported per tree
+    eng = get_engine()
+    scene = table2.compile()
+    eng.upload(scene)
+    batch = RayBatch.from_arrays([[2, 0, 0]], [[1, 0, 0]])
+    segs = eng.trace_tree(batch, 300, max_trace_time=1e-9)
+    assert segs.timed_out and bool(segs.capped[0])
+    segs = eng.trace_tree(batch, 300, max_trace_time=600.0)
+    assert not segs.timed_out and segs.n_valid == 300
+
+
+def _limited_scene():
+    far = oa.Mirror([4, 0, 0], radius=1, max_interact_count=3)   # leaf 0: reflects three times per ray id, then transparent
+    back = oa.Mirror([8, 0, 0], radius=1)                        # leaf 1
+    table = oa.OpticalTable()
+    table.add_components([far, back])
+    return table
+
+
+@pytest.mark.parametrize("path", ["fused", "tree"])
+def test_ids_outside_the_count_table_are_not_counted(path):
+    """Direct engine callers pass their own ids: the table has `n_classes` columns and an id beyond them must not be
+    used as an index anywhere (k_gen_counts wrote out of range in round 1; count_gate already guarded)."""
+    table = _limited_scene()
+    eng = get_engine()
+    scene = table.compile()
+    eng.upload(scene)
+    n = 512
+    o = np.tile([0.0, 0.0, 0.0], (n, 1)) + np.linspace(-0.5, 0.5, n)[:, None] * np.array([0, 1, 0])
+    batch = RayBatch.from_arrays(o, np.tile([1.0, 0, 0], (n, 1)))
+    batch.id = torch.full((n,), 2_000_000_000, dtype=torch.int32, device=batch.device)
+    batch.id[::2] = -7
+    guard = torch.zeros((1, 8), dtype=torch.int32, device=batch.device)  # n_classes = 8: every id is outside
+    sentinel = guard.clone()
+    segs = eng.trace(batch, 12, counts=guard) if path == "fused" else eng.trace_tree(batch, 12, counts=guard)
+    torch.cuda.synchronize()
+    assert torch.equal(guard, sentinel)  # nothing counted, nothing written
+    host = segs.to_host(reference_order=True)
+    # an uncounted ray always finds the limited mirror open: origin -> far (reflected) -> escape, for every ray
+    per_ray = np.bincount(host["ray"], minlength=n)
+    assert per_ray.min() == per_ray.max() == 2
+    assert int(np.sum(host["surface"] == 0)) == n
+
+
+@pytest.mark.parametrize("path", ["fused", "tree"])
+def test_shared_ids_in_one_launch_never_overrun_a_counter(path):
+    """All rays of a launch in ONE class (a caller that did not split them into rounds, as `table.py` does).  One-launch
+    kernel: the gate is an atomic increment-below-cap, so exactly `max_interact_count` rays are reflected (which ones is
+    unspecified) and the counter stops at the cap.  Generation kernels gate per TREE (FIFO inside a tree): rays of
+    different trees that share an id all see the counter as it stood before the generation, so more may pass — but the
+    table still ends at the cap, never beyond it (include/optable_hip.h states the precondition)."""
+    table = _limited_scene()
+    eng = get_engine()
+    scene = table.compile()
+    eng.upload(scene)
+    n = 4096
+    o = np.tile([0.0, 0.0, 0.0], (n, 1)) + np.linspace(-0.5, 0.5, n)[:, None] * np.array([0, 1, 0])
+    batch = RayBatch.from_arrays(o, np.tile([1.0, 0, 0], (n, 1)))
+    batch.id = torch.zeros(n, dtype=torch.int32, device=batch.device)
+    counts = torch.zeros((1, 1), dtype=torch.int32, device=batch.device)
+    segs = eng.trace(batch, 12, counts=counts) if path == "fused" else eng.trace_tree(batch, 12, counts=counts)
+    host = segs.to_host(reference_order=True)
+    reflected_at_far = int(np.sum(host["surface"] == 0))
+    if path == "fused":
+        assert int(counts[0, 0]) == 3 and reflected_at_far == 3
+    else:
+        assert 1 <= int(counts[0, 0]) <= 3 and reflected_at_far >= 3
+
+
+def test_two_term_sellmeier_at_one_micron():
+    """A padded third term must not poison the common denominator at lambda^2 == C (0/0 in round 1 with C = 1)."""
+    glass = SellmeierMaterial("two-term", [1.03961212, 0.231792344], [0.00600069867, 0.0200179144])
+    kind, B, C = glass.device_spec()
+    assert kind == "sellmeier" and B[2] == 0.0 and C[2] < 0.0
+    slab = oa.GlassSlab([0, 0, 0], width=2, height=2, thickness=0.5, n1=oa.Vacuum(), n2=glass, reflectivity=0)
+    table = oa.OpticalTable()  # unit 1e-2 m: wavelength 1e-4 model units == exactly 1 um
+    table.add_components([slab])
+    ray = oa.Ray([-3, 0.1, 0], [1, 0.05, 0], wavelength=1e-4, w0=61e-4)
+    out = table.ray_tracing([ray])
+    inside = [r for r in out if abs(r.n - 1.0) > 1e-6]
+    assert inside and all(np.isfinite(r.n) for r in out)
+    assert inside[0].n == pytest.approx(glass.sellmeier_n(1e-6), rel=1e-12)
+    for prec in ("f64", "f32"):
+        b = RayBatch.from_arrays([[-3, 0.1, 0]], [[1, 0.05, 0]], wavelength=1e-4, precision=prec)
+        segs = table.trace_batch(b, max_segments=4).to_host(reference_order=True)
+        assert np.all(np.isfinite(segs["n"])) and len(segs["n"]) == 3

@@ -7,14 +7,13 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(1, os.path.join(ROOT, "tests"))
 import numpy as np
 import torch
 import optable_amd as oa
 from optable_amd import abi
 from optable_amd.batch import RayBatch, SegmentBatch
 from optable_amd.engine import get_engine
-import scenes
+from optable_amd import workloads as scenes  # the BASELINE configs (scene + ray generators)
 
 if os.environ.get('OT_LIB'):  # kernel-variant experiments: an alternative build of the library
     abi.LIB_PATH = os.path.abspath(os.environ['OT_LIB'])
@@ -24,8 +23,6 @@ if os.environ.get('RGC'):  # experiment: top-level grid resolution (cells per co
     _scene.ROOT_GRID_CELLS_PER_COMPONENT = float(os.environ['RGC'])
 if os.environ.get('LDSKB'):
     eng.set_option(abi.OPT_LDS_LIMIT_KB, int(os.environ['LDSKB']))
-if os.environ.get('SORT'):
-    eng.set_option(abi.OPT_SORT, int(os.environ['SORT']))
 if os.environ.get('MINW'):
     eng.set_option(abi.OPT_MIN_WAVES, int(os.environ['MINW']))
 if os.environ.get('BPC'):

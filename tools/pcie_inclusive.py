@@ -3,12 +3,11 @@
 (RayBatch.from_arrays = H2D), trace, full segment history back to host numpy (SegmentBatch.to_host = D2H)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(1, os.path.join(ROOT, "tests"))
-import numpy as np, torch
+sys.path.insert(0, ROOT); import numpy as np, torch
 import optable_amd as oa
 from optable_amd.batch import RayBatch
 from optable_amd import dist as odist
-import scenes
+from optable_amd import workloads as scenes  # the BASELINE configs (scene + ray generators)
 
 n, K = 1_000_000, 5
 table = oa.OpticalTable(); table.add_components(scenes.cfg2_components(oa))

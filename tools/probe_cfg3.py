@@ -2,12 +2,11 @@
 """Where cfg 3's time goes: the same 8x4 lattice of poses populated with one component kind at a time."""
 import os, sys
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, ROOT); sys.path.insert(1, os.path.join(ROOT, "tests"))
-import numpy as np, torch
+sys.path.insert(0, ROOT); import numpy as np, torch
 import optable_amd as oa
 from optable_amd.batch import RayBatch, SegmentBatch
 from optable_amd.engine import get_engine
-import scenes
+from optable_amd import workloads as scenes  # the BASELINE configs (scene + ray generators)
 
 def lattice(kind_of):
     rng = np.random.default_rng(1)

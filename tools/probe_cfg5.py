@@ -1,11 +1,10 @@
 import os, sys
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
-sys.path.insert(0, ROOT); sys.path.insert(1, os.path.join(ROOT, "tests"))
-import numpy as np, torch
+sys.path.insert(0, ROOT); import numpy as np, torch
 import optable_amd as oa
 from optable_amd.batch import RayBatch, SegmentBatch
 from optable_amd.engine import get_engine
-import scenes
+from optable_amd import workloads as scenes  # the BASELINE configs (scene + ray generators)
 eng = get_engine()
 n, K = int(os.environ.get('N', 4_000_000)), 50
 o, d = scenes.cfg5_rays(n, 3)

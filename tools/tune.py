@@ -9,13 +9,12 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(1, os.path.join(ROOT, "tests"))
 import numpy as np
 import optable_amd as oa
 from optable_amd import abi
 from optable_amd.batch import RayBatch, SegmentBatch
 from optable_amd.engine import get_engine
-import scenes
+from optable_amd import workloads as scenes  # the BASELINE configs (scene + ray generators)
 
 n, K = int(os.environ.get("N", 1_000_000)), 5
 prec = os.environ.get("PREC", "f64")
