@@ -27,7 +27,9 @@ def test_bench_line_contract(workload, rays):
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in line, key
     assert line["n_gpus"] == 1 and line["steps"] == 3 and line["warmup"] == 1 and line["vs_baseline"] is None
-    assert line["scaling"] == "weak" and line["higher_is_better"] is True and line["data"] == "synthetic"
+    # cfg 2 repeats its size on every GPU; cfg 5 names a total that is sharded over the GPUs
+    assert line["scaling"] == ("weak" if workload == "cfg2" else "strong")
+    assert line["higher_is_better"] is True and line["data"] == "synthetic"
     assert line["config"]["rays_per_gpu"] == rays and "model" not in line["config"]
     roof = line["roofline"]
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
