@@ -269,6 +269,159 @@ __global__ __launch_bounds__((blocked_threads<T, F>()), (blocked_minw<T, F>())) 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_trace_rolling: heavy scenes whose rays are unrelated after the first bounce (top-level grid: cfg 3).
+// k_trace_blocked gives every wave a fixed chunk that lives as long as its longest ray, so its late passes run with
+// a handful of lanes, and a pass costs about the same whether 64 lanes work in it or 3.  Stamps inside the kernel
+// (tools/stamp_phases.py) show where a pass goes: ~50 % nearest hit, ~20 % waiting for its loads, ~27 % record +
+// interaction + waiting for its stores — gfx9 counts loads and stores in ONE in-order counter (vmcnt), so the
+// state loads of a pass wait for the 25 record / state stores of the pass before it to be acknowledged.
+// Here every wave owns ONE list of up to CAP live rays (LDS, entry = ray index | segment index << 32).  A round
+// processes the list in passes of 64, survivors go to the next list,
+// and whenever 64 slots are free the wave draws a ticket of 64 consecutive fresh rays from a device-wide queue:
+// passes are full until the queue is empty, rays of different generations share a pass, and no wave waits for the
+// slowest chunk of its workgroup (workgroups are persistent: every wave runs until queue and list are empty).
+// Output slots are [k][ray] as in the other kernels: the result does not depend on which wave traced a ray or when.
+// Tried on top and dropped (cfg 3, fp32, 1e7 rays; 4.9 ms as it stands): a ring buffer with the next pass's records
+// prefetched before this pass's stores, with and without forcing the wait ahead of the stores (5.9 - 6.2 ms: 19 more
+// live registers and per-lane source selects cost more than the hidden latency returns); a branch-free planar test
+// in the cell loop (5.5 ms: the early exits do pay, whole waves leave a candidate together more often than not);
+// a resumable grid walk that visits at most 1 / 2 / 4 cells per pass and parks long walks for the next pass
+// (14.4 / 11.1 / 8.7 ms: every extra pass pays the pass's load -> trace -> store latency again).
+template <class T> struct Fetched {
+    RayState<T> r;
+    int64_t i;
+    int32_t k, cls, fl;
+    bool valid;
+};
+template <class T>
+__device__ __forceinline__ Fetched<T> fetch_ray(const RaysT<T>& in, const StateT<T>& st, unsigned long long entry, bool valid) {
+    Fetched<T> f;
+    f.valid = valid;
+    f.i = (int64_t)(entry & 0x7fffffffull);
+    f.k = (int32_t)(entry >> 32);
+    f.cls = f.fl = 0;
+    f.r = {};
+    if (valid) {
+        const int64_t i = f.i;
+        const bool fresh = f.k == 0;  // first segment: the caller's arrays; later ones: the per-ray scratch record
+        f.fl = in.flags[i];
+        f.cls = in.id[i];
+        f.r.ox = (fresh ? in.ox : st.f[0])[i]; f.r.oy = (fresh ? in.oy : st.f[1])[i]; f.r.oz = (fresh ? in.oz : st.f[2])[i];
+        f.r.dx = (fresh ? in.dx : st.f[3])[i]; f.r.dy = (fresh ? in.dy : st.f[4])[i]; f.r.dz = (fresh ? in.dz : st.f[5])[i];
+        f.r.qr = (fresh ? in.qr : st.f[6])[i]; f.r.qi = (fresh ? in.qi : st.f[7])[i]; f.r.I = (fresh ? in.I : st.f[8])[i];
+        f.r.n = (fresh ? in.n : st.f[9])[i]; f.r.pl = (fresh ? in.pl : st.f[10])[i];
+        f.r.wl = in.wl[i];
+        f.r.len = (fresh && in.len) ? in.len[i] : Num<T>::inf();
+        f.r.has_q = (f.fl & OT_RAY_HAS_Q) != 0;
+    }
+    return f;
+}
+
+template <class T, uint32_t F, bool SCENE_IN_LDS, bool NT>
+__global__ __launch_bounds__((blocked_threads<T, F>()), (blocked_minw<T, F>())) void k_trace_rolling(
+    SceneBlob blob, T unit, RaysT<T> in, int64_t n, int32_t K, SegsT<T> out, int32_t* __restrict__ seg_count, int32_t* counts,
+    int32_t n_classes, StateT<T> st, int32_t CAP, unsigned long long* queue) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    const uint32_t* base = blob.words;
+    uint32_t* tail = lds;
+    if (SCENE_IN_LDS) {
+        for (int w = threadIdx.x; w < blob.n_words; w += blockDim.x) lds[w] = blob.words[w];
+        base = lds;
+        tail = lds + ((blob.n_words + 3) & ~3);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long* cur = reinterpret_cast<unsigned long long*>(tail) + wave * 2 * CAP;  // wave-private lists
+    unsigned long long* nxt = cur + CAP;
+    __syncthreads();  // the only workgroup barrier: the scene image is staged
+    const Scene<T> sc = bind_scene<T>(base, blob, unit);
+    int alive = 0;  // wave-uniform
+    bool exhausted = false;
+#ifdef OT_STAMP
+    unsigned long long st_acc[5] = {0, 0, 0, 0, 0};
+#define OT_STAMP_AT(k) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long _t = __builtin_amdgcn_s_memtime(); st_acc[k] += _t - st_last; st_last = _t; } while (0)
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#else
+#define OT_STAMP_AT(k) do {} while (0)
+#endif
+    for (;;) {
+        while (!exhausted && alive + 64 <= CAP) {  // room for one more ticket of fresh rays
+            unsigned long long first = 0;
+            if (lane == 0) first = atomicAdd(queue, 64ull);
+            first = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(first >> 32)) << 32) |
+                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(first & 0xffffffffull));
+            if (first >= (unsigned long long)n) { exhausted = true; break; }
+            const int cnt = (int)((unsigned long long)n - first < 64ull ? (unsigned long long)n - first : 64ull);
+            if (lane < cnt) cur[alive + lane] = first + (unsigned long long)lane;  // segment index 0
+            alive += cnt;
+        }
+        if (alive == 0) break;  // queue and list are empty
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // (Holding a remainder back so that every pass is full was measured too: 54.8 instead of 44 lanes per pass
+        // and 20 % fewer passes, but each pass 35 % longer — 5.19 vs 4.88 ms.)
+        const int todo = alive;
+        int next_alive = 0;
+        for (int p0 = 0; p0 < todo; p0 += 64) {
+            const int p = p0 + lane;
+            const Fetched<T> cu = fetch_ray(in, st, p < todo ? cur[p] : 0ull, p < todo);
+            OT_STAMP_AT(0);
+            const RayState<T>& r = cu.r;
+            const int64_t i = cu.i;
+            const int32_t k = cu.k;
+            bool active = cu.valid, survive = false;
+            if (active && (cu.fl & OT_RAY_DEAD)) {  // optical_component.py:349: returned as it came
+                store_segment<T, NT>(out, i, r, r.len, (int32_t)i, -2);
+                seg_count[i] = 1;
+                active = false;
+            }
+            const GateCtx gate = {counts, n_classes, cu.cls, nullptr, nullptr, 0, 0};
+            const Hit<T> h = nearest_hit<T, F, GATE_PLAIN>(sc, r, active, gate);
+            OT_STAMP_AT(1);
+            if (active) {
+                const int64_t slot = (int64_t)k * n + i;
+                int32_t used = k + 1;
+                if (h.node < 0) {
+                    store_segment<T, NT>(out, slot, r, r.len, (int32_t)i, -1);
+                } else {
+                    store_segment<T, NT>(out, slot, r, h.t, (int32_t)i, sc.nodes[h.node].leaf_id);
+                    RayState<T> child;
+                    MatCache<T> mc = {T(1)};
+                    if constexpr (F & F_REFRACT) mc = make_matcache(sc, r.wl);
+                    const int nk = interact<T, F, 1>(sc, r, h, &child, mc);
+                    if (nk == 1) {
+                        survive = k + 1 < K;
+                        if (survive) {
+                            st.f[0][i] = child.ox; st.f[1][i] = child.oy; st.f[2][i] = child.oz;
+                            st.f[3][i] = child.dx; st.f[4][i] = child.dy; st.f[5][i] = child.dz;
+                            st.f[6][i] = child.qr; st.f[7][i] = child.qi; st.f[8][i] = child.I;
+                            st.f[9][i] = child.n; st.f[10][i] = child.pl;
+                        }
+                    } else if (nk > 1) {
+                        used = -(k + 1);
+                    }
+                }
+                if (!survive) seg_count[i] = used;
+            }
+            OT_STAMP_AT(2);
+            const unsigned long long mk = __ballot(survive);
+            if (survive) nxt[next_alive + __popcll(mk & ((1ull << lane) - 1ull))] = ((unsigned long long)(k + 1) << 32) | (unsigned long long)i;
+            next_alive += __popcll(mk);
+            OT_STAMP_AT(3);
+#ifdef OT_STAMP
+            st_acc[4] += 1;
+#endif
+        }
+        // the list and the scratch records written above are read by other lanes of this wave in the next round: LDS
+        // and global accesses of one wave complete in issue order, the fence only stops the compiler from moving them
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        unsigned long long* t = cur; cur = nxt; nxt = t;
+        alive = next_alive;
+    }
+#ifdef OT_STAMP
+    if (lane == 0) for (int q = 0; q < 5; ++q) atomicAdd(&queue[8 + q], st_acc[q]);
+#endif
+}
+
 // k_stream_ceiling: the fused kernel's memory traffic with no tracing — reads one ray record,
 // writes K segment records per ray through the same SoA streams.  What this access pattern can
 // reach on the device; reported next to the trace kernel (bench.py).

@@ -68,8 +68,10 @@ struct ot_ctx {
     // scene images above this stay in global memory (L2): a 100+ KB LDS image leaves one block per CU,
     // and on cfg 5 the lost occupancy cost 1.5x (tools/bench_configs.py)
     int32_t opt_lds_limit_kb = 64;
-    int32_t opt_kernel = 0;  // 0 auto, 1 fused (lane per ray), 2 blocked (chunk per workgroup)
+    int32_t opt_kernel = 0;  // 0 auto, 1 fused (lane per ray), 2 blocked (fixed chunk per wave; auto uses rolling lists)
+    int32_t opt_list_cap = 128;  // k_trace_rolling: live rays per wave (cfg 3: 128 beats 256 and 512)
     Scratch blocked;
+    size_t blocked_queue_off = 0;
     int32_t opt_nt = 1, opt_minw = 4, opt_blocks_per_cu = 0;  // defaults from tools/tune.py on MI355X
     Scratch gen, scan_tmp, mon;
 };
@@ -391,7 +393,15 @@ int ot_scene_upload(ot_ctx* c, const ot_scene_desc* s) {
     c->cache_mat = -1;
     for (int i = 0; i < s->n_materials; ++i)
         if (s->materials[i].kind == OT_MAT_SELLMEIER) { c->cache_mat = i; break; }
-    if (c->root_grid >= 0) c->features |= F_ROOT | F_AABB;
+    if (c->root_grid >= 0) {
+        c->features |= F_ROOT | F_AABB;
+        const double* g = s->aux + s->root_grid;
+        const int64_t cells = (int64_t)g[2] * (int64_t)g[3];
+        const double* items = g + 11 + cells + 1;
+        const int64_t n_items = (int64_t)g[11 + cells];
+        for (int64_t k = 0; k < n_items; ++k)
+            if (s->nodes[(int)items[k]].kind != OT_NODE_LEAF) { c->features |= F_SUBTREE; break; }
+    }
     if (c->slot_max) { (void)hipFree(c->slot_max); c->slot_max = nullptr; }
     if (s->n_count_slots > 0) {
         std::vector<int32_t> smax(s->n_count_slots, 0);
@@ -474,7 +484,8 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
     const int64_t cap = (int64_t)c->n_cus * per_cu;
     const int grid = (int)(blocks_needed < cap ? blocks_needed : cap);
     // smallest instantiation that covers the scene's features, then the launch options
-    constexpr uint32_t FA = F_AABB | F_LENS, FB = F_AABB | F_LENS | F_REFRACT, FC = FB | F_GRID | F_ROOT,
+    constexpr uint32_t FA = F_AABB | F_LENS, FB = F_AABB | F_LENS | F_REFRACT, FC = FB | F_GRID | F_ROOT | F_SUBTREE,
+                       FR = FB | F_ROOT,  // planar scenes under a top-level grid that lists leaves only (cfg 3)
                        FD = F_AABB | F_REFRACT | F_CURVED | F_GRID;  // spherical / aspheric optics in gridded groups (cfg 5)
     const uint32_t need = c->features;
     // Heavy scenes (many nodes per segment => VALU-bound, uneven path lengths) use the blocked
@@ -504,9 +515,47 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
                                (img_lds && img + (size_t)wpb * 2 * CHUNK * sizeof(int32_t) > 156 * 1024)))
             CHUNK >>= 1;
         const size_t per_field = align_up(sizeof(T) * (size_t)n);
-        if (c->blocked.ensure(11 * per_field)) return fail(OT_ERR_HIP, "hipMalloc of blocked-trace scratch failed");
+        if (c->blocked.ensure(11 * per_field + 256)) return fail(OT_ERR_HIP, "hipMalloc of blocked-trace scratch failed");
+        c->blocked_queue_off = 11 * per_field;
         StateT<T> st;
         for (int k = 0; k < 11; ++k) st.f[k] = (T*)((uint8_t*)c->blocked.p + k * per_field);
+        // Scenes under a top-level grid (many separate components, rays of a wave unrelated after the first bounce):
+        // rolling lists, persistent workgroups.  Scenes whose rays all run through the same sequence of surfaces
+        // (cfg 5) keep generation-pure passes: mixing generations in a pass costs them more than the tails do
+        // (cfg 5 fp32: 36.6 vs 31.6 ms; cfg 3 fp32: 5.1 vs 5.5 ms).
+        if (c->root_grid >= 0 && c->opt_kernel != 2) {
+            unsigned long long* queue = (unsigned long long*)((uint8_t*)c->blocked.p + 11 * per_field);
+            using KernR = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, SegsT<T>, int32_t*, int32_t*, int32_t, StateT<T>, int32_t,
+                                   unsigned long long*);
+            const int fr = (need & ~FR) == 0 ? 0 : ((need & ~FC) == 0 ? 1 : 2);
+            static const KernR tr[3][2] = {{k_trace_rolling<T, FR, false, true>, k_trace_rolling<T, FR, true, true>},
+                                           {k_trace_rolling<T, FC, false, true>, k_trace_rolling<T, FC, true, true>},
+                                           {k_trace_rolling<T, F_ALL, false, true>, k_trace_rolling<T, F_ALL, true, true>}};
+            KernR kr = tr[fr][img_lds ? 1 : 0];
+            int32_t CAP = c->opt_list_cap;
+            while (CAP > 128 && img_lds && img + (size_t)wpb * 2 * CAP * sizeof(unsigned long long) > 156 * 1024) CAP >>= 1;
+            const size_t lds_r = (img_lds ? img : 0) + (size_t)wpb * 2 * CAP * sizeof(unsigned long long);
+            if (lds_r > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
+            int per_cu_r = 0;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_r, (const void*)kr, 64 * wpb, lds_r));
+            if (per_cu_r < 1) per_cu_r = 1;
+            if (c->opt_blocks_per_cu > 0) per_cu_r = c->opt_blocks_per_cu;
+            const int64_t want = (n + 64 * (int64_t)wpb - 1) / (64 * (int64_t)wpb);  // one ticket per wave at least
+            const int64_t capr = (int64_t)c->n_cus * per_cu_r;
+            const int gridr = (int)(want < capr ? want : capr);
+#ifdef OT_STAMP
+            HIP_TRY(hipMemsetAsync(queue, 0, 16 * sizeof(unsigned long long), c->stream));
+#else
+            HIP_TRY(hipMemsetAsync(queue, 0, sizeof(unsigned long long), c->stream));
+#endif
+            hipEvent_t ev0, ev1;
+            rc = timing_pair(c, &ev0, &ev1);
+            if (rc) return rc;
+            hipExtLaunchKernelGGL(kr, dim3(gridr), dim3(64 * wpb), (uint32_t)lds_r, c->stream, ev0, ev1, 0u, blob, (T)c->unit, view<T>(rays), n,
+                                  K, view<T>(out), seg_count, counts, n_classes, st, CAP, queue);
+            HIP_TRY(hipGetLastError());
+            return 0;
+        }
         using KernB = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, SegsT<T>, int32_t*, int32_t*, int32_t, StateT<T>, int32_t);
         const int fb = (need & ~FC) == 0 ? 0 : ((need & ~FD) == 0 ? 1 : 2), ntb = c->opt_nt ? 1 : 0;
         static const KernB tb[3][2][2] = {
@@ -729,6 +778,9 @@ int ot_set_option(ot_ctx* c, int32_t option, int32_t value) {
         case OT_OPT_LDS_LIMIT_KB:
             if (value < 0 || value > 150) return fail(OT_ERR_INVALID, "OT_OPT_LDS_LIMIT_KB takes 0..150");
             c->opt_lds_limit_kb = value; return 0;
+        case OT_OPT_LIST_CAP:
+            if (value != 128 && value != 256 && value != 512 && value != 1024) return fail(OT_ERR_INVALID, "OT_OPT_LIST_CAP takes 128, 256, 512 or 1024");
+            c->opt_list_cap = value; return 0;
         case OT_OPT_BLOCKS_PER_CU:
             if (value < 0 || value > 65536) return fail(OT_ERR_INVALID, "OT_OPT_BLOCKS_PER_CU out of range");
             c->opt_blocks_per_cu = value; return 0;
@@ -769,6 +821,15 @@ int ot_bench_stream_f32(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, co
     return bench_stream<float>(c, rays, n, K, out, seg_count);
 }
 
+#ifdef OT_STAMP
+// diagnostic builds only (make STAMP=1): wave-cycles the last k_trace_rolling launch spent per phase
+int ot_debug_stamps(ot_ctx* c, unsigned long long* out5) {
+    if (!c || !c->blocked.p) return fail(OT_ERR_INVALID, "no rolling launch yet");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out5, (uint8_t*)c->blocked.p + c->blocked_queue_off + 8 * sizeof(unsigned long long), 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return 0;
+}
+#endif
 int ot_timing_enable(ot_ctx* c, int enabled) {
     if (!c) return fail(OT_ERR_INVALID, "ctx is NULL");
     if (!enabled) {

@@ -23,6 +23,10 @@ if os.environ.get('RGC'):  # experiment: top-level grid resolution (cells per co
     _scene.ROOT_GRID_CELLS_PER_COMPONENT = float(os.environ['RGC'])
 if os.environ.get('LDSKB'):
     eng.set_option(abi.OPT_LDS_LIMIT_KB, int(os.environ['LDSKB']))
+if os.environ.get('CAP'):
+    eng.set_option(abi.OPT_LIST_CAP, int(os.environ['CAP']))
+if os.environ.get('KERNEL'):
+    eng.set_option(abi.OPT_KERNEL, int(os.environ['KERNEL']))
 if os.environ.get('MINW'):
     eng.set_option(abi.OPT_MIN_WAVES, int(os.environ['MINW']))
 if os.environ.get('BPC'):
@@ -31,10 +35,11 @@ Q = lambda wl: 1j * np.pi * scenes.W0**2 / wl
 
 
 def run(name, comps, o, d, wl, K, prec, reps=5):
-    for kern in ((1, 2) if os.environ.get('BOTH') else (0,)):
+    base = int(os.environ.get('KERNEL', 0))
+    for kern in ((1, 2) if os.environ.get('BOTH') else (base,)):
         eng.set_option(abi.OPT_KERNEL, kern)
         _run(f'{name} k{kern}', comps, o, d, wl, K, prec, reps)
-    eng.set_option(abi.OPT_KERNEL, 0)
+    eng.set_option(abi.OPT_KERNEL, base)
 
 
 def _run(name, comps, o, d, wl, K, prec, reps=5):

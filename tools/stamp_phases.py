@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Where a pass of k_trace_rolling spends its wave-cycles (diagnostic build, `make -C optable_amd/csrc
+liboptable_hip_stamp.so`): s_memtime stamps around list read + loads / nearest hit / records + interaction /
+compaction, with an s_waitcnt(0) at every stamp so that memory latency is charged to the phase that issued it.
+    python tools/stamp_phases.py [cfg3|cfg5] [f32|f64] [n_rays]"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from optable_amd import abi
+
+abi.LIB_PATH = os.path.join(ROOT, "optable_amd", "csrc", "liboptable_hip_stamp.so")
+import optable_amd as oa
+from optable_amd import workloads as W
+from optable_amd.batch import RayBatch, SegmentBatch
+from optable_amd.engine import get_engine
+
+name = sys.argv[1] if len(sys.argv) > 1 else "cfg3"
+prec = sys.argv[2] if len(sys.argv) > 2 else "f32"
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 3_000_000
+wl = W.baseline_workloads(oa)[name]
+eng = get_engine()
+for k, v in (("CAP", abi.OPT_LIST_CAP), ("KERNEL", abi.OPT_KERNEL)):
+    if os.environ.get(k):
+        eng.set_option(v, int(os.environ[k]))
+table = oa.OpticalTable()
+table.add_components(wl.components())
+eng.upload(table.compile())
+o, d, lam = wl.rays(n, 0)
+batch = RayBatch.from_arrays(o, d, wavelength=lam, q=1j * np.pi * W.W0**2 / lam, precision=prec)
+out = SegmentBatch(n * wl.max_segments, prec, batch.device)
+for _ in range(3):
+    eng.trace(batch, wl.max_segments, out=out)
+eng.timing(True)
+eng.trace(batch, wl.max_segments, out=out)
+ms, cnt = eng.timing_read()
+eng.timing(False)
+acc = (C.c_ulonglong * 5)()
+eng.lib.ot_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
+abi.check(eng.lib.ot_debug_stamps(eng._ctx, acc), eng.lib)
+load, hit, inter, comp, passes = [int(x) for x in acc]
+tot = load + hit + inter + comp
+segs = int(out.count.abs().sum().item())
+print(f"{name} {prec} n={n}: {ms / cnt:.3f} ms (stamped build), {passes} passes for {segs} segments = {segs / passes:.1f} lanes per pass")
+for label, v in (("list + loads (waited)", load), ("nearest hit", hit), ("record + interact + state (waited)", inter), ("compaction", comp)):
+    print(f"   {label:36s} {v / passes:9.0f} cycles per pass  {100 * v / tot:5.1f} %")
