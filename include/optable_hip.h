@@ -265,7 +265,7 @@ enum ot_option {
     OT_OPT_NT_STORES = 1,      /* segment records written with non-temporal stores (0/1)        */
     OT_OPT_MIN_WAVES = 2,      /* 0: compiler's choice; 4: cap registers for 4 waves per SIMD  */
     OT_OPT_BLOCKS_PER_CU = 3,  /* persistent-grid size in 256-thread blocks per CU (0 = auto)  */
-    OT_OPT_KERNEL = 4,         /* 0 auto; 1 lane-per-ray kernel; 2 chunk-per-workgroup kernel   */
+    OT_OPT_KERNEL = 4,         /* 0 auto; 1 lane-per-ray kernel; 2 rolling-list kernel (heavy scenes) */
     OT_OPT_LDS_LIMIT_KB = 5,   /* scene images above this many KB are read from global memory   */
     OT_OPT_LIST_CAP = 6        /* heavy scenes: live rays per wave in the rolling list (default 256)  */
 };

@@ -3,7 +3,8 @@
 // optable_hip.hip.
 //   k_trace_fused<T>     one lane per ray, every segment of the ray in one launch (non-branching scenes, light
 //                        scene tables).  HBM-bound: SoA streams, 64 consecutive elements per wave instruction.
-//   k_trace_blocked<T>   the same trace for heavy scenes: wave-owned chunks, survivors compacted every segment.
+//   k_trace_rolling<T>   the same trace for heavy scenes: persistent waves, each with its own list of live rays that
+//                        is compacted every segment and refilled from a device-wide queue.
 //   k_stream_ceiling<T>  the fused kernel's streams with no tracing (roofline companion).
 //   k_gen_trace<T>       one breadth-first generation of branching ray trees (optical_table.py:115-134):
 //                        rank within the tree, trace, ordered slot allocation by decoupled look-back;
@@ -151,122 +152,16 @@ __global__ __launch_bounds__(256, MINW) void k_trace_fused(SceneBlob blob, T uni
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// k_trace_blocked: the same trace for HEAVY scenes (many nodes, long and uneven paths).
-// One lane per ray wastes lanes twice there: rays of a wave end after different numbers of
-// segments, and the segment loop runs as long as its longest ray.  Here every WAVE owns a chunk of
-// CHUNK (256 to 1024) consecutive rays and advances them generation by generation: after every segment the
-// surviving rays are compacted (order preserving: ballot + popcount) into a dense index list in
-// LDS, so every pass runs with a full wave until the chunk drains.  The four waves of a workgroup
-// share only the staged scene image; each has its own lists and its own chunks, so there is no
-// workgroup barrier inside the loop (a first version with one 1024-ray chunk per workgroup spent
-// 57 % of its wave-cycles waiting, mostly at the two barriers per pass: profiles/).
-// The state of a live ray travels through a per-ray scratch record in global memory (L2/MALL
-// resident); segment records go to the same [k][ray] slots as k_trace_fused, so the two kernels
-// are interchangeable bit for bit.
-template <class T> struct StateT {
-    T* f[11];  // ox oy oz dx dy dz qr qi I n pl  (wavelength, id, flags stay in the input arrays)
-};
-
 #ifndef OT_BLOCKED_MINW
 #define OT_BLOCKED_MINW 1
 #endif
-template <class T, uint32_t F> constexpr int blocked_minw() { return (sizeof(T) == 8 && F == 86u) ? OT_BLOCKED_MINW : 1; }
-// largest workgroup an instantiation may be launched with: 512 threads = 2 waves/SIMD = 256 VGPRs, which every
-// instantiation fits except the all-features fp64 one (it would spill 44 bytes per lane)
-template <class T, uint32_t F> constexpr int blocked_threads() { return (sizeof(T) == 8 && F == F_ALL) ? 256 : 512; }
-
-template <class T, uint32_t F, bool SCENE_IN_LDS, bool NT>
-__global__ __launch_bounds__((blocked_threads<T, F>()), (blocked_minw<T, F>())) void k_trace_blocked(SceneBlob blob, T unit, RaysT<T> in, int64_t n, int32_t K, SegsT<T> out,
-                                                       int32_t* __restrict__ seg_count, int32_t* counts, int32_t n_classes,
-                                                       StateT<T> st, int32_t CHUNK) {
-    extern __shared__ __align__(16) uint32_t lds[];
-    const uint32_t* base = blob.words;
-    uint32_t* tail = lds;
-    if (SCENE_IN_LDS) {
-        for (int w = threadIdx.x; w < blob.n_words; w += blockDim.x) lds[w] = blob.words[w];
-        base = lds;
-        tail = lds + ((blob.n_words + 3) & ~3);
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int32_t* cur = reinterpret_cast<int32_t*>(tail) + wave * 2 * CHUNK;  // wave-private lists
-    int32_t* nxt = cur + CHUNK;
-    __syncthreads();  // the only workgroup barrier: the scene image is staged
-    const Scene<T> sc = bind_scene<T>(base, blob, unit);
-    const int64_t n_chunks = (n + CHUNK - 1) / CHUNK;
-    const int wpb = blockDim.x >> 6;  // 4 waves per workgroup, 8 when a large scene image fills the CU's LDS
-    for (int64_t ch = (int64_t)blockIdx.x * wpb + wave; ch < n_chunks; ch += (int64_t)gridDim.x * wpb) {  // wave-uniform
-        const int64_t first = ch * CHUNK;
-        int alive = (int)((n - first) < CHUNK ? (n - first) : CHUNK);
-        for (int32_t k = 0; k < K && alive > 0; ++k) {
-            int next_alive = 0;
-            for (int p0 = 0; p0 < alive; p0 += 64) {
-                const int p = p0 + lane;
-                bool active = p < alive;
-                const int j = active ? (k == 0 ? p : cur[p]) : 0;
-                const int64_t i = first + j;
-                RayState<T> r = {};
-                int32_t cls = 0;
-                bool survive = false;
-                if (active) {
-                    const int32_t fl = in.flags[i];
-                    cls = in.id[i];
-                    if (k == 0) {
-                        r = load_ray(in, i, fl);
-                        if (fl & OT_RAY_DEAD) {
-                            store_segment<T, NT>(out, i, r, r.len, (int32_t)i, -2);
-                            seg_count[i] = 1;
-                            active = false;
-                        }
-                    } else {
-                        r.ox = st.f[0][i]; r.oy = st.f[1][i]; r.oz = st.f[2][i];
-                        r.dx = st.f[3][i]; r.dy = st.f[4][i]; r.dz = st.f[5][i];
-                        r.qr = st.f[6][i]; r.qi = st.f[7][i]; r.I = st.f[8][i]; r.n = st.f[9][i]; r.pl = st.f[10][i];
-                        r.wl = in.wl[i];
-                        r.len = Num<T>::inf();
-                        r.has_q = (fl & OT_RAY_HAS_Q) != 0;
-                    }
-                }
-                const GateCtx gate = {counts, n_classes, cls, nullptr, nullptr, 0, 0};
-                const Hit<T> h = nearest_hit<T, F, GATE_PLAIN>(sc, r, active, gate);
-                if (active) {
-                    const int64_t slot = (int64_t)k * n + i;
-                    int32_t used = k + 1;
-                    if (h.node < 0) {
-                        store_segment<T, NT>(out, slot, r, r.len, (int32_t)i, -1);
-                    } else {
-                        store_segment<T, NT>(out, slot, r, h.t, (int32_t)i, sc.nodes[h.node].leaf_id);
-                        RayState<T> child;
-                        MatCache<T> mc = {T(1)};
-                        if constexpr (F & F_REFRACT) mc = make_matcache(sc, r.wl);
-                        const int nk = interact<T, F, 1>(sc, r, h, &child, mc);
-                        if (nk == 1) {
-                            survive = k + 1 < K;
-                            if (survive) {
-                                st.f[0][i] = child.ox; st.f[1][i] = child.oy; st.f[2][i] = child.oz;
-                                st.f[3][i] = child.dx; st.f[4][i] = child.dy; st.f[5][i] = child.dz;
-                                st.f[6][i] = child.qr; st.f[7][i] = child.qi; st.f[8][i] = child.I;
-                                st.f[9][i] = child.n; st.f[10][i] = child.pl;
-                            }
-                        } else if (nk > 1) {
-                            used = -(k + 1);
-                        }
-                    }
-                    if (!survive) seg_count[i] = used;
-                }
-                // order-preserving append of this pass's survivors (wave-private list: no barrier)
-                const unsigned long long mask = __ballot(survive);
-                if (survive) nxt[next_alive + __popcll(mask & ((1ull << lane) - 1ull))] = j;
-                next_alive += __popcll(mask);
-            }
-            // the list written above is read by other lanes of this wave in the next generation, and
-            // so is the scratch state: LDS and global accesses of one wave complete in issue order,
-            // the fence only stops the compiler from moving them
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            int32_t* t = cur; cur = nxt; nxt = t;
-            alive = next_alive;
-        }
-    }
+template <class T, uint32_t F> constexpr int blocked_minw() { return 1; }
+// largest workgroup an instantiation may be launched with.  Waves of k_trace_rolling never synchronise after the scene
+// image is staged, so the workgroup size only decides how many waves share one image: 512 threads = 2 waves per SIMD =
+// 256 VGPRs fit every instantiation except the all-features fp64 one (it would spill 44 bytes per lane); the fp32
+// curved-surface preset (cfg 5: 152 VGPRs) may run 768 = 3 waves per SIMD on one 54 KB image.
+template <class T, uint32_t F> constexpr int blocked_threads() {
+    return (sizeof(T) == 8 && F == F_ALL) ? 256 : ((sizeof(T) == 4 && F == (F_AABB | F_REFRACT | F_CURVED | F_GRID)) ? 768 : 512);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -288,40 +183,27 @@ __global__ __launch_bounds__((blocked_threads<T, F>()), (blocked_minw<T, F>())) 
 // in the cell loop (5.5 ms: the early exits do pay, whole waves leave a candidate together more often than not);
 // a resumable grid walk that visits at most 1 / 2 / 4 cells per pass and parks long walks for the next pass
 // (14.4 / 11.1 / 8.7 ms: every extra pass pays the pass's load -> trace -> store latency again).
-template <class T> struct Fetched {
-    RayState<T> r;
-    int64_t i;
-    int32_t k, cls, fl;
-    bool valid;
+// Per-wave scratch of k_trace_rolling: the records of the wave's live rays, stored by LIST POSITION (not by ray
+// index), one allocation for the launch: wave w owns [w][field][CAP].  A pass reads positions p0 .. p0+63 and
+// writes its survivors to positions next_alive .. (< p0 + 64, all read already): the compaction happens in place,
+// every access is 64 consecutive elements, and a few MB per XCD of such records stay in L2 between the pass that
+// writes them and the pass that reads them.  (Round 2 first kept the records by ray index in 11 arrays of n: the
+// rays of a pass are scattered over those, wavelength / flags / id were gathered from the caller's arrays on every
+// pass, and rocprofv3 showed 18 GB of HBM traffic for 3.3 GB of algorithmic bytes on cfg 3.)
+template <class T> struct WaveScratch {
+    uint8_t* base;
+    int64_t wave_bytes;  // bytes per wave: CAP * (12 * sizeof(T) + 8)
+    int32_t cap;
+    // fields 0..11: ox oy oz dx dy dz qr qi I n pl wavelength; then int32 flags, int32 id
+    __device__ __forceinline__ T* f(int64_t wave, int k) const { return reinterpret_cast<T*>(base + wave * wave_bytes) + (int64_t)k * cap; }
+    __device__ __forceinline__ int32_t* flags(int64_t wave) const { return reinterpret_cast<int32_t*>(base + wave * wave_bytes + (int64_t)12 * cap * sizeof(T)); }
+    __device__ __forceinline__ int32_t* id(int64_t wave) const { return flags(wave) + cap; }
 };
-template <class T>
-__device__ __forceinline__ Fetched<T> fetch_ray(const RaysT<T>& in, const StateT<T>& st, unsigned long long entry, bool valid) {
-    Fetched<T> f;
-    f.valid = valid;
-    f.i = (int64_t)(entry & 0x7fffffffull);
-    f.k = (int32_t)(entry >> 32);
-    f.cls = f.fl = 0;
-    f.r = {};
-    if (valid) {
-        const int64_t i = f.i;
-        const bool fresh = f.k == 0;  // first segment: the caller's arrays; later ones: the per-ray scratch record
-        f.fl = in.flags[i];
-        f.cls = in.id[i];
-        f.r.ox = (fresh ? in.ox : st.f[0])[i]; f.r.oy = (fresh ? in.oy : st.f[1])[i]; f.r.oz = (fresh ? in.oz : st.f[2])[i];
-        f.r.dx = (fresh ? in.dx : st.f[3])[i]; f.r.dy = (fresh ? in.dy : st.f[4])[i]; f.r.dz = (fresh ? in.dz : st.f[5])[i];
-        f.r.qr = (fresh ? in.qr : st.f[6])[i]; f.r.qi = (fresh ? in.qi : st.f[7])[i]; f.r.I = (fresh ? in.I : st.f[8])[i];
-        f.r.n = (fresh ? in.n : st.f[9])[i]; f.r.pl = (fresh ? in.pl : st.f[10])[i];
-        f.r.wl = in.wl[i];
-        f.r.len = (fresh && in.len) ? in.len[i] : Num<T>::inf();
-        f.r.has_q = (f.fl & OT_RAY_HAS_Q) != 0;
-    }
-    return f;
-}
 
 template <class T, uint32_t F, bool SCENE_IN_LDS, bool NT>
 __global__ __launch_bounds__((blocked_threads<T, F>()), (blocked_minw<T, F>())) void k_trace_rolling(
     SceneBlob blob, T unit, RaysT<T> in, int64_t n, int32_t K, SegsT<T> out, int32_t* __restrict__ seg_count, int32_t* counts,
-    int32_t n_classes, StateT<T> st, int32_t CAP, unsigned long long* queue) {
+    int32_t n_classes, WaveScratch<T> ws, int32_t CAP, unsigned long long* queue, int32_t mix) {
     extern __shared__ __align__(16) uint32_t lds[];
     const uint32_t* base = blob.words;
     uint32_t* tail = lds;
@@ -335,8 +217,15 @@ __global__ __launch_bounds__((blocked_threads<T, F>()), (blocked_minw<T, F>())) 
     unsigned long long* nxt = cur + CAP;
     __syncthreads();  // the only workgroup barrier: the scene image is staged
     const Scene<T> sc = bind_scene<T>(base, blob, unit);
+    const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;  // this wave's scratch
+    T* const s_ox = ws.f(gw, 0); T* const s_oy = ws.f(gw, 1); T* const s_oz = ws.f(gw, 2);
+    T* const s_dx = ws.f(gw, 3); T* const s_dy = ws.f(gw, 4); T* const s_dz = ws.f(gw, 5);
+    T* const s_qr = ws.f(gw, 6); T* const s_qi = ws.f(gw, 7); T* const s_I = ws.f(gw, 8);
+    T* const s_n = ws.f(gw, 9); T* const s_pl = ws.f(gw, 10); T* const s_wl = ws.f(gw, 11);
+    int32_t* const s_fl = ws.flags(gw);
+    int32_t* const s_id = ws.id(gw);
     int alive = 0;  // wave-uniform
-    bool exhausted = false;
+    bool exhausted = false, fresh_fill = false;
 #ifdef OT_STAMP
     unsigned long long st_acc[5] = {0, 0, 0, 0, 0};
 #define OT_STAMP_AT(k) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long _t = __builtin_amdgcn_s_memtime(); st_acc[k] += _t - st_last; st_last = _t; } while (0)
@@ -345,7 +234,10 @@ __global__ __launch_bounds__((blocked_threads<T, F>()), (blocked_minw<T, F>())) 
 #define OT_STAMP_AT(k) do {} while (0)
 #endif
     for (;;) {
-        while (!exhausted && alive + 64 <= CAP) {  // room for one more ticket of fresh rays
+        // mix: top up whenever 64 slots are free (rays of all generations share the list); otherwise only an EMPTY list
+        // is refilled, CAP rays at once, and every pass is pure in its generation (scenes whose rays all run through
+        // the same sequence of surfaces: a pass then tests one kind of surface, cfg 5)
+        while (!exhausted && alive + 64 <= CAP && (mix || alive == 0 || (alive & 63) == 0 && fresh_fill)) {
             unsigned long long first = 0;
             if (lane == 0) first = atomicAdd(queue, 64ull);
             first = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(first >> 32)) << 32) |
@@ -354,7 +246,9 @@ __global__ __launch_bounds__((blocked_threads<T, F>()), (blocked_minw<T, F>())) 
             const int cnt = (int)((unsigned long long)n - first < 64ull ? (unsigned long long)n - first : 64ull);
             if (lane < cnt) cur[alive + lane] = first + (unsigned long long)lane;  // segment index 0
             alive += cnt;
+            fresh_fill = true;  // a refill of an empty list goes on until the list is full
         }
+        fresh_fill = false;
         if (alive == 0) break;  // queue and list are empty
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         // (Holding a remainder back so that every pass is full was measured too: 54.8 instead of 44 lanes per pass
@@ -363,20 +257,37 @@ __global__ __launch_bounds__((blocked_threads<T, F>()), (blocked_minw<T, F>())) 
         int next_alive = 0;
         for (int p0 = 0; p0 < todo; p0 += 64) {
             const int p = p0 + lane;
-            const Fetched<T> cu = fetch_ray(in, st, p < todo ? cur[p] : 0ull, p < todo);
+            bool active = p < todo;
+            const unsigned long long entry = active ? cur[p] : 0ull;
+            const int64_t i = (int64_t)(entry & 0x7fffffffull);
+            const int32_t k = (int32_t)(entry >> 32);
+            RayState<T> r = {};
+            int32_t cls = 0, fl = 0;
+            if (active) {
+                if (k == 0) {  // first segment: the caller's arrays (a ticket is 64 consecutive rays)
+                    fl = in.flags[i];
+                    cls = in.id[i];
+                    r = load_ray(in, i, fl);
+                } else {  // later ones: this wave's scratch, by list position
+                    r.ox = s_ox[p]; r.oy = s_oy[p]; r.oz = s_oz[p]; r.dx = s_dx[p]; r.dy = s_dy[p]; r.dz = s_dz[p];
+                    r.qr = s_qr[p]; r.qi = s_qi[p]; r.I = s_I[p]; r.n = s_n[p]; r.pl = s_pl[p]; r.wl = s_wl[p];
+                    fl = s_fl[p];
+                    cls = s_id[p];
+                    r.len = Num<T>::inf();
+                    r.has_q = (fl & OT_RAY_HAS_Q) != 0;
+                }
+            }
             OT_STAMP_AT(0);
-            const RayState<T>& r = cu.r;
-            const int64_t i = cu.i;
-            const int32_t k = cu.k;
-            bool active = cu.valid, survive = false;
-            if (active && (cu.fl & OT_RAY_DEAD)) {  // optical_component.py:349: returned as it came
+            bool survive = false;
+            if (active && (fl & OT_RAY_DEAD)) {  // optical_component.py:349: returned as it came
                 store_segment<T, NT>(out, i, r, r.len, (int32_t)i, -2);
                 seg_count[i] = 1;
                 active = false;
             }
-            const GateCtx gate = {counts, n_classes, cu.cls, nullptr, nullptr, 0, 0};
+            const GateCtx gate = {counts, n_classes, cls, nullptr, nullptr, 0, 0};
             const Hit<T> h = nearest_hit<T, F, GATE_PLAIN>(sc, r, active, gate);
             OT_STAMP_AT(1);
+            RayState<T> child = {};
             if (active) {
                 const int64_t slot = (int64_t)k * n + i;
                 int32_t used = k + 1;
@@ -384,29 +295,25 @@ __global__ __launch_bounds__((blocked_threads<T, F>()), (blocked_minw<T, F>())) 
                     store_segment<T, NT>(out, slot, r, r.len, (int32_t)i, -1);
                 } else {
                     store_segment<T, NT>(out, slot, r, h.t, (int32_t)i, sc.nodes[h.node].leaf_id);
-                    RayState<T> child;
                     MatCache<T> mc = {T(1)};
                     if constexpr (F & F_REFRACT) mc = make_matcache(sc, r.wl);
                     const int nk = interact<T, F, 1>(sc, r, h, &child, mc);
-                    if (nk == 1) {
-                        survive = k + 1 < K;
-                        if (survive) {
-                            st.f[0][i] = child.ox; st.f[1][i] = child.oy; st.f[2][i] = child.oz;
-                            st.f[3][i] = child.dx; st.f[4][i] = child.dy; st.f[5][i] = child.dz;
-                            st.f[6][i] = child.qr; st.f[7][i] = child.qi; st.f[8][i] = child.I;
-                            st.f[9][i] = child.n; st.f[10][i] = child.pl;
-                        }
-                    } else if (nk > 1) {
-                        used = -(k + 1);
-                    }
+                    if (nk == 1) survive = k + 1 < K;
+                    else if (nk > 1) used = -(k + 1);
                 }
                 if (!survive) seg_count[i] = used;
             }
-            OT_STAMP_AT(2);
             const unsigned long long mk = __ballot(survive);
-            if (survive) nxt[next_alive + __popcll(mk & ((1ull << lane) - 1ull))] = ((unsigned long long)(k + 1) << 32) | (unsigned long long)i;
+            if (survive) {  // in-place compaction: q < p0 + 64, and every position below p0 + 64 has been read
+                const int q = next_alive + __popcll(mk & ((1ull << lane) - 1ull));
+                nxt[q] = ((unsigned long long)(k + 1) << 32) | (unsigned long long)i;
+                s_ox[q] = child.ox; s_oy[q] = child.oy; s_oz[q] = child.oz; s_dx[q] = child.dx; s_dy[q] = child.dy; s_dz[q] = child.dz;
+                s_qr[q] = child.qr; s_qi[q] = child.qi; s_I[q] = child.I; s_n[q] = child.n; s_pl[q] = child.pl; s_wl[q] = r.wl;
+                s_fl[q] = fl;
+                s_id[q] = cls;
+            }
             next_alive += __popcll(mk);
-            OT_STAMP_AT(3);
+            OT_STAMP_AT(2);
 #ifdef OT_STAMP
             st_acc[4] += 1;
 #endif

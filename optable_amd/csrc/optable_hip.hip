@@ -68,8 +68,9 @@ struct ot_ctx {
     // scene images above this stay in global memory (L2): a 100+ KB LDS image leaves one block per CU,
     // and on cfg 5 the lost occupancy cost 1.5x (tools/bench_configs.py)
     int32_t opt_lds_limit_kb = 64;
-    int32_t opt_kernel = 0;  // 0 auto, 1 fused (lane per ray), 2 blocked (fixed chunk per wave; auto uses rolling lists)
+    int32_t opt_kernel = 0;  // 0 auto, 1 fused (lane per ray), 2 rolling lists (the heavy-scene kernel)
     int32_t opt_list_cap = 128;  // k_trace_rolling: live rays per wave (cfg 3: 128 beats 256 and 512)
+    int32_t opt_list_cap_pure = 0;  // generation-pure lists: 0 = the chunk rule below
     Scratch blocked;
     size_t blocked_queue_off = 0;
     int32_t opt_nt = 1, opt_minw = 4, opt_blocks_per_cu = 0;  // defaults from tools/tune.py on MI355X
@@ -492,96 +493,72 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
     // kernel; light ones are HBM-bound and keep one lane per ray with perfectly coalesced streams.
     const bool use_blocked = c->opt_kernel == 2 || (c->opt_kernel == 0 && c->n_nodes >= 24 && K > 2);
     if (use_blocked) {
-        // Where the scene image lives.  Up to 64 KB: LDS, 256-thread workgroups, several per CU.  Up to ~140 KB
-        // (cfg 5: 260 nodes, 96 KB in fp64): still LDS, but ONE 512-thread workgroup per CU so that the CU keeps
-        // 8 waves — the register-limited occupancy of these kernels anyway.  Reading such an image from L2
-        // instead makes every leaf test a 64-lane gather of ~4 cache lines per lane (each ray tests its own
-        // micro-mirror): cfg 5 ran at the L1 line rate, 10.8k cycles per wave-segment per CU.
+        // Heavy scenes: persistent waves with their own lists of live rays (k_trace_rolling).
+        using KernR = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, SegsT<T>, int32_t*, int32_t*, int32_t, WaveScratch<T>, int32_t,
+                               unsigned long long*, int32_t);
+        // Scenes under a top-level grid (many separate components, rays of a wave unrelated after the first bounce)
+        // mix generations in a list and top it up continuously.  Scenes whose rays all run through the same sequence
+        // of surfaces (cfg 5) keep generation-pure lists: mixing costs them more than the tails do (cfg 5 fp32:
+        // 36.6 vs 31.6 ms; cfg 3 fp32: 5.1 vs 5.5 ms).
+        const bool mix = c->root_grid >= 0;
+        const int fr = (mix && (need & ~FR) == 0) ? 0 : ((need & ~FC) == 0 ? 1 : ((need & ~FD) == 0 ? 2 : 3));
+        static const KernR tr[4][2] = {{k_trace_rolling<T, FR, false, true>, k_trace_rolling<T, FR, true, true>},
+                                       {k_trace_rolling<T, FC, false, true>, k_trace_rolling<T, FC, true, true>},
+                                       {k_trace_rolling<T, FD, false, true>, k_trace_rolling<T, FD, true, true>},
+                                       {k_trace_rolling<T, F_ALL, false, true>, k_trace_rolling<T, F_ALL, true, true>}};
+        static const int max_threads[4] = {blocked_threads<T, FR>(), blocked_threads<T, FC>(), blocked_threads<T, FD>(), blocked_threads<T, F_ALL>()};
+        // Where the scene image lives and how many waves share it.  The waves never synchronise after staging, so the
+        // workgroup size is only packaging: take the one that keeps most waves resident per CU (registers and LDS
+        // decide; cfg 5 fp32: 54 KB image, 152 VGPRs -> one 768-thread workgroup = 12 waves, against 2 x 256 threads
+        // = 8 waves).  Images beyond what LDS holds next to the lists are read from L2.
         const size_t img = ((bytes + 15) / 16) * 16;
-        int wpb = 4;
-        bool img_lds = in_lds;
-        const bool fits512 = !(f64 && (need & ~FC) != 0 && (need & ~FD) != 0);  // see blocked_threads()
-        if (!in_lds && fits512 && c->opt_lds_limit_kb >= 64 && img + 8 * 2 * 256 * sizeof(int32_t) <= 156 * 1024) {
-            img_lds = true;
-            wpb = 8;
+        const size_t entry = sizeof(unsigned long long);
+        int32_t cap0 = mix ? c->opt_list_cap : (c->opt_list_cap_pure > 0 ? c->opt_list_cap_pure : 256);
+        int best_wpb = 4, best_waves = 0, best_per_cu = 1, best_cap = cap0;
+        bool best_lds = false;
+        for (int pass = 0; pass < 2 && best_waves == 0; ++pass) {  // pass 0: image in LDS; pass 1: image in L2
+            const bool lds_img = pass == 0;
+            if (lds_img && (c->opt_lds_limit_kb == 0 || img > 140 * 1024)) continue;
+            for (int wpb = 4; wpb * 64 <= max_threads[fr]; wpb += 4) {
+                int32_t CAP = cap0;
+                while (CAP > 128 && lds_img && img + (size_t)wpb * 2 * CAP * entry > 156 * 1024) CAP >>= 1;
+                const size_t lds_b = (lds_img ? img : 0) + (size_t)wpb * 2 * CAP * entry;
+                if (lds_b > 158 * 1024) continue;
+                KernR kq = tr[fr][lds_img ? 1 : 0];
+                if (lds_b > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+                int per_cu = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kq, 64 * wpb, lds_b) != hipSuccess) per_cu = 0;
+                if (per_cu * wpb > best_waves) { best_waves = per_cu * wpb; best_wpb = wpb; best_per_cu = per_cu; best_cap = CAP; best_lds = lds_img; }
+            }
         }
-        // rays per wave-owned chunk.  Longer chunks keep a wave full for longer (a chunk lives as long as its
-        // longest ray: cfg 5 fp64 84 / 78 / 76 ms at 256 / 512 / 1024 rays with the image in L2) but their index
-        // lists take LDS from the scene image when that is staged too (cfg 3: 8.5 / 8.5 / 10.9 ms), and a small
-        // batch needs enough chunks to give every SIMD a few waves (128-ray chunks lose again: more passes run
-        // half empty).
-        int32_t CHUNK = in_lds ? 256 : 1024;
-        while (CHUNK > 256 && (n / CHUNK < (int64_t)c->n_cus * 16 ||
-                               (img_lds && img + (size_t)wpb * 2 * CHUNK * sizeof(int32_t) > 156 * 1024)))
-            CHUNK >>= 1;
-        const size_t per_field = align_up(sizeof(T) * (size_t)n);
-        if (c->blocked.ensure(11 * per_field + 256)) return fail(OT_ERR_HIP, "hipMalloc of blocked-trace scratch failed");
-        c->blocked_queue_off = 11 * per_field;
-        StateT<T> st;
-        for (int k = 0; k < 11; ++k) st.f[k] = (T*)((uint8_t*)c->blocked.p + k * per_field);
-        // Scenes under a top-level grid (many separate components, rays of a wave unrelated after the first bounce):
-        // rolling lists, persistent workgroups.  Scenes whose rays all run through the same sequence of surfaces
-        // (cfg 5) keep generation-pure passes: mixing generations in a pass costs them more than the tails do
-        // (cfg 5 fp32: 36.6 vs 31.6 ms; cfg 3 fp32: 5.1 vs 5.5 ms).
-        if (c->root_grid >= 0 && c->opt_kernel != 2) {
-            unsigned long long* queue = (unsigned long long*)((uint8_t*)c->blocked.p + 11 * per_field);
-            using KernR = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, SegsT<T>, int32_t*, int32_t*, int32_t, StateT<T>, int32_t,
-                                   unsigned long long*);
-            const int fr = (need & ~FR) == 0 ? 0 : ((need & ~FC) == 0 ? 1 : 2);
-            static const KernR tr[3][2] = {{k_trace_rolling<T, FR, false, true>, k_trace_rolling<T, FR, true, true>},
-                                           {k_trace_rolling<T, FC, false, true>, k_trace_rolling<T, FC, true, true>},
-                                           {k_trace_rolling<T, F_ALL, false, true>, k_trace_rolling<T, F_ALL, true, true>}};
-            KernR kr = tr[fr][img_lds ? 1 : 0];
-            int32_t CAP = c->opt_list_cap;
-            while (CAP > 128 && img_lds && img + (size_t)wpb * 2 * CAP * sizeof(unsigned long long) > 156 * 1024) CAP >>= 1;
-            const size_t lds_r = (img_lds ? img : 0) + (size_t)wpb * 2 * CAP * sizeof(unsigned long long);
-            if (lds_r > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
-            int per_cu_r = 0;
-            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_r, (const void*)kr, 64 * wpb, lds_r));
-            if (per_cu_r < 1) per_cu_r = 1;
-            if (c->opt_blocks_per_cu > 0) per_cu_r = c->opt_blocks_per_cu;
-            const int64_t want = (n + 64 * (int64_t)wpb - 1) / (64 * (int64_t)wpb);  // one ticket per wave at least
-            const int64_t capr = (int64_t)c->n_cus * per_cu_r;
-            const int gridr = (int)(want < capr ? want : capr);
+        if (best_waves == 0) return fail(OT_ERR_HIP, "no launch configuration fits this scene image");
+        const int wpb = best_wpb;
+        const int32_t CAP = best_cap;
+        KernR kr = tr[fr][best_lds ? 1 : 0];
+        const size_t lds_r = (best_lds ? img : 0) + (size_t)wpb * 2 * CAP * entry;
+        if (lds_r > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
+        int per_cu_r = best_per_cu;
+        if (c->opt_blocks_per_cu > 0) per_cu_r = c->opt_blocks_per_cu;
+        const int64_t want = (n + 64 * (int64_t)wpb - 1) / (64 * (int64_t)wpb);  // one ticket per wave at least
+        const int64_t capr = (int64_t)c->n_cus * per_cu_r;
+        const int gridr = (int)(want < capr ? want : capr);
+        // per-wave record scratch (by list position) + the ticket counter
+        const size_t wave_bytes = align_up((size_t)CAP * (12 * sizeof(T) + 8));
+        const size_t scratch_bytes = wave_bytes * (size_t)gridr * wpb;
+        if (c->blocked.ensure(scratch_bytes + 256)) return fail(OT_ERR_HIP, "hipMalloc of rolling-trace scratch failed");
+        c->blocked_queue_off = scratch_bytes;
+        WaveScratch<T> ws = {(uint8_t*)c->blocked.p, (int64_t)wave_bytes, CAP};
+        unsigned long long* queue = (unsigned long long*)((uint8_t*)c->blocked.p + scratch_bytes);
 #ifdef OT_STAMP
-            HIP_TRY(hipMemsetAsync(queue, 0, 16 * sizeof(unsigned long long), c->stream));
+        HIP_TRY(hipMemsetAsync(queue, 0, 16 * sizeof(unsigned long long), c->stream));
 #else
-            HIP_TRY(hipMemsetAsync(queue, 0, sizeof(unsigned long long), c->stream));
+        HIP_TRY(hipMemsetAsync(queue, 0, sizeof(unsigned long long), c->stream));
 #endif
-            hipEvent_t ev0, ev1;
-            rc = timing_pair(c, &ev0, &ev1);
-            if (rc) return rc;
-            hipExtLaunchKernelGGL(kr, dim3(gridr), dim3(64 * wpb), (uint32_t)lds_r, c->stream, ev0, ev1, 0u, blob, (T)c->unit, view<T>(rays), n,
-                                  K, view<T>(out), seg_count, counts, n_classes, st, CAP, queue);
-            HIP_TRY(hipGetLastError());
-            return 0;
-        }
-        using KernB = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, SegsT<T>, int32_t*, int32_t*, int32_t, StateT<T>, int32_t);
-        const int fb = (need & ~FC) == 0 ? 0 : ((need & ~FD) == 0 ? 1 : 2), ntb = c->opt_nt ? 1 : 0;
-        static const KernB tb[3][2][2] = {
-            {{k_trace_blocked<T, FC, false, false>, k_trace_blocked<T, FC, false, true>},
-             {k_trace_blocked<T, FC, true, false>, k_trace_blocked<T, FC, true, true>}},
-            {{k_trace_blocked<T, FD, false, false>, k_trace_blocked<T, FD, false, true>},
-             {k_trace_blocked<T, FD, true, false>, k_trace_blocked<T, FD, true, true>}},
-            {{k_trace_blocked<T, F_ALL, false, false>, k_trace_blocked<T, F_ALL, false, true>},
-             {k_trace_blocked<T, F_ALL, true, false>, k_trace_blocked<T, F_ALL, true, true>}}};
-        KernB kb = tb[fb][img_lds ? 1 : 0][ntb];
-        const size_t lds_b = (img_lds ? img : 0) + (size_t)wpb * 2 * CHUNK * sizeof(int32_t);
-        if (lds_b > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
-        const int64_t n_chunks = (n + wpb * (int64_t)CHUNK - 1) / (wpb * (int64_t)CHUNK);  // workgroups needed: one chunk per wave
-        // One workgroup per four chunks up to 64 per CU (queued, not resident: LDS and registers decide how
-        // many run at once).  Chunk costs are very uneven — a chunk lives as long as its longest ray — and
-        // short-lived workgroups let the dispatcher balance them: cfg 3 at 1e7 rays 11.0 -> 8.5 ms fp64,
-        // 7.3 -> 6.1 ms fp32 against persistent LDS-fit workgroups; flat from 64 per CU on.
-        int fitb = 64;
-        if (c->opt_blocks_per_cu > 0) fitb = c->opt_blocks_per_cu;
-        const int64_t capb = (int64_t)c->n_cus * fitb;
-        const int gridb = (int)(n_chunks < capb ? n_chunks : capb);
         hipEvent_t ev0, ev1;
         rc = timing_pair(c, &ev0, &ev1);
         if (rc) return rc;
-        hipExtLaunchKernelGGL(kb, dim3(gridb), dim3(64 * wpb), (uint32_t)lds_b, c->stream, ev0, ev1, 0u, blob, (T)c->unit, view<T>(rays), n,
-                              K, view<T>(out), seg_count, counts, n_classes, st, CHUNK);
+        hipExtLaunchKernelGGL(kr, dim3(gridr), dim3(64 * wpb), (uint32_t)lds_r, c->stream, ev0, ev1, 0u, blob, (T)c->unit, view<T>(rays), n,
+                              K, view<T>(out), seg_count, counts, n_classes, ws, CAP, queue, mix ? 1 : 0);
         HIP_TRY(hipGetLastError());
         return 0;
     }
@@ -773,14 +750,14 @@ int ot_set_option(ot_ctx* c, int32_t option, int32_t value) {
             if (value != 0 && value != 4) return fail(OT_ERR_INVALID, "OT_OPT_MIN_WAVES takes 0 or 4");
             c->opt_minw = value; return 0;
         case OT_OPT_KERNEL:
-            if (value < 0 || value > 2) return fail(OT_ERR_INVALID, "OT_OPT_KERNEL takes 0 (auto), 1 (fused) or 2 (blocked)");
+            if (value < 0 || value > 2) return fail(OT_ERR_INVALID, "OT_OPT_KERNEL takes 0 (auto), 1 (lane per ray) or 2 (rolling lists)");
             c->opt_kernel = value; return 0;
         case OT_OPT_LDS_LIMIT_KB:
             if (value < 0 || value > 150) return fail(OT_ERR_INVALID, "OT_OPT_LDS_LIMIT_KB takes 0..150");
             c->opt_lds_limit_kb = value; return 0;
         case OT_OPT_LIST_CAP:
             if (value != 128 && value != 256 && value != 512 && value != 1024) return fail(OT_ERR_INVALID, "OT_OPT_LIST_CAP takes 128, 256, 512 or 1024");
-            c->opt_list_cap = value; return 0;
+            c->opt_list_cap = value; c->opt_list_cap_pure = value; return 0;
         case OT_OPT_BLOCKS_PER_CU:
             if (value < 0 || value > 65536) return fail(OT_ERR_INVALID, "OT_OPT_BLOCKS_PER_CU out of range");
             c->opt_blocks_per_cu = value; return 0;

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""One BASELINE workload, a handful of device traces and nothing else: the program rocprofv3 wraps for the
+profiles/ summaries (tools/profile_r02.sh).  Sizes are what one GPU sees in the quoted configuration.
+    python3 tools/profile_workload.py cfg3|cfg4|cfg5|cfg4b|monitor [reps]
+cfg4b = cfg 4 with reflectivity 0.2 (ray trees, generation kernels); monitor = Monitor.record over a cfg 2 history."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+import optable_amd as oa
+from optable_amd import workloads as W
+from optable_amd.batch import RayBatch, SegmentBatch
+from optable_amd.engine import get_engine
+
+name = sys.argv[1]
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+SIZES = {"cfg2": 1_000_000, "cfg3": 10_000_000, "cfg4": 160_000_000, "cfg5": 12_500_000, "cfg4b": 12_800_000, "monitor": 1_000_000}
+n = int(os.environ.get("RAYS", SIZES[name]))
+eng = get_engine()
+Q = lambda lam: 1j * np.pi * W.W0**2 / lam
+
+if name in ("cfg2", "cfg3", "cfg5"):
+    wl = W.baseline_workloads(oa)[name]
+    table = oa.OpticalTable()
+    table.add_components(wl.components())
+    eng.upload(table.compile())
+    o, d, lam = wl.rays(n, 0)
+    batch = RayBatch.from_arrays(o, d, wavelength=lam, q=Q(lam), precision=wl.precision)
+    out = SegmentBatch(n * wl.max_segments, wl.precision, batch.device)
+    for _ in range(reps + 2):
+        eng.trace(batch, wl.max_segments, out=out)
+    torch.cuda.synchronize()
+    print(f"{name}: {n} rays, {int(out.count.abs().sum())} segments per trace, {reps + 2} traces")
+elif name in ("cfg4", "cfg4b"):
+    table = oa.OpticalTable()
+    table.add_components(W.cfg4_components(oa, reflectivity=0.2 if name == "cfg4b" else 0))
+    scene = table.compile()
+    eng.upload(scene)
+    nb = n // W.CFG4_WAVELENGTHS
+    o, d, _ = W.cfg4_rays(nb, 4, n_wavelengths=1)
+    base = RayBatch.from_arrays(o, d, wavelength=W.WL, q=Q(W.WL), precision="f64")
+    batch = base.multiplexed_in_wavelength(np.linspace(400e-7, 1100e-7, W.CFG4_WAVELENGTHS))
+    if name == "cfg4":
+        out = SegmentBatch(batch.n * 3, "f64", batch.device)
+        for _ in range(reps):
+            eng.trace(batch, 3, out=out)
+        torch.cuda.synchronize()
+        print(f"cfg4: {batch.n} ray-wavelength pairs, {int(out.count.abs().sum())} segments per trace, {reps} traces")
+    else:
+        for _ in range(max(reps // 2, 2)):
+            t0 = time.perf_counter()
+            segs = eng.trace_tree(batch, 12, out_capacity=batch.n * 13)
+            torch.cuda.synchronize()
+            print(f"cfg4b: {batch.n} trees, {segs.n_valid} segments, {1e3 * (time.perf_counter() - t0):.1f} ms wall")
+else:  # Monitor.record over the [k][ray] history of a cfg 2 trace
+    wl = W.baseline_workloads(oa)["cfg2"]
+    table = oa.OpticalTable()
+    table.add_components(wl.components())
+    mon = oa.Monitor([7.5, 0, 0], 5, 5)
+    o, d, lam = wl.rays(n, 0)
+    batch = RayBatch.from_arrays(o, d, wavelength=lam, q=Q(lam))
+    segs = table.trace_batch(batch, max_segments=5)
+    for _ in range(reps):
+        hits = table.record_batch(mon, segs)
+    torch.cuda.synchronize()
+    print(f"monitor: {segs.capacity} slots, {len(hits)} hits per pass, {reps} passes")
