@@ -144,6 +144,10 @@ typedef struct ot_scene_desc {
 enum ot_ray_flags {
     OT_RAY_HAS_Q = 1,   /* qo is not None (ray.py:98-104)        */
     OT_RAY_DEAD = 2     /* alive == False on input (optical_component.py:349) */
+    /* bits 8..31: zero for a caller's rays.  In the `next` buffers of ot_trace_generation_* they carry
+     * (node index + 1) of the surface a ray was emitted on — a ray is never tested against the plane it
+     * starts on (the reference rejects that root, t = 0, by |t| < 1e-9) — so a generation's output can be
+     * handed back as the next call's input unchanged. */
 };
 
 /* One ray = one Ray object of the reference (ray.py:63-104): 12 reals + id + flags.

@@ -306,3 +306,17 @@ class SegmentBatch:
             order = np.argsort(out["ray"], kind="stable")
             out = {k: v[order] for k, v in out.items()}
         return out
+
+    def export_rays_csv(self, filename, rays=None):
+        """The reference's ray CSV (optical_table.py:447-500) for this history, in the reference's row order
+        (input-ray-major, then segment order), written from the columns (export.py)."""
+        from . import export
+
+        host = self.to_host(reference_order=True)
+        if rays is None:
+            has_q = True
+        else:
+            flags = rays.flags.cpu().numpy()
+            has_q = (flags[host["ray"]] & abi.RAY_HAS_Q) != 0
+        export.write_rays_csv(filename, host, has_q)
+

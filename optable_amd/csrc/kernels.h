@@ -92,6 +92,7 @@ template <class T> __device__ __forceinline__ RayState<T> load_ray(const RaysT<T
     r.I = in.I[i]; r.n = in.n[i]; r.pl = in.pl[i];
     r.len = in.len ? in.len[i] : Num<T>::inf();
     r.has_q = (flags & OT_RAY_HAS_Q) != 0;
+    r.last = (int32_t)((uint32_t)flags >> 8) - 1;  // bits 8..31: node the ray was emitted on, plus one (generation buffers; 0 for a caller's ray)
     return r;
 }
 
@@ -192,12 +193,13 @@ template <class T, uint32_t F> constexpr int blocked_threads() {
 // pass, and rocprofv3 showed 18 GB of HBM traffic for 3.3 GB of algorithmic bytes on cfg 3.)
 template <class T> struct WaveScratch {
     uint8_t* base;
-    int64_t wave_bytes;  // bytes per wave: CAP * (12 * sizeof(T) + 8)
+    int64_t wave_bytes;  // bytes per wave: CAP * (12 * sizeof(T) + 12)
     int32_t cap;
-    // fields 0..11: ox oy oz dx dy dz qr qi I n pl wavelength; then int32 flags, int32 id
+    // fields 0..11: ox oy oz dx dy dz qr qi I n pl wavelength; then int32 flags, int32 id, int32 node the ray starts on
     __device__ __forceinline__ T* f(int64_t wave, int k) const { return reinterpret_cast<T*>(base + wave * wave_bytes) + (int64_t)k * cap; }
     __device__ __forceinline__ int32_t* flags(int64_t wave) const { return reinterpret_cast<int32_t*>(base + wave * wave_bytes + (int64_t)12 * cap * sizeof(T)); }
     __device__ __forceinline__ int32_t* id(int64_t wave) const { return flags(wave) + cap; }
+    __device__ __forceinline__ int32_t* last(int64_t wave) const { return flags(wave) + 2 * cap; }
 };
 
 template <class T, uint32_t F, bool SCENE_IN_LDS, bool NT>
@@ -224,6 +226,7 @@ __global__ __launch_bounds__((blocked_threads<T, F>()), (blocked_minw<T, F>())) 
     T* const s_n = ws.f(gw, 9); T* const s_pl = ws.f(gw, 10); T* const s_wl = ws.f(gw, 11);
     int32_t* const s_fl = ws.flags(gw);
     int32_t* const s_id = ws.id(gw);
+    int32_t* const s_last = ws.last(gw);
     int alive = 0;  // wave-uniform
     bool exhausted = false, fresh_fill = false;
 #ifdef OT_STAMP
@@ -273,6 +276,7 @@ __global__ __launch_bounds__((blocked_threads<T, F>()), (blocked_minw<T, F>())) 
                     r.qr = s_qr[p]; r.qi = s_qi[p]; r.I = s_I[p]; r.n = s_n[p]; r.pl = s_pl[p]; r.wl = s_wl[p];
                     fl = s_fl[p];
                     cls = s_id[p];
+                    r.last = s_last[p];
                     r.len = Num<T>::inf();
                     r.has_q = (fl & OT_RAY_HAS_Q) != 0;
                 }
@@ -311,6 +315,7 @@ __global__ __launch_bounds__((blocked_threads<T, F>()), (blocked_minw<T, F>())) 
                 s_qr[q] = child.qr; s_qi[q] = child.qi; s_I[q] = child.I; s_n[q] = child.n; s_pl[q] = child.pl; s_wl[q] = r.wl;
                 s_fl[q] = fl;
                 s_id[q] = cls;
+                s_last[q] = child.last;
             }
             next_alive += __popcll(mk);
             OT_STAMP_AT(2);
@@ -539,7 +544,7 @@ __global__ __launch_bounds__(256, (gen_minw<T, F, SCENE_IN_LDS>())) void k_gen_t
             next.dx[d] = k.dx; next.dy[d] = k.dy; next.dz[d] = k.dz;
             next.wl[d] = k.wl; next.qr[d] = k.qr; next.qi[d] = k.qi;
             next.I[d] = k.I; next.n[d] = k.n; next.pl[d] = k.pl;
-            next.flags[d] = fl & OT_RAY_HAS_Q;
+            next.flags[d] = (fl & OT_RAY_HAS_Q) | ((k.last + 1) << 8);  // the node the child starts on rides in bits 8..31
             next.id[d] = cls;
             next_tree[d] = t;
         };

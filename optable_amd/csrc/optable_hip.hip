@@ -543,7 +543,7 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
         const int64_t capr = (int64_t)c->n_cus * per_cu_r;
         const int gridr = (int)(want < capr ? want : capr);
         // per-wave record scratch (by list position) + the ticket counter
-        const size_t wave_bytes = align_up((size_t)CAP * (12 * sizeof(T) + 8));
+        const size_t wave_bytes = align_up((size_t)CAP * (12 * sizeof(T) + 12));
         const size_t scratch_bytes = wave_bytes * (size_t)gridr * wpb;
         if (c->blocked.ensure(scratch_bytes + 256)) return fail(OT_ERR_HIP, "hipMalloc of rolling-trace scratch failed");
         c->blocked_queue_off = scratch_bytes;

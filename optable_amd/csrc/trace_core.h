@@ -100,6 +100,7 @@ template <class T> struct RayState {
     T wl, qr, qi, I, n, pl;
     T len;  // +inf == None
     int32_t has_q;
+    int32_t last;  // node the ray starts on (it was emitted there), -1 for a caller's ray
 };
 
 template <class T> struct Hit {
@@ -587,6 +588,12 @@ __device__ __forceinline__ void test_leaf(const Scene<T>& sc, const DNode<T>& nd
     const bool limited = (F & F_LIMIT) && nd.max_count >= 0;
     T t, Px, Py, Pz;
     if (!(F & F_CURVED) || planar) {
+        // A ray cannot meet the plane it starts on a second time: the only root is t = 0, which the reference's
+        // |t| < 1e-9 guard rejects (optical_component.py:184).  Saying so by identity instead of by distance is
+        // the same rule in exact arithmetic and immune to rounding of the start point — in single precision a
+        // start point 1e-5 off its plane at coordinates ~30 produced a second "hit" just beyond the guard
+        // (8 in 10^4 rays of cfg 3 left the fp64 path that way, tools/fp32_divergence.py).
+        if (idx == r.last) return;
         // Planar leaf, evaluated lazily: only the local x row is needed to know t
         // (t = -o_x/d_x, optical_component.py:171-179).  Exact rejections first: parallel,
         // behind the ray (sign test == t < 0), t == 0.  Then a CONSERVATIVE far test (1e-9
@@ -651,7 +658,7 @@ __device__ __forceinline__ void test_planar_lean(const Scene<T>& sc, const DNode
     const T Px = lox + t * ldx, Py = loy + t * ldy, Pz = loz + t * ldz;
     const bool inside = nd.shape == OT_SHAPE_CIRCLE ? (Px * Px + Py * Py + Pz * Pz <= nd.r2)
                                                     : (abs_t(Py) <= nd.p[0] && abs_t(Pz) <= nd.p[1]);
-    bool ok = ldx != T(0) && s != T(0) && ((s > T(0)) == (ldx > T(0)));
+    bool ok = idx != r.last && ldx != T(0) && s != T(0) && ((s > T(0)) == (ldx > T(0)));
     ok = ok && !(abs_t(t) < Num<T>::eps_t() || t < T(0) || t > r.len);
     ok = ok && (t < best.t || (t == best.t && idx < best.node)) && inside;
     if (ok && (nd.flags & OT_NODE_CHECK_AABB)) {  // the leaf's own AABB test (component_group.py:104-107), only for would-be hits
@@ -927,7 +934,7 @@ __device__ __forceinline__ int interact(const Scene<T>& sc, const RayState<T>& r
             const T inv = rsqrt_t(lx * lx + ly * ly + lz * lz);
             to_lab(nd, lx * inv, ly * inv, lz * inv, k.dx, k.dy, k.dz);
             k.ox = Ox; k.oy = Oy; k.oz = Oz;
-            k.wl = r.wl; k.has_q = r.has_q; k.len = Num<T>::inf();
+            k.wl = r.wl; k.has_q = r.has_q; k.len = Num<T>::inf(); k.last = h.node;
             k.I = I; k.qr = qr; k.qi = qi; k.n = n; k.pl = pl;
             // constant indices only: kids[nk] with a run-time nk would put both children into private scratch
             // (240 B per lane in the fp64 generation kernel of round 1)

@@ -242,3 +242,11 @@ class MonitorHits:
 
     def tZList(self, sort="YZ"):
         return self.directionList(sort) @ self._axis("Z")
+
+    def export_rays_npz(self, filename: str):
+        """`Monitor.export_rays_npz` (monitor.py:255-269) from the device tensors: the same five arrays in the
+        monitor's default "YZ" order (xList / yList are the hit point along the monitor's Y / Z tangents,
+        tXList / tYList the direction along them)."""
+        print(f"Exporting {len(self)} rays to {filename} ...")
+        arrays = {"xList": self.yList(), "yList": self.zList(), "tXList": self.tYList(), "tYList": self.tZList(), "IList": self.IList()}
+        np.savez(filename, **{k: v.double().cpu().numpy() for k, v in arrays.items()})

@@ -13,7 +13,6 @@ after each (engine.trace_tree).  A non-branching scene is ONE launch bounded by 
 be cut inside it.  Not modelled: the per-second progress print.  Render / GUI are out of scope.
 """
 import copy
-import csv
 from typing import List, Union
 
 import numpy as np
@@ -22,7 +21,7 @@ from . import abi
 from .assemblies import *  # noqa: F401,F403  (reference re-exports, optical_table.py:1-3)
 from .components import *  # noqa: F401,F403
 from .components import OpticalComponent
-from .geometry import base_merge_bboxs, _NO_BOX, to_mathematical_str, get_attr_str, out_of_scope
+from .geometry import base_merge_bboxs, _NO_BOX, out_of_scope
 from .monitors import Monitor
 from .rays import Ray
 from .scene import compile_scene
@@ -309,22 +308,23 @@ class OpticalTable:
         res = minimize(cost, x0=[F10, F20], method="Nelder-Mead", options={"disp": True, "xatol": 1e-5, "maxiter": 50})
         return res.x[0], res.x[1]
 
-    # -- exports (optical_table.py:448-500) -----------------------------------------------------------
+    # -- exports (optical_table.py:447-500), written from columns (export.py) ---------------------------
     def gather_rays_csv(self):
-        return [{"origin": to_mathematical_str(str(r.origin.tolist())),
-                 "transform_matrix": to_mathematical_str(str(r.transform_matrix.tolist())),
-                 "intensity": get_attr_str(r, "intensity", "None"), "length": get_attr_str(r, "length", "None"),
-                 "qo": to_mathematical_str(str(get_attr_str(r, "qo", "None"))),
-                 "n": to_mathematical_str(str(get_attr_str(r, "n", "None")))} for r in self.rays]
+        from . import export
+
+        cols, has_q = export.columns_of_rays(self.rays)
+        return [dict(zip(export.HEADER, row)) for row in export.rays_csv_rows(cols, has_q)]
 
     def export_rays_csv(self, filename: str):
-        rows = self.gather_rays_csv()
-        print(f"Exporting rays to {filename} ...")
-        with open(filename, "w", newline="") as fh:
-            writer = csv.writer(fh)
-            writer.writerow(rows[0].keys() if rows else [])
-            for row in rows:
-                writer.writerow(row.values())
+        from . import export
+
+        cols, has_q = export.columns_of_rays(self.rays)
+        export.write_rays_csv(filename, cols, has_q)
+
+    def export_batch_csv(self, segs, filename: str, rays=None):
+        """`export_rays_csv` for a SegmentBatch, straight from its columns: no Ray objects.  `rays`: the traced
+        RayBatch (tells which rays carry a Gaussian q, ray.py:98-104); without it every segment prints its q."""
+        segs.export_rays_csv(filename, rays)
 
     def materialize(self, segs, sources, select=None):
         """SegmentBatch -> List[Ray] for the input rays in `select` only (all when None), in the

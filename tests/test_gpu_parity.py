@@ -338,7 +338,7 @@ def test_acceleration_grids_do_not_change_results(case):
 
 
 @pytest.mark.filterwarnings("ignore::RuntimeWarning")  # unused slots are uninitialised memory; they are masked before any assert
-@pytest.mark.parametrize("case,min_same", [("cfg3", 0.97), ("cfg5", 0.90)])
+@pytest.mark.parametrize("case,min_same", [("cfg3", 0.999), ("cfg5", 0.999)])  # measured: 99.997 % / 100 % (tests/test_gpu_fp32_contract.py audits the rest)
 def test_fp32_heavy_scenes_track_fp64(case, min_same):
     """BASELINE cfg 3 / cfg 5 are quoted in fp32.  Single precision cannot promise per-ray identity over
     20-50 bounces (a ray grazing an aperture edge flips between hit and miss at 6e-8 relative), so the
