@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define OT_ABI_VERSION 4  /* 3: ot_trace_generation_f32; 4: ot_bench_stream_f32 */
+#define OT_ABI_VERSION 5  /* 3: ot_trace_generation_f32; 4: ot_bench_stream_f32; 5: OT_OPT_LIST_CAP, ray flags bits 8..31, ot_debug_generation_mismatches */
 
 /* ---- status codes ------------------------------------------------------------------- */
 enum ot_status {
@@ -242,6 +242,11 @@ int ot_trace_generation_f32(ot_ctx* ctx, const ot_rays* rays, const int32_t* ray
                             int64_t out_capacity, int64_t* seg_cursor, const ot_rays* next,
                             int32_t* next_tree, int64_t next_capacity, int64_t* n_next,
                             int32_t* counts, int32_t n_count_classes);
+
+/* Diagnostic: how often the two passes of a generation (count, then emit: both run the same trace) disagreed about a
+ * ray since the ctx was created.  Expected 0; a disagreement is contained (nothing is written outside the slots the
+ * count pass reserved) and shows up as a zero-intensity dead ray in the next generation. */
+int ot_debug_generation_mismatches(ot_ctx* ctx, int64_t* count);
 
 /* Monitor.record (monitor.py:183-193): intersect finished segments with a rectangular
  * monitor plane, honouring segment length.  hit_index receives the slot indices of the segments

@@ -6,9 +6,10 @@
 //   k_trace_rolling<T>   the same trace for heavy scenes: persistent waves, each with its own list of live rays that
 //                        is compacted every segment and refilled from a device-wide queue.
 //   k_stream_ceiling<T>  the fused kernel's streams with no tracing (roofline companion).
-//   k_gen_trace<T>       one breadth-first generation of branching ray trees (optical_table.py:115-134):
-//                        rank within the tree, trace, ordered slot allocation by decoupled look-back;
-//                        k_gen_rank / k_gen_counts keep interact-count gates FIFO-exact, k_gen_finish closes it.
+//   k_gen_pass<T>        one breadth-first generation of branching ray trees (optical_table.py:115-134) in two
+//                        streaming passes: count (rank within the tree, trace) -> scan of wave totals -> emit (trace
+//                        again, ordered slots); k_gen_trace (single pass, look-back) remains as the probe pass that,
+//                        with k_gen_rank / k_gen_counts, keeps interact-count gates FIFO-exact; k_gen_finish closes it.
 //   k_mon_*              Monitor.record over a segment stream (monitor.py:183-193).
 #pragma once
 
@@ -551,6 +552,128 @@ __global__ __launch_bounds__(256, (gen_minw<T, F, SCENE_IN_LDS>())) void k_gen_t
         if (nk > 0) put(ch[0], d0);
         if (nk > 1) put(ch[1], d0 + 1);
         __syncthreads();  // s_tile / s_base / s_wave_total are rewritten by the next tile
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_gen_pass: a generation in TWO streaming passes instead of one pass with an ordered look-back.
+//   COUNT  (EMIT = false): rank within the tree, trace, interaction -> per ray one byte (processed | children << 1)
+//          and per WAVE one packed total (processed << 32 | children).
+//   (host) exclusive scan over the wave totals (hipCUB), n / 64 words.
+//   EMIT   (EMIT = true):  the same trace again; slots = scanned wave prefix + rank inside the wave (two ballot /
+//          shuffle scans); segment and children written once, in stable order, straight from registers.
+// Neither pass has a workgroup barrier, a ticket or a dependency on another wave, so both run at the occupancy
+// their registers allow and stream at memory speed; the price is reading a generation's rays twice (116 of ~440
+// bytes per processed ray).  The single-pass kernel (k_gen_trace below, still used as the probe pass of count-limited
+// scenes) spent 70 % of its wave-cycles waiting: a tile's 90 KB of stores, the next tile's loads behind them (gfx9
+// counts loads and stores in one in-order counter), the trace and the look-back were strictly serial per workgroup,
+// and three workgroups per CU (168 VGPRs: both children of every ray live across the look-back) could not hide it —
+// cfg 4 with reflectivity 0.2: 26.6 ms in round 1, 20.0 ms with four look-back windows in flight and no scratch,
+// and now the two passes.
+// Both passes run the same device code on the same inputs, so they take the same decisions; should a last-bit
+// difference between the two compilations ever flip one (a hit within an ulp of an aperture edge, sin(theta_t)
+// within an ulp of 1), EMIT still never writes outside the slots COUNT reserved: it emits at most the counted number
+// of children, fills a missing one with a zero-intensity dead ray, and counts the event in `mismatch` (tests
+// assert 0).
+template <class T, uint32_t F, bool SCENE_IN_LDS, bool EMIT>
+__global__ __launch_bounds__(256) void k_gen_pass(SceneBlob blob, T unit, RaysT<T> in, const int32_t* __restrict__ tree, int64_t n,
+                                                  const int32_t* __restrict__ budget, const int64_t* cursor, SegsT<T> out,
+                                                  int64_t out_capacity, RaysOutT<T> next, int32_t* next_tree, int64_t next_capacity,
+                                                  uint8_t* code, unsigned long long* wave_total, const unsigned long long* wave_prefix,
+                                                  int32_t* counts, int32_t n_classes, const int32_t* rank, unsigned long long* mismatch) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    const uint32_t* base = blob.words;
+    if (SCENE_IN_LDS) {
+        for (int w = threadIdx.x; w < blob.n_words; w += blockDim.x) lds[w] = blob.words[w];
+        __syncthreads();
+        base = lds;
+    }
+    const Scene<T> sc = bind_scene<T>(base, blob, unit);
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t gwave = i >> 6;
+    // rank of the ray inside its tree, as in k_gen_trace: rays beyond the tree's remaining budget are dropped
+    int32_t my_tree = -1;
+    long long start = -1;
+    if (i < n) {
+        my_tree = tree[i];
+        if (lane == 0 || tree[i - 1] != my_tree) start = i;
+    }
+    long long head = start;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const long long up = __shfl_up(head, off, 64);
+        if (lane >= off && up > head) head = up;
+    }
+    if (i < n && head == i - lane) head = tree_head(tree, i - lane);
+    const bool active = i < n && (i - head) < (int64_t)budget[my_tree];
+    RayState<T> r = {};
+    int32_t cls = 0, fl = 0;
+    if (active) {
+        fl = in.flags[i];
+        r = load_ray(in, i, fl);
+        cls = in.id[i];
+    }
+    const bool dead = active && (fl & OT_RAY_DEAD);
+    const GateCtx gate = {counts, n_classes, cls, rank, nullptr, n, i};
+    const Hit<T> h = nearest_hit<T, F, GATE_TABLE>(sc, r, active && !dead, gate);
+    int32_t nk = 0;
+    RayState<T> ch[2];  // indexed by constants only
+    if (active && !dead && h.node >= 0) nk = interact<T, F, 2>(sc, r, h, ch, make_matcache(sc, r.wl));
+    if (!EMIT) {
+        if (i < n) code[i] = (uint8_t)((active ? 1 : 0) | (nk << 1));
+        // wave totals: processed rays and children
+        const int n_act = __popcll(__ballot(active));
+        int kids = nk;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) kids += __shfl_xor(kids, off, 64);
+        if (lane == 0 && (gwave << 6) < n) wave_total[gwave] = ((unsigned long long)n_act << 32) | (unsigned long long)kids;
+        return;
+    }
+    // EMIT: slots from the scanned wave prefix and the counted codes
+    const int32_t c = i < n ? (int32_t)code[i] : 0;
+    const bool c_active = (c & 1) != 0;
+    const int32_t c_nk = c >> 1;
+    const unsigned long long act_mask = __ballot(c_active);
+    const int seg_rank = __popcll(act_mask & ((1ull << lane) - 1ull));
+    int kid_incl = c_nk;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int up = __shfl_up(kid_incl, off, 64);
+        if (lane >= off) kid_incl += up;
+    }
+    const unsigned long long before = (gwave << 6) < n ? wave_prefix[gwave] : 0ull;
+    if (c_active != active || (active && c_nk != nk)) atomicAdd(mismatch, 1ull);  // see the header: never expected
+    if (c_active) {
+        const int64_t slot = *cursor + (int64_t)(before >> 32) + seg_rank;
+        if (slot < out_capacity) {
+            const int32_t t = my_tree;
+            if (dead || !active) store_segment(out, slot, r, r.len, t, -2);
+            else if (h.node < 0) store_segment(out, slot, r, r.len, t, -1);
+            else store_segment(out, slot, r, h.t, t, sc.nodes[h.node].leaf_id);
+        }
+    }
+    const int64_t d0 = (int64_t)(before & 0xffffffffull) + (kid_incl - c_nk);
+    auto put = [&](const RayState<T>& k, int64_t d, bool real) {
+        if (d >= next_capacity) return;
+        next.ox[d] = k.ox; next.oy[d] = k.oy; next.oz[d] = k.oz;
+        next.dx[d] = k.dx; next.dy[d] = k.dy; next.dz[d] = k.dz;
+        next.wl[d] = k.wl; next.qr[d] = k.qr; next.qi[d] = k.qi;
+        next.I[d] = real ? k.I : T(0); next.n[d] = k.n; next.pl[d] = k.pl;
+        next.flags[d] = real ? ((fl & OT_RAY_HAS_Q) | ((k.last + 1) << 8)) : OT_RAY_DEAD;
+        next.id[d] = cls;
+        next_tree[d] = my_tree;
+    };
+    if (c_nk > 0) put(nk > 0 ? ch[0] : r, d0, nk > 0);
+    if (c_nk > 1) put(nk > 1 ? ch[1] : r, d0 + 1, nk > 1);
+}
+
+// totals of a generation from the scanned wave totals: segments written and rays of the next generation
+__global__ void k_gen_totals(const unsigned long long* wave_total, const unsigned long long* wave_prefix, int64_t n_waves, int64_t* totals) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned long long all = wave_prefix[n_waves - 1] + wave_total[n_waves - 1];
+        totals[0] = (int64_t)(all >> 32);
+        totals[1] = (int64_t)(all & 0xffffffffull);
     }
 }
 

@@ -75,6 +75,7 @@ struct ot_ctx {
     size_t blocked_queue_off = 0;
     int32_t opt_nt = 1, opt_minw = 4, opt_blocks_per_cu = 0;  // defaults from tools/tune.py on MI355X
     Scratch gen, scan_tmp, mon;
+    unsigned long long* gen_mismatch = nullptr;  // count / emit disagreements of k_gen_pass (expected: 0)
 };
 
 static int flush_events(ot_ctx* c) {
@@ -347,6 +348,7 @@ int ot_ctx_destroy(ot_ctx* c) {
     if (c->blob32) (void)hipFree(c->blob32);
     if (c->slot_max) (void)hipFree(c->slot_max);
     if (c->gen.p) (void)hipFree(c->gen.p);
+    if (c->gen_mismatch) (void)hipFree(c->gen_mismatch);
     if (c->scan_tmp.p) (void)hipFree(c->scan_tmp.p);
     if (c->mon.p) (void)hipFree(c->mon.p);
     if (c->blocked.p) (void)hipFree(c->blocked.p);
@@ -626,27 +628,38 @@ static int trace_generation(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
     const size_t sz_slot = align_up(sizeof(int32_t) * n * (ns > 0 ? ns : 1));
     const int64_t n_tiles = (n + 255) / 256;
     const size_t sz_lb = align_up(sizeof(unsigned long long) * (n_tiles + 1));  // tile states + the ticket
-    const size_t sz_tot = align_up(sizeof(int64_t) * 2);
-    const size_t total = sz_lb + sz_tot + (ns > 0 ? 3 * sz_slot : 0);
+    const size_t sz_tot = align_up(sizeof(int64_t) * 2 + sizeof(unsigned long long));
+    const int64_t n_waves = (n + 63) / 64;
+    const size_t sz_code = align_up((size_t)n), sz_wave = align_up(sizeof(unsigned long long) * n_waves);
+    const size_t total = sz_lb + sz_tot + sz_code + 2 * sz_wave + (ns > 0 ? 3 * sz_slot : 0);
     if (c->gen.ensure(total)) return fail(OT_ERR_HIP, "hipMalloc of generation scratch failed");
     uint8_t* p = (uint8_t*)c->gen.p;
     LookBack lb;
     lb.state = (unsigned long long*)p;
     lb.ticket = lb.state + n_tiles;
     p += sz_lb;
-    int64_t* totals = (int64_t*)p; p += sz_tot;
+    int64_t* totals = (int64_t*)p;
+    unsigned long long* mismatch = (unsigned long long*)(totals + 2);
+    p += sz_tot;
+    uint8_t* code = p; p += sz_code;
+    unsigned long long* wave_total = (unsigned long long*)p; p += sz_wave;
+    unsigned long long* wave_prefix = (unsigned long long*)p; p += sz_wave;
     int32_t* probe = (int32_t*)p; p += sz_slot;
     int32_t* probe_ex = (int32_t*)p; p += sz_slot;
     int32_t* rank = (int32_t*)p;
-    size_t tmp = 0;
-    if (ns > 0) {
-        hipcub::DeviceScan::ExclusiveSum((void*)nullptr, tmp, probe, probe_ex, (int)n, c->stream);
-        if (c->scan_tmp.ensure(tmp + 256)) return fail(OT_ERR_HIP, "hipMalloc of scan scratch failed");
-    }
+    size_t tmp = 0, tmp_w = 0;
+    if (ns > 0) hipcub::DeviceScan::ExclusiveSum((void*)nullptr, tmp, probe, probe_ex, (int)n, c->stream);
+    hipcub::DeviceScan::ExclusiveSum((void*)nullptr, tmp_w, wave_total, wave_prefix, (int)n_waves, c->stream);
+    if (c->scan_tmp.ensure((tmp > tmp_w ? tmp : tmp_w) + 256)) return fail(OT_ERR_HIP, "hipMalloc of scan scratch failed");
     const int block = 256;
     const int g1 = (int)((n + block - 1) / block);
     rc = timing_begin(c);
     if (rc) return rc;
+    if (!c->gen_mismatch) {
+        HIP_TRY(hipMalloc((void**)&c->gen_mismatch, sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(c->gen_mismatch, 0, sizeof(unsigned long long), c->stream));
+    }
+    mismatch = c->gen_mismatch;  // lives with the ctx: accumulated over all generations (ot_debug_generation_mismatches)
     SceneBlob blob;
     constexpr bool f64 = sizeof(T) == 8;
     const size_t bytes = f64 ? c->bytes64 : c->bytes32;
@@ -665,11 +678,14 @@ static int trace_generation(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
     constexpr uint32_t FG = F_AABB | F_LENS | F_REFRACT;
     const bool small = (c->features & ~FG) == 0;
     auto k_probe = in_lds ? k_gen_trace<T, F_ALL, true, true> : k_gen_trace<T, F_ALL, false, true>;
-    auto k_main = small ? (in_lds ? k_gen_trace<T, FG, true, false> : k_gen_trace<T, FG, false, false>)
-                        : (in_lds ? k_gen_trace<T, F_ALL, true, false> : k_gen_trace<T, F_ALL, false, false>);
+    auto k_count = small ? (in_lds ? k_gen_pass<T, FG, true, false> : k_gen_pass<T, FG, false, false>)
+                         : (in_lds ? k_gen_pass<T, F_ALL, true, false> : k_gen_pass<T, F_ALL, false, false>);
+    auto k_emit = small ? (in_lds ? k_gen_pass<T, FG, true, true> : k_gen_pass<T, FG, false, true>)
+                        : (in_lds ? k_gen_pass<T, F_ALL, true, true> : k_gen_pass<T, F_ALL, false, true>);
     if (lds_bytes > 48 * 1024) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        HIP_TRY(hipFuncSetAttribute((const void*)k_main, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        HIP_TRY(hipFuncSetAttribute((const void*)k_emit, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     }
     if (ns > 0) {  // FIFO-exact interact-count gating: probe -> per-slot scan -> rank within the tree
         HIP_TRY(hipMemsetAsync(probe, 0, sizeof(int32_t) * n * ns, c->stream));
@@ -681,10 +697,16 @@ static int trace_generation(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
             HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->scan_tmp.p, tmp, probe + (int64_t)s * n, probe_ex + (int64_t)s * n, (int)n, c->stream));
         hipLaunchKernelGGL(k_gen_rank, dim3(g1), dim3(block), 0, c->stream, tree, n, ns, probe_ex, rank);
     }
-    HIP_TRY(hipMemsetAsync(lb.state, 0, sizeof(unsigned long long) * (n_tiles + 1), c->stream));  // tile states and the ticket
-    hipLaunchKernelGGL(k_main, dim3(grid), dim3(block), lds_bytes, c->stream, blob, (T)c->unit, view<T>(rays), tree, n, budget,
-                       seg_cursor, view<T>(out), out_capacity, lb, view_out<T>(next), next_tree, next_capacity, totals, counts,
-                       n_classes, (const int32_t*)rank, (int32_t*)nullptr);
+    // count -> scan of the wave totals -> emit (kernels.h: k_gen_pass)
+    hipLaunchKernelGGL(k_count, dim3(g1), dim3(block), lds_bytes, c->stream, blob, (T)c->unit, view<T>(rays), tree, n, budget,
+                       seg_cursor, view<T>(out), out_capacity, view_out<T>(next), next_tree, next_capacity, code, wave_total,
+                       (const unsigned long long*)wave_prefix, counts, n_classes, (const int32_t*)rank, mismatch);
+    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->scan_tmp.p, tmp_w, wave_total, wave_prefix, (int)n_waves, c->stream));
+    hipLaunchKernelGGL(k_gen_totals, dim3(1), dim3(64), 0, c->stream, (const unsigned long long*)wave_total,
+                       (const unsigned long long*)wave_prefix, n_waves, totals);
+    hipLaunchKernelGGL(k_emit, dim3(g1), dim3(block), lds_bytes, c->stream, blob, (T)c->unit, view<T>(rays), tree, n, budget,
+                       seg_cursor, view<T>(out), out_capacity, view_out<T>(next), next_tree, next_capacity, code, wave_total,
+                       (const unsigned long long*)wave_prefix, counts, n_classes, (const int32_t*)rank, mismatch);
     if (ns > 0)
         hipLaunchKernelGGL(k_gen_counts, dim3(g1), dim3(block), 0, c->stream, tree, rays->id, n, ns, rank, probe, c->slot_max, counts,
                            n_classes);
@@ -739,6 +761,17 @@ int ot_monitor_record_f64(ot_ctx* c, const ot_monitor* mon, const ot_segments* s
     hipLaunchKernelGGL(k_mon_compact, dim3(grid), dim3(block), 0, c->stream, hit, off, P, tt, n, hit_index, (double*)Px, (double*)Py,
                        (double*)Pz, (double*)t, n_hits);
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int ot_debug_generation_mismatches(ot_ctx* c, int64_t* out) {
+    if (!c || !out) return fail(OT_ERR_INVALID, "NULL argument");
+    *out = 0;
+    if (!c->gen_mismatch) return 0;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    unsigned long long v = 0;
+    HIP_TRY(hipMemcpy(&v, c->gen_mismatch, sizeof(v), hipMemcpyDeviceToHost));
+    *out = (int64_t)v;
     return 0;
 }
 

@@ -229,6 +229,12 @@ class Engine:
         abi.check(fn(self._ctx, C.byref(rs), rays.n, int(max_segments), C.byref(ss),
                                                out.count.data_ptr()), self.lib)
 
+    def generation_mismatches(self):
+        """Diagnostic counter of the two-pass generation kernels (include/optable_hip.h); expected 0."""
+        v = C.c_int64()
+        abi.check(self.lib.ot_debug_generation_mismatches(self._ctx, C.byref(v)), self.lib)
+        return v.value
+
     def synchronize(self):
         abi.check(self.lib.ot_ctx_synchronize(self._ctx), self.lib)
 

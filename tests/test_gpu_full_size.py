@@ -85,9 +85,12 @@ def test_cfg3_full_size_fp32():
     torch.cuda.empty_cache()
 
 
-def test_cfg4_shard_closed_form_fp64():
-    """The per-GPU shard of configs[3] on 4 GPUs: 2.5e6 rays x 64 wavelengths = 1.6e8 ray-wavelength
-    pairs through an N-BK7 slab, fp64.  Every pair yields exactly 3 segments, the exit ray is parallel
+@pytest.mark.parametrize("nb", [2_500_000, 5_000_000], ids=["4gpu-shard-1.6e8", "2gpu-shard-3.2e8"])
+def test_cfg4_shard_closed_form_fp64(nb):
+    """The per-GPU shard of configs[3] (1e7 rays x 64 wavelengths, "sharded 2 and 4 GPUs"): 2.5e6 base rays on 4 GPUs
+    = 1.6e8 ray-wavelength pairs, 5e6 on 2 GPUs = 3.2e8 pairs (33 GB of rays, 100 GB of segment history: what
+    `bench.py --workload cfg4 --gpus 2` traces per rank), through an N-BK7 slab, fp64.
+    Every pair yields exactly 3 segments, the exit ray is parallel
     to the entry ray, displaced sideways by thickness*sin(ti - tt)/cos(tt) with sin(tt) = sin(ti)/n(wl),
     and its optical path is the geometric lengths weighted by n — all evaluated here independently
     from the Sellmeier table on the host (material.py:115-120)."""
@@ -95,7 +98,7 @@ def test_cfg4_shard_closed_form_fp64():
     import optable_amd as oa
     from optable_amd.batch import RayBatch
 
-    nb, nwl, K = 2_500_000, 64, 3
+    nwl, K = 64, 3
     thickness = 0.5
     rng = np.random.default_rng(4)
     jit = rng.uniform(-0.3, 0.3, (nb, 2))
@@ -139,6 +142,7 @@ def test_cfg4_shard_closed_form_fp64():
     assert float((f["intensity"] - 1).abs().max()) == 0.0
     del f, surf, perp, along, rx, ry, rz
     _shard_equals_whole(table, batch, segs, 40_000_000, 41_000_000, K)
+    del segs, batch, n_dev, tt, shift, inner, opl
     torch.cuda.empty_cache()
 
 

@@ -121,3 +121,27 @@ def test_two_term_sellmeier_at_one_micron():
         b = RayBatch.from_arrays([[-3, 0.1, 0]], [[1, 0.05, 0]], wavelength=1e-4, precision=prec)
         segs = table.trace_batch(b, max_segments=4).to_host(reference_order=True)
         assert np.all(np.isfinite(segs["n"])) and len(segs["n"]) == 3
+
+
+def test_two_pass_generations_agree_with_themselves():
+    """A generation is traced twice (count, then emit: kernels.h k_gen_pass); both passes must take the same decisions
+    for every ray.  2e6 trees of the branching cfg 4 variant (every hit splits, TIR inside the slab) and the cavity."""
+    from optable_amd import workloads as W
+
+    eng = get_engine()
+    before = eng.generation_mismatches()
+    table = oa.OpticalTable()
+    table.add_components(W.cfg4_components(oa, reflectivity=0.2))
+    o, d, wl = W.cfg4_rays(30_000, 4)
+    batch = RayBatch.from_arrays(o, d, wavelength=wl, q=1j * np.pi * W.W0**2 / wl)
+    scene = table.compile()
+    eng.upload(scene)
+    segs = eng.trace_tree(batch, 12, out_capacity=batch.n * 13)
+    assert segs.n_valid == 12 * batch.n
+    for prec in ("f64", "f32"):
+        t2, sc = _cavity_table()
+        b = RayBatch.from_arrays(np.tile([2.0, 0, 0], (4096, 1)) + np.linspace(0, 1e-3, 4096)[:, None] * np.array([0, 1, 0]),
+                                 np.tile([1.0, 0, 0], (4096, 1)), precision=prec)
+        eng.upload(t2.compile())
+        eng.trace_tree(b, 300)
+    assert eng.generation_mismatches() == before
