@@ -85,6 +85,41 @@ __device__ __forceinline__ void store_segment(const SegsT<T>& out, int64_t slot,
     st<NT>(out.ray + slot, tree); st<NT>(out.surface + slot, surface);
 }
 
+// Paired stores: lanes 2j and 2j+1 hold records for two ADJACENT slots.  Instead of fourteen stores of one element
+// per lane, the pair takes the fields two at a time: after one DPP exchange the even lane holds both lanes' values of
+// field A and writes them as ONE 16-byte store (fp64; 8 bytes in fp32), the odd lane does the same for field B.
+// Half as many store instructions, each twice as wide: the widest coalesced form a structure-of-arrays layout allows
+// (MI355X_MICROARCH.md: 16 bytes per lane is what streaming stores want).  Needs an even slot on the even lane, both
+// lanes storing, and arrays aligned to the vector: the caller checks and falls back to store_segment otherwise.
+__device__ __forceinline__ int dpp_xor1(int v) { return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true); }  // quad_perm [1,0,3,2]
+__device__ __forceinline__ float xchg1(float v) { return __int_as_float(dpp_xor1(__float_as_int(v))); }
+__device__ __forceinline__ double xchg1(double v) {
+    return __hiloint2double(dpp_xor1(__double2hiint(v)), dpp_xor1(__double2loint(v)));
+}
+__device__ __forceinline__ int32_t xchg1(int32_t v) { return dpp_xor1(v); }
+template <bool NT, class V>
+__device__ __forceinline__ void store_pair(V* A, V* B, int64_t slot, V a, V b, bool odd) {
+    typedef V vec2 __attribute__((ext_vector_type(2)));
+    const V got = xchg1(odd ? a : b);  // what the partner does not store itself
+    vec2 v;
+    v.x = odd ? got : a;
+    v.y = odd ? b : got;
+    vec2* p = reinterpret_cast<vec2*>(odd ? B + (slot - 1) : A + slot);
+    if (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+template <class T, bool NT>
+__device__ __forceinline__ void store_segment_paired(const SegsT<T>& out, int64_t slot, const RayState<T>& r, T len, int32_t tree,
+                                                     int32_t surface, bool odd) {
+    store_pair<NT>(out.ox, out.oy, slot, r.ox, r.oy, odd);
+    store_pair<NT>(out.oz, out.dx, slot, r.oz, r.dx, odd);
+    store_pair<NT>(out.dy, out.dz, slot, r.dy, r.dz, odd);
+    store_pair<NT>(out.len, out.I, slot, len, r.I, odd);
+    store_pair<NT>(out.qr, out.qi, slot, r.qr, r.qi, odd);
+    store_pair<NT>(out.n, out.pl, slot, r.n, r.pl, odd);
+    store_pair<NT>(out.ray, out.surface, slot, tree, surface, odd);
+}
+
 template <class T> __device__ __forceinline__ RayState<T> load_ray(const RaysT<T>& in, int64_t i, int32_t flags) {
     RayState<T> r;
     r.ox = in.ox[i]; r.oy = in.oy[i]; r.oz = in.oz[i];
@@ -101,7 +136,7 @@ template <class T> __device__ __forceinline__ RayState<T> load_ray(const RaysT<T
 // k_trace_fused: the hot kernel
 template <class T, uint32_t F, bool SCENE_IN_LDS, int MINW, bool NT>
 __global__ __launch_bounds__(256, MINW) void k_trace_fused(SceneBlob blob, T unit, RaysT<T> in, int64_t n, int32_t K, SegsT<T> out,
-                                                     int32_t* __restrict__ seg_count, int32_t* counts, int32_t n_classes) {
+                                                     int32_t* __restrict__ seg_count, int32_t* counts, int32_t n_classes, int32_t pair) {
     extern __shared__ __align__(16) uint32_t lds[];
     const uint32_t* base = blob.words;
     if (SCENE_IN_LDS) {
@@ -132,14 +167,22 @@ __global__ __launch_bounds__(256, MINW) void k_trace_fused(SceneBlob blob, T uni
             if (!__any(active)) break;
             const GateCtx gate = {counts, n_classes, cls, nullptr, nullptr, 0, 0};
             const Hit<T> h = nearest_hit<T, F, GATE_PLAIN>(sc, r, active, gate);
+            // segment record: pairs of lanes that both store write two fields per 16-byte store (store_segment_paired)
+            const unsigned long long storing = __ballot(active);
+            const bool both = pair && ((storing >> (threadIdx.x & 62)) & 3ull) == 3ull;
+            if (both) {
+                const bool hit = h.node >= 0;
+                store_segment_paired<T, NT>(out, (int64_t)k * n + i, r, hit ? h.t : r.len, (int32_t)i, hit ? sc.nodes[h.node].leaf_id : -1,
+                                            (threadIdx.x & 1) != 0);
+            }
             if (active) {
                 const int64_t slot = (int64_t)k * n + i;
                 used = k + 1;
                 if (h.node < 0) {  // escaped: archived unchanged (optical_table.py:132-134)
-                    store_segment<T, NT>(out, slot, r, r.len, (int32_t)i, -1);
+                    if (!both) store_segment<T, NT>(out, slot, r, r.len, (int32_t)i, -1);
                     active = false;
                 } else {
-                    store_segment<T, NT>(out, slot, r, h.t, (int32_t)i, sc.nodes[h.node].leaf_id);
+                    if (!both) store_segment<T, NT>(out, slot, r, h.t, (int32_t)i, sc.nodes[h.node].leaf_id);
                     RayState<T> child;
                     const int nk = interact<T, F, 1>(sc, r, h, &child, mc);
                     if (nk == 1) r = child;
@@ -339,13 +382,15 @@ __global__ __launch_bounds__((blocked_threads<T, F>()), (blocked_minw<T, F>())) 
 // writes K segment records per ray through the same SoA streams.  What this access pattern can
 // reach on the device; reported next to the trace kernel (bench.py).
 template <class T, bool NT>
-__global__ __launch_bounds__(256) void k_stream_ceiling(RaysT<T> in, int64_t n, int32_t K, SegsT<T> out, int32_t* seg_count) {
+__global__ __launch_bounds__(256) void k_stream_ceiling(RaysT<T> in, int64_t n, int32_t K, SegsT<T> out, int32_t* seg_count, int32_t pair) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         RayState<T> r = load_ray(in, i, in.flags[i]);
         const int32_t cls = in.id[i];
+        const bool both = pair && (i | 1) < n;  // n is even when `pair` is set: both lanes of a pair are in range
         for (int32_t k = 0; k < K; ++k) {
-            store_segment<T, NT>(out, (int64_t)k * n + i, r, r.len, (int32_t)i, cls);
+            if (both) store_segment_paired<T, NT>(out, (int64_t)k * n + i, r, r.len, (int32_t)i, cls, (threadIdx.x & 1) != 0);
+            else store_segment<T, NT>(out, (int64_t)k * n + i, r, r.len, (int32_t)i, cls);
             r.ox += T(1);  // keep the K records distinct so the stores cannot be merged
         }
         seg_count[i] = K;

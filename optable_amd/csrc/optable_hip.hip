@@ -73,6 +73,7 @@ struct ot_ctx {
     int32_t opt_list_cap_pure = 0;  // generation-pure lists: 0 = the chunk rule below
     Scratch blocked;
     size_t blocked_queue_off = 0;
+    int32_t opt_pair = 1;  // paired 16-byte segment stores in the lane-per-ray kernel
     int32_t opt_nt = 1, opt_minw = 4, opt_blocks_per_cu = 0;  // defaults from tools/tune.py on MI355X
     Scratch gen, scan_tmp, mon;
     unsigned long long* gen_mismatch = nullptr;  // count / emit disagreements of k_gen_pass (expected: 0)
@@ -438,11 +439,24 @@ static int check_segs(const ot_segments* s) {
 
 static size_t align_up(size_t x) { return (x + 255) / 256 * 256; }
 
+// paired segment stores (kernels.h store_segment_paired): slot k*n + i is even on even lanes iff n is even, and every
+// segment array must be aligned to two elements
+// fp64 only: measured on cfg 4 (1.6e8 pairs) 12.73 -> 12.08 ms (5230 -> 5510 GB/s, 97 % of the stream ceiling), cfg 2
+// 0.108 -> 0.106 ms; in fp32 the pair is an 8-byte store and the kernel is VALU-bound: the exchange costs 7-13 %.
+template <class T> static int32_t pair_ok(const ot_ctx* c, const ot_segments* s, int64_t n) {
+    if (!c->opt_pair || (n & 1) || sizeof(T) != 8) return 0;
+    const void* real[] = {s->ox, s->oy, s->oz, s->dx, s->dy, s->dz, s->length, s->intensity, s->q_re, s->q_im, s->n, s->pathlength};
+    for (const void* p : real)
+        if ((uintptr_t)p % (2 * sizeof(T))) return 0;
+    if ((uintptr_t)s->ray % 8 || (uintptr_t)s->surface % 8) return 0;
+    return 1;
+}
+
 // Address of one k_trace_fused instantiation, or nullptr for the combinations the launch logic never selects: the
 // 128-register cap (MINW = 4) on the fp64 Snell kernel would spill (145 VGPRs wanted), so it is not even compiled.
 template <class T, uint32_t FM, bool L, int W, bool N>
 static auto fused_ptr() {
-    using Kern = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, SegsT<T>, int32_t*, int32_t*, int32_t);
+    using Kern = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, SegsT<T>, int32_t*, int32_t*, int32_t, int32_t);
     if constexpr (sizeof(T) == 8 && W == 4 && (FM & F_REFRACT) != 0) return (Kern) nullptr;
     else return (Kern)k_trace_fused<T, FM, L, W, N>;
 }
@@ -567,7 +581,7 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
     hipEvent_t ev0, ev1;
     rc = timing_pair(c, &ev0, &ev1);
     if (rc) return rc;
-    using Kern = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, SegsT<T>, int32_t*, int32_t*, int32_t);
+    using Kern = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, SegsT<T>, int32_t*, int32_t*, int32_t, int32_t);
     const int fi = (need & ~FA) == 0 ? 0 : ((need & ~FB) == 0 ? 1 : 2);
     // the 128-register cap pays for the mirror/lens kernel only; the Snell kernel would spill (fp64: 145 VGPRs)
     const int mw = (c->opt_minw == 4 && (fi == 0 || (fi == 1 && !f64))) ? 1 : 0, nt = c->opt_nt ? 1 : 0;
@@ -584,7 +598,7 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
     const size_t lds_bytes = in_lds ? bytes : 0;
     if (lds_bytes > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), (uint32_t)lds_bytes, c->stream, ev0, ev1, 0u, blob, (T)c->unit, view<T>(rays), n, K,
-                          view<T>(out), seg_count, counts, n_classes);
+                          view<T>(out), seg_count, counts, n_classes, pair_ok<T>(c, out, n));
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -779,6 +793,7 @@ int ot_set_option(ot_ctx* c, int32_t option, int32_t value) {
     if (!c) return fail(OT_ERR_INVALID, "ctx is NULL");
     switch (option) {
         case OT_OPT_NT_STORES: c->opt_nt = value != 0; return 0;
+        case OT_OPT_PAIR_STORES: c->opt_pair = value != 0; return 0;
         case OT_OPT_MIN_WAVES: 
             if (value != 0 && value != 4) return fail(OT_ERR_INVALID, "OT_OPT_MIN_WAVES takes 0 or 4");
             c->opt_minw = value; return 0;
@@ -815,9 +830,9 @@ static int bench_stream(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, co
     rc = timing_begin(c);
     if (rc) return rc;
     if (c->opt_nt)
-        hipLaunchKernelGGL((k_stream_ceiling<T, true>), dim3(grid), dim3(block), 0, c->stream, view<T>(rays), n, K, view<T>(out), seg_count);
+        hipLaunchKernelGGL((k_stream_ceiling<T, true>), dim3(grid), dim3(block), 0, c->stream, view<T>(rays), n, K, view<T>(out), seg_count, pair_ok<T>(c, out, n));
     else
-        hipLaunchKernelGGL((k_stream_ceiling<T, false>), dim3(grid), dim3(block), 0, c->stream, view<T>(rays), n, K, view<T>(out), seg_count);
+        hipLaunchKernelGGL((k_stream_ceiling<T, false>), dim3(grid), dim3(block), 0, c->stream, view<T>(rays), n, K, view<T>(out), seg_count, pair_ok<T>(c, out, n));
     HIP_TRY(hipGetLastError());
     return timing_end(c);
 }
