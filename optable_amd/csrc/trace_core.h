@@ -241,10 +241,14 @@ template <class T> __device__ __forceinline__ T sag(const DNode<T>& nd, T r) { r
 // p[7] = EFL/(n+1) for the exact one.  One division instead of three, none for the exact form.  The normal
 // and curvature (sag_d1 / sag_d2 below) keep the reference's expression term by term: their finite
 // differences amplify rounding by 1/h^2.
+// A paraboloid base (kappa = -1: p[6] = (1 + kappa) / R^2 = 0) has sqrt(1 - 0) = 1 in all three forms below; the branch
+// is wave-uniform wherever the node is, and skips the square root and the division without changing a bit of the
+// result (1 + 1 = 2 and its reciprocal are exact).
 template <class T> __device__ __forceinline__ T sag_search(const DNode<T>& nd, T r2) {
     if (nd.shape == OT_SHAPE_ASPHERE_PARAM) {
         const T r4 = r2 * r2;
-        return div_t(r2 * nd.p[7], T(1) + sqrt_t(T(1) - nd.p[6] * r2)) + nd.p[3] * r4 + nd.p[4] * r4 * r2 + nd.p[5] * r4 * r4;
+        const T base = nd.p[6] == T(0) ? (r2 * nd.p[7]) * T(0.5) : div_t(r2 * nd.p[7], T(1) + sqrt_t(T(1) - nd.p[6] * r2));
+        return base + nd.p[3] * r4 + nd.p[4] * r4 * r2 + nd.p[5] * r4 * r4;
     }
     return nd.p[7] * (sqrt_t(T(1) + nd.p[6] * r2) - T(1));
 }
@@ -254,6 +258,7 @@ template <class T> __device__ __forceinline__ T asphere_sign(const DNode<T>& nd,
     if (nd.shape == OT_SHAPE_ASPHERE_PARAM) {
         const T r4 = r2 * r2;
         const T poly = nd.p[3] * r4 + nd.p[4] * r4 * r2 + nd.p[5] * r4 * r4;
+        if (nd.p[6] == T(0)) return (x + poly) * T(2) + r2 * nd.p[7];
         return (x + poly) * (T(1) + sqrt_t(T(1) - nd.p[6] * r2)) + r2 * nd.p[7];
     }
     return x + nd.p[7] * (sqrt_t(T(1) + nd.p[6] * r2) - T(1));
@@ -261,8 +266,11 @@ template <class T> __device__ __forceinline__ T asphere_sign(const DNode<T>& nd,
 // dF/dr divided by r, analytic, as a function of r^2 (Newton slope of the root polish only: it
 // steers the iteration, the root it converges to does not depend on it)
 template <class T> __device__ __forceinline__ T sag_slope_over_r(const DNode<T>& nd, T r2) {
-    if (nd.shape == OT_SHAPE_ASPHERE_PARAM)
-        return div_t(nd.p[7], sqrt_t(T(1) - nd.p[6] * r2)) + r2 * (T(4) * nd.p[3] + r2 * (T(6) * nd.p[4] + r2 * T(8) * nd.p[5]));
+    if (nd.shape == OT_SHAPE_ASPHERE_PARAM) {
+        const T dpoly = r2 * (T(4) * nd.p[3] + r2 * (T(6) * nd.p[4] + r2 * T(8) * nd.p[5]));
+        if (nd.p[6] == T(0)) return nd.p[7] + dpoly;
+        return div_t(nd.p[7], sqrt_t(T(1) - nd.p[6] * r2)) + dpoly;
+    }
     return div_t(nd.p[6] * nd.p[7], sqrt_t(T(1) + nd.p[6] * r2));
 }
 // fp64: the reference's central differences, h = 1e-4*radius, reproduced term by term.
