@@ -449,7 +449,7 @@ __device__ __forceinline__ T polish_root(const Scene<T>& sc, const DNode<T>& nd,
 // far enough, inside the length and inside the shape's boundary.  Planar leaves: test_leaf.
 template <class T, uint32_t F>
 __device__ __forceinline__ bool hit_leaf(const Scene<T>& sc, const DNode<T>& nd, T ox, T oy, T oz, T dx, T dy, T dz, T len, T& t_out,
-                                         T& Px, T& Py, T& Pz, T prune_t = Num<T>::inf()) {
+                                         T& Px, T& Py, T& Pz, T prune_t = Num<T>::inf(), bool own = false) {
     if constexpr (F & F_CURVED) {
         const T EPS = Num<T>::eps_t();
         if (nd.shape == OT_SHAPE_POINT) return false;  // f = |P| never changes sign (surfaces.py:73-80)
@@ -512,6 +512,11 @@ __device__ __forceinline__ bool hit_leaf(const Scene<T>& sc, const DNode<T>& nd,
             // quantised to ~2e-6 at R ~ 30, so a sample lands on g == 0 exactly for several percent of
             // the rays and the product test would drop those roots; compare signs instead.
             const bool crossing = sizeof(T) == 4 ? ((gl < T(0)) != (gr < T(0))) : (gl * gr < T(0));
+            // A ray that was emitted ON this surface (own) has a root at its start point: the bracket that holds t = 0
+            // shows a sign change, brentq converges to that root and the |t| < EPS filter throws it away
+            // (optical_component.py:221-227).  The samples are taken as always — a second crossing further along still
+            // shows in its own interval — but polishing the root at the start point only to discard it is skipped.
+            if (crossing && own && tl <= T(0) && tr >= T(0)) { tl = tr; gl = gr; continue; }
             if (crossing) {
                 const T t = polish_root<T, F>(sc, nd, ox, oy, oz, dx, dy, dz, tl, tr, gl, gr);
                 if (t >= T(0) && abs_t(t) >= EPS && t <= len) {
@@ -633,7 +638,7 @@ __device__ __forceinline__ void test_leaf(const Scene<T>& sc, const DNode<T>& nd
         T ox, oy, oz, dx, dy, dz;
         to_local(nd, rx, ry, rz, ox, oy, oz);
         to_local(nd, r.dx, r.dy, r.dz, dx, dy, dz);
-        if (!hit_leaf<T, F>(sc, nd, ox, oy, oz, dx, dy, dz, r.len, t, Px, Py, Pz, prune_t)) return;
+        if (!hit_leaf<T, F>(sc, nd, ox, oy, oz, dx, dy, dz, r.len, t, Px, Py, Pz, prune_t, idx == r.last)) return;
     }
     if constexpr (F & F_LIMIT) {
         if (GATE == GATE_PROBE) {
