@@ -153,7 +153,7 @@ def make_batch(oa, wl, n, rank, device, seed_shift=0):
 
 def kernel_name(scene, wl):
     heavy = scene.n_nodes >= 24
-    return ("k_trace_blocked" if heavy else "k_trace_fused") + ("<double>" if wl.precision == "f64" else "<float>")
+    return ("k_trace_rolling" if heavy else "k_trace_fused") + ("<double>" if wl.precision == "f64" else "<float>")
 
 
 def committed_counters(name):
@@ -205,6 +205,46 @@ def survey_config(oa, eng, name, device):
     if counters:
         rec["sq_counters"] = counters
     del out, batch
+    torch.cuda.empty_cache()
+    return rec
+
+
+def survey_branching(oa, eng, device):
+    """cfg 4 with reflectivity 0.2 (SURVEY.md §8d branching variant): 1.28e7 ray trees x 12 segments through the
+    generation kernels (count / scan / emit per generation); device time from the library's HIP events."""
+    import numpy as np
+    import torch
+    from optable_amd import workloads as W
+    from optable_amd.batch import RayBatch
+
+    table = oa.OpticalTable()
+    table.add_components(W.cfg4_components(oa, reflectivity=0.2))
+    scene = table.compile()
+    eng.upload(scene)
+    nb = 200_000
+    o, d, _ = W.cfg4_rays(nb, 4, n_wavelengths=1)
+    base = RayBatch.from_arrays(o, d, wavelength=W.WL, q=1j * np.pi * W.W0**2 / W.WL, precision="f64", device=device)
+    batch = base.multiplexed_in_wavelength(np.linspace(400e-7, 1100e-7, W.CFG4_WAVELENGTHS))
+    eng.trace_tree(batch, 12, out_capacity=batch.n * 13)  # warm: scratch and generation buffers
+    eng.timing(True)
+    t0 = time.perf_counter()
+    segs = eng.trace_tree(batch, 12, out_capacity=batch.n * 13)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ms, launches = eng.timing_read()
+    eng.timing(False)
+    n_seg = int(segs.n_valid)
+    alg = n_seg * 104 * 2 + (n_seg - batch.n) * 104  # per processed ray: record read + segment written; per child: record written
+    rec = {"workload": "cfg4 with reflectivity 0.2: 1.28e7 ray trees (2e5 rays x 64 wavelengths) x 12 segments, fp64, generation kernels",
+           "rays": batch.n, "dtype": "f64", "kernel": "k_gen_pass<double> (count + emit) per generation", "leaf_surfaces": scene.n_leaves,
+           "generations": int(launches), "ms_per_trace": ms, "wall_ms_per_trace": wall * 1e3, "segments_per_ray": n_seg / batch.n,
+           "segments_per_s": n_seg / (ms / 1e3), "intersections_per_s": n_seg * scene.n_leaves / (ms / 1e3),
+           "algorithmic_gbs": alg / (ms / 1e3) / 1e9, "hbm_frac": alg / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, "bound": "hbm",
+           "generation_mismatches": eng.generation_mismatches()}
+    counters = committed_counters("cfg4b")
+    if counters:
+        rec["sq_counters"] = counters
+    del segs, batch, base
     torch.cuda.empty_cache()
     return rec
 
@@ -442,6 +482,10 @@ def main():
                     line["configs"].append(survey_config(oa, eng, name, device))
                 except Exception as exc:  # noqa: BLE001 — the headline is still worth printing
                     line["configs"].append({"workload": name, "error": f"{type(exc).__name__}: {exc}"})
+            try:
+                line["configs"].append(survey_branching(oa, eng, device))
+            except Exception as exc:  # noqa: BLE001
+                line["configs"].append({"workload": "cfg4 branching", "error": f"{type(exc).__name__}: {exc}"})
             batches = [make_batch(oa, wl, min(n, 200_000), rank, device)]
             eng.upload(scene)
         if world == 1 and not args.no_cpu_baseline and not args.dry_run:
