@@ -264,13 +264,11 @@ __global__ __launch_bounds__((blocked_threads<T, F>()), (blocked_minw<T, F>())) 
     __syncthreads();  // the only workgroup barrier: the scene image is staged
     const Scene<T> sc = bind_scene<T>(base, blob, unit);
     const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;  // this wave's scratch
-    T* const s_ox = ws.f(gw, 0); T* const s_oy = ws.f(gw, 1); T* const s_oz = ws.f(gw, 2);
-    T* const s_dx = ws.f(gw, 3); T* const s_dy = ws.f(gw, 4); T* const s_dz = ws.f(gw, 5);
-    T* const s_qr = ws.f(gw, 6); T* const s_qi = ws.f(gw, 7); T* const s_I = ws.f(gw, 8);
-    T* const s_n = ws.f(gw, 9); T* const s_pl = ws.f(gw, 10); T* const s_wl = ws.f(gw, 11);
-    int32_t* const s_fl = ws.flags(gw);
-    int32_t* const s_id = ws.id(gw);
-    int32_t* const s_last = ws.last(gw);
+    // ONE base pointer per wave; field f of list position p is element p + f * CAP (twelve reals, then flags / id / node
+    // as 32-bit words behind them).  Fourteen separate base pointers cost 28 scalar registers that the kernel does not
+    // have (106 of 102 in use: the compiler was spilling scalars into vector lanes).
+    T* const srec = ws.f(gw, 0);
+    int32_t* const sint = ws.flags(gw);
     int alive = 0;  // wave-uniform
     bool exhausted = false, fresh_fill = false;
 #ifdef OT_STAMP
@@ -316,11 +314,13 @@ __global__ __launch_bounds__((blocked_threads<T, F>()), (blocked_minw<T, F>())) 
                     cls = in.id[i];
                     r = load_ray(in, i, fl);
                 } else {  // later ones: this wave's scratch, by list position
-                    r.ox = s_ox[p]; r.oy = s_oy[p]; r.oz = s_oz[p]; r.dx = s_dx[p]; r.dy = s_dy[p]; r.dz = s_dz[p];
-                    r.qr = s_qr[p]; r.qi = s_qi[p]; r.I = s_I[p]; r.n = s_n[p]; r.pl = s_pl[p]; r.wl = s_wl[p];
-                    fl = s_fl[p];
-                    cls = s_id[p];
-                    r.last = s_last[p];
+                    r.ox = srec[p]; r.oy = srec[p + CAP]; r.oz = srec[p + 2 * CAP];
+                    r.dx = srec[p + 3 * CAP]; r.dy = srec[p + 4 * CAP]; r.dz = srec[p + 5 * CAP];
+                    r.qr = srec[p + 6 * CAP]; r.qi = srec[p + 7 * CAP]; r.I = srec[p + 8 * CAP];
+                    r.n = srec[p + 9 * CAP]; r.pl = srec[p + 10 * CAP]; r.wl = srec[p + 11 * CAP];
+                    fl = sint[p];
+                    cls = sint[p + CAP];
+                    r.last = sint[p + 2 * CAP];
                     r.len = Num<T>::inf();
                     r.has_q = (fl & OT_RAY_HAS_Q) != 0;
                 }
@@ -355,11 +355,13 @@ __global__ __launch_bounds__((blocked_threads<T, F>()), (blocked_minw<T, F>())) 
             if (survive) {  // in-place compaction: q < p0 + 64, and every position below p0 + 64 has been read
                 const int q = next_alive + __popcll(mk & ((1ull << lane) - 1ull));
                 nxt[q] = ((unsigned long long)(k + 1) << 32) | (unsigned long long)i;
-                s_ox[q] = child.ox; s_oy[q] = child.oy; s_oz[q] = child.oz; s_dx[q] = child.dx; s_dy[q] = child.dy; s_dz[q] = child.dz;
-                s_qr[q] = child.qr; s_qi[q] = child.qi; s_I[q] = child.I; s_n[q] = child.n; s_pl[q] = child.pl; s_wl[q] = r.wl;
-                s_fl[q] = fl;
-                s_id[q] = cls;
-                s_last[q] = child.last;
+                srec[q] = child.ox; srec[q + CAP] = child.oy; srec[q + 2 * CAP] = child.oz;
+                srec[q + 3 * CAP] = child.dx; srec[q + 4 * CAP] = child.dy; srec[q + 5 * CAP] = child.dz;
+                srec[q + 6 * CAP] = child.qr; srec[q + 7 * CAP] = child.qi; srec[q + 8 * CAP] = child.I;
+                srec[q + 9 * CAP] = child.n; srec[q + 10 * CAP] = child.pl; srec[q + 11 * CAP] = r.wl;
+                sint[q] = fl;
+                sint[q + CAP] = cls;
+                sint[q + 2 * CAP] = child.last;
             }
             next_alive += __popcll(mk);
             OT_STAMP_AT(2);
