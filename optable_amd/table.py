@@ -102,6 +102,8 @@ class OpticalTable:
                 print(f"Ray tracing time exceeds the maximum tracing time after {cap} traces. "
                       f"({capped} ray tree(s) truncated)")
             self.rays.extend(traced)
+        elif len(rays):  # an exhausted limit: the reference's loop does not start, nothing is archived, the message is printed
+            print(f"Ray tracing time exceeds the maximum tracing time after 0 traces. ({len(rays)} ray tree(s) truncated)")
         return _clone_rays(self.rays)
 
     def trace_batch(self, batch, max_segments=None, counts=None, scene=None):
