@@ -8,8 +8,8 @@
 //   k_stream_ceiling<T>  the fused kernel's streams with no tracing (roofline companion).
 //   k_gen_pass<T>        one breadth-first generation of branching ray trees (optical_table.py:115-134) in two
 //                        streaming passes: count (rank within the tree, trace) -> scan of wave totals -> emit (trace
-//                        again, ordered slots); k_gen_trace (single pass, look-back) remains as the probe pass that,
-//                        with k_gen_rank / k_gen_counts, keeps interact-count gates FIFO-exact; k_gen_finish closes it.
+//                        again, ordered slots); k_gen_probe / k_gen_rank / k_gen_counts keep interact-count gates
+//                        FIFO-exact; k_gen_finish closes the generation.
 //   k_mon_*              Monitor.record over a segment stream (monitor.py:183-193).
 #pragma once
 
@@ -416,86 +416,14 @@ __device__ __forceinline__ int64_t tree_head(const int32_t* __restrict__ tree, i
     return lo;
 }
 
-// Ordered single-pass allocation of child slots (decoupled look-back): tiles of 256 rays are handed out by an
-// atomic ticket, so a tile with a smaller index is always held by a workgroup that is already running.  A tile
-// publishes its child count as an AGGREGATE, then walks back over its predecessors (one wave, 64 tiles per read)
-// adding aggregates until it meets an inclusive PREFIX, and publishes its own prefix.  Flag and value share one
-// 64-bit word, so a reader never sees one without the other and RELAXED device-scope atomics suffice
-// (acquire/release at device scope invalidate / write back the XCD's L2 around every access: 3.5x slower here).
-// The next generation is therefore written once, in parent order then child order, straight from the registers
-// of the trace (an earlier version parked both children of every ray in scratch, scanned the counts and
-// compacted in a second kernel: 40 % of the generation's bytes).
-struct LookBack {
-    unsigned long long* state;   // [n_tiles] (flag << 62) | value, zeroed before the launch
-    unsigned long long* ticket;  // next tile to hand out, zeroed before the launch
-};
-static constexpr unsigned long long LB_AGG = 1ull << 62, LB_PREFIX = 2ull << 62, LB_MASK = (1ull << 62) - 1ull;
-// the 62-bit value carries two counts: processed rays = segment slots (bits 32..61, n < 2^30) and children (bits 0..31)
-static constexpr int LB_SEG_SHIFT = 32;
-
-// Exclusive prefix of `total` over the tiles before `tile`; publishes this tile's aggregate and inclusive prefix.
-// Called by ONE full wave (all 64 lanes); every lane returns the same value.
-// The walk reads LB_WINDOWS windows of 64 predecessors per round trip, all loads in flight together: with ~800
-// workgroups resident, a tile that finishes its trace typically finds the nearest inclusive prefix a few hundred
-// tiles back (everything nearer has only published an aggregate), and walking there one window per L2/fabric
-// round trip (the first version) was the longest link of the load -> trace -> look-back -> store chain.
-static constexpr int LB_WINDOWS = 4;
-__device__ __forceinline__ unsigned long long lookback_exclusive(const LookBack& lb, int64_t tile, unsigned long long total, int lane) {
-    unsigned long long before = 0;
-    if (tile > 0) {
-        if (lane == 0) __hip_atomic_store(&lb.state[tile], LB_AGG | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        long long part = 0;  // per-lane partial sum, reduced once at the end
-        for (int64_t wbase = tile - 1;;) {
-            unsigned long long v[LB_WINDOWS];
-#pragma unroll
-            for (int j = 0; j < LB_WINDOWS; ++j) {
-                const int64_t idx = wbase - 64 * j - lane;  // lane 0 = nearest predecessor of window j
-                v[j] = LB_PREFIX;                           // before tile 0: an inclusive prefix of zero
-                if (idx >= 0) v[j] = __hip_atomic_load(&lb.state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            bool found = false;
-            int consumed = LB_WINDOWS;  // windows fully accounted for in this round
-#pragma unroll
-            for (int j = 0; j < LB_WINDOWS; ++j) {
-                if (found || consumed < LB_WINDOWS) continue;  // wave-uniform
-                const unsigned flag = (unsigned)(v[j] >> 62);
-                const unsigned long long m_prefix = __ballot(flag == 2u), m_empty = __ballot(flag == 0u);
-                unsigned long long need = ~0ull;  // the lanes up to and including the nearest prefix
-                if (m_prefix) {
-                    const int pl = __ffsll((long long)m_prefix) - 1;
-                    need = pl == 63 ? ~0ull : ((1ull << (pl + 1)) - 1ull);
-                }
-                if (m_empty & need) { consumed = j; continue; }  // one of them is still working: read again from here
-                if ((need >> lane) & 1ull) part += (long long)(v[j] & LB_MASK);
-                if (m_prefix) found = true;
-            }
-            if (found) break;
-            wbase -= 64 * consumed;
-            if (consumed < LB_WINDOWS) __builtin_amdgcn_s_sleep(24);  // ~0.6 us
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-        before = (unsigned long long)part;
-    }
-    if (lane == 0) __hip_atomic_store(&lb.state[tile], LB_PREFIX | (before + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return before;
-}
-
-// PROBE = true: the pre-pass that records geometric hits of count-limited leaves (no outputs).
-// Registers: both children of every ray stay live across the look-back (they are stored afterwards, straight from
-// registers).  The planar fp64 instantiation wants 176 VGPRs, 8 more than three waves per SIMD allow: it is capped there
-// (no spill with the scene image in LDS; the L2-image variant would spill 4 registers and keeps the compiler's choice).
-template <class T, uint32_t F, bool L> constexpr int gen_minw() { return (L && sizeof(T) == 8 && F == (F_AABB | F_LENS | F_REFRACT)) ? 3 : 1; }
-
-template <class T, uint32_t F, bool SCENE_IN_LDS, bool PROBE>
-__global__ __launch_bounds__(256, (gen_minw<T, F, SCENE_IN_LDS>())) void k_gen_trace(SceneBlob blob, T unit, RaysT<T> in, const int32_t* tree, int64_t n,
-                                                   const int32_t* budget, const int64_t* cursor,
-                                                   SegsT<T> out, int64_t out_capacity, LookBack lb, RaysOutT<T> next,
-                                                   int32_t* next_tree, int64_t next_capacity, int64_t* totals,
-                                                   int32_t* counts, int32_t n_classes, const int32_t* rank, int32_t* probe) {
+// k_gen_probe: the pre-pass of a generation in a scene with count-limited leaves.  It only records which limited
+// leaves each ray hits GEOMETRICALLY (probe[slot][i] = 1; no outputs, no children): a per-slot scan of these flags
+// then gives every ray the number of EARLIER rays of its tree that hit the leaf, which is what makes the gate
+// FIFO-exact inside a generation (optical_component.py:140-149, 359-362; k_gen_rank / k_gen_counts below).
+template <class T, uint32_t F, bool SCENE_IN_LDS>
+__global__ __launch_bounds__(256) void k_gen_probe(SceneBlob blob, T unit, RaysT<T> in, const int32_t* __restrict__ tree, int64_t n,
+                                                   const int32_t* __restrict__ budget, int32_t* counts, int32_t n_classes, int32_t* probe) {
     extern __shared__ __align__(16) uint32_t lds[];
-    __shared__ long long s_tile, s_base;
-    __shared__ unsigned long long s_wave_total[4];
     const uint32_t* base = blob.words;
     if (SCENE_IN_LDS) {
         for (int w = threadIdx.x; w < blob.n_words; w += blockDim.x) lds[w] = blob.words[w];
@@ -503,103 +431,31 @@ __global__ __launch_bounds__(256, (gen_minw<T, F, SCENE_IN_LDS>())) void k_gen_t
         base = lds;
     }
     const Scene<T> sc = bind_scene<T>(base, blob, unit);
-    const int64_t cur0 = *cursor;
-    const int64_t n_tiles = (n + 255) / 256;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (;;) {
-        if (threadIdx.x == 0) s_tile = (long long)atomicAdd(lb.ticket, 1ull);
-        __syncthreads();
-        const int64_t tile = s_tile;
-        if (tile >= n_tiles) break;  // workgroup-uniform
-        const int64_t i = tile * 256 + threadIdx.x;
-        // Rank of the ray inside its tree (rays beyond the tree's remaining max_trace_num budget are dropped,
-        // optical_table.py:138-144).  The head of the tree is the nearest earlier ray of this WAVE that starts a
-        // tree (max-scan of start flags) unless the tree began before the wave: those lanes all look up the head
-        // of the wave's first ray — the same addresses for all of them, one cache line per step.
-        int32_t my_tree = -1;
-        long long start = -1;
-        if (i < n) {
-            my_tree = tree[i];
-            if (lane == 0 || tree[i - 1] != my_tree) start = i;
-        }
-        long long head = start;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const long long up = __shfl_up(head, off, 64);
-            if (lane >= off && up > head) head = up;
-        }
-        if (i < n && head == i - lane) head = tree_head(tree, i - lane);  // the run reaches back to the wave's first ray
-        bool active = i < n && (i - head) < (int64_t)budget[my_tree];
-        RayState<T> r = {};
-        int32_t cls = 0, fl = 0;
-        if (active) {
-            fl = in.flags[i];
-            r = load_ray(in, i, fl);
-            cls = in.id[i];
-        }
-        const bool dead = active && (fl & OT_RAY_DEAD);
-        const GateCtx gate = {counts, n_classes, cls, rank, probe, n, i};
-        if (PROBE) {
-            (void)nearest_hit<T, F, GATE_PROBE>(sc, r, active && !dead, gate);
-            __syncthreads();  // s_tile is rewritten at the top of the loop
-            continue;
-        }
-        const Hit<T> h = nearest_hit<T, F, GATE_TABLE>(sc, r, active && !dead, gate);
-        int32_t nk = 0, t = 0;
-        RayState<T> ch[2];  // only ever indexed by constants: both children stay in registers
-        if (active) {
-            t = tree[i];
-            if (!dead && h.node >= 0) nk = interact<T, F, 2>(sc, r, h, ch, make_matcache(sc, r.wl));
-        }
-        // segment and child slots: inclusive scan of both counts inside the wave (packed: segments high, children
-        // low), wave totals through LDS, tile prefix by look-back
-        const unsigned long long mine = ((unsigned long long)(active ? 1 : 0) << LB_SEG_SHIFT) | (unsigned long long)nk;
-        unsigned long long incl = mine;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned long long up = (unsigned long long)__shfl_up((long long)incl, off, 64);
-            if (lane >= off) incl += up;
-        }
-        if (lane == 63) s_wave_total[wave] = incl;
-        __syncthreads();
-        if (wave == 0) {  // look-back by a whole wave: 64 predecessors per read
-            const unsigned long long total = s_wave_total[0] + s_wave_total[1] + s_wave_total[2] + s_wave_total[3];
-            const unsigned long long before = lookback_exclusive(lb, tile, total, lane);
-            if (lane == 0) {
-                s_base = (long long)before;
-                if (tile == n_tiles - 1) {  // generation totals for k_gen_finish and the host
-                    const unsigned long long all = before + total;
-                    totals[0] = (int64_t)(all >> LB_SEG_SHIFT);          // segments written
-                    totals[1] = (int64_t)(all & 0xffffffffull);          // rays in the next generation
-                }
-            }
-        }
-        __syncthreads();
-        unsigned long long before_me = (unsigned long long)s_base + (incl - mine);
-        for (int w = 0; w < wave; ++w) before_me += s_wave_total[w];
-        if (active) {
-            const int64_t slot = cur0 + (int64_t)(before_me >> LB_SEG_SHIFT);
-            if (slot < out_capacity) {
-                if (dead) store_segment(out, slot, r, r.len, t, -2);
-                else if (h.node < 0) store_segment(out, slot, r, r.len, t, -1);
-                else store_segment(out, slot, r, h.t, t, sc.nodes[h.node].leaf_id);
-            }
-        }
-        const int64_t d0 = (int64_t)(before_me & 0xffffffffull);
-        auto put = [&](const RayState<T>& k, int64_t d) {
-            if (d >= next_capacity) return;
-            next.ox[d] = k.ox; next.oy[d] = k.oy; next.oz[d] = k.oz;
-            next.dx[d] = k.dx; next.dy[d] = k.dy; next.dz[d] = k.dz;
-            next.wl[d] = k.wl; next.qr[d] = k.qr; next.qi[d] = k.qi;
-            next.I[d] = k.I; next.n[d] = k.n; next.pl[d] = k.pl;
-            next.flags[d] = (fl & OT_RAY_HAS_Q) | ((k.last + 1) << 8);  // the node the child starts on rides in bits 8..31
-            next.id[d] = cls;
-            next_tree[d] = t;
-        };
-        if (nk > 0) put(ch[0], d0);
-        if (nk > 1) put(ch[1], d0 + 1);
-        __syncthreads();  // s_tile / s_base / s_wave_total are rewritten by the next tile
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int32_t my_tree = -1;
+    long long start = -1;
+    if (i < n) {
+        my_tree = tree[i];
+        if (lane == 0 || tree[i - 1] != my_tree) start = i;
     }
+    long long head = start;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const long long up = __shfl_up(head, off, 64);
+        if (lane >= off && up > head) head = up;
+    }
+    if (i < n && head == i - lane) head = tree_head(tree, i - lane);
+    const bool active = i < n && (i - head) < (int64_t)budget[my_tree];
+    RayState<T> r = {};
+    int32_t cls = 0, fl = 0;
+    if (active) {
+        fl = in.flags[i];
+        r = load_ray(in, i, fl);
+        cls = in.id[i];
+    }
+    const GateCtx gate = {counts, n_classes, cls, nullptr, probe, n, i};
+    (void)nearest_hit<T, F, GATE_PROBE>(sc, r, active && !(fl & OT_RAY_DEAD), gate);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -611,8 +467,8 @@ __global__ __launch_bounds__(256, (gen_minw<T, F, SCENE_IN_LDS>())) void k_gen_t
 //          shuffle scans); segment and children written once, in stable order, straight from registers.
 // Neither pass has a workgroup barrier, a ticket or a dependency on another wave, so both run at the occupancy
 // their registers allow and stream at memory speed; the price is reading a generation's rays twice (116 of ~440
-// bytes per processed ray).  The single-pass kernel (k_gen_trace below, still used as the probe pass of count-limited
-// scenes) spent 70 % of its wave-cycles waiting: a tile's 90 KB of stores, the next tile's loads behind them (gfx9
+// bytes per processed ray).  The single-pass kernel of round 1 (tiles handed out by an atomic ticket, decoupled look-back
+// over packed (segments, children) words, children held in registers across it) spent 70 % of its wave-cycles waiting: a tile's 90 KB of stores, the next tile's loads behind them (gfx9
 // counts loads and stores in one in-order counter), the trace and the look-back were strictly serial per workgroup,
 // and three workgroups per CU (168 VGPRs: both children of every ray live across the look-back) could not hide it —
 // cfg 4 with reflectivity 0.2: 26.6 ms in round 1, 20.0 ms with four look-back windows in flight and no scratch,
@@ -639,7 +495,7 @@ __global__ __launch_bounds__(256) void k_gen_pass(SceneBlob blob, T unit, RaysT<
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t gwave = i >> 6;
-    // rank of the ray inside its tree, as in k_gen_trace: rays beyond the tree's remaining budget are dropped
+    // rank of the ray inside its tree (as in k_gen_probe): rays beyond the tree's remaining budget are dropped
     int32_t my_tree = -1;
     long long start = -1;
     if (i < n) {

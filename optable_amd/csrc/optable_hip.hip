@@ -640,18 +640,12 @@ static int trace_generation(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
     // scratch carve-up
     const int ns = c->n_slots;
     const size_t sz_slot = align_up(sizeof(int32_t) * n * (ns > 0 ? ns : 1));
-    const int64_t n_tiles = (n + 255) / 256;
-    const size_t sz_lb = align_up(sizeof(unsigned long long) * (n_tiles + 1));  // tile states + the ticket
     const size_t sz_tot = align_up(sizeof(int64_t) * 2 + sizeof(unsigned long long));
     const int64_t n_waves = (n + 63) / 64;
     const size_t sz_code = align_up((size_t)n), sz_wave = align_up(sizeof(unsigned long long) * n_waves);
-    const size_t total = sz_lb + sz_tot + sz_code + 2 * sz_wave + (ns > 0 ? 3 * sz_slot : 0);
+    const size_t total = sz_tot + sz_code + 2 * sz_wave + (ns > 0 ? 3 * sz_slot : 0);
     if (c->gen.ensure(total)) return fail(OT_ERR_HIP, "hipMalloc of generation scratch failed");
     uint8_t* p = (uint8_t*)c->gen.p;
-    LookBack lb;
-    lb.state = (unsigned long long*)p;
-    lb.ticket = lb.state + n_tiles;
-    p += sz_lb;
     int64_t* totals = (int64_t*)p;
     unsigned long long* mismatch = (unsigned long long*)(totals + 2);
     p += sz_tot;
@@ -684,14 +678,12 @@ static int trace_generation(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
     blob.root = c->root_grid;
     blob.cache_mat = c->cache_mat;
     const bool in_lds = bytes <= (size_t)c->opt_lds_limit_kb * 1024;
-    const int64_t cap = (int64_t)c->n_cus * (c->opt_blocks_per_cu > 0 ? c->opt_blocks_per_cu : 4);
-    const int grid = (int)(g1 < cap ? g1 : cap);
     const size_t lds_bytes = in_lds ? bytes : 0;
     // beam splitters and partially reflecting slabs are planar scenes: they get the small instantiation
     // (145 instead of 255 VGPRs, 3 waves/SIMD instead of 1); count gates need the full one
     constexpr uint32_t FG = F_AABB | F_LENS | F_REFRACT;
     const bool small = (c->features & ~FG) == 0;
-    auto k_probe = in_lds ? k_gen_trace<T, F_ALL, true, true> : k_gen_trace<T, F_ALL, false, true>;
+    auto k_probe = in_lds ? k_gen_probe<T, F_ALL, true> : k_gen_probe<T, F_ALL, false>;
     auto k_count = small ? (in_lds ? k_gen_pass<T, FG, true, false> : k_gen_pass<T, FG, false, false>)
                          : (in_lds ? k_gen_pass<T, F_ALL, true, false> : k_gen_pass<T, F_ALL, false, false>);
     auto k_emit = small ? (in_lds ? k_gen_pass<T, FG, true, true> : k_gen_pass<T, FG, false, true>)
@@ -703,10 +695,8 @@ static int trace_generation(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
     }
     if (ns > 0) {  // FIFO-exact interact-count gating: probe -> per-slot scan -> rank within the tree
         HIP_TRY(hipMemsetAsync(probe, 0, sizeof(int32_t) * n * ns, c->stream));
-        HIP_TRY(hipMemsetAsync(lb.ticket, 0, sizeof(unsigned long long), c->stream));
-        hipLaunchKernelGGL(k_probe, dim3(grid), dim3(block), lds_bytes, c->stream, blob, (T)c->unit, view<T>(rays), tree, n, budget,
-                           seg_cursor, view<T>(out), out_capacity, lb, view_out<T>(next), next_tree, next_capacity, totals,
-                           counts, n_classes, (const int32_t*)nullptr, probe);
+        hipLaunchKernelGGL(k_probe, dim3(g1), dim3(block), lds_bytes, c->stream, blob, (T)c->unit, view<T>(rays), tree, n, budget,
+                           counts, n_classes, probe);
         for (int s = 0; s < ns; ++s)
             HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->scan_tmp.p, tmp, probe + (int64_t)s * n, probe_ex + (int64_t)s * n, (int)n, c->stream));
         hipLaunchKernelGGL(k_gen_rank, dim3(g1), dim3(block), 0, c->stream, tree, n, ns, probe_ex, rank);
