@@ -794,7 +794,7 @@ int ot_set_option(ot_ctx* c, int32_t option, int32_t value) {
             if (value < 0 || value > 150) return fail(OT_ERR_INVALID, "OT_OPT_LDS_LIMIT_KB takes 0..150");
             c->opt_lds_limit_kb = value; return 0;
         case OT_OPT_LIST_CAP:
-            if (value != 128 && value != 256 && value != 512 && value != 1024) return fail(OT_ERR_INVALID, "OT_OPT_LIST_CAP takes 128, 256, 512 or 1024");
+            if (value < 64 || value > 1024 || value % 64) return fail(OT_ERR_INVALID, "OT_OPT_LIST_CAP takes a multiple of 64 up to 1024");
             c->opt_list_cap = value; c->opt_list_cap_pure = value; return 0;
         case OT_OPT_BLOCKS_PER_CU:
             if (value < 0 || value > 65536) return fail(OT_ERR_INVALID, "OT_OPT_BLOCKS_PER_CU out of range");
