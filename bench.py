@@ -55,6 +55,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-sustained", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU time spent on the oracle baseline (bounded sample)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the real thing) or gloo (rehearsal: ranks may share a card)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and run the collectives even with one rank (rehearsal of the RCCL calls on a 1-GPU box)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / sharding / gather rehearsal without a GPU: no trace, fabricated per-ray state (tests)")
     return ap.parse_args(argv)
@@ -260,7 +262,7 @@ def main():
     if args.gpus != world:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
                  f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
-    distributed = world > 1
+    distributed = world > 1 or args.force_dist
 
     import numpy as np
     import torch

@@ -70,6 +70,7 @@ struct ot_ctx {
     int32_t opt_lds_limit_kb = 64;
     int32_t opt_kernel = 0;  // 0 auto, 1 fused (lane per ray), 2 rolling lists (the heavy-scene kernel)
     int32_t opt_list_cap = 128;  // k_trace_rolling: live rays per wave (cfg 3: 128 beats 256 and 512)
+    int32_t opt_mix = -1;  // -1 auto (scenes under a top-level grid mix generations), 0 never
     int32_t opt_list_cap_pure = 0;  // generation-pure lists: 0 = the chunk rule below
     Scratch blocked;
     size_t blocked_queue_off = 0;
@@ -516,7 +517,7 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
         // mix generations in a list and top it up continuously.  Scenes whose rays all run through the same sequence
         // of surfaces (cfg 5) keep generation-pure lists: mixing costs them more than the tails do (cfg 5 fp32:
         // 36.6 vs 31.6 ms; cfg 3 fp32: 5.1 vs 5.5 ms).
-        const bool mix = c->root_grid >= 0;
+        const bool mix = c->opt_mix < 0 ? c->root_grid >= 0 : (c->opt_mix != 0 && c->root_grid >= 0);
         const int fr = (mix && (need & ~FR) == 0) ? 0 : ((need & ~FC) == 0 ? 1 : ((need & ~FD) == 0 ? 2 : 3));
         static const KernR tr[4][2] = {{k_trace_rolling<T, FR, false, true>, k_trace_rolling<T, FR, true, true>},
                                        {k_trace_rolling<T, FC, false, true>, k_trace_rolling<T, FC, true, true>},
@@ -784,6 +785,7 @@ int ot_set_option(ot_ctx* c, int32_t option, int32_t value) {
     switch (option) {
         case OT_OPT_NT_STORES: c->opt_nt = value != 0; return 0;
         case OT_OPT_PAIR_STORES: c->opt_pair = value != 0; return 0;
+        case OT_OPT_MIX_GENERATIONS: c->opt_mix = value < 0 ? -1 : (value != 0); return 0;
         case OT_OPT_MIN_WAVES: 
             if (value != 0 && value != 4) return fail(OT_ERR_INVALID, "OT_OPT_MIN_WAVES takes 0 or 4");
             c->opt_minw = value; return 0;

@@ -60,3 +60,16 @@ def test_two_ranks_on_one_card_gloo_rehearsal():
     assert line["n_gpus"] == 2 and line["config"]["rays_per_gpu"] == 20000 and line["config"]["rays_total"] == 40000
     assert line["gathered_shape"] == [12, 40000] and line["gather_ms"] > 0 and "gather_error" not in line
     assert line["config"]["segments_per_ray"] == 5.0
+
+
+def test_one_rank_rccl_rehearsal():
+    """The RCCL calls of the multi-GPU path (init with device_id, barrier, all_reduce MAX / SUM, the end-of-job gather) with
+    the one rank a 1-GPU box allows: `torchrun --nproc-per-node 1 bench.py --gpus 1 --force-dist` uses backend nccl."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                          "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "3", "--warmup", "1",
+                          "--rays", "20000", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["n_gpus"] == 1 and line["gathered_shape"] == [12, 20000] and line["gather_ms"] > 0 and "gather_error" not in line
