@@ -67,7 +67,11 @@ template <> struct Num<float> {
 };
 
 // Device copy of ot_node in the kernel's real type (built by the host in ot_scene_upload).
-template <class T> struct alignas(16) DNode {  // 16-byte aligned records (208 / 368 bytes): LDS reads of a node can be 128 bits wide
+// Record stride: 53 dwords in fp32, 94 in fp64.  When 64 lanes read the same field of 64 DIFFERENT nodes (the grid walks),
+// the LDS bank of lane l is (stride * node_l + field) mod 32: an odd stride (53) sends different nodes to different banks,
+// where the natural 52 dwords (a multiple of 4) left only 8 distinct banks — 21 % of the LDS cycles of cfg 3 were bank
+// conflicts, 4 % with the pad (tools/lds_probe.sh); cfg 3 +1 %, cfg 5 fp32 19.65 -> 19.2 ms.
+template <class T> struct DNode {
     T M[9];
     T org[3];
     T aabb[6];
@@ -76,6 +80,7 @@ template <class T> struct alignas(16) DNode {  // 16-byte aligned records (208 /
     T refl, trans, focal, roc;
     T inv_focal, r2, rad2, pad1;  // 1/focal_length; circle radius^2 or cap aperture^2; sphere/cylinder R^2
     int32_t kind, end, flags, shape, inter, mat1, mat2, roc_kind, max_count, slot, aux, leaf_id;
+    int32_t bank_pad[sizeof(T) == 4 ? 1 : 2];
 };
 template <class T> struct DMat {
     T n;

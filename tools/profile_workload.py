@@ -22,6 +22,10 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 SIZES = {"cfg2": 1_000_000, "cfg3": 10_000_000, "cfg4": 160_000_000, "cfg5": 12_500_000, "cfg4b": 12_800_000, "monitor": 1_000_000}
 n = int(os.environ.get("RAYS", SIZES[name]))
 eng = get_engine()
+from optable_amd import abi as _abi
+for _env, _opt in (("CAP", _abi.OPT_LIST_CAP), ("MIX", _abi.OPT_MIX_GENERATIONS), ("KERNEL", _abi.OPT_KERNEL)):
+    if os.environ.get(_env):
+        eng.set_option(_opt, int(os.environ[_env]))
 Q = lambda lam: 1j * np.pi * W.W0**2 / lam
 
 if name in ("cfg2", "cfg3", "cfg5"):
