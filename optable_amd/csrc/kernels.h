@@ -71,12 +71,19 @@ template <class T> __device__ __forceinline__ Scene<T> bind_scene(const uint32_t
 // Segment records are written once and never re-read by the trace: NT = true marks the stores
 // non-temporal so they stream past L2 / Infinity Cache instead of evicting the scene and inputs.
 template <bool NT, class V> __device__ __forceinline__ void st(V* p, V v) {
+#ifdef OT_EXPERIMENT_PLAIN_STORES
+    *p = v;
+#else
     if (NT) __builtin_nontemporal_store(v, p);
     else *p = v;
+#endif
 }
 template <class T, bool NT = false>
 __device__ __forceinline__ void store_segment(const SegsT<T>& out, int64_t slot, const RayState<T>& r, T len, int32_t tree,
                                               int32_t surface) {
+#ifdef OT_EXPERIMENT_NO_SEGSTORE  // timing experiment only: how much of a heavy-scene pass is the segment record
+    if (slot >= 0) { st<NT>(out.surface + slot, surface); return; }
+#endif
     st<NT>(out.ox + slot, r.ox); st<NT>(out.oy + slot, r.oy); st<NT>(out.oz + slot, r.oz);
     st<NT>(out.dx + slot, r.dx); st<NT>(out.dy + slot, r.dy); st<NT>(out.dz + slot, r.dz);
     st<NT>(out.len + slot, len); st<NT>(out.I + slot, r.I);

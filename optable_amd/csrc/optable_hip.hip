@@ -519,10 +519,14 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
         // 36.6 vs 31.6 ms; cfg 3 fp32: 5.1 vs 5.5 ms).
         const bool mix = c->opt_mix < 0 ? c->root_grid >= 0 : (c->opt_mix != 0 && c->root_grid >= 0);
         const int fr = (mix && (need & ~FR) == 0) ? 0 : ((need & ~FC) == 0 ? 1 : ((need & ~FD) == 0 ? 2 : 3));
-        static const KernR tr[4][2] = {{k_trace_rolling<T, FR, false, true>, k_trace_rolling<T, FR, true, true>},
-                                       {k_trace_rolling<T, FC, false, true>, k_trace_rolling<T, FC, true, true>},
-                                       {k_trace_rolling<T, FD, false, true>, k_trace_rolling<T, FD, true, true>},
-                                       {k_trace_rolling<T, F_ALL, false, true>, k_trace_rolling<T, F_ALL, true, true>}};
+        // [preset][image in LDS][non-temporal segment stores].  Mixed lists write the [k][ray] slots of a pass in fragments
+        // of several tickets: partial lines that the L2 can merge with what neighbouring passes write if the stores are
+        // PLAIN (cfg 3 fp32: 5.62 ms with non-temporal stores, 4.38 ms with plain ones, interleaved A/B); generation-pure
+        // lists write longer runs and keep the non-temporal stores (cfg 5: 19.3 vs 19.6 ms).
+#define OT_R(FM) {{k_trace_rolling<T, FM, false, false>, k_trace_rolling<T, FM, false, true>}, {k_trace_rolling<T, FM, true, false>, k_trace_rolling<T, FM, true, true>}}
+        static const KernR tr[4][2][2] = {OT_R(FR), OT_R(FC), OT_R(FD), OT_R(F_ALL)};
+#undef OT_R
+        const int nt_r = (mix || !c->opt_nt) ? 0 : 1;
         static const int max_threads[4] = {blocked_threads<T, FR>(), blocked_threads<T, FC>(), blocked_threads<T, FD>(), blocked_threads<T, F_ALL>()};
         // Where the scene image lives and how many waves share it.  The waves never synchronise after staging, so the
         // workgroup size is only packaging: take the one that keeps most waves resident per CU (registers and LDS
@@ -541,7 +545,7 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
                 while (CAP > 128 && lds_img && img + (size_t)wpb * 2 * CAP * entry > 156 * 1024) CAP >>= 1;
                 const size_t lds_b = (lds_img ? img : 0) + (size_t)wpb * 2 * CAP * entry;
                 if (lds_b > 158 * 1024) continue;
-                KernR kq = tr[fr][lds_img ? 1 : 0];
+                KernR kq = tr[fr][lds_img ? 1 : 0][nt_r];
                 if (lds_b > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
                 int per_cu = 0;
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kq, 64 * wpb, lds_b) != hipSuccess) per_cu = 0;
@@ -551,7 +555,7 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
         if (best_waves == 0) return fail(OT_ERR_HIP, "no launch configuration fits this scene image");
         const int wpb = best_wpb;
         const int32_t CAP = best_cap;
-        KernR kr = tr[fr][best_lds ? 1 : 0];
+        KernR kr = tr[fr][best_lds ? 1 : 0][nt_r];
         const size_t lds_r = (best_lds ? img : 0) + (size_t)wpb * 2 * CAP * entry;
         if (lds_r > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
         int per_cu_r = best_per_cu;
