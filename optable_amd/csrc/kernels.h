@@ -127,12 +127,15 @@ __device__ __forceinline__ void store_segment_paired(const SegsT<T>& out, int64_
     store_pair<NT>(out.ray, out.surface, slot, tree, surface, odd);
 }
 
+// The caller's ray records are read exactly once per trace: non-temporal loads keep them from displacing what is
+// re-read (per-wave records, scene image in L2 mode).  Worth 1 % on cfg 4 (11.79 -> 11.67 ms, interleaved A/B), nothing on cfg 3 / 5.
+template <class V> __device__ __forceinline__ V ld_once(const V* p) { return __builtin_nontemporal_load(p); }
 template <class T> __device__ __forceinline__ RayState<T> load_ray(const RaysT<T>& in, int64_t i, int32_t flags) {
     RayState<T> r;
-    r.ox = in.ox[i]; r.oy = in.oy[i]; r.oz = in.oz[i];
-    r.dx = in.dx[i]; r.dy = in.dy[i]; r.dz = in.dz[i];
-    r.wl = in.wl[i]; r.qr = in.qr[i]; r.qi = in.qi[i];
-    r.I = in.I[i]; r.n = in.n[i]; r.pl = in.pl[i];
+    r.ox = ld_once(in.ox + i); r.oy = ld_once(in.oy + i); r.oz = ld_once(in.oz + i);
+    r.dx = ld_once(in.dx + i); r.dy = ld_once(in.dy + i); r.dz = ld_once(in.dz + i);
+    r.wl = ld_once(in.wl + i); r.qr = ld_once(in.qr + i); r.qi = ld_once(in.qi + i);
+    r.I = ld_once(in.I + i); r.n = ld_once(in.n + i); r.pl = ld_once(in.pl + i);
     r.len = in.len ? in.len[i] : Num<T>::inf();
     r.has_q = (flags & OT_RAY_HAS_Q) != 0;
     r.last = (int32_t)((uint32_t)flags >> 8) - 1;  // bits 8..31: node the ray was emitted on, plus one (generation buffers; 0 for a caller's ray)

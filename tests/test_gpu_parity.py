@@ -291,8 +291,8 @@ def test_launch_options_do_not_change_results():
 
 @pytest.mark.parametrize("case", ["cfg2", "cfg3", "cfg5"])
 def test_blocked_kernel_equals_lane_per_ray_kernel(case):
-    """k_trace_blocked (chunk per workgroup, compaction between generations) and k_trace_fused (lane per
-    ray) are interchangeable: same slots, same bits."""
+    """k_trace_rolling (persistent waves, per-wave lists of live rays compacted every segment) and k_trace_fused (lane
+    per ray) are interchangeable: same slots, same bits."""
     import torch
     import optable_amd as oa
     from optable_amd.engine import get_engine
@@ -314,6 +314,51 @@ def test_blocked_kernel_equals_lane_per_ray_kernel(case):
     valid = a.valid_mask()
     for f in abi.SEG_FIELDS + ("ray", "surface"):
         assert torch.equal(a.field(f)[valid], b.field(f)[valid]), f
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+@pytest.mark.parametrize("case", ["cfg3", "cfg5"])  # mixed lists under a top-level grid / generation-pure lists
+def test_heavy_kernel_edge_sizes_dead_rays_and_finite_lengths(case, prec):
+    """The list machinery of k_trace_rolling at its corners — fewer rays than a ticket, exactly one / two tickets, one ray
+    more, a cap of one segment, rays that are dead on input (optical_component.py:349) and rays of finite length
+    (optical_component.py:184-190) — against the lane-per-ray kernel, bit for bit."""
+    import torch
+    import optable_amd as oa
+    from optable_amd.batch import RayBatch
+    from optable_amd.engine import get_engine
+
+    comps, gen, _, K, _ = CASES[case]
+    table = _table(comps(oa))
+    eng = get_engine()
+    q = 1j * np.pi * scenes.W0**2 / scenes.WL
+    try:
+        for n, cap in ((1, K), (63, K), (64, 1), (65, 3), (129, K), (1000, K)):
+            o, d = gen(n)
+            batch = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=q, precision=prec)
+            batch.flags[::7] |= abi.RAY_DEAD
+            length = torch.full((n,), float("inf"), dtype=batch.ox.dtype, device=batch.device)
+            length[1::5] = 6.0  # shorter than the way to most components: those rays end as escapes of finite length
+            batch.length = length
+            eng.set_option(abi.OPT_KERNEL, 1)
+            a = table.trace_batch(batch, max_segments=cap)
+            eng.set_option(abi.OPT_KERNEL, 2)
+            b = table.trace_batch(batch, max_segments=cap)
+            assert torch.equal(a.count, b.count), (n, cap)
+            valid = a.valid_mask()
+            for f in abi.SEG_FIELDS + ("ray", "surface"):
+                x, y = a.field(f)[valid], b.field(f)[valid]
+                if prec == "f64" or f in ("ray", "surface"):
+                    assert torch.equal(x, y), (f, n, cap)
+                else:
+                    # single precision: the two kernels are different instantiations of the same source (feature masks
+                    # ALL vs {AABB, LENS, REFRACT, ROOT}) and the compiler contracts a few expressions differently:
+                    # last-digit differences that grow over the bounces (measured: <= 5e-5 at coordinates ~30)
+                    fin = torch.isfinite(x)
+                    assert torch.equal(fin, torch.isfinite(y)), (f, n, cap)
+                    assert torch.allclose(x[fin], y[fin], rtol=2e-4, atol=2e-4), (f, n, cap)
+            assert int((a.surface.view(cap, n)[0][::7] == -2).sum()) == len(range(0, n, 7))  # dead rays came back as they were
+    finally:
+        eng.set_option(abi.OPT_KERNEL, 0)
 
 
 @pytest.mark.parametrize("case", ["cfg3", "cfg5"])
