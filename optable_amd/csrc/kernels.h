@@ -264,7 +264,7 @@ template <class T> struct WaveScratch {
 template <class T, uint32_t F, bool SCENE_IN_LDS, bool NT>
 __global__ __launch_bounds__((blocked_threads<T, F>()), (blocked_minw<T, F>())) void k_trace_rolling(
     SceneBlob blob, T unit, RaysT<T> in, int64_t n, int32_t K, SegsT<T> out, int32_t* __restrict__ seg_count, int32_t* counts,
-    int32_t n_classes, WaveScratch<T> ws, int32_t CAP, unsigned long long* queue, int32_t mix) {
+    int32_t n_classes, WaveScratch<T> ws, int32_t CAP, unsigned long long* queue, int32_t mix, int32_t flat_cap) {
     extern __shared__ __align__(16) uint32_t lds[];
     const uint32_t* base = blob.words;
     uint32_t* tail = lds;
@@ -276,6 +276,15 @@ __global__ __launch_bounds__((blocked_threads<T, F>()), (blocked_minw<T, F>())) 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long* cur = reinterpret_cast<unsigned long long*>(tail) + wave * 2 * CAP;  // wave-private lists
     unsigned long long* nxt = cur + CAP;
+    // F_FLAT: per-wave key table and pair queue of flat_grid_hit, behind the lists of all waves
+    FlatLds<T> flat = {nullptr, nullptr, 0};
+    if constexpr ((F & F_FLAT) != 0) {
+        const int per_wave = (64 * 8 + flat_cap * 2 + 15) & ~15;
+        uint8_t* fb = reinterpret_cast<uint8_t*>(reinterpret_cast<unsigned long long*>(tail) + (blockDim.x >> 6) * 2 * CAP) + wave * per_wave;
+        flat.key = reinterpret_cast<unsigned long long*>(fb);
+        flat.queue = reinterpret_cast<uint16_t*>(fb + 64 * 8);
+        flat.queue_cap = flat_cap;
+    }
     __syncthreads();  // the only workgroup barrier: the scene image is staged
     const Scene<T> sc = bind_scene<T>(base, blob, unit);
     const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;  // this wave's scratch
@@ -348,7 +357,9 @@ __global__ __launch_bounds__((blocked_threads<T, F>()), (blocked_minw<T, F>())) 
                 active = false;
             }
             const GateCtx gate = {counts, n_classes, cls, nullptr, nullptr, 0, 0};
-            const Hit<T> h = nearest_hit<T, F, GATE_PLAIN>(sc, r, active, gate);
+            Hit<T> h;
+            if constexpr ((F & F_FLAT) != 0 && sizeof(T) == 4) h = flat_grid_hit<F, GATE_PLAIN>(sc, r, active, gate, flat, lane);
+            else h = nearest_hit<T, F, GATE_PLAIN>(sc, r, active, gate);
             OT_STAMP_AT(1);
             RayState<T> child = {};
             if (active) {

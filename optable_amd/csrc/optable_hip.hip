@@ -55,6 +55,7 @@ struct ot_ctx {
     int32_t n_nodes = 0, n_mats = 0, n_aux = 0, n_slots = 0, max_children = 0;
     double unit = 1e-2;
     uint32_t features = 0;
+    int32_t root_max_items = 0;  // most items in one cell of the top-level grid
     int32_t root_grid = -1;  // aux offset of the top-level grid
     int32_t cache_mat = -1;  // first Sellmeier material
     int32_t* slot_max = nullptr;  // device [n_slots]: max_interact_count per count slot
@@ -70,6 +71,7 @@ struct ot_ctx {
     int32_t opt_lds_limit_kb = 64;
     int32_t opt_kernel = 0;  // 0 auto, 1 fused (lane per ray), 2 rolling lists (the heavy-scene kernel)
     int32_t opt_list_cap = 128;  // k_trace_rolling: live rays per wave (cfg 3: 128 beats 256 and 512)
+    int32_t opt_flat = 1;  // fp32 planar top-level-grid scenes: wave-wide pair queue (flat_grid_hit)
     int32_t opt_mix = -1;  // -1 auto (scenes under a top-level grid mix generations), 0 never
     int32_t opt_list_cap_pure = 0;  // generation-pure lists: 0 = the chunk rule below
     Scratch blocked;
@@ -406,6 +408,11 @@ int ot_scene_upload(ot_ctx* c, const ot_scene_desc* s) {
         const int64_t n_items = (int64_t)g[11 + cells];
         for (int64_t k = 0; k < n_items; ++k)
             if (s->nodes[(int)items[k]].kind != OT_NODE_LEAF) { c->features |= F_SUBTREE; break; }
+        c->root_max_items = 0;
+        for (int64_t k = 0; k < cells; ++k) {
+            const int m = (int)(g[11 + k + 1] - g[11 + k]);
+            if (m > c->root_max_items) c->root_max_items = m;
+        }
     }
     if (c->slot_max) { (void)hipFree(c->slot_max); c->slot_max = nullptr; }
     if (s->n_count_slots > 0) {
@@ -462,6 +469,15 @@ static auto fused_ptr() {
     else return (Kern)k_trace_fused<T, FM, L, W, N>;
 }
 
+// the pair-queue variant of the heavy-scene kernel exists in single precision only (trace_core.h flat_grid_hit)
+template <class T, bool L>
+static auto rolling_flat_ptr() {
+    using KernR = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, SegsT<T>, int32_t*, int32_t*, int32_t, WaveScratch<T>, int32_t,
+                           unsigned long long*, int32_t, int32_t);
+    if constexpr (sizeof(T) == 4) return (KernR)k_trace_rolling<T, (F_AABB | F_LENS | F_REFRACT | F_ROOT | F_FLAT), L, false>;
+    else return (KernR) nullptr;
+}
+
 template <class T>
 static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, const ot_segments* out, int32_t* seg_count,
                        int32_t* counts, int32_t n_classes) {
@@ -512,13 +528,13 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
     if (use_blocked) {
         // Heavy scenes: persistent waves with their own lists of live rays (k_trace_rolling).
         using KernR = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, SegsT<T>, int32_t*, int32_t*, int32_t, WaveScratch<T>, int32_t,
-                               unsigned long long*, int32_t);
+                               unsigned long long*, int32_t, int32_t);
         // Scenes under a top-level grid (many separate components, rays of a wave unrelated after the first bounce)
         // mix generations in a list and top it up continuously.  Scenes whose rays all run through the same sequence
         // of surfaces (cfg 5) keep generation-pure lists: mixing costs them more than the tails do (cfg 5 fp32:
         // 36.6 vs 31.6 ms; cfg 3 fp32: 5.1 vs 5.5 ms).
         const bool mix = c->opt_mix < 0 ? c->root_grid >= 0 : (c->opt_mix != 0 && c->root_grid >= 0);
-        const int fr = (mix && (need & ~FR) == 0) ? 0 : ((need & ~FC) == 0 ? 1 : ((need & ~FD) == 0 ? 2 : 3));
+        const int fr = (c->root_grid >= 0 && (need & ~FR) == 0) ? 0 : ((need & ~FC) == 0 ? 1 : ((need & ~FD) == 0 ? 2 : 3));
         // [preset][image in LDS][non-temporal segment stores].  Mixed lists write the [k][ray] slots of a pass in fragments
         // of several tickets: partial lines that the L2 can merge with what neighbouring passes write if the stores are
         // PLAIN (cfg 3 fp32: 5.62 ms with non-temporal stores, 4.38 ms with plain ones, interleaved A/B); generation-pure
@@ -527,6 +543,10 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
         static const KernR tr[4][2][2] = {OT_R(FR), OT_R(FC), OT_R(FD), OT_R(F_ALL)};
 #undef OT_R
         const int nt_r = (mix || !c->opt_nt) ? 0 : 1;
+        // fp32 planar scenes under a top-level grid of leaves: candidates through a wave-wide pair queue (flat_grid_hit)
+        const int32_t flat_cap = 64 * FLAT_CELLS * (c->root_max_items > 0 ? c->root_max_items : 1);
+        const bool flat_ok = !f64 && c->opt_flat && mix && (need & ~FR) == 0 && c->n_nodes <= 1024 && flat_cap <= 8192;
+        static const KernR flat_k[2] = {rolling_flat_ptr<T, false>(), rolling_flat_ptr<T, true>()};
         static const int max_threads[4] = {blocked_threads<T, FR>(), blocked_threads<T, FC>(), blocked_threads<T, FD>(), blocked_threads<T, F_ALL>()};
         // Where the scene image lives and how many waves share it.  The waves never synchronise after staging, so the
         // workgroup size is only packaging: take the one that keeps most waves resident per CU (registers and LDS
@@ -534,6 +554,7 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
         // = 8 waves).  Images beyond what LDS holds next to the lists are read from L2.
         const size_t img = ((bytes + 15) / 16) * 16;
         const size_t entry = sizeof(unsigned long long);
+        const size_t flat_bytes = ((size_t)(64 * 8 + (size_t)flat_cap * 2) + 15) & ~(size_t)15;  // per wave (kernels.h)
         int32_t cap0 = mix ? c->opt_list_cap : (c->opt_list_cap_pure > 0 ? c->opt_list_cap_pure : 256);
         int best_wpb = 4, best_waves = 0, best_per_cu = 1, best_cap = cap0;
         bool best_lds = false;
@@ -543,9 +564,9 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
             for (int wpb = 4; wpb * 64 <= max_threads[fr]; wpb += 4) {
                 int32_t CAP = cap0;
                 while (CAP > 128 && lds_img && img + (size_t)wpb * 2 * CAP * entry > 156 * 1024) CAP >>= 1;
-                const size_t lds_b = (lds_img ? img : 0) + (size_t)wpb * 2 * CAP * entry;
+                const size_t lds_b = (lds_img ? img : 0) + (size_t)wpb * 2 * CAP * entry + (flat_ok ? (size_t)wpb * flat_bytes : 0);
                 if (lds_b > 158 * 1024) continue;
-                KernR kq = tr[fr][lds_img ? 1 : 0][nt_r];
+                KernR kq = flat_ok ? flat_k[lds_img ? 1 : 0] : tr[fr][lds_img ? 1 : 0][nt_r];
                 if (lds_b > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
                 int per_cu = 0;
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kq, 64 * wpb, lds_b) != hipSuccess) per_cu = 0;
@@ -555,8 +576,8 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
         if (best_waves == 0) return fail(OT_ERR_HIP, "no launch configuration fits this scene image");
         const int wpb = best_wpb;
         const int32_t CAP = best_cap;
-        KernR kr = tr[fr][best_lds ? 1 : 0][nt_r];
-        const size_t lds_r = (best_lds ? img : 0) + (size_t)wpb * 2 * CAP * entry;
+        KernR kr = flat_ok ? flat_k[best_lds ? 1 : 0] : tr[fr][best_lds ? 1 : 0][nt_r];
+        const size_t lds_r = (best_lds ? img : 0) + (size_t)wpb * 2 * CAP * entry + (flat_ok ? (size_t)wpb * flat_bytes : 0);
         if (lds_r > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
         int per_cu_r = best_per_cu;
         if (c->opt_blocks_per_cu > 0) per_cu_r = c->opt_blocks_per_cu;
@@ -579,7 +600,7 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
         rc = timing_pair(c, &ev0, &ev1);
         if (rc) return rc;
         hipExtLaunchKernelGGL(kr, dim3(gridr), dim3(64 * wpb), (uint32_t)lds_r, c->stream, ev0, ev1, 0u, blob, (T)c->unit, view<T>(rays), n,
-                              K, view<T>(out), seg_count, counts, n_classes, ws, CAP, queue, mix ? 1 : 0);
+                              K, view<T>(out), seg_count, counts, n_classes, ws, CAP, queue, mix ? 1 : 0, flat_ok ? flat_cap : 0);
         HIP_TRY(hipGetLastError());
         return 0;
     }
@@ -790,6 +811,7 @@ int ot_set_option(ot_ctx* c, int32_t option, int32_t value) {
         case OT_OPT_NT_STORES: c->opt_nt = value != 0; return 0;
         case OT_OPT_PAIR_STORES: c->opt_pair = value != 0; return 0;
         case OT_OPT_MIX_GENERATIONS: c->opt_mix = value < 0 ? -1 : (value != 0); return 0;
+        case OT_OPT_FLAT_QUEUE: c->opt_flat = value != 0; return 0;
         case OT_OPT_MIN_WAVES: 
             if (value != 0 && value != 4) return fail(OT_ERR_INVALID, "OT_OPT_MIN_WAVES takes 0 or 4");
             c->opt_minw = value; return 0;

@@ -48,7 +48,9 @@ enum : uint32_t {
     F_ROOT = 128,    // the top-level component list carries a 2-D grid walked cell by cell (DDA)
     F_MISC = 256,    // the rarer curved shapes: cylinder walls, polygons in a tilted plane (needs F_CURVED)
     F_SUBTREE = 512, // cells of the top-level grid may list whole groups (stale boxes, gridded groups) besides leaves
-    F_ALL = 1023
+    F_ALL = 1023,
+    F_FLAT = 1024    // (not part of F_ALL) fp32 planar scenes under a top-level grid: candidates go through a wave-wide
+                     // queue of (ray, leaf) pairs and are tested with full lanes (flat_grid_hit)
 };
 
 template <class T> struct Num;
@@ -832,6 +834,143 @@ __device__ __forceinline__ void root_grid_hit(const Scene<T>& sc, const RayState
         if (tmax0 < tmax1) { c0 += s0; tmax0 += dt0; if (c0 < 0 || c0 >= g0) return; }
         else { c1 += s1; tmax1 += dt1; if (c1 < 0 || c1 >= g1) return; }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// flat_grid_hit: the nearest hit through the top-level grid for the 64 rays of a WAVE together.
+// In root_grid_hit every lane walks its own cells and tests its own candidates, so the wave is as slow as its slowest
+// lane at every step: on cfg 3 the longest of 64 walks is 6.2 cells (mean 1.95) and the wave runs 16.7 candidate
+// tests per pass where a ray needs 4.0 — the cell loop is ~85 % of the kernel's VALU instructions at 21 % active
+// lanes.  Here the walk and the tests are separated:
+//   walk   every lane steps through up to FLAT_CELLS cells WITHOUT testing and notes the item ranges of those cells;
+//          one wave-wide scan of the counts gives every lane its place in a queue of (lane, leaf) pairs in LDS;
+//   test   the wave takes the pairs 64 at a time: lane q tests pair q (the ray's origin, direction, length and
+//          start leaf come from the owner lane's registers by ds_bpermute), so every lane has a real
+//          candidate; a hit goes into the ray's slot of a key table with ONE 64-bit LDS atomic minimum on
+//          (t as ordered bits << 32 | node index): the smallest t wins, exact ties go to the lower node index — the
+//          rule of optical_table.py:119-123 / component_group.py:118-120;
+//   round  a lane is done when its best hit lies inside the part of the ray the walk has covered, or when the walk left
+//          the grid; the others walk on (second and later rounds have few lanes, but also few pairs).
+// Finally each lane repeats the test of its winning leaf to get the hit point (same code, same inputs: same bits).
+// Single precision only (a double t does not fit the key next to the index) and planar leaves only (preset FR):
+// results are bit-identical to root_grid_hit (tests/test_gpu_parity.py: grid against plain pass).
+#ifndef OT_FLAT_CELLS
+#define OT_FLAT_CELLS 3
+#endif
+static constexpr int FLAT_CELLS = OT_FLAT_CELLS;
+template <class T> struct FlatLds {
+    unsigned long long* key;   // [64]
+    uint16_t* queue;           // [queue_cap]
+    int32_t queue_cap;
+};
+__device__ __forceinline__ int wave_excl_scan_i32(int v, int lane, int& total) {
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
+    }
+    total = __shfl(incl, 63, 64);
+    return incl - v;
+}
+template <uint32_t F, int GATE>
+__device__ __forceinline__ Hit<float> flat_grid_hit(const Scene<float>& sc, const RayState<float>& r, bool active, const GateCtx& gate,
+                                                    const FlatLds<float>& L, int lane) {
+    typedef float T;
+    Hit<T> best;
+    best.t = Num<T>::inf(); best.node = -1; best.px = best.py = best.pz = T(0);
+    const RayInv<T> ri = make_inv(r.dx, r.dy, r.dz);
+    L.key[lane] = ~0ull;
+    // grid header and DDA start (root_grid_hit's, per lane)
+    const T* g = sc.aux + sc.root;
+    const int a0 = (int)g[0], a1 = (int)g[1], g0 = (int)g[2], g1 = (int)g[3];
+    const T org0 = g[4], org1 = g[5], inv0 = g[6], inv1 = g[7], margin = g[8], size0 = g[9], size1 = g[10];
+    const T o0 = pick(a0, r.ox, r.oy, r.oz), o1 = pick(a1, r.ox, r.oy, r.oz);
+    const T d0 = pick(a0, r.dx, r.dy, r.dz), d1 = pick(a1, r.dx, r.dy, r.dz);
+    const T i0 = pick(a0, ri.inv[0], ri.inv[1], ri.inv[2]), i1 = pick(a1, ri.inv[0], ri.inv[1], ri.inv[2]);
+    const bool par0 = abs_t(d0) <= T(1e-12), par1 = abs_t(d1) <= T(1e-12);
+    bool walking = active;
+    T tin = T(0), tout = Num<T>::inf();
+    const T hi0 = org0 + size0 * T(g0), hi1 = org1 + size1 * T(g1);
+    if (par0) { if (o0 < org0 || o0 > hi0) walking = false; }
+    else { const T a = (org0 - o0) * i0, b = (hi0 - o0) * i0; tin = max_t(tin, min_t(a, b)); tout = min_t(tout, max_t(a, b)); }
+    if (par1) { if (o1 < org1 || o1 > hi1) walking = false; }
+    else { const T a = (org1 - o1) * i1, b = (hi1 - o1) * i1; tin = max_t(tin, min_t(a, b)); tout = min_t(tout, max_t(a, b)); }
+    if (!(tin <= tout)) walking = false;
+    auto clampi = [](T c, int n) { return c <= T(0) ? 0 : (c >= T(n - 1) ? n - 1 : (int)c); };
+    int c0 = clampi((o0 + tin * d0 - org0) * inv0, g0), c1 = clampi((o1 + tin * d1 - org1) * inv1, g1);
+    const int s0 = d0 > T(0) ? 1 : -1, s1 = d1 > T(0) ? 1 : -1;
+    T tmax0 = par0 ? Num<T>::inf() : (org0 + size0 * T(c0 + (s0 > 0 ? 1 : 0)) - o0) * i0;
+    T tmax1 = par1 ? Num<T>::inf() : (org1 + size1 * T(c1 + (s1 > 0 ? 1 : 0)) - o1) * i1;
+    const T dt0 = par0 ? Num<T>::inf() : size0 * abs_t(i0), dt1 = par1 ? Num<T>::inf() : size1 * abs_t(i1);
+    const T* start = g + 11;
+    const T* items = start + (g0 * g1 + 1);
+    const T slack = T(4) * margin;
+    while (__any(walking)) {  // rounds (wave-uniform)
+        // ---- walk: up to FLAT_CELLS cells, item ranges only
+        int kb[FLAT_CELLS], ke[FLAT_CELLS], cnt = 0;
+        T covered = T(0);
+        bool left = !walking;
+#pragma unroll
+        for (int w = 0; w < FLAT_CELLS; ++w) {
+            kb[w] = ke[w] = 0;
+            if (!left) {
+                const int cidx = c1 * g0 + c0;
+                kb[w] = (int)start[cidx];
+                ke[w] = (int)start[cidx + 1];
+                cnt += ke[w] - kb[w];
+                covered = min_t(tmax0, tmax1);
+                if (tmax0 < tmax1) { c0 += s0; tmax0 += dt0; if (c0 < 0 || c0 >= g0) left = true; }
+                else { c1 += s1; tmax1 += dt1; if (c1 < 0 || c1 >= g1) left = true; }
+            }
+        }
+        // ---- queue: one scan of the counts, every lane writes its pairs
+        int total;
+        int off = wave_excl_scan_i32(cnt, lane, total);
+        if (total > L.queue_cap) total = L.queue_cap;  // never reached: the host sizes the queue for 64 x FLAT_CELLS x the fullest cell
+#pragma unroll
+        for (int w = 0; w < FLAT_CELLS; ++w)
+            for (int k = kb[w]; k < ke[w]; ++k, ++off)
+                if (off < L.queue_cap) L.queue[off] = (uint16_t)((lane << 10) | (int)items[k]);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // ---- test: 64 pairs at a time, every lane a real candidate
+        for (int q0 = 0; q0 < total; q0 += 64) {
+            const int q = q0 + lane;
+            const int pair = q < total ? (int)L.queue[q] : 0;
+            const int src = pair >> 10, item = pair & 1023;
+            // the ray of the pair, straight from its owner's registers (ds_bpermute: a crossbar read, no bank conflicts)
+            const T sx = __shfl(r.ox, src, 64), sy = __shfl(r.oy, src, 64), sz = __shfl(r.oz, src, 64);
+            const T sdx = __shfl(r.dx, src, 64), sdy = __shfl(r.dy, src, 64), sdz = __shfl(r.dz, src, 64);
+            const T slen = __shfl(r.len, src, 64);
+            const int slast = __shfl(r.last, src, 64);
+            if (q < total) {
+                RayState<T> rr = {};
+                rr.ox = sx; rr.oy = sy; rr.oz = sz; rr.dx = sdx; rr.dy = sdy; rr.dz = sdz; rr.len = slen; rr.last = slast;
+                const RayInv<T> rinv = make_inv(rr.dx, rr.dy, rr.dz);  // three v_rcp_f32: cheaper than 768 B of LDS per wave (occupancy)
+                const unsigned long long cur = L.key[src];  // the ray's best so far (may be stale: it only prunes)
+                Hit<T> cand;
+                cand.t = __uint_as_float((unsigned)(cur >> 32));  // ~0 -> NaN bits: treat as +inf
+                cand.node = (int)(cur & 0xffffffffull);
+                if (cur == ~0ull) { cand.t = Num<T>::inf(); cand.node = -1; }
+                cand.px = cand.py = cand.pz = T(0);
+                const int before = cand.node;
+                const T tb = cand.t;
+                test_leaf<T, F, GATE, false, true>(sc, sc.nodes[item], item, rr, cand, gate, &rinv);
+                if (cand.node != before || cand.t != tb)  // the candidate beat what this lane saw: let the table decide
+                    atomicMin(&L.key[src], ((unsigned long long)__float_as_uint(cand.t) << 32) | (unsigned long long)(unsigned)cand.node);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // ---- verdict: done when the best hit lies inside the covered part of the ray, or the walk left the grid
+        const unsigned long long mine = L.key[lane];
+        if (mine != ~0ull) { best.t = __uint_as_float((unsigned)(mine >> 32)); best.node = (int)(mine & 0xffffffffull); }
+        if (walking) walking = !left && !(best.t + slack < covered);
+    }
+    // the hit point of the winner: the same test once more, in the ray's own lane
+    Hit<T> h;
+    h.t = Num<T>::inf(); h.node = -1; h.px = h.py = h.pz = T(0);
+    if (active && best.node >= 0) test_leaf<T, F, GATE, false, true>(sc, sc.nodes[best.node], best.node, r, h, gate, &ri);
+    return h;
 }
 
 // Nearest hit over the whole scene for one ray (all lanes of the wave walk the node list with

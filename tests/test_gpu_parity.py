@@ -361,6 +361,39 @@ def test_heavy_kernel_edge_sizes_dead_rays_and_finite_lengths(case, prec):
         eng.set_option(abi.OPT_KERNEL, 0)
 
 
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_pair_queue_walk_equals_per_lane_walk(prec):
+    """The cooperative top-level walk of k_trace_rolling (trace_core.h flat_grid_hit: candidate (ray, node) pairs queued in
+    LDS and tested 64 at a time by whichever lanes are free) against the same kernel with every lane testing its own
+    candidates: the same bits for every ray, at sizes with several tickets per wave and a ragged tail.  The queue exists in
+    single precision only (the key packs a 32-bit t next to the node index); in fp64 the option must be a no-op."""
+    import torch
+    import optable_amd as oa
+    from optable_amd.batch import RayBatch
+    from optable_amd.engine import get_engine
+
+    comps, gen, _, K, _ = CASES["cfg3"]
+    table = _table(comps(oa))
+    eng = get_engine()
+    q = 1j * np.pi * scenes.W0**2 / scenes.WL
+    try:
+        eng.set_option(abi.OPT_KERNEL, 2)
+        for n in (64, 4097, 200_003):
+            o, d = gen(n)
+            batch = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=q, precision=prec)
+            eng.set_option(abi.OPT_FLAT_QUEUE, 0)
+            a = table.trace_batch(batch, max_segments=K)
+            eng.set_option(abi.OPT_FLAT_QUEUE, 1)
+            b = table.trace_batch(batch, max_segments=K)
+            assert torch.equal(a.count, b.count), n
+            valid = a.valid_mask()
+            for f in abi.SEG_FIELDS + ("ray", "surface"):
+                assert torch.equal(a.field(f)[valid], b.field(f)[valid]), (f, n)
+    finally:
+        eng.set_option(abi.OPT_KERNEL, 0)
+        eng.set_option(abi.OPT_FLAT_QUEUE, 1)
+
+
 @pytest.mark.parametrize("case", ["cfg3", "cfg5"])
 def test_acceleration_grids_do_not_change_results(case):
     """Group grids and the top-level grid only choose WHICH nodes get tested; every bit of the output

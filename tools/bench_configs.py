@@ -23,6 +23,8 @@ if os.environ.get('RGC'):  # experiment: top-level grid resolution (cells per co
     _scene.ROOT_GRID_CELLS_PER_COMPONENT = float(os.environ['RGC'])
 if os.environ.get('LDSKB'):
     eng.set_option(abi.OPT_LDS_LIMIT_KB, int(os.environ['LDSKB']))
+if os.environ.get('FLAT'):
+    eng.set_option(abi.OPT_FLAT_QUEUE, int(os.environ['FLAT']))
 if os.environ.get('MIX'):
     eng.set_option(abi.OPT_MIX_GENERATIONS, int(os.environ['MIX']))
 if os.environ.get('NT'):
