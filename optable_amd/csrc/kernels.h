@@ -231,11 +231,14 @@ template <class T, uint32_t F> constexpr int blocked_threads() {
 // (tools/stamp_phases.py) show where a pass goes: ~50 % nearest hit, ~20 % waiting for its loads, ~27 % record +
 // interaction + waiting for its stores — gfx9 counts loads and stores in ONE in-order counter (vmcnt), so the
 // state loads of a pass wait for the 25 record / state stores of the pass before it to be acknowledged.
-// Here every wave owns ONE list of up to CAP live rays (LDS, entry = ray index | segment index << 32).  A round
-// processes the list in passes of 64, survivors go to the next list,
-// and whenever 64 slots are free the wave draws a ticket of 64 consecutive fresh rays from a device-wide queue:
-// passes are full until the queue is empty, rays of different generations share a pass, and no wave waits for the
-// slowest chunk of its workgroup (workgroups are persistent: every wave runs until queue and list are empty).
+// Here every wave owns ONE list of up to CAP live rays: a ring in LDS (entry = ray index | segment index << 32).
+// A pass takes the 64 OLDEST entries, its survivors go to the tail, and whenever 64 slots are free the wave draws a
+// ticket of 64 consecutive fresh rays from a device-wide queue and appends it: with mixed lists every pass is full
+// until the queue is empty (FIFO: no ray waits behind younger ones), rays of different generations share a pass, and
+// no wave waits for the slowest chunk of its workgroup (workgroups are persistent: every wave runs until queue and
+// list are empty).  (Before the ring a list was worked off in rounds — passes of 64 and a remainder, 44 lanes per
+// pass on average; holding the remainder back in that scheme meant moving its records and lost, 5.19 vs 4.88 ms;
+// the ring needs no move: cfg 3 fp32 4.22 -> 4.02 ms, cfg 5 fp64 40.2 -> 36.0 ms, cfg 5 fp32 19.3 -> 19.6 ms.)
 // Output slots are [k][ray] as in the other kernels: the result does not depend on which wave traced a ray or when.
 // Tried on top and dropped (cfg 3, fp32, 1e7 rays; 4.9 ms as it stands): a ring buffer with the next pass's records
 // prefetched before this pass's stores, with and without forcing the wait ahead of the stores (5.9 - 6.2 ms: 19 more
@@ -244,10 +247,10 @@ template <class T, uint32_t F> constexpr int blocked_threads() {
 // a resumable grid walk that visits at most 1 / 2 / 4 cells per pass and parks long walks for the next pass
 // (14.4 / 11.1 / 8.7 ms: every extra pass pays the pass's load -> trace -> store latency again).
 // Per-wave scratch of k_trace_rolling: the records of the wave's live rays, stored by LIST POSITION (not by ray
-// index), one allocation for the launch: wave w owns [w][field][CAP].  A pass reads positions p0 .. p0+63 and
-// writes its survivors to positions next_alive .. (< p0 + 64, all read already): the compaction happens in place,
-// every access is 64 consecutive elements, and a few MB per XCD of such records stay in L2 between the pass that
-// writes them and the pass that reads them.  (Round 2 first kept the records by ray index in 11 arrays of n: the
+// index), one allocation for the launch: wave w owns [w][field][CAP].  A pass reads 64 consecutive ring positions
+// and writes its survivors to the tail (generation-pure lists: to the start of the round's range, all read already,
+// so the compaction happens in place): every access is 64 consecutive elements (two runs where the ring wraps), and
+// a few MB per XCD of such records stay in L2 between the pass that writes them and the pass that reads them.  (Round 2 first kept the records by ray index in 11 arrays of n: the
 // rays of a pass are scattered over those, wavelength / flags / id were gathered from the caller's arrays on every
 // pass, and rocprofv3 showed 18 GB of HBM traffic for 3.3 GB of algorithmic bytes on cfg 3.)
 template <class T> struct WaveScratch {
@@ -267,20 +270,19 @@ __global__ __launch_bounds__((blocked_threads<T, F>()), (blocked_minw<T, F>())) 
     int32_t n_classes, WaveScratch<T> ws, int32_t CAP, unsigned long long* queue, int32_t mix, int32_t flat_cap) {
     extern __shared__ __align__(16) uint32_t lds[];
     const uint32_t* base = blob.words;
-    uint32_t* tail = lds;
+    uint32_t* lds_tail = lds;
     if (SCENE_IN_LDS) {
         for (int w = threadIdx.x; w < blob.n_words; w += blockDim.x) lds[w] = blob.words[w];
         base = lds;
-        tail = lds + ((blob.n_words + 3) & ~3);
+        lds_tail = lds + ((blob.n_words + 3) & ~3);
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    unsigned long long* cur = reinterpret_cast<unsigned long long*>(tail) + wave * 2 * CAP;  // wave-private lists
-    unsigned long long* nxt = cur + CAP;
+    unsigned long long* ring = reinterpret_cast<unsigned long long*>(lds_tail) + wave * CAP;  // wave-private list (a ring of CAP entries)
     // F_FLAT: per-wave key table and pair queue of flat_grid_hit, behind the lists of all waves
     FlatLds<T> flat = {nullptr, nullptr, 0};
     if constexpr ((F & F_FLAT) != 0) {
         const int per_wave = (64 * 8 + flat_cap * 2 + 15) & ~15;
-        uint8_t* fb = reinterpret_cast<uint8_t*>(reinterpret_cast<unsigned long long*>(tail) + (blockDim.x >> 6) * 2 * CAP) + wave * per_wave;
+        uint8_t* fb = reinterpret_cast<uint8_t*>(reinterpret_cast<unsigned long long*>(lds_tail) + (blockDim.x >> 6) * CAP) + wave * per_wave;
         flat.key = reinterpret_cast<unsigned long long*>(fb);
         flat.queue = reinterpret_cast<uint16_t*>(fb + 64 * 8);
         flat.queue_cap = flat_cap;
@@ -288,13 +290,14 @@ __global__ __launch_bounds__((blocked_threads<T, F>()), (blocked_minw<T, F>())) 
     __syncthreads();  // the only workgroup barrier: the scene image is staged
     const Scene<T> sc = bind_scene<T>(base, blob, unit);
     const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;  // this wave's scratch
-    // ONE base pointer per wave; field f of list position p is element p + f * CAP (twelve reals, then flags / id / node
+    // ONE base pointer per wave; field f of ring position p is element p + f * CAP (twelve reals, then flags / id / node
     // as 32-bit words behind them).  Fourteen separate base pointers cost 28 scalar registers that the kernel does not
     // have (106 of 102 in use: the compiler was spilling scalars into vector lanes).
     T* const srec = ws.f(gw, 0);
     int32_t* const sint = ws.flags(gw);
-    int alive = 0;  // wave-uniform
-    bool exhausted = false, fresh_fill = false;
+    const int M = CAP - 1;  // CAP is a power of two (host)
+    int head = 0, tail = 0, alive = 0, round_left = 0;  // wave-uniform: `alive` entries from ring position `head`; survivors and tickets go to `tail`
+    bool exhausted = false;
 #ifdef OT_STAMP
     unsigned long long st_acc[5] = {0, 0, 0, 0, 0};
 #define OT_STAMP_AT(k) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long _t = __builtin_amdgcn_s_memtime(); st_acc[k] += _t - st_last; st_last = _t; } while (0)
@@ -303,31 +306,39 @@ __global__ __launch_bounds__((blocked_threads<T, F>()), (blocked_minw<T, F>())) 
 #define OT_STAMP_AT(k) do {} while (0)
 #endif
     for (;;) {
-        // mix: top up whenever 64 slots are free (rays of all generations share the list); otherwise only an EMPTY list
-        // is refilled, CAP rays at once, and every pass is pure in its generation (scenes whose rays all run through
-        // the same sequence of surfaces: a pass then tests one kind of surface, cfg 5)
-        while (!exhausted && alive + 64 <= CAP && (mix || alive == 0 || (alive & 63) == 0 && fresh_fill)) {
-            unsigned long long first = 0;
-            if (lane == 0) first = atomicAdd(queue, 64ull);
-            first = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(first >> 32)) << 32) |
-                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(first & 0xffffffffull));
-            if (first >= (unsigned long long)n) { exhausted = true; break; }
-            const int cnt = (int)((unsigned long long)n - first < 64ull ? (unsigned long long)n - first : 64ull);
-            if (lane < cnt) cur[alive + lane] = first + (unsigned long long)lane;  // segment index 0
-            alive += cnt;
-            fresh_fill = true;  // a refill of an empty list goes on until the list is full
+        // mix: top up whenever 64 slots are free (rays of all generations share the list), so every pass is full until
+        // the queue is empty; otherwise only an EMPTY list is refilled, CAP rays at once, and the list is worked off in
+        // rounds that are pure in their generation (scenes whose rays all run through the same sequence of surfaces: a
+        // pass then tests one kind of surface, cfg 5)
+        if (mix || (round_left == 0 && alive == 0)) {
+            while (!exhausted && alive + 64 <= CAP) {
+                unsigned long long first = 0;
+                if (lane == 0) first = atomicAdd(queue, 64ull);
+                first = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(first >> 32)) << 32) |
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(first & 0xffffffffull));
+                if (first >= (unsigned long long)n) { exhausted = true; break; }
+                const int cnt = (int)((unsigned long long)n - first < 64ull ? (unsigned long long)n - first : 64ull);
+                if (lane < cnt) ring[(tail + lane) & M] = first + (unsigned long long)lane;  // segment index 0
+                tail = (tail + cnt) & M;
+                alive += cnt;
+            }
         }
-        fresh_fill = false;
         if (alive == 0) break;  // queue and list are empty
+        if (round_left == 0) {
+            round_left = alive;
+            // generation-pure lists start every round at position 0 and compact IN PLACE (survivors go to positions
+            // already read): the records a round touches are the shrinking prefix the last round wrote, which stays in L2
+            if (!mix) tail = head;
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        // (Holding a remainder back so that every pass is full was measured too: 54.8 instead of 44 lanes per pass
-        // and 20 % fewer passes, but each pass 35 % longer — 5.19 vs 4.88 ms.)
-        const int todo = alive;
-        int next_alive = 0;
-        for (int p0 = 0; p0 < todo; p0 += 64) {
-            const int p = p0 + lane;
-            bool active = p < todo;
-            const unsigned long long entry = active ? cur[p] : 0ull;
+        // One pass: the 64 oldest entries (FIFO: no ray waits behind younger ones).  Survivors and fresh tickets go to
+        // the tail, so a pass never has to wait for a remainder: with mixed lists it is full whenever 64 rays are alive.
+        const int avail = mix ? alive : round_left;
+        const int take = avail < 64 ? avail : 64;
+        {
+            const int p = (head + lane) & M;
+            bool active = lane < take;
+            const unsigned long long entry = active ? ring[p] : 0ull;
             const int64_t i = (int64_t)(entry & 0x7fffffffull);
             const int32_t k = (int32_t)(entry >> 32);
             RayState<T> r = {};
@@ -337,7 +348,7 @@ __global__ __launch_bounds__((blocked_threads<T, F>()), (blocked_minw<T, F>())) 
                     fl = in.flags[i];
                     cls = in.id[i];
                     r = load_ray(in, i, fl);
-                } else {  // later ones: this wave's scratch, by list position
+                } else {  // later ones: this wave's scratch, by ring position
                     r.ox = srec[p]; r.oy = srec[p + CAP]; r.oz = srec[p + 2 * CAP];
                     r.dx = srec[p + 3 * CAP]; r.dy = srec[p + 4 * CAP]; r.dz = srec[p + 5 * CAP];
                     r.qr = srec[p + 6 * CAP]; r.qi = srec[p + 7 * CAP]; r.I = srec[p + 8 * CAP];
@@ -378,9 +389,12 @@ __global__ __launch_bounds__((blocked_threads<T, F>()), (blocked_minw<T, F>())) 
                 if (!survive) seg_count[i] = used;
             }
             const unsigned long long mk = __ballot(survive);
-            if (survive) {  // in-place compaction: q < p0 + 64, and every position below p0 + 64 has been read
-                const int q = next_alive + __popcll(mk & ((1ull << lane) - 1ull));
-                nxt[q] = ((unsigned long long)(k + 1) << 32) | (unsigned long long)i;
+            if (survive) {
+                // to the tail of the ring.  It may wrap onto the positions this pass has just read (at most `take` of
+                // them: alive <= CAP and survivors <= take); every record load of the pass was issued before these stores
+                // and accesses of one wave complete in issue order
+                const int q = (tail + __popcll(mk & ((1ull << lane) - 1ull))) & M;
+                ring[q] = ((unsigned long long)(k + 1) << 32) | (unsigned long long)i;
                 srec[q] = child.ox; srec[q + CAP] = child.oy; srec[q + 2 * CAP] = child.oz;
                 srec[q + 3 * CAP] = child.dx; srec[q + 4 * CAP] = child.dy; srec[q + 5 * CAP] = child.dz;
                 srec[q + 6 * CAP] = child.qr; srec[q + 7 * CAP] = child.qi; srec[q + 8 * CAP] = child.I;
@@ -389,17 +403,19 @@ __global__ __launch_bounds__((blocked_threads<T, F>()), (blocked_minw<T, F>())) 
                 sint[q + CAP] = cls;
                 sint[q + 2 * CAP] = child.last;
             }
-            next_alive += __popcll(mk);
+            head = (head + take) & M;
+            tail = (tail + __popcll(mk)) & M;
+            alive += __popcll(mk) - take;
+            round_left -= take;
+            if (!mix && round_left == 0) head = (tail - alive) & M;  // the next round reads what this one wrote
             OT_STAMP_AT(2);
 #ifdef OT_STAMP
             st_acc[4] += 1;
 #endif
         }
-        // the list and the scratch records written above are read by other lanes of this wave in the next round: LDS
-        // and global accesses of one wave complete in issue order, the fence only stops the compiler from moving them
+        // the ring and the scratch records written above are read by other lanes of this wave in a later pass: LDS and
+        // global accesses of one wave complete in issue order, the fence only stops the compiler from moving them
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        unsigned long long* t = cur; cur = nxt; nxt = t;
-        alive = next_alive;
     }
 #ifdef OT_STAMP
     if (lane == 0) for (int q = 0; q < 5; ++q) atomicAdd(&queue[8 + q], st_acc[q]);

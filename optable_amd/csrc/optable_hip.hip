@@ -563,8 +563,8 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
             if (lds_img && (c->opt_lds_limit_kb == 0 || img > 140 * 1024)) continue;
             for (int wpb = 4; wpb * 64 <= max_threads[fr]; wpb += 4) {
                 int32_t CAP = cap0;
-                while (CAP > 128 && lds_img && img + (size_t)wpb * 2 * CAP * entry > 156 * 1024) CAP >>= 1;
-                const size_t lds_b = (lds_img ? img : 0) + (size_t)wpb * 2 * CAP * entry + (flat_ok ? (size_t)wpb * flat_bytes : 0);
+                while (CAP > 128 && lds_img && img + (size_t)wpb * CAP * entry > 156 * 1024) CAP >>= 1;
+                const size_t lds_b = (lds_img ? img : 0) + (size_t)wpb * CAP * entry + (flat_ok ? (size_t)wpb * flat_bytes : 0);
                 if (lds_b > 158 * 1024) continue;
                 KernR kq = flat_ok ? flat_k[lds_img ? 1 : 0] : tr[fr][lds_img ? 1 : 0][nt_r];
                 if (lds_b > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
@@ -577,7 +577,7 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
         const int wpb = best_wpb;
         const int32_t CAP = best_cap;
         KernR kr = flat_ok ? flat_k[best_lds ? 1 : 0] : tr[fr][best_lds ? 1 : 0][nt_r];
-        const size_t lds_r = (best_lds ? img : 0) + (size_t)wpb * 2 * CAP * entry + (flat_ok ? (size_t)wpb * flat_bytes : 0);
+        const size_t lds_r = (best_lds ? img : 0) + (size_t)wpb * CAP * entry + (flat_ok ? (size_t)wpb * flat_bytes : 0);
         if (lds_r > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
         int per_cu_r = best_per_cu;
         if (c->opt_blocks_per_cu > 0) per_cu_r = c->opt_blocks_per_cu;
@@ -822,7 +822,7 @@ int ot_set_option(ot_ctx* c, int32_t option, int32_t value) {
             if (value < 0 || value > 150) return fail(OT_ERR_INVALID, "OT_OPT_LDS_LIMIT_KB takes 0..150");
             c->opt_lds_limit_kb = value; return 0;
         case OT_OPT_LIST_CAP:
-            if (value < 64 || value > 1024 || value % 64) return fail(OT_ERR_INVALID, "OT_OPT_LIST_CAP takes a multiple of 64 up to 1024");
+            if (value < 64 || value > 1024 || (value & (value - 1))) return fail(OT_ERR_INVALID, "OT_OPT_LIST_CAP takes a power of two, 64..1024");
             c->opt_list_cap = value; c->opt_list_cap_pure = value; return 0;
         case OT_OPT_BLOCKS_PER_CU:
             if (value < 0 || value > 65536) return fail(OT_ERR_INVALID, "OT_OPT_BLOCKS_PER_CU out of range");
