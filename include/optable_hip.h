@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define OT_ABI_VERSION 5  /* 3: ot_trace_generation_f32; 4: ot_bench_stream_f32; 5: OT_OPT_LIST_CAP, ray flags bits 8..31, ot_debug_generation_mismatches */
+#define OT_ABI_VERSION 6  /* 3: ot_trace_generation_f32; 4: ot_bench_stream_f32; 5: OT_OPT_LIST_CAP, ray flags bits 8..31, ot_debug_generation_mismatches; 6: ot_debug_last_launch, OT_OPT_FLAT_QUEUE */
 
 /* ---- status codes ------------------------------------------------------------------- */
 enum ot_status {
@@ -247,6 +247,12 @@ int ot_trace_generation_f32(ot_ctx* ctx, const ot_rays* rays, const int32_t* ray
  * ray since the ctx was created.  Expected 0; a disagreement is contained (nothing is written outside the slots the
  * count pass reserved) and shows up as a zero-intensity dead ray in the next generation. */
 int ot_debug_generation_mismatches(ot_ctx* ctx, int64_t* count);
+
+/* Diagnostic: the shape of the last ot_trace_* launch on this ctx, for profiles and tuning notes.
+ * info[0] kernel (1 lane per ray, 2 rolling lists), [1] threads per workgroup, [2] workgroups per CU the occupancy
+ * query allowed, [3] workgroups launched, [4] dynamic LDS bytes per workgroup, [5] list capacity per wave (rolling),
+ * [6] 1 = mixed generations, [7] 1 = candidate pair queue (OT_OPT_FLAT_QUEUE took effect). */
+int ot_debug_last_launch(ot_ctx* ctx, int32_t info[8]);
 
 /* Monitor.record (monitor.py:183-193): intersect finished segments with a rectangular
  * monitor plane, honouring segment length.  hit_index receives the slot indices of the segments

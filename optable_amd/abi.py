@@ -7,7 +7,7 @@ __graft_entry__ as g; g.build()"` or `make -C optable_amd/csrc`).
 import ctypes as C
 import os
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "liboptable_hip.so")
 
@@ -92,6 +92,7 @@ SYMBOLS = {
     "ot_timing_reset": (C.c_int, [_vp]),
     "ot_set_option": (C.c_int, [_vp, _i32, _i32]),
     "ot_debug_generation_mismatches": (C.c_int, [_vp, C.POINTER(_i64)]),
+    "ot_debug_last_launch": (C.c_int, [_vp, C.POINTER(_i32 * 8)]),
     "ot_bench_stream_f64": (C.c_int, [_vp, C.POINTER(OtRays), _i64, _i32, C.POINTER(OtSegments), _vp]),
     "ot_bench_stream_f32": (C.c_int, [_vp, C.POINTER(OtRays), _i64, _i32, C.POINTER(OtSegments), _vp]),
 }

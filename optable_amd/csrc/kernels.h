@@ -213,7 +213,10 @@ __global__ __launch_bounds__(256, MINW) void k_trace_fused(SceneBlob blob, T uni
 #ifndef OT_BLOCKED_MINW
 #define OT_BLOCKED_MINW 1
 #endif
-template <class T, uint32_t F> constexpr int blocked_minw() { return 1; }
+#ifndef OT_FLAT_WAVES
+#define OT_FLAT_WAVES 5
+#endif
+template <class T, uint32_t F> constexpr int blocked_minw() { return (F & F_FLAT) ? OT_FLAT_WAVES : 1; }
 // largest workgroup an instantiation may be launched with.  Waves of k_trace_rolling never synchronise after the scene
 // image is staged, so the workgroup size only decides how many waves share one image: 512 threads = 2 waves per SIMD =
 // 256 VGPRs fit every instantiation except the all-features fp64 one (it would spill 44 bytes per lane).  The fp32
@@ -221,7 +224,7 @@ template <class T, uint32_t F> constexpr int blocked_minw() { return 1; }
 // spills 6 of the 138 registers it would like (28 bytes of scratch per lane, deliberately: 16 instead of 12 waves per CU
 // took cfg 5 from 20.97 to 19.68 ms, A/B in one run).
 template <class T, uint32_t F> constexpr int blocked_threads() {
-    return (sizeof(T) == 8 && F == F_ALL) ? 256 : ((sizeof(T) == 4 && F == (F_AABB | F_REFRACT | F_CURVED | F_GRID)) ? OT_FD32_THREADS : 512);
+    return ((sizeof(T) == 8 && F == F_ALL) || ((F & F_FLAT) && OT_FLAT_WAVES > 1)) ? 256 : ((sizeof(T) == 4 && F == (F_AABB | F_REFRACT | F_CURVED | F_GRID)) ? OT_FD32_THREADS : 512);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -279,12 +282,13 @@ __global__ __launch_bounds__((blocked_threads<T, F>()), (blocked_minw<T, F>())) 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long* ring = reinterpret_cast<unsigned long long*>(lds_tail) + wave * CAP;  // wave-private list (a ring of CAP entries)
     // F_FLAT: per-wave key table and pair queue of flat_grid_hit, behind the lists of all waves
-    FlatLds<T> flat = {nullptr, nullptr, 0};
+    FlatLds<T> flat = {nullptr, nullptr, nullptr, 0};
     if constexpr ((F & F_FLAT) != 0) {
-        const int per_wave = (64 * 8 + flat_cap * 2 + 15) & ~15;
+        const int per_wave = (64 * 24 + flat_cap * 2 + 15) & ~15;
         uint8_t* fb = reinterpret_cast<uint8_t*>(reinterpret_cast<unsigned long long*>(lds_tail) + (blockDim.x >> 6) * CAP) + wave * per_wave;
         flat.key = reinterpret_cast<unsigned long long*>(fb);
-        flat.queue = reinterpret_cast<uint16_t*>(fb + 64 * 8);
+        flat.point = reinterpret_cast<float4*>(fb + 64 * 8);
+        flat.queue = reinterpret_cast<uint16_t*>(fb + 64 * 24);
         flat.queue_cap = flat_cap;
     }
     __syncthreads();  // the only workgroup barrier: the scene image is staged
@@ -299,11 +303,13 @@ __global__ __launch_bounds__((blocked_threads<T, F>()), (blocked_minw<T, F>())) 
     int head = 0, tail = 0, alive = 0, round_left = 0;  // wave-uniform: `alive` entries from ring position `head`; survivors and tickets go to `tail`
     bool exhausted = false;
 #ifdef OT_STAMP
-    unsigned long long st_acc[5] = {0, 0, 0, 0, 0};
+    unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define OT_STAMP_AT(k) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long _t = __builtin_amdgcn_s_memtime(); st_acc[k] += _t - st_last; st_last = _t; } while (0)
     unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#define OT_FLAT_STAMP_ARGS , st_acc, st_last
 #else
 #define OT_STAMP_AT(k) do {} while (0)
+#define OT_FLAT_STAMP_ARGS
 #endif
     for (;;) {
         // mix: top up whenever 64 slots are free (rays of all generations share the list), so every pass is full until
@@ -369,7 +375,7 @@ __global__ __launch_bounds__((blocked_threads<T, F>()), (blocked_minw<T, F>())) 
             }
             const GateCtx gate = {counts, n_classes, cls, nullptr, nullptr, 0, 0};
             Hit<T> h;
-            if constexpr ((F & F_FLAT) != 0 && sizeof(T) == 4) h = flat_grid_hit<F, GATE_PLAIN>(sc, r, active, gate, flat, lane);
+            if constexpr ((F & F_FLAT) != 0 && sizeof(T) == 4) h = flat_grid_hit<F, GATE_PLAIN>(sc, r, active, gate, flat, lane OT_FLAT_STAMP_ARGS);
             else h = nearest_hit<T, F, GATE_PLAIN>(sc, r, active, gate);
             OT_STAMP_AT(1);
             RayState<T> child = {};
@@ -418,7 +424,7 @@ __global__ __launch_bounds__((blocked_threads<T, F>()), (blocked_minw<T, F>())) 
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
 #ifdef OT_STAMP
-    if (lane == 0) for (int q = 0; q < 5; ++q) atomicAdd(&queue[8 + q], st_acc[q]);
+    if (lane == 0) for (int q = 0; q < 12; ++q) atomicAdd(&queue[8 + q], st_acc[q]);
 #endif
 }
 

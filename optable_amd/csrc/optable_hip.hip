@@ -56,6 +56,7 @@ struct ot_ctx {
     double unit = 1e-2;
     uint32_t features = 0;
     int32_t root_max_items = 0;  // most items in one cell of the top-level grid
+    int64_t root_n_items = 0;    // entries of all its cells together
     int32_t root_grid = -1;  // aux offset of the top-level grid
     int32_t cache_mat = -1;  // first Sellmeier material
     int32_t* slot_max = nullptr;  // device [n_slots]: max_interact_count per count slot
@@ -70,6 +71,7 @@ struct ot_ctx {
     // and on cfg 5 the lost occupancy cost 1.5x (tools/bench_configs.py)
     int32_t opt_lds_limit_kb = 64;
     int32_t opt_kernel = 0;  // 0 auto, 1 fused (lane per ray), 2 rolling lists (the heavy-scene kernel)
+    int32_t last_launch[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // ot_debug_last_launch
     int32_t opt_list_cap = 128;  // k_trace_rolling: live rays per wave (cfg 3: 128 beats 256 and 512)
     int32_t opt_flat = 1;  // fp32 planar top-level-grid scenes: wave-wide pair queue (flat_grid_hit)
     int32_t opt_mix = -1;  // -1 auto (scenes under a top-level grid mix generations), 0 never
@@ -409,6 +411,7 @@ int ot_scene_upload(ot_ctx* c, const ot_scene_desc* s) {
         for (int64_t k = 0; k < n_items; ++k)
             if (s->nodes[(int)items[k]].kind != OT_NODE_LEAF) { c->features |= F_SUBTREE; break; }
         c->root_max_items = 0;
+        c->root_n_items = n_items;
         for (int64_t k = 0; k < cells; ++k) {
             const int m = (int)(g[11 + k + 1] - g[11 + k]);
             if (m > c->root_max_items) c->root_max_items = m;
@@ -545,7 +548,7 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
         const int nt_r = (mix || !c->opt_nt) ? 0 : 1;
         // fp32 planar scenes under a top-level grid of leaves: candidates through a wave-wide pair queue (flat_grid_hit)
         const int32_t flat_cap = 64 * FLAT_CELLS * (c->root_max_items > 0 ? c->root_max_items : 1);
-        const bool flat_ok = !f64 && c->opt_flat && mix && (need & ~FR) == 0 && c->n_nodes <= 1024 && flat_cap <= 8192;
+        const bool flat_ok = !f64 && c->opt_flat && mix && (need & ~FR) == 0 && c->root_n_items <= 1024 && flat_cap <= 8192;  // queue entry = lane << 10 | index into the grid's item list
         static const KernR flat_k[2] = {rolling_flat_ptr<T, false>(), rolling_flat_ptr<T, true>()};
         static const int max_threads[4] = {blocked_threads<T, FR>(), blocked_threads<T, FC>(), blocked_threads<T, FD>(), blocked_threads<T, F_ALL>()};
         // Where the scene image lives and how many waves share it.  The waves never synchronise after staging, so the
@@ -554,14 +557,14 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
         // = 8 waves).  Images beyond what LDS holds next to the lists are read from L2.
         const size_t img = ((bytes + 15) / 16) * 16;
         const size_t entry = sizeof(unsigned long long);
-        const size_t flat_bytes = ((size_t)(64 * 8 + (size_t)flat_cap * 2) + 15) & ~(size_t)15;  // per wave (kernels.h)
+        const size_t flat_bytes = ((size_t)(64 * 24 + (size_t)flat_cap * 2) + 15) & ~(size_t)15;  // per wave (kernels.h)
         int32_t cap0 = mix ? c->opt_list_cap : (c->opt_list_cap_pure > 0 ? c->opt_list_cap_pure : 256);
         int best_wpb = 4, best_waves = 0, best_per_cu = 1, best_cap = cap0;
         bool best_lds = false;
         for (int pass = 0; pass < 2 && best_waves == 0; ++pass) {  // pass 0: image in LDS; pass 1: image in L2
             const bool lds_img = pass == 0;
             if (lds_img && (c->opt_lds_limit_kb == 0 || img > 140 * 1024)) continue;
-            for (int wpb = 4; wpb * 64 <= max_threads[fr]; wpb += 4) {
+            for (int wpb = 4; wpb * 64 <= (flat_ok ? blocked_threads<T, FR | F_FLAT>() : max_threads[fr]); wpb += 4) {
                 int32_t CAP = cap0;
                 while (CAP > 128 && lds_img && img + (size_t)wpb * CAP * entry > 156 * 1024) CAP >>= 1;
                 const size_t lds_b = (lds_img ? img : 0) + (size_t)wpb * CAP * entry + (flat_ok ? (size_t)wpb * flat_bytes : 0);
@@ -592,7 +595,7 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
         WaveScratch<T> ws = {(uint8_t*)c->blocked.p, (int64_t)wave_bytes, CAP};
         unsigned long long* queue = (unsigned long long*)((uint8_t*)c->blocked.p + scratch_bytes);
 #ifdef OT_STAMP
-        HIP_TRY(hipMemsetAsync(queue, 0, 16 * sizeof(unsigned long long), c->stream));
+        HIP_TRY(hipMemsetAsync(queue, 0, 24 * sizeof(unsigned long long), c->stream));
 #else
         HIP_TRY(hipMemsetAsync(queue, 0, sizeof(unsigned long long), c->stream));
 #endif
@@ -602,6 +605,8 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
         hipExtLaunchKernelGGL(kr, dim3(gridr), dim3(64 * wpb), (uint32_t)lds_r, c->stream, ev0, ev1, 0u, blob, (T)c->unit, view<T>(rays), n,
                               K, view<T>(out), seg_count, counts, n_classes, ws, CAP, queue, mix ? 1 : 0, flat_ok ? flat_cap : 0);
         HIP_TRY(hipGetLastError());
+        const int32_t shape[8] = {2, 64 * wpb, per_cu_r, gridr, (int32_t)lds_r, CAP, mix ? 1 : 0, flat_ok ? 1 : 0};
+        for (int q = 0; q < 8; ++q) c->last_launch[q] = shape[q];
         return 0;
     }
     hipEvent_t ev0, ev1;
@@ -626,6 +631,8 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
     hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), (uint32_t)lds_bytes, c->stream, ev0, ev1, 0u, blob, (T)c->unit, view<T>(rays), n, K,
                           view<T>(out), seg_count, counts, n_classes, pair_ok<T>(c, out, n));
     HIP_TRY(hipGetLastError());
+    const int32_t shape[8] = {1, (int32_t)block, 0, (int32_t)grid, (int32_t)lds_bytes, 0, 0, 0};
+    for (int q = 0; q < 8; ++q) c->last_launch[q] = shape[q];
     return 0;
 }
 
@@ -794,6 +801,12 @@ int ot_monitor_record_f64(ot_ctx* c, const ot_monitor* mon, const ot_segments* s
     return 0;
 }
 
+int ot_debug_last_launch(ot_ctx* c, int32_t info[8]) {
+    if (!c || !info) return fail(OT_ERR_INVALID, "NULL argument");
+    for (int q = 0; q < 8; ++q) info[q] = c->last_launch[q];
+    return 0;
+}
+
 int ot_debug_generation_mismatches(ot_ctx* c, int64_t* out) {
     if (!c || !out) return fail(OT_ERR_INVALID, "NULL argument");
     *out = 0;
@@ -869,7 +882,7 @@ int ot_bench_stream_f32(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, co
 int ot_debug_stamps(ot_ctx* c, unsigned long long* out5) {
     if (!c || !c->blocked.p) return fail(OT_ERR_INVALID, "no rolling launch yet");
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(out5, (uint8_t*)c->blocked.p + c->blocked_queue_off + 8 * sizeof(unsigned long long), 5 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out5, (uint8_t*)c->blocked.p + c->blocked_queue_off + 8 * sizeof(unsigned long long), 12 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return 0;
 }
 #endif

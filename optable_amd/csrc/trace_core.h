@@ -155,6 +155,12 @@ __device__ __forceinline__ double div_t(double a, double b) {
 // stream ceiling), and their contract is a tolerance against fp64, not correctly rounded quotients.
 __device__ __forceinline__ float rcp_t(float b) { return __builtin_amdgcn_rcpf(b); }
 __device__ __forceinline__ float div_t(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+// a0*b0 + a1*b1 + a2*b2 with the roundings WRITTEN DOWN (one product rounded, two fused steps).  Left to the compiler's
+// contraction the same source expression fuses differently in different surroundings, and the planar leaf test exists in
+// two shapes (test_leaf with early exits, the branch-free slot of flat_grid_hit) whose results must agree bit for bit.
+__device__ __forceinline__ float fma_t(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_t(double a, double b, double c) { return __builtin_fma(a, b, c); }
+template <class T> __device__ __forceinline__ T dot3_t(T a0, T b0, T a1, T b1, T a2, T b2) { return fma_t(a2, b2, fma_t(a1, b1, a0 * b0)); }
 
 // ---------------------------------------------------------------------------------------------
 // solver.py:5-48 with the per-axis reciprocal hoisted out (RayInv is built once per segment).
@@ -367,7 +373,7 @@ template <class T> __device__ __forceinline__ bool csg_inside(const T* prog, T P
 
 template <class T, uint32_t F>
 __device__ __forceinline__ bool planar_boundary(const Scene<T>& sc, const DNode<T>& nd, T Px, T Py, T Pz) {
-    if (nd.shape == OT_SHAPE_CIRCLE) return Px * Px + Py * Py + Pz * Pz <= nd.r2;
+    if (nd.shape == OT_SHAPE_CIRCLE) return dot3_t(Px, Px, Py, Py, Pz, Pz) <= nd.r2;
     if (nd.shape == OT_SHAPE_RECT) return abs_t(Py) <= nd.p[0] && abs_t(Pz) <= nd.p[1];
     if constexpr (F & F_POLY) {
         if (nd.shape == OT_SHAPE_POLYGON2D) return poly_inside(sc.aux + nd.aux, Px, Py, Pz);
@@ -619,11 +625,11 @@ __device__ __forceinline__ void test_leaf(const Scene<T>& sc, const DNode<T>& nd
         // behind the ray (sign test == t < 0), t == 0.  Then a CONSERVATIVE far test (1e-9
         // slack) drops leaves that cannot beat the current best; it is skipped for
         // count-limited leaves, whose gate must see every geometric hit.
-        const T lox = nd.M[0] * rx + nd.M[3] * ry + nd.M[6] * rz;
-        const T ldx = nd.M[0] * r.dx + nd.M[3] * r.dy + nd.M[6] * r.dz;
+        const T lox = dot3_t(nd.M[0], rx, nd.M[3], ry, nd.M[6], rz);
+        const T ldx = dot3_t(nd.M[0], r.dx, nd.M[3], r.dy, nd.M[6], r.dz);
         const T s = -lox;
         if (ldx == T(0) || s == T(0) || ((s > T(0)) != (ldx > T(0)))) return;
-        if (!limited && abs_t(s) > best.t * abs_t(ldx) * (T(1) + T(1e-9))) return;
+        if (!limited && abs_t(s) > best.t * abs_t(ldx) * (T(1) + (sizeof(T) == 4 ? T(1e-6) : T(1e-9)))) return;  // (1 + 1e-9 is 1 in single precision)
         t = div_t(s, ldx);
         if (abs_t(t) < Num<T>::eps_t() || t < T(0) || t > r.len) return;
         if (!limited && !(t < best.t || (!ORDERED && t == best.t && idx < best.node))) return;
@@ -631,9 +637,9 @@ __device__ __forceinline__ void test_leaf(const Scene<T>& sc, const DNode<T>& nd
             T u1, u2;
             if (!slab_inv(r.ox, r.oy, r.oz, *ri, nd.aabb, u1, u2)) return;
         }
-        const T loy = nd.M[1] * rx + nd.M[4] * ry + nd.M[7] * rz, loz = nd.M[2] * rx + nd.M[5] * ry + nd.M[8] * rz;
-        const T ldy = nd.M[1] * r.dx + nd.M[4] * r.dy + nd.M[7] * r.dz, ldz = nd.M[2] * r.dx + nd.M[5] * r.dy + nd.M[8] * r.dz;
-        Px = lox + t * ldx; Py = loy + t * ldy; Pz = loz + t * ldz;
+        const T loy = dot3_t(nd.M[1], rx, nd.M[4], ry, nd.M[7], rz), loz = dot3_t(nd.M[2], rx, nd.M[5], ry, nd.M[8], rz);
+        const T ldy = dot3_t(nd.M[1], r.dx, nd.M[4], r.dy, nd.M[7], r.dz), ldz = dot3_t(nd.M[2], r.dx, nd.M[5], r.dy, nd.M[8], r.dz);
+        Px = fma_t(t, ldx, lox); Py = fma_t(t, ldy, loy); Pz = fma_t(t, ldz, loz);
         if (!planar_boundary<T, F>(sc, nd, Px, Py, Pz)) return;
     } else {
         const T prune_t = limited ? Num<T>::inf() : best.t;
@@ -657,37 +663,6 @@ __device__ __forceinline__ void test_leaf(const Scene<T>& sc, const DNode<T>& nd
     if (t < best.t || (!ORDERED && t == best.t && idx < best.node)) {
         best.t = t; best.node = idx; best.px = Px; best.py = Py; best.pz = Pz;
     }
-}
-
-// The planar leaf test of test_leaf without early exits, for the cell loop of the top-level grid.  There the 64
-// lanes of a wave test 64 different leaves at 64 different stages of rejection, so an early exit saves nothing —
-// the wave runs on until its last lane is through — while every exit costs a branch (exec-mask save / restore,
-// scalar spills).  Everything is evaluated, the verdict is one conjunction, the update five selects.  The
-// arithmetic is test_leaf's, expression by expression: results are bit-identical.  Circles and rectangles only,
-// no count gate (a top-level grid is never built over count-limited leaves).
-template <class T, uint32_t F>
-__device__ __forceinline__ void test_planar_lean(const Scene<T>& sc, const DNode<T>& nd, int idx, const RayState<T>& r, Hit<T>& best,
-                                                 const RayInv<T>& ri) {
-    const T rx = r.ox - nd.org[0], ry = r.oy - nd.org[1], rz = r.oz - nd.org[2];
-    const T lox = nd.M[0] * rx + nd.M[3] * ry + nd.M[6] * rz;
-    const T ldx = nd.M[0] * r.dx + nd.M[3] * r.dy + nd.M[6] * r.dz;
-    const T s = -lox;
-    const T t = div_t(s, ldx);
-    const T loy = nd.M[1] * rx + nd.M[4] * ry + nd.M[7] * rz, loz = nd.M[2] * rx + nd.M[5] * ry + nd.M[8] * rz;
-    const T ldy = nd.M[1] * r.dx + nd.M[4] * r.dy + nd.M[7] * r.dz, ldz = nd.M[2] * r.dx + nd.M[5] * r.dy + nd.M[8] * r.dz;
-    const T Px = lox + t * ldx, Py = loy + t * ldy, Pz = loz + t * ldz;
-    const bool inside = nd.shape == OT_SHAPE_CIRCLE ? (Px * Px + Py * Py + Pz * Pz <= nd.r2)
-                                                    : (abs_t(Py) <= nd.p[0] && abs_t(Pz) <= nd.p[1]);
-    bool ok = idx != r.last && ldx != T(0) && s != T(0) && ((s > T(0)) == (ldx > T(0)));
-    ok = ok && !(abs_t(t) < Num<T>::eps_t() || t < T(0) || t > r.len);
-    ok = ok && (t < best.t || (t == best.t && idx < best.node)) && inside;
-    if (ok && (nd.flags & OT_NODE_CHECK_AABB)) {  // the leaf's own AABB test (component_group.py:104-107), only for would-be hits
-        T u1, u2;
-        ok = slab_inv(r.ox, r.oy, r.oz, ri, nd.aabb, u1, u2);
-    }
-    best.t = ok ? t : best.t;
-    best.node = ok ? idx : best.node;
-    best.px = ok ? Px : best.px; best.py = ok ? Py : best.py; best.pz = ok ? Pz : best.pz;
 }
 
 template <class T> __device__ __forceinline__ T pick(int axis, T x, T y, T z) { return axis == 0 ? x : (axis == 1 ? y : z); }
@@ -817,17 +792,14 @@ __device__ __forceinline__ void root_grid_hit(const Scene<T>& sc, const RayState
             const int item = (int)items[k];
             const DNode<T>& nd = sc.nodes[item];
             // the compiler lists leaves directly wherever it can (scene.py:_root_grid): cheap planar rejections
-            // first, the leaf's own AABB test last; subtrees (stale boxes, gridded groups) take the general walk
-#ifdef OT_LEAN_TEST  // measured on cfg 3 (fp32, 1e7 rays): 5.54 ms with the branch-free test against 5.09 ms with the early exits
-            constexpr bool lean = (F & (F_LIMIT | F_POLY | F_CURVED)) == 0 && GATE == GATE_PLAIN;
-#else
-            constexpr bool lean = false;
-#endif
+            // first, the leaf's own AABB test last; subtrees (stale boxes, gridded groups) take the general walk.
+            // (A branch-free planar test was measured here, cfg 3 fp32: 5.54 against 5.09 ms with the early exits —
+            // in a per-lane walk whole waves leave a candidate together often enough; in the slots of flat_grid_hit,
+            // where 64 lanes hold 64 unrelated pairs, it is the other way round.)
             if constexpr (F & F_SUBTREE) {
                 if (nd.kind != OT_NODE_LEAF) { walk_subtree<T, F, GATE>(sc, item, r, ri, best, gate); continue; }
             }
-            if constexpr (lean) test_planar_lean<T, F>(sc, nd, item, r, best, ri);
-            else test_leaf<T, F, GATE, false, true>(sc, nd, item, r, best, gate, &ri);
+            test_leaf<T, F, GATE, false, true>(sc, nd, item, r, best, gate, &ri);
         }
         const T texit = min_t(tmax0, tmax1);
         if (best.t + slack < texit) return;  // nothing in later cells can be nearer (or tie)
@@ -851,7 +823,8 @@ __device__ __forceinline__ void root_grid_hit(const Scene<T>& sc, const RayState
 //          rule of optical_table.py:119-123 / component_group.py:118-120;
 //   round  a lane is done when its best hit lies inside the part of the ray the walk has covered, or when the walk left
 //          the grid; the others walk on (second and later rounds have few lanes, but also few pairs).
-// Finally each lane repeats the test of its winning leaf to get the hit point (same code, same inputs: same bits).
+// The lane that holds a ray's minimum after a slot leaves the hit point next to the key (computed from the ray's own
+// values: the same bits as a test in the ray's own lane).
 // Single precision only (a double t does not fit the key next to the index) and planar leaves only (preset FR):
 // results are bit-identical to root_grid_hit (tests/test_gpu_parity.py: grid against plain pass).
 #ifndef OT_FLAT_CELLS
@@ -860,22 +833,36 @@ __device__ __forceinline__ void root_grid_hit(const Scene<T>& sc, const RayState
 static constexpr int FLAT_CELLS = OT_FLAT_CELLS;
 template <class T> struct FlatLds {
     unsigned long long* key;   // [64]
+    float4* point;             // [64] hit point of the key's candidate
     uint16_t* queue;           // [queue_cap]
     int32_t queue_cap;
 };
-__device__ __forceinline__ int wave_excl_scan_i32(int v, int lane, int& total) {
+// exclusive add-scan over the 64 lanes in six DPP adds (row_shr 1 / 2 / 4 / 8 inside the rows of 16, then row_bcast 15 /
+// 31 across the rows) — no LDS crossbar round trips; the wave total comes back in a scalar register.  Called with all 64
+// lanes enabled.
+__device__ __forceinline__ int wave_excl_scan_i32(int v, int& total) {
     int incl = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int up = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += up;
-    }
-    total = __shfl(incl, 63, 64);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false);  // row_shr:1
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false);  // row_shr:2
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false);  // row_shr:4
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false);  // row_shr:8
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1 and 3
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2 and 3
+    total = __builtin_amdgcn_readlane(incl, 63);
     return incl - v;
 }
+#ifdef OT_STAMP  // diagnostic build: phases of a call into st_acc[5..] (walk, queue, test, verdict; [9] slots, [10] rounds)
+#define OT_FLAT_STAMP_PARAMS , unsigned long long* st_acc, unsigned long long& st_last
+#define OT_FLAT_AT(k) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long _t = __builtin_amdgcn_s_memtime(); st_acc[k] += _t - st_last; st_last = _t; } while (0)
+#define OT_FLAT_COUNT(k) do { st_acc[k] += 1; } while (0)
+#else
+#define OT_FLAT_STAMP_PARAMS
+#define OT_FLAT_AT(k) do {} while (0)
+#define OT_FLAT_COUNT(k) do {} while (0)
+#endif
 template <uint32_t F, int GATE>
 __device__ __forceinline__ Hit<float> flat_grid_hit(const Scene<float>& sc, const RayState<float>& r, bool active, const GateCtx& gate,
-                                                    const FlatLds<float>& L, int lane) {
+                                                    const FlatLds<float>& L, int lane OT_FLAT_STAMP_PARAMS) {
     typedef float T;
     Hit<T> best;
     best.t = Num<T>::inf(); best.node = -1; best.px = best.py = best.pz = T(0);
@@ -906,6 +893,7 @@ __device__ __forceinline__ Hit<float> flat_grid_hit(const Scene<float>& sc, cons
     const T* start = g + 11;
     const T* items = start + (g0 * g1 + 1);
     const T slack = T(4) * margin;
+    const int max_items = L.queue_cap / (64 * FLAT_CELLS);  // the host sizes the queue for 64 lanes x FLAT_CELLS x the fullest cell
     while (__any(walking)) {  // rounds (wave-uniform)
         // ---- walk: up to FLAT_CELLS cells, item ranges only
         int kb[FLAT_CELLS], ke[FLAT_CELLS], cnt = 0;
@@ -924,53 +912,84 @@ __device__ __forceinline__ Hit<float> flat_grid_hit(const Scene<float>& sc, cons
                 else { c1 += s1; tmax1 += dt1; if (c1 < 0 || c1 >= g1) left = true; }
             }
         }
-        // ---- queue: one scan of the counts, every lane writes its pairs
+        OT_FLAT_AT(5);
+        OT_FLAT_COUNT(10);
+        // ---- queue: one scan of the counts, every lane writes its pairs (lane << 10 | index into the grid's item list).
+        // The trip count of the inner loop is the fullest cell of the grid — the same for every lane, so the writes are
+        // predicated stores in straight-line code; the item itself is looked up by the lane that tests the pair.
         int total;
-        int off = wave_excl_scan_i32(cnt, lane, total);
-        if (total > L.queue_cap) total = L.queue_cap;  // never reached: the host sizes the queue for 64 x FLAT_CELLS x the fullest cell
+        int off = wave_excl_scan_i32(cnt, total);
 #pragma unroll
-        for (int w = 0; w < FLAT_CELLS; ++w)
-            for (int k = kb[w]; k < ke[w]; ++k, ++off)
-                if (off < L.queue_cap) L.queue[off] = (uint16_t)((lane << 10) | (int)items[k]);
+        for (int w = 0; w < FLAT_CELLS; ++w) {
+            const int c = ke[w] - kb[w];
+            for (int j = 0; j < max_items; ++j)
+                if (j < c) L.queue[off + j] = (uint16_t)((lane << 10) | (kb[w] + j));
+            off += c;
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        OT_FLAT_AT(6);
         // ---- test: 64 pairs at a time, every lane a real candidate
         for (int q0 = 0; q0 < total; q0 += 64) {
+            OT_FLAT_COUNT(9);
             const int q = q0 + lane;
             const int pair = q < total ? (int)L.queue[q] : 0;
-            const int src = pair >> 10, item = pair & 1023;
+            const int src = pair >> 10, item = (int)items[pair & 1023];
             // the ray of the pair, straight from its owner's registers (ds_bpermute: a crossbar read, no bank conflicts)
             const T sx = __shfl(r.ox, src, 64), sy = __shfl(r.oy, src, 64), sz = __shfl(r.oz, src, 64);
             const T sdx = __shfl(r.dx, src, 64), sdy = __shfl(r.dy, src, 64), sdz = __shfl(r.dz, src, 64);
             const T slen = __shfl(r.len, src, 64);
             const int slast = __shfl(r.last, src, 64);
-            if (q < total) {
-                RayState<T> rr = {};
-                rr.ox = sx; rr.oy = sy; rr.oz = sz; rr.dx = sdx; rr.dy = sdy; rr.dz = sdz; rr.len = slen; rr.last = slast;
-                const RayInv<T> rinv = make_inv(rr.dx, rr.dy, rr.dz);  // three v_rcp_f32: cheaper than 768 B of LDS per wave (occupancy)
+            {
+                // The planar test of test_leaf WITHOUT its early exits: the 64 lanes hold 64 different pairs at 64 different
+                // stages of rejection, so an exit saves nothing — the wave runs on until its last lane is through — while
+                // every exit costs an exec-mask save / restore (the slot was 336 instructions, 57 of them register moves
+                // and 21 such branches, before).  Everything is evaluated, the verdict is one conjunction.  The arithmetic
+                // is test_leaf's, expression by expression: bit-identical results (test_pair_queue_walk_equals_per_lane_walk).
+                const DNode<T>& nd = sc.nodes[item];
                 const unsigned long long cur = L.key[src];  // the ray's best so far (may be stale: it only prunes)
-                Hit<T> cand;
-                cand.t = __uint_as_float((unsigned)(cur >> 32));  // ~0 -> NaN bits: treat as +inf
-                cand.node = (int)(cur & 0xffffffffull);
-                if (cur == ~0ull) { cand.t = Num<T>::inf(); cand.node = -1; }
-                cand.px = cand.py = cand.pz = T(0);
-                const int before = cand.node;
-                const T tb = cand.t;
-                test_leaf<T, F, GATE, false, true>(sc, sc.nodes[item], item, rr, cand, gate, &rinv);
-                if (cand.node != before || cand.t != tb)  // the candidate beat what this lane saw: let the table decide
-                    atomicMin(&L.key[src], ((unsigned long long)__float_as_uint(cand.t) << 32) | (unsigned long long)(unsigned)cand.node);
+                const T best_t = cur == ~0ull ? Num<T>::inf() : __uint_as_float((unsigned)(cur >> 32));
+                const int best_node = cur == ~0ull ? -1 : (int)(cur & 0xffffffffull);
+                const T rx = sx - nd.org[0], ry = sy - nd.org[1], rz = sz - nd.org[2];
+                const T lox = dot3_t(nd.M[0], rx, nd.M[3], ry, nd.M[6], rz);
+                const T ldx = dot3_t(nd.M[0], sdx, nd.M[3], sdy, nd.M[6], sdz);
+                const T s = -lox;
+                const T t = div_t(s, ldx);
+                const T loy = dot3_t(nd.M[1], rx, nd.M[4], ry, nd.M[7], rz), loz = dot3_t(nd.M[2], rx, nd.M[5], ry, nd.M[8], rz);
+                const T ldy = dot3_t(nd.M[1], sdx, nd.M[4], sdy, nd.M[7], sdz), ldz = dot3_t(nd.M[2], sdx, nd.M[5], sdy, nd.M[8], sdz);
+                const T Px = fma_t(t, ldx, lox), Py = fma_t(t, ldy, loy), Pz = fma_t(t, ldz, loz);
+                const int sh = nd.shape;
+                const bool inside = sh == OT_SHAPE_CIRCLE ? (dot3_t(Px, Px, Py, Py, Pz, Pz) <= nd.r2)
+                                                          : (sh == OT_SHAPE_RECT && abs_t(Py) <= nd.p[0] && abs_t(Pz) <= nd.p[1]);
+                bool ok = q < total && item != slast && ldx != T(0) && s != T(0) && ((s > T(0)) == (ldx > T(0)));
+                ok = ok && !(abs_t(t) < Num<T>::eps_t() || t < T(0) || t > slen);
+                ok = ok && (t < best_t || (t == best_t && item < best_node)) && inside;
+                if (ok && (nd.flags & OT_NODE_CHECK_AABB)) {  // the leaf's own AABB test (component_group.py:104-107), for would-be hits
+                    const RayInv<T> rinv = make_inv(sdx, sdy, sdz);
+                    T u1, u2;
+                    ok = slab_inv(sx, sy, sz, rinv, nd.aabb, u1, u2);
+                }
+                if (ok) {  // the candidate beat what this lane saw: let the table decide
+                    const unsigned long long mine = ((unsigned long long)__float_as_uint(t) << 32) | (unsigned long long)(unsigned)item;
+                    atomicMin(&L.key[src], mine);
+                    // whoever holds the minimum after the atomics of this slot leaves its hit point next to the key (the
+                    // same pair can sit in the queue twice when a leaf is listed in two cells: same key, same point)
+                    if (L.key[src] == mine) L.point[src] = make_float4(Px, Py, Pz, 0.f);
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        OT_FLAT_AT(7);
         // ---- verdict: done when the best hit lies inside the covered part of the ray, or the walk left the grid
         const unsigned long long mine = L.key[lane];
         if (mine != ~0ull) { best.t = __uint_as_float((unsigned)(mine >> 32)); best.node = (int)(mine & 0xffffffffull); }
         if (walking) walking = !left && !(best.t + slack < covered);
+        OT_FLAT_AT(8);
     }
-    // the hit point of the winner: the same test once more, in the ray's own lane
-    Hit<T> h;
-    h.t = Num<T>::inf(); h.node = -1; h.px = h.py = h.pz = T(0);
-    if (active && best.node >= 0) test_leaf<T, F, GATE, false, true>(sc, sc.nodes[best.node], best.node, r, h, gate, &ri);
-    return h;
+    // the hit point of the winner was computed by the lane that tested it, from this ray's own values: same bits as a
+    // test in the ray's own lane
+    if (active && best.node >= 0) { const float4 pt = L.point[lane]; best.px = pt.x; best.py = pt.y; best.pz = pt.z; }
+    else { best.t = Num<T>::inf(); best.node = -1; }
+    return best;
 }
 
 // Nearest hit over the whole scene for one ray (all lanes of the wave walk the node list with

@@ -229,6 +229,13 @@ class Engine:
         abi.check(fn(self._ctx, C.byref(rs), rays.n, int(max_segments), C.byref(ss),
                                                out.count.data_ptr()), self.lib)
 
+    def last_launch(self):
+        """Shape of the last trace launch (include/optable_hip.h: ot_debug_last_launch) as a dict."""
+        info = (C.c_int32 * 8)()
+        abi.check(self.lib.ot_debug_last_launch(self._ctx, C.byref(info)), self.lib)
+        keys = ("kernel", "threads", "workgroups_per_cu", "workgroups", "lds_bytes", "list_cap", "mixed", "pair_queue")
+        return dict(zip(keys, (int(v) for v in info)))
+
     def generation_mismatches(self):
         """Diagnostic counter of the two-pass generation kernels (include/optable_hip.h); expected 0."""
         v = C.c_int64()

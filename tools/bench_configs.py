@@ -77,6 +77,8 @@ def _run(name, comps, o, d, wl, K, prec, reps=5):
         segs = int(out.count.sum().item())
         t = ms / cnt / 1e3
         mode = "fused"
+        if os.environ.get("SHAPE"):
+            print("   launch:", eng.last_launch(), flush=True)
         if os.environ.get("CEILING"):  # the same streams with no tracing (fixed K records per ray)
             eng.timing(True)
             for _ in range(reps):

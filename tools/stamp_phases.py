@@ -38,12 +38,18 @@ eng.timing(True)
 eng.trace(batch, wl.max_segments, out=out)
 ms, cnt = eng.timing_read()
 eng.timing(False)
-acc = (C.c_ulonglong * 5)()
+acc = (C.c_ulonglong * 12)()
 eng.lib.ot_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
 abi.check(eng.lib.ot_debug_stamps(eng._ctx, acc), eng.lib)
-load, hit, inter, comp, passes = [int(x) for x in acc]
+load, hit, inter, comp, passes = [int(x) for x in acc][:5]
+walk, queue, test, verdict, slots, rounds = [int(x) for x in acc][5:11]
 tot = load + hit + inter + comp
 segs = int(out.count.abs().sum().item())
 print(f"{name} {prec} n={n}: {ms / cnt:.3f} ms (stamped build), {passes} passes for {segs} segments = {segs / passes:.1f} lanes per pass")
 for label, v in (("list + loads (waited)", load), ("nearest hit", hit), ("record + interact + state (waited)", inter), ("compaction", comp)):
     print(f"   {label:36s} {v / passes:9.0f} cycles per pass  {100 * v / tot:5.1f} %")
+if rounds:  # the pair-queue walk (flat_grid_hit): its phases are part of none of the above ("nearest hit" holds only the setup)
+    tot2 = tot + walk + queue + test + verdict
+    print(f"   pair queue: {rounds / passes:.2f} rounds and {slots / passes:.2f} slots of 64 pairs per pass")
+    for label, v in (("walk", walk), ("scan + queue", queue), ("pair tests", test), ("verdict", verdict)):
+        print(f"   {label:36s} {v / passes:9.0f} cycles per pass  {100 * v / tot2:5.1f} % of {tot2 / passes:.0f}")
