@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define OT_ABI_VERSION 6  /* 3: ot_trace_generation_f32; 4: ot_bench_stream_f32; 5: OT_OPT_LIST_CAP, ray flags bits 8..31, ot_debug_generation_mismatches; 6: ot_debug_last_launch, OT_OPT_FLAT_QUEUE */
+#define OT_ABI_VERSION 6  /* 3: ot_trace_generation_f32; 4: ot_bench_stream_f32; 5: OT_OPT_LIST_CAP, ray flags bits 8..31, ot_debug_generation_mismatches; 6: ot_debug_last_launch, OT_OPT_FLAT_QUEUE, OT_OPT_LDS_RECORDS */
 
 /* ---- status codes ------------------------------------------------------------------- */
 enum ot_status {
@@ -251,7 +251,7 @@ int ot_debug_generation_mismatches(ot_ctx* ctx, int64_t* count);
 /* Diagnostic: the shape of the last ot_trace_* launch on this ctx, for profiles and tuning notes.
  * info[0] kernel (1 lane per ray, 2 rolling lists), [1] threads per workgroup, [2] workgroups per CU the occupancy
  * query allowed, [3] workgroups launched, [4] dynamic LDS bytes per workgroup, [5] list capacity per wave (rolling),
- * [6] 1 = mixed generations, [7] 1 = candidate pair queue (OT_OPT_FLAT_QUEUE took effect). */
+ * [6] 1 = mixed generations, [7] bit 0 = candidate pair queue (OT_OPT_FLAT_QUEUE took effect), bit 1 = records in LDS. */
 int ot_debug_last_launch(ot_ctx* ctx, int32_t info[8]);
 
 /* Monitor.record (monitor.py:183-193): intersect finished segments with a rectangular
@@ -285,7 +285,8 @@ enum ot_option {
     OT_OPT_LIST_CAP = 6,       /* heavy scenes: live rays per wave in the rolling list: a power of two (default 128) */
     OT_OPT_PAIR_STORES = 7,    /* lane-per-ray kernel: lane pairs write two fields per 16-byte store (0/1) */
     OT_OPT_MIX_GENERATIONS = 8,/* heavy scenes: -1 auto, 0 generation-pure lists even under a top-level grid */
-    OT_OPT_FLAT_QUEUE = 9      /* fp32 planar scenes under a top-level grid: wave-wide candidate queue (0/1) */
+    OT_OPT_FLAT_QUEUE = 9,     /* fp32 planar scenes under a top-level grid: wave-wide candidate queue (0/1) */
+    OT_OPT_LDS_RECORDS = 10    /* ... with the records of the live rays in LDS: -1 auto, 0 never, 1 whenever it fits */
 };
 int ot_set_option(ot_ctx* ctx, int32_t option, int32_t value);
 

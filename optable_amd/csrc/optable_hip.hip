@@ -72,6 +72,7 @@ struct ot_ctx {
     int32_t opt_lds_limit_kb = 64;
     int32_t opt_kernel = 0;  // 0 auto, 1 fused (lane per ray), 2 rolling lists (the heavy-scene kernel)
     int32_t last_launch[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // ot_debug_last_launch
+    int32_t opt_rec_lds = -1;    // pair-queue scenes: records of the live rays in LDS (-1 auto, 0 never, 1 whenever it fits)
     int32_t opt_list_cap = 128;  // k_trace_rolling: live rays per wave (cfg 3: 128 beats 256 and 512)
     int32_t opt_flat = 1;  // fp32 planar top-level-grid scenes: wave-wide pair queue (flat_grid_hit)
     int32_t opt_mix = -1;  // -1 auto (scenes under a top-level grid mix generations), 0 never
@@ -480,6 +481,14 @@ static auto rolling_flat_ptr() {
     if constexpr (sizeof(T) == 4) return (KernR)k_trace_rolling<T, (F_AABB | F_LENS | F_REFRACT | F_ROOT | F_FLAT), L, false>;
     else return (KernR) nullptr;
 }
+// ... and with the records of the live rays in LDS next to the scene image
+template <class T>
+static auto rolling_flat_lds_ptr() {
+    using KernR = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, SegsT<T>, int32_t*, int32_t*, int32_t, WaveScratch<T>, int32_t,
+                           unsigned long long*, int32_t, int32_t);
+    if constexpr (sizeof(T) == 4) return (KernR)k_trace_rolling<T, (F_AABB | F_LENS | F_REFRACT | F_ROOT | F_FLAT), true, false, true>;
+    else return (KernR) nullptr;
+}
 
 template <class T>
 static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, const ot_segments* out, int32_t* seg_count,
@@ -558,6 +567,7 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
         const size_t img = ((bytes + 15) / 16) * 16;
         const size_t entry = sizeof(unsigned long long);
         const size_t flat_bytes = ((size_t)(64 * 24 + (size_t)flat_cap * 2) + 15) & ~(size_t)15;  // per wave (kernels.h)
+        constexpr int REC_LDS_MIN_WAVES = 12;
         int32_t cap0 = mix ? c->opt_list_cap : (c->opt_list_cap_pure > 0 ? c->opt_list_cap_pure : 256);
         int best_wpb = 4, best_waves = 0, best_per_cu = 1, best_cap = cap0;
         bool best_lds = false;
@@ -576,11 +586,30 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
                 if (per_cu * wpb > best_waves) { best_waves = per_cu * wpb; best_wpb = wpb; best_per_cu = per_cu; best_cap = CAP; best_lds = lds_img; }
             }
         }
+        // Pair-queue scenes: the records of the live rays (15 words x CAP per wave) in LDS as well, when at least
+        // REC_LDS_MIN_WAVES waves per CU still fit.  A pass then touches global memory only for a ray's first load and
+        // for the segment records it writes — nothing it has to wait for (gfx9 retires loads and stores in order, so with
+        // the records in global memory every pass's loads queue behind the 29 stores of the pass before).
+        bool rec_lds = false;
+        if (flat_ok && c->opt_rec_lds != 0 && c->opt_lds_limit_kb != 0) {
+            const KernR kl = rolling_flat_lds_ptr<T>();
+            const size_t per_wave = (size_t)cap0 * entry + flat_bytes + (size_t)15 * cap0 * 4;
+            int rw = 0, rwpb = 0;
+            for (int wpb = 4; wpb <= 16; wpb += 4) {
+                const size_t lds_b = img + (size_t)wpb * per_wave;
+                if (lds_b > 158 * 1024) continue;
+                HIP_TRY(hipFuncSetAttribute((const void*)kl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+                int per_cu = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kl, 64 * wpb, lds_b) != hipSuccess) per_cu = 0;
+                if (per_cu * wpb > rw) { rw = per_cu * wpb; rwpb = wpb; best_per_cu = per_cu; }
+            }
+            if (rw >= (c->opt_rec_lds > 0 ? 4 : REC_LDS_MIN_WAVES)) { rec_lds = true; best_wpb = rwpb; best_cap = cap0; best_lds = true; best_waves = rw; }
+        }
         if (best_waves == 0) return fail(OT_ERR_HIP, "no launch configuration fits this scene image");
         const int wpb = best_wpb;
         const int32_t CAP = best_cap;
-        KernR kr = flat_ok ? flat_k[best_lds ? 1 : 0] : tr[fr][best_lds ? 1 : 0][nt_r];
-        const size_t lds_r = (best_lds ? img : 0) + (size_t)wpb * CAP * entry + (flat_ok ? (size_t)wpb * flat_bytes : 0);
+        KernR kr = rec_lds ? rolling_flat_lds_ptr<T>() : (flat_ok ? flat_k[best_lds ? 1 : 0] : tr[fr][best_lds ? 1 : 0][nt_r]);
+        const size_t lds_r = (best_lds ? img : 0) + (size_t)wpb * CAP * entry + (flat_ok ? (size_t)wpb * flat_bytes : 0) + (rec_lds ? (size_t)wpb * 15 * CAP * 4 : 0);
         if (lds_r > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
         int per_cu_r = best_per_cu;
         if (c->opt_blocks_per_cu > 0) per_cu_r = c->opt_blocks_per_cu;
@@ -605,7 +634,7 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
         hipExtLaunchKernelGGL(kr, dim3(gridr), dim3(64 * wpb), (uint32_t)lds_r, c->stream, ev0, ev1, 0u, blob, (T)c->unit, view<T>(rays), n,
                               K, view<T>(out), seg_count, counts, n_classes, ws, CAP, queue, mix ? 1 : 0, flat_ok ? flat_cap : 0);
         HIP_TRY(hipGetLastError());
-        const int32_t shape[8] = {2, 64 * wpb, per_cu_r, gridr, (int32_t)lds_r, CAP, mix ? 1 : 0, flat_ok ? 1 : 0};
+        const int32_t shape[8] = {2, 64 * wpb, per_cu_r, gridr, (int32_t)lds_r, CAP, mix ? 1 : 0, (flat_ok ? 1 : 0) | (rec_lds ? 2 : 0)};
         for (int q = 0; q < 8; ++q) c->last_launch[q] = shape[q];
         return 0;
     }
@@ -837,6 +866,9 @@ int ot_set_option(ot_ctx* c, int32_t option, int32_t value) {
         case OT_OPT_LIST_CAP:
             if (value < 64 || value > 1024 || (value & (value - 1))) return fail(OT_ERR_INVALID, "OT_OPT_LIST_CAP takes a power of two, 64..1024");
             c->opt_list_cap = value; c->opt_list_cap_pure = value; return 0;
+        case OT_OPT_LDS_RECORDS:
+            if (value < -1 || value > 1) return fail(OT_ERR_INVALID, "OT_OPT_LDS_RECORDS takes -1 (auto), 0 or 1");
+            c->opt_rec_lds = value; return 0;
         case OT_OPT_BLOCKS_PER_CU:
             if (value < 0 || value > 65536) return fail(OT_ERR_INVALID, "OT_OPT_BLOCKS_PER_CU out of range");
             c->opt_blocks_per_cu = value; return 0;

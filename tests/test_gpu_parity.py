@@ -389,9 +389,24 @@ def test_pair_queue_walk_equals_per_lane_walk(prec):
             valid = a.valid_mask()
             for f in abi.SEG_FIELDS + ("ray", "surface"):
                 assert torch.equal(a.field(f)[valid], b.field(f)[valid]), (f, n)
+            # the same kernel with the records of the live rays in LDS instead of the per-wave global scratch, and the launch
+            # shape says which variant ran
+            eng.set_option(abi.OPT_LDS_RECORDS, 0)
+            c0 = table.trace_batch(batch, max_segments=K)
+            shape0 = eng.last_launch()
+            eng.set_option(abi.OPT_LDS_RECORDS, 1)
+            c1 = table.trace_batch(batch, max_segments=K)
+            shape1 = eng.last_launch()
+            assert shape0["kernel"] == 2 and shape0["pair_queue"] == (1 if prec == "f32" else 0)
+            assert shape1["pair_queue"] == (3 if prec == "f32" else 0)
+            assert torch.equal(c0.count, c1.count) and torch.equal(c0.count, a.count), n
+            for f in abi.SEG_FIELDS + ("ray", "surface"):
+                assert torch.equal(c0.field(f)[valid], c1.field(f)[valid]), (f, n)
+                assert torch.equal(c0.field(f)[valid], a.field(f)[valid]), (f, n)
     finally:
         eng.set_option(abi.OPT_KERNEL, 0)
         eng.set_option(abi.OPT_FLAT_QUEUE, 1)
+        eng.set_option(abi.OPT_LDS_RECORDS, -1)
 
 
 @pytest.mark.parametrize("case", ["cfg3", "cfg5"])

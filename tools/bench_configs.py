@@ -25,6 +25,8 @@ if os.environ.get('LDSKB'):
     eng.set_option(abi.OPT_LDS_LIMIT_KB, int(os.environ['LDSKB']))
 if os.environ.get('FLAT'):
     eng.set_option(abi.OPT_FLAT_QUEUE, int(os.environ['FLAT']))
+if os.environ.get('RECLDS'):
+    eng.set_option(abi.OPT_LDS_RECORDS, int(os.environ['RECLDS']))
 if os.environ.get('MIX'):
     eng.set_option(abi.OPT_MIX_GENERATIONS, int(os.environ['MIX']))
 if os.environ.get('NT'):

@@ -23,7 +23,7 @@ prec = sys.argv[2] if len(sys.argv) > 2 else "f32"
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 3_000_000
 wl = W.baseline_workloads(oa)[name]
 eng = get_engine()
-for k, v in (("CAP", abi.OPT_LIST_CAP), ("KERNEL", abi.OPT_KERNEL)):
+for k, v in (("CAP", abi.OPT_LIST_CAP), ("KERNEL", abi.OPT_KERNEL), ("RECLDS", abi.OPT_LDS_RECORDS), ("FLAT", abi.OPT_FLAT_QUEUE)):
     if os.environ.get(k):
         eng.set_option(v, int(os.environ[k]))
 table = oa.OpticalTable()
