@@ -9,7 +9,7 @@
 //   k_gen_pass<T>        one breadth-first generation of branching ray trees (optical_table.py:115-134) in two
 //                        streaming passes: count (rank within the tree, trace) -> scan of wave totals -> emit (trace
 //                        again, ordered slots); k_gen_probe / k_gen_rank / k_gen_counts keep interact-count gates
-//                        FIFO-exact; k_gen_finish closes the generation.
+//                        FIFO-exact; k_gen_totals publishes the generation's totals between the two passes.
 //   k_mon_*              Monitor.record over a segment stream (monitor.py:183-193).
 #pragma once
 
@@ -491,18 +491,14 @@ __global__ __launch_bounds__(256) void k_gen_probe(SceneBlob blob, T unit, RaysT
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int32_t my_tree = -1;
-    long long start = -1;
+    int start_lane = -1;
     if (i < n) {
         my_tree = tree[i];
-        if (lane == 0 || tree[i - 1] != my_tree) start = i;
+        if (lane == 0 || tree[i - 1] != my_tree) start_lane = lane;
     }
-    long long head = start;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const long long up = __shfl_up(head, off, 64);
-        if (lane >= off && up > head) head = up;
-    }
-    if (i < n && head == i - lane) head = tree_head(tree, i - lane);
+    const int head_lane = wave_incl_max_i32(start_lane);  // see k_gen_pass
+    int64_t head = (i - lane) + head_lane;
+    if (i < n && head_lane == 0) head = tree_head(tree, i - lane);
     const bool active = i < n && (i - head) < (int64_t)budget[my_tree];
     RayState<T> r = {};
     int32_t cls = 0, fl = 0;
@@ -540,7 +536,7 @@ __global__ __launch_bounds__(256) void k_gen_probe(SceneBlob blob, T unit, RaysT
 static constexpr bool GEN_NT = false;
 template <class T, uint32_t F, bool SCENE_IN_LDS, bool EMIT>
 __global__ __launch_bounds__(256) void k_gen_pass(SceneBlob blob, T unit, RaysT<T> in, const int32_t* __restrict__ tree, int64_t n,
-                                                  const int32_t* __restrict__ budget, const int64_t* cursor, SegsT<T> out,
+                                                  int32_t* __restrict__ budget, const int64_t* cursor, SegsT<T> out,
                                                   int64_t out_capacity, RaysOutT<T> next, int32_t* next_tree, int64_t next_capacity,
                                                   uint8_t* code, unsigned long long* wave_total, const unsigned long long* wave_prefix,
                                                   int32_t* counts, int32_t n_classes, const int32_t* rank, unsigned long long* mismatch) {
@@ -555,21 +551,27 @@ __global__ __launch_bounds__(256) void k_gen_pass(SceneBlob blob, T unit, RaysT<
     const int lane = threadIdx.x & 63;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t gwave = i >> 6;
-    // rank of the ray inside its tree (as in k_gen_probe): rays beyond the tree's remaining budget are dropped
+    // rank of the ray inside its tree (as in k_gen_probe): rays beyond the tree's remaining budget are dropped.  A
+    // generation lists its rays tree by tree, so the head of ray i's tree is the nearest earlier start in its wave (a
+    // max-scan of lane numbers: six DPP steps) or, when the tree began before the wave, a lower bound of tree[].
     int32_t my_tree = -1;
-    long long start = -1;
+    int start_lane = -1;
     if (i < n) {
         my_tree = tree[i];
-        if (lane == 0 || tree[i - 1] != my_tree) start = i;
+        if (lane == 0 || tree[i - 1] != my_tree) start_lane = lane;
     }
-    long long head = start;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const long long up = __shfl_up(head, off, 64);
-        if (lane >= off && up > head) head = up;
+    const int head_lane = wave_incl_max_i32(start_lane);
+    int64_t head = (i - lane) + head_lane;
+    if (i < n && head_lane == 0) head = tree_head(tree, i - lane);
+    const int32_t c = (EMIT && i < n) ? (int32_t)code[i] : 0;  // EMIT: what the count pass decided
+    const bool active = EMIT ? (c & 1) != 0 : (i < n && (i - head) < (int64_t)budget[my_tree]);
+    if (EMIT && i < n && (i == n - 1 || tree[i + 1] != my_tree)) {
+        // Last ray of its tree in this generation: the tree's budget shrinks by the rays processed (optical_table.py:
+        // 138-144).  Only the count pass reads budgets, and it has finished: one writer per tree, no reader.
+        const int64_t in_gen = i - head + 1;
+        const int32_t b = budget[my_tree];
+        budget[my_tree] = b - (int32_t)(in_gen < b ? in_gen : b);
     }
-    if (i < n && head == i - lane) head = tree_head(tree, i - lane);
-    const bool active = i < n && (i - head) < (int64_t)budget[my_tree];
     RayState<T> r = {};
     int32_t cls = 0, fl = 0;
     if (active) {
@@ -587,36 +589,30 @@ __global__ __launch_bounds__(256) void k_gen_pass(SceneBlob blob, T unit, RaysT<
         if (i < n) code[i] = (uint8_t)((active ? 1 : 0) | (nk << 1));
         // wave totals: processed rays and children
         const int n_act = __popcll(__ballot(active));
-        int kids = nk;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) kids += __shfl_xor(kids, off, 64);
+        int kids;
+        wave_excl_scan_i32(nk, kids);
         if (lane == 0 && (gwave << 6) < n) wave_total[gwave] = ((unsigned long long)n_act << 32) | (unsigned long long)kids;
         return;
     }
     // EMIT: slots from the scanned wave prefix and the counted codes
-    const int32_t c = i < n ? (int32_t)code[i] : 0;
-    const bool c_active = (c & 1) != 0;
+    const bool c_active = active;
     const int32_t c_nk = c >> 1;
     const unsigned long long act_mask = __ballot(c_active);
     const int seg_rank = __popcll(act_mask & ((1ull << lane) - 1ull));
-    int kid_incl = c_nk;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int up = __shfl_up(kid_incl, off, 64);
-        if (lane >= off) kid_incl += up;
-    }
+    int kids_total;
+    const int kid_excl = wave_excl_scan_i32(c_nk, kids_total);
     const unsigned long long before = (gwave << 6) < n ? wave_prefix[gwave] : 0ull;
-    if (c_active != active || (active && c_nk != nk)) atomicAdd(mismatch, 1ull);  // see the header: never expected
+    if (c_active && c_nk != nk) atomicAdd(mismatch, 1ull);  // see the header: never expected
     if (c_active) {
         const int64_t slot = *cursor + (int64_t)(before >> 32) + seg_rank;
         if (slot < out_capacity) {
             const int32_t t = my_tree;
-            if (dead || !active) store_segment<T, GEN_NT>(out, slot, r, r.len, t, -2);
+            if (dead) store_segment<T, GEN_NT>(out, slot, r, r.len, t, -2);
             else if (h.node < 0) store_segment<T, GEN_NT>(out, slot, r, r.len, t, -1);
             else store_segment<T, GEN_NT>(out, slot, r, h.t, t, sc.nodes[h.node].leaf_id);
         }
     }
-    const int64_t d0 = (int64_t)(before & 0xffffffffull) + (kid_incl - c_nk);
+    const int64_t d0 = (int64_t)(before & 0xffffffffull) + kid_excl;
     auto put = [&](const RayState<T>& k, int64_t d, bool real) {
         if (d >= next_capacity) return;
         st<GEN_NT>(next.ox + d, k.ox); st<GEN_NT>(next.oy + d, k.oy); st<GEN_NT>(next.oz + d, k.oz);
@@ -631,12 +627,18 @@ __global__ __launch_bounds__(256) void k_gen_pass(SceneBlob blob, T unit, RaysT<
     if (c_nk > 1) put(nk > 1 ? ch[1] : r, d0 + 1, nk > 1);
 }
 
-// totals of a generation from the scanned wave totals: segments written and rays of the next generation
-__global__ void k_gen_totals(const unsigned long long* wave_total, const unsigned long long* wave_prefix, int64_t n_waves, int64_t* totals) {
+// totals of a generation from the scanned wave totals: segments written and rays of the next generation.  Runs between
+// the two passes: the emit pass takes its first slot from totals[2] (the cursor as it stood), so the caller's cursor
+// and next-generation count can be published here and the generation needs no closing kernel.
+__global__ void k_gen_totals(const unsigned long long* wave_total, const unsigned long long* wave_prefix, int64_t n_waves, int64_t* totals,
+                             int64_t* cursor, int64_t* n_next) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const unsigned long long all = wave_prefix[n_waves - 1] + wave_total[n_waves - 1];
         totals[0] = (int64_t)(all >> 32);
         totals[1] = (int64_t)(all & 0xffffffffull);
+        totals[2] = *cursor;
+        *cursor += totals[0];
+        *n_next = totals[1];
     }
 }
 
@@ -659,21 +661,6 @@ __global__ void k_gen_counts(const int32_t* tree, const int32_t* ids, int64_t n,
             const int32_t total = *c + rank[(int64_t)s * n + i] + probe[(int64_t)s * n + i];
             *c = total < slot_max[s] ? total : (*c > slot_max[s] ? *c : slot_max[s]);
         }
-    }
-}
-
-__global__ void k_gen_finish(const int32_t* tree, int64_t n, int32_t* budget, const int64_t* totals, int64_t* cursor,
-                             int64_t* n_next) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (i == n - 1 || tree[i + 1] != tree[i]) {  // last ray of its tree in this generation
-        const int64_t in_gen = i - tree_head(tree, i) + 1;
-        const int32_t b = budget[tree[i]];
-        budget[tree[i]] = b - (int32_t)(in_gen < b ? in_gen : b);
-    }
-    if (i == n - 1) {  // the trace kernel read *cursor at its start, so it is advanced here, after it
-        *cursor += totals[0];
-        *n_next = totals[1];
     }
 }
 

@@ -702,14 +702,14 @@ static int trace_generation(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
     // scratch carve-up
     const int ns = c->n_slots;
     const size_t sz_slot = align_up(sizeof(int32_t) * n * (ns > 0 ? ns : 1));
-    const size_t sz_tot = align_up(sizeof(int64_t) * 2 + sizeof(unsigned long long));
+    const size_t sz_tot = align_up(sizeof(int64_t) * 4);
     const int64_t n_waves = (n + 63) / 64;
     const size_t sz_code = align_up((size_t)n), sz_wave = align_up(sizeof(unsigned long long) * n_waves);
     const size_t total = sz_tot + sz_code + 2 * sz_wave + (ns > 0 ? 3 * sz_slot : 0);
     if (c->gen.ensure(total)) return fail(OT_ERR_HIP, "hipMalloc of generation scratch failed");
     uint8_t* p = (uint8_t*)c->gen.p;
     int64_t* totals = (int64_t*)p;
-    unsigned long long* mismatch = (unsigned long long*)(totals + 2);
+    unsigned long long* mismatch = nullptr;
     p += sz_tot;
     uint8_t* code = p; p += sz_code;
     unsigned long long* wave_total = (unsigned long long*)p; p += sz_wave;
@@ -765,18 +765,17 @@ static int trace_generation(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
     }
     // count -> scan of the wave totals -> emit (kernels.h: k_gen_pass)
     hipLaunchKernelGGL(k_count, dim3(g1), dim3(block), lds_bytes, c->stream, blob, (T)c->unit, view<T>(rays), tree, n, budget,
-                       seg_cursor, view<T>(out), out_capacity, view_out<T>(next), next_tree, next_capacity, code, wave_total,
+                       (const int64_t*)seg_cursor, view<T>(out), out_capacity, view_out<T>(next), next_tree, next_capacity, code, wave_total,
                        (const unsigned long long*)wave_prefix, counts, n_classes, (const int32_t*)rank, mismatch);
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->scan_tmp.p, tmp_w, wave_total, wave_prefix, (int)n_waves, c->stream));
     hipLaunchKernelGGL(k_gen_totals, dim3(1), dim3(64), 0, c->stream, (const unsigned long long*)wave_total,
-                       (const unsigned long long*)wave_prefix, n_waves, totals);
+                       (const unsigned long long*)wave_prefix, n_waves, totals, seg_cursor, n_next);
     hipLaunchKernelGGL(k_emit, dim3(g1), dim3(block), lds_bytes, c->stream, blob, (T)c->unit, view<T>(rays), tree, n, budget,
-                       seg_cursor, view<T>(out), out_capacity, view_out<T>(next), next_tree, next_capacity, code, wave_total,
+                       (const int64_t*)(totals + 2), view<T>(out), out_capacity, view_out<T>(next), next_tree, next_capacity, code, wave_total,
                        (const unsigned long long*)wave_prefix, counts, n_classes, (const int32_t*)rank, mismatch);
     if (ns > 0)
         hipLaunchKernelGGL(k_gen_counts, dim3(g1), dim3(block), 0, c->stream, tree, rays->id, n, ns, rank, probe, c->slot_max, counts,
                            n_classes);
-    hipLaunchKernelGGL(k_gen_finish, dim3(g1), dim3(block), 0, c->stream, tree, n, budget, totals, seg_cursor, n_next);
     HIP_TRY(hipGetLastError());
     return timing_end(c);
 }

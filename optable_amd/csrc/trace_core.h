@@ -575,7 +575,7 @@ __device__ __forceinline__ int wave_min_i32(int v) {
 //               hits geometrically (probe[slot*stride + idx] = 1); nothing else is evaluated.
 //   GATE_TABLE  branching generation proper: pass iff counts + (number of EARLIER rays of this
 //               tree in this generation that hit the leaf) < max, i.e. the reference's FIFO order;
-//               the table is updated once per tree afterwards (k_gen_finish).
+//               the table is updated once per tree afterwards (k_gen_counts).
 enum { GATE_PLAIN = 0, GATE_PROBE = 1, GATE_TABLE = 2 };
 struct GateCtx {
     int32_t* counts;      // [n_slots][n_classes]
@@ -850,6 +850,16 @@ __device__ __forceinline__ int wave_excl_scan_i32(int v, int& total) {
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2 and 3
     total = __builtin_amdgcn_readlane(incl, 63);
     return incl - v;
+}
+// inclusive max-scan over the 64 lanes, same DPP steps (identity -1: lanes without a source keep their own value)
+__device__ __forceinline__ int wave_incl_max_i32(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(-1, v, 0x111, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(-1, v, 0x112, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(-1, v, 0x114, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(-1, v, 0x118, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(-1, v, 0x142, 0xa, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(-1, v, 0x143, 0xc, 0xf, false));
+    return v;
 }
 #ifdef OT_STAMP  // diagnostic build: phases of a call into st_acc[5..] (walk, queue, test, verdict; [9] slots, [10] rounds)
 #define OT_FLAT_STAMP_PARAMS , unsigned long long* st_acc, unsigned long long& st_last
