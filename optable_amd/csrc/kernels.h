@@ -270,7 +270,7 @@ template <class T> struct WaveScratch {
 // REC_LDS: the records of the live rays live in LDS instead of the per-wave global scratch (the pair-queue variant for
 // planar scenes: small image, 95 registers — LDS, not registers, decides how many waves fit).
 template <class T, uint32_t F, bool SCENE_IN_LDS, bool NT, bool REC_LDS = false>
-__global__ __launch_bounds__((REC_LDS ? 1024 : blocked_threads<T, F>()), (REC_LDS ? 1 : blocked_minw<T, F>())) void k_trace_rolling(
+__global__ __launch_bounds__((REC_LDS ? 768 : blocked_threads<T, F>()), (REC_LDS ? 1 : blocked_minw<T, F>())) void k_trace_rolling(
     SceneBlob blob, T unit, RaysT<T> in, int64_t n, int32_t K, SegsT<T> out, int32_t* __restrict__ seg_count, int32_t* counts,
     int32_t n_classes, WaveScratch<T> ws, int32_t CAP, unsigned long long* queue, int32_t mix, int32_t flat_cap) {
     extern __shared__ __align__(16) uint32_t lds[];
@@ -293,12 +293,12 @@ __global__ __launch_bounds__((REC_LDS ? 1024 : blocked_threads<T, F>()), (REC_LD
         flat.queue = reinterpret_cast<uint16_t*>(fb + 64 * 24);
         flat.queue_cap = flat_cap;
     }
-    // REC_LDS: [waves][15][CAP] 32-bit words behind the lists and the pair-queue areas of all waves
+    // REC_LDS: [waves][12 reals + 3 words][CAP] behind the lists and the pair-queue areas of all waves
     uint32_t* lds_rec = nullptr;
     if constexpr (REC_LDS) {
         const int per_wave_flat = (F & F_FLAT) ? ((64 * 24 + flat_cap * 2 + 15) & ~15) : 0;
         uint8_t* rb = reinterpret_cast<uint8_t*>(reinterpret_cast<unsigned long long*>(lds_tail) + (blockDim.x >> 6) * CAP) + (blockDim.x >> 6) * per_wave_flat;
-        lds_rec = reinterpret_cast<uint32_t*>(rb) + wave * 15 * CAP;
+        lds_rec = reinterpret_cast<uint32_t*>(rb) + wave * (12 * (int)(sizeof(T) / 4) + 3) * CAP;
     }
     __syncthreads();  // the only workgroup barrier: the scene image is staged
     const Scene<T> sc = bind_scene<T>(base, blob, unit);
@@ -307,7 +307,7 @@ __global__ __launch_bounds__((REC_LDS ? 1024 : blocked_threads<T, F>()), (REC_LD
     // as 32-bit words behind them).  Fourteen separate base pointers cost 28 scalar registers that the kernel does not
     // have (106 of 102 in use: the compiler was spilling scalars into vector lanes).
     T* const srec = REC_LDS ? reinterpret_cast<T*>(lds_rec) : ws.f(gw, 0);
-    int32_t* const sint = REC_LDS ? reinterpret_cast<int32_t*>(lds_rec) + 12 * CAP : ws.flags(gw);
+    int32_t* const sint = REC_LDS ? reinterpret_cast<int32_t*>(lds_rec) + 12 * (int)(sizeof(T) / 4) * CAP : ws.flags(gw);
     const int M = CAP - 1;  // CAP is a power of two (host)
     int head = 0, tail = 0, alive = 0, round_left = 0;  // wave-uniform: `alive` entries from ring position `head`; survivors and tickets go to `tail`
     bool exhausted = false;

@@ -591,25 +591,33 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
         // for the segment records it writes — nothing it has to wait for (gfx9 retires loads and stores in order, so with
         // the records in global memory every pass's loads queue behind the 29 stores of the pass before).
         bool rec_lds = false;
-        if (flat_ok && c->opt_rec_lds != 0 && c->opt_lds_limit_kb != 0) {
-            const KernR kl = rolling_flat_lds_ptr<T>();
-            const size_t per_wave = (size_t)cap0 * entry + flat_bytes + (size_t)15 * cap0 * 4;
-            int rw = 0, rwpb = 0;
-            for (int wpb = 4; wpb <= 16; wpb += 4) {
-                const size_t lds_b = img + (size_t)wpb * per_wave;
-                if (lds_b > 158 * 1024) continue;
-                HIP_TRY(hipFuncSetAttribute((const void*)kl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
-                int per_cu = 0;
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kl, 64 * wpb, lds_b) != hipSuccess) per_cu = 0;
-                if (per_cu * wpb > rw) { rw = per_cu * wpb; rwpb = wpb; best_per_cu = per_cu; }
+        const size_t rec_bytes = 12 * sizeof(T) + 12;  // per record
+        // (Offered to the curved-surface preset too, cfg 5 fp32: its 74 KB image leaves room for 8 such waves only —
+        // 31.2 instead of 19.7 ms — so the variant is compiled for the pair-queue preset alone.)
+        const KernR kl = flat_ok ? rolling_flat_lds_ptr<T>() : (KernR) nullptr;
+        if (kl && c->opt_rec_lds != 0 && c->opt_lds_limit_kb != 0 && img <= 140 * 1024) {
+            int rw = 0, rwpb = 0, rcap = 0, rper = 0;
+            for (int32_t capl = cap0; capl >= 128; capl >>= 1) {
+                const size_t per_wave = (size_t)capl * entry + (flat_ok ? flat_bytes : 0) + rec_bytes * capl;
+                for (int wpb = 4; wpb <= 12; wpb += 4) {
+                    const size_t lds_b = img + (size_t)wpb * per_wave;
+                    if (lds_b > 158 * 1024) continue;
+                    HIP_TRY(hipFuncSetAttribute((const void*)kl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+                    int per_cu = 0;
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kl, 64 * wpb, lds_b) != hipSuccess) per_cu = 0;
+                    if (per_cu * wpb > rw) { rw = per_cu * wpb; rwpb = wpb; rcap = capl; rper = per_cu; }
+                }
+                if (rw >= REC_LDS_MIN_WAVES) break;  // the largest list that still gives the waves
             }
-            if (rw >= (c->opt_rec_lds > 0 ? 4 : REC_LDS_MIN_WAVES)) { rec_lds = true; best_wpb = rwpb; best_cap = cap0; best_lds = true; best_waves = rw; }
+            if (rw >= (c->opt_rec_lds > 0 ? 4 : REC_LDS_MIN_WAVES)) {
+                rec_lds = true; best_wpb = rwpb; best_cap = rcap; best_lds = true; best_waves = rw; best_per_cu = rper;
+            }
         }
         if (best_waves == 0) return fail(OT_ERR_HIP, "no launch configuration fits this scene image");
         const int wpb = best_wpb;
         const int32_t CAP = best_cap;
-        KernR kr = rec_lds ? rolling_flat_lds_ptr<T>() : (flat_ok ? flat_k[best_lds ? 1 : 0] : tr[fr][best_lds ? 1 : 0][nt_r]);
-        const size_t lds_r = (best_lds ? img : 0) + (size_t)wpb * CAP * entry + (flat_ok ? (size_t)wpb * flat_bytes : 0) + (rec_lds ? (size_t)wpb * 15 * CAP * 4 : 0);
+        KernR kr = rec_lds ? kl : (flat_ok ? flat_k[best_lds ? 1 : 0] : tr[fr][best_lds ? 1 : 0][nt_r]);
+        const size_t lds_r = (best_lds ? img : 0) + (size_t)wpb * CAP * entry + (flat_ok ? (size_t)wpb * flat_bytes : 0) + (rec_lds ? (size_t)wpb * rec_bytes * CAP : 0);
         if (lds_r > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
         int per_cu_r = best_per_cu;
         if (c->opt_blocks_per_cu > 0) per_cu_r = c->opt_blocks_per_cu;
