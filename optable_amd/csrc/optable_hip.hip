@@ -72,6 +72,10 @@ struct ot_ctx {
     int32_t opt_lds_limit_kb = 64;
     int32_t opt_kernel = 0;  // 0 auto, 1 fused (lane per ray), 2 rolling lists (the heavy-scene kernel)
     int32_t last_launch[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // ot_debug_last_launch
+    // heavy-scene launch plan per precision (a dozen occupancy queries): recomputed after an upload or an option change
+    struct RollingPlan { uint64_t epoch = 0; int wpb = 4, per_cu = 1; int32_t cap = 128; bool lds = false, rec_lds = false; };
+    RollingPlan plan[2];
+    uint64_t plan_epoch = 1;
     int32_t opt_rec_lds = -1;    // pair-queue scenes: records of the live rays in LDS (-1 auto, 0 never, 1 whenever it fits)
     int32_t opt_list_cap = 128;  // k_trace_rolling: live rays per wave (cfg 3: 128 beats 256 and 512)
     int32_t opt_flat = 1;  // fp32 planar top-level-grid scenes: wave-wide pair queue (flat_grid_hit)
@@ -427,6 +431,7 @@ int ot_scene_upload(ot_ctx* c, const ot_scene_desc* s) {
         HIP_TRY(hipMemcpy(c->slot_max, smax.data(), sizeof(int32_t) * smax.size(), hipMemcpyHostToDevice));
     }
     c->has_scene = true;
+    ++c->plan_epoch;
     return 0;
 }
 
@@ -568,52 +573,57 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
         const size_t entry = sizeof(unsigned long long);
         const size_t flat_bytes = ((size_t)(64 * 24 + (size_t)flat_cap * 2) + 15) & ~(size_t)15;  // per wave (kernels.h)
         constexpr int REC_LDS_MIN_WAVES = 12;
+        const size_t rec_bytes = 12 * sizeof(T) + 12;  // per record of a live ray
+        const KernR kl = flat_ok ? rolling_flat_lds_ptr<T>() : (KernR) nullptr;  // pair queue + records in LDS
         int32_t cap0 = mix ? c->opt_list_cap : (c->opt_list_cap_pure > 0 ? c->opt_list_cap_pure : 256);
         int best_wpb = 4, best_waves = 0, best_per_cu = 1, best_cap = cap0;
-        bool best_lds = false;
-        for (int pass = 0; pass < 2 && best_waves == 0; ++pass) {  // pass 0: image in LDS; pass 1: image in L2
-            const bool lds_img = pass == 0;
-            if (lds_img && (c->opt_lds_limit_kb == 0 || img > 140 * 1024)) continue;
-            for (int wpb = 4; wpb * 64 <= (flat_ok ? blocked_threads<T, FR | F_FLAT>() : max_threads[fr]); wpb += 4) {
-                int32_t CAP = cap0;
-                while (CAP > 128 && lds_img && img + (size_t)wpb * CAP * entry > 156 * 1024) CAP >>= 1;
-                const size_t lds_b = (lds_img ? img : 0) + (size_t)wpb * CAP * entry + (flat_ok ? (size_t)wpb * flat_bytes : 0);
-                if (lds_b > 158 * 1024) continue;
-                KernR kq = flat_ok ? flat_k[lds_img ? 1 : 0] : tr[fr][lds_img ? 1 : 0][nt_r];
-                if (lds_b > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
-                int per_cu = 0;
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kq, 64 * wpb, lds_b) != hipSuccess) per_cu = 0;
-                if (per_cu * wpb > best_waves) { best_waves = per_cu * wpb; best_wpb = wpb; best_per_cu = per_cu; best_cap = CAP; best_lds = lds_img; }
-            }
-        }
-        // Pair-queue scenes: the records of the live rays (15 words x CAP per wave) in LDS as well, when at least
-        // REC_LDS_MIN_WAVES waves per CU still fit.  A pass then touches global memory only for a ray's first load and
-        // for the segment records it writes — nothing it has to wait for (gfx9 retires loads and stores in order, so with
-        // the records in global memory every pass's loads queue behind the 29 stores of the pass before).
-        bool rec_lds = false;
-        const size_t rec_bytes = 12 * sizeof(T) + 12;  // per record
-        // (Offered to the curved-surface preset too, cfg 5 fp32: its 74 KB image leaves room for 8 such waves only —
-        // 31.2 instead of 19.7 ms — so the variant is compiled for the pair-queue preset alone.)
-        const KernR kl = flat_ok ? rolling_flat_lds_ptr<T>() : (KernR) nullptr;
-        if (kl && c->opt_rec_lds != 0 && c->opt_lds_limit_kb != 0 && img <= 140 * 1024) {
-            int rw = 0, rwpb = 0, rcap = 0, rper = 0;
-            for (int32_t capl = cap0; capl >= 128; capl >>= 1) {
-                const size_t per_wave = (size_t)capl * entry + (flat_ok ? flat_bytes : 0) + rec_bytes * capl;
-                for (int wpb = 4; wpb <= 12; wpb += 4) {
-                    const size_t lds_b = img + (size_t)wpb * per_wave;
+        bool best_lds = false, rec_lds = false;
+        ot_ctx::RollingPlan& plan = c->plan[f64 ? 1 : 0];
+        if (plan.epoch == c->plan_epoch) {
+            best_wpb = plan.wpb; best_per_cu = plan.per_cu; best_cap = plan.cap; best_lds = plan.lds; rec_lds = plan.rec_lds; best_waves = 1;
+        } else {
+            for (int pass = 0; pass < 2 && best_waves == 0; ++pass) {  // pass 0: image in LDS; pass 1: image in L2
+                const bool lds_img = pass == 0;
+                if (lds_img && (c->opt_lds_limit_kb == 0 || img > 140 * 1024)) continue;
+                for (int wpb = 4; wpb * 64 <= (flat_ok ? blocked_threads<T, FR | F_FLAT>() : max_threads[fr]); wpb += 4) {
+                    int32_t CAP = cap0;
+                    while (CAP > 128 && lds_img && img + (size_t)wpb * CAP * entry > 156 * 1024) CAP >>= 1;
+                    const size_t lds_b = (lds_img ? img : 0) + (size_t)wpb * CAP * entry + (flat_ok ? (size_t)wpb * flat_bytes : 0);
                     if (lds_b > 158 * 1024) continue;
-                    HIP_TRY(hipFuncSetAttribute((const void*)kl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+                    KernR kq = flat_ok ? flat_k[lds_img ? 1 : 0] : tr[fr][lds_img ? 1 : 0][nt_r];
+                    if (lds_b > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
                     int per_cu = 0;
-                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kl, 64 * wpb, lds_b) != hipSuccess) per_cu = 0;
-                    if (per_cu * wpb > rw) { rw = per_cu * wpb; rwpb = wpb; rcap = capl; rper = per_cu; }
+                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kq, 64 * wpb, lds_b) != hipSuccess) per_cu = 0;
+                    if (per_cu * wpb > best_waves) { best_waves = per_cu * wpb; best_wpb = wpb; best_per_cu = per_cu; best_cap = CAP; best_lds = lds_img; }
                 }
-                if (rw >= REC_LDS_MIN_WAVES) break;  // the largest list that still gives the waves
             }
-            if (rw >= (c->opt_rec_lds > 0 ? 4 : REC_LDS_MIN_WAVES)) {
-                rec_lds = true; best_wpb = rwpb; best_cap = rcap; best_lds = true; best_waves = rw; best_per_cu = rper;
+            // Pair-queue scenes: the records of the live rays (15 words x CAP per wave) in LDS as well, when at least
+            // REC_LDS_MIN_WAVES waves per CU still fit.  A pass then touches global memory only for a ray's first load and
+            // for the segment records it writes — nothing it has to wait for (gfx9 retires loads and stores in order, so with
+            // the records in global memory every pass's loads queue behind the 29 stores of the pass before).
+            // (Offered to the curved-surface preset too, cfg 5 fp32: its 74 KB image leaves room for 8 such waves only —
+            // 31.2 instead of 19.7 ms — so the variant is compiled for the pair-queue preset alone.)
+            if (kl && c->opt_rec_lds != 0 && c->opt_lds_limit_kb != 0 && img <= 140 * 1024) {
+                int rw = 0, rwpb = 0, rcap = 0, rper = 0;
+                for (int32_t capl = cap0; capl >= 128; capl >>= 1) {
+                    const size_t per_wave = (size_t)capl * entry + (flat_ok ? flat_bytes : 0) + rec_bytes * capl;
+                    for (int wpb = 4; wpb <= 12; wpb += 4) {
+                        const size_t lds_b = img + (size_t)wpb * per_wave;
+                        if (lds_b > 158 * 1024) continue;
+                        HIP_TRY(hipFuncSetAttribute((const void*)kl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+                        int per_cu = 0;
+                        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kl, 64 * wpb, lds_b) != hipSuccess) per_cu = 0;
+                        if (per_cu * wpb > rw) { rw = per_cu * wpb; rwpb = wpb; rcap = capl; rper = per_cu; }
+                    }
+                    if (rw >= REC_LDS_MIN_WAVES) break;  // the largest list that still gives the waves
+                }
+                if (rw >= (c->opt_rec_lds > 0 ? 4 : REC_LDS_MIN_WAVES)) {
+                    rec_lds = true; best_wpb = rwpb; best_cap = rcap; best_lds = true; best_waves = rw; best_per_cu = rper;
+                }
             }
+            if (best_waves == 0) return fail(OT_ERR_HIP, "no launch configuration fits this scene image");
+            plan.epoch = c->plan_epoch; plan.wpb = best_wpb; plan.per_cu = best_per_cu; plan.cap = best_cap; plan.lds = best_lds; plan.rec_lds = rec_lds;
         }
-        if (best_waves == 0) return fail(OT_ERR_HIP, "no launch configuration fits this scene image");
         const int wpb = best_wpb;
         const int32_t CAP = best_cap;
         KernR kr = rec_lds ? kl : (flat_ok ? flat_k[best_lds ? 1 : 0] : tr[fr][best_lds ? 1 : 0][nt_r]);
@@ -856,6 +866,7 @@ int ot_debug_generation_mismatches(ot_ctx* c, int64_t* out) {
 
 int ot_set_option(ot_ctx* c, int32_t option, int32_t value) {
     if (!c) return fail(OT_ERR_INVALID, "ctx is NULL");
+    ++c->plan_epoch;  // launch plans depend on the options
     switch (option) {
         case OT_OPT_NT_STORES: c->opt_nt = value != 0; return 0;
         case OT_OPT_PAIR_STORES: c->opt_pair = value != 0; return 0;
