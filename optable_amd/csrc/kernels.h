@@ -71,19 +71,12 @@ template <class T> __device__ __forceinline__ Scene<T> bind_scene(const uint32_t
 // Segment records are written once and never re-read by the trace: NT = true marks the stores
 // non-temporal so they stream past L2 / Infinity Cache instead of evicting the scene and inputs.
 template <bool NT, class V> __device__ __forceinline__ void st(V* p, V v) {
-#ifdef OT_EXPERIMENT_PLAIN_STORES
-    *p = v;
-#else
     if (NT) __builtin_nontemporal_store(v, p);
     else *p = v;
-#endif
 }
 template <class T, bool NT = false>
 __device__ __forceinline__ void store_segment(const SegsT<T>& out, int64_t slot, const RayState<T>& r, T len, int32_t tree,
                                               int32_t surface) {
-#ifdef OT_EXPERIMENT_NO_SEGSTORE  // timing experiment only: how much of a heavy-scene pass is the segment record
-    if (slot >= 0) { st<NT>(out.surface + slot, surface); return; }
-#endif
     st<NT>(out.ox + slot, r.ox); st<NT>(out.oy + slot, r.oy); st<NT>(out.oz + slot, r.oz);
     st<NT>(out.dx + slot, r.dx); st<NT>(out.dy + slot, r.dy); st<NT>(out.dz + slot, r.dz);
     st<NT>(out.len + slot, len); st<NT>(out.I + slot, r.I);
@@ -207,16 +200,9 @@ __global__ __launch_bounds__(256, MINW) void k_trace_fused(SceneBlob blob, T uni
     }
 }
 
-#ifndef OT_FD32_THREADS
-#define OT_FD32_THREADS 1024
-#endif
-#ifndef OT_BLOCKED_MINW
-#define OT_BLOCKED_MINW 1
-#endif
-#ifndef OT_FLAT_WAVES
-#define OT_FLAT_WAVES 5
-#endif
-template <class T, uint32_t F> constexpr int blocked_minw() { return (F & F_FLAT) ? OT_FLAT_WAVES : 1; }
+// workgroups per CU the compiler has to leave room for (registers).  The pair-queue kernel is compiled for five 256-thread
+// workgroups = 5 waves per SIMD (96 registers: it uses 95).
+template <class T, uint32_t F> constexpr int blocked_minw() { return (F & F_FLAT) ? 5 : 1; }
 // largest workgroup an instantiation may be launched with.  Waves of k_trace_rolling never synchronise after the scene
 // image is staged, so the workgroup size only decides how many waves share one image: 512 threads = 2 waves per SIMD =
 // 256 VGPRs fit every instantiation except the all-features fp64 one (it would spill 44 bytes per lane).  The fp32
@@ -224,7 +210,7 @@ template <class T, uint32_t F> constexpr int blocked_minw() { return (F & F_FLAT
 // spills 6 of the 138 registers it would like (28 bytes of scratch per lane, deliberately: 16 instead of 12 waves per CU
 // took cfg 5 from 20.97 to 19.68 ms, A/B in one run).
 template <class T, uint32_t F> constexpr int blocked_threads() {
-    return ((sizeof(T) == 8 && F == F_ALL) || ((F & F_FLAT) && OT_FLAT_WAVES > 1)) ? 256 : ((sizeof(T) == 4 && F == (F_AABB | F_REFRACT | F_CURVED | F_GRID)) ? OT_FD32_THREADS : 512);
+    return ((sizeof(T) == 8 && F == F_ALL) || (F & F_FLAT)) ? 256 : ((sizeof(T) == 4 && F == (F_AABB | F_REFRACT | F_CURVED | F_GRID)) ? 1024 : 512);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -825,8 +825,10 @@ __device__ __forceinline__ void root_grid_hit(const Scene<T>& sc, const RayState
 //          the grid; the others walk on (second and later rounds have few lanes, but also few pairs).
 // The lane that holds a ray's minimum after a slot leaves the hit point next to the key (computed from the ray's own
 // values: the same bits as a test in the ray's own lane).
-// Single precision only (a double t does not fit the key next to the index) and planar leaves only (preset FR):
-// results are bit-identical to root_grid_hit (tests/test_gpu_parity.py: grid against plain pass).
+// Single precision only and planar leaves only (preset FR): results are bit-identical to root_grid_hit
+// (test_pair_queue_walk_equals_per_lane_walk).  A double-precision form was built and measured — t alone in the key,
+// the node index voted in a second table by the lanes at the minimum — and is bit-identical too, but cfg 3 fp64 takes
+// 5.51-5.54 ms with it and without it (139 registers, 3 waves per SIMD): not kept.
 #ifndef OT_FLAT_CELLS
 #define OT_FLAT_CELLS 3
 #endif
