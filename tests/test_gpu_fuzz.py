@@ -238,3 +238,83 @@ def test_random_large_scene_fp32_tracks_fp64(seed):
     for f in ("ox", "oy", "oz"):
         err = np.abs(out["f64"][f][k64] - out["f32"][f][k32].astype(np.float64))
         assert err.max() < 2e-3, (f, err.max())
+
+
+def random_planar_scene(oa, rng):
+    """14-48 planar components with circular / rectangular apertures only, overlapping and tilted out of the plane at
+    random: the scenes the pair-queue kernel is launched for (preset FR: planar leaves directly under a top-level grid)."""
+    comps = []
+    glasses = [oa.Glass_NBK7, oa.Glass_UVFS, oa.Glass_NSF57]
+    for _ in range(int(rng.integers(14, 49))):
+        pos = [rng.uniform(3, 40), rng.uniform(-6, 6), rng.uniform(-0.4, 0.4)]
+        ang = rng.uniform(-np.pi, np.pi)
+        kind = int(rng.integers(0, 5))
+        glass = glasses[int(rng.integers(0, len(glasses)))]()
+        if kind == 0:
+            c = oa.Mirror(pos, radius=rng.uniform(0.5, 1.6)).RotZ(ang)
+        elif kind == 1:
+            c = oa.Lens(pos, focal_length=rng.uniform(3, 12), radius=rng.uniform(0.6, 1.4)).RotZ(0.3 * ang)
+        elif kind == 2:
+            c = oa.GlassSlab(pos, width=2, height=2, thickness=rng.uniform(0.2, 0.8), n1=oa.Vacuum(), n2=glass).RotZ(0.4 * ang)
+        elif kind == 3:
+            c = oa.Prism(pos, width=1.5, height=2, n1=1, n2=glass).RotZ(ang)
+        else:
+            c = oa.SquareMirror(pos, width=rng.uniform(1.0, 2.5), height=1.2).RotZ(ang).RotY(rng.uniform(-0.3, 0.3))
+        comps.append(c)
+    return comps
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_planar_scene_pair_queue_variants_agree(seed, oracle):
+    """fp32 heavy-scene kernel on random planar scenes in its three forms — every lane walking its own cells, the wave-wide
+    pair queue over global records, the pair queue with the records in LDS — and the lane-per-ray kernel: the same bits
+    from all four (ragged ray counts, dead rays, finite lengths, dispersive glass, a different wavelength per ray, mirrors
+    tilted out of the table plane), and the fp64 trace of the same scene against the oracle."""
+    import torch
+    import optable_amd as oa
+    from optable_amd.batch import RayBatch
+    from optable_amd.engine import get_engine
+
+    rng = np.random.default_rng(5000 + seed)
+    table = oa.OpticalTable()
+    table.add_components(random_planar_scene(oa, rng))
+    scene = table.compile()
+    assert scene.root_grid >= 0
+    n, K = 20_000 + 37 * seed, 12
+    o = np.stack([np.zeros(n), rng.uniform(-6, 6, n), rng.uniform(-0.3, 0.3, n)], 1)
+    d = np.stack([np.ones(n), rng.uniform(-0.15, 0.15, n), rng.uniform(-0.03, 0.03, n)], 1)
+    wl = rng.uniform(400e-7, 1100e-7, n)
+    batch = RayBatch.from_arrays(o, d, wavelength=wl, q=1j * np.pi * scenes.W0**2 / wl, precision="f32")
+    batch.flags[::11] |= abi.RAY_DEAD
+    length = torch.full((n,), float("inf"), dtype=batch.ox.dtype, device=batch.device)
+    length[3::7] = 9.0
+    batch.length = length
+    eng = get_engine()
+    outs, shapes = [], []
+    try:
+        for kern, flat, rec in ((2, 0, 0), (2, 1, 0), (2, 1, 1), (1, 0, 0)):  # the last one: the lane-per-ray kernel
+            eng.set_option(abi.OPT_KERNEL, kern)
+            eng.set_option(abi.OPT_FLAT_QUEUE, flat)
+            eng.set_option(abi.OPT_LDS_RECORDS, rec)
+            outs.append(table.trace_batch(batch, max_segments=K))
+            shapes.append(eng.last_launch()["pair_queue"])
+    finally:
+        eng.set_option(abi.OPT_KERNEL, 0)
+        eng.set_option(abi.OPT_FLAT_QUEUE, 1)
+        eng.set_option(abi.OPT_LDS_RECORDS, -1)
+    assert shapes[:2] == [0, 1] and shapes[2] in (1, 3) and shapes[3] == 0  # (3 unless the image leaves no room for the records)
+    valid = outs[0].valid_mask()
+    for other in outs[1:]:
+        assert torch.equal(outs[0].count, other.count)
+        for f in abi.SEG_FIELDS + ("ray", "surface"):
+            assert torch.equal(outs[0].field(f)[valid], other.field(f)[valid]), f
+    # and the scene itself, in double precision, against the oracle
+    b64 = RayBatch.from_arrays(o, d, wavelength=wl, q=1j * np.pi * scenes.W0**2 / wl)
+    got = table.trace_batch(b64, max_segments=K).to_host(reference_order=True)
+    ref = oracle.trace(scene, b64.to_host(), max_trace_num=K)
+    a, b = _sequences(got, n), _sequences(ref, n)
+    same = np.array([x == y for x, y in zip(a, b)])
+    assert (~same).mean() <= 0.002, f"{(~same).sum()} of {n} rays took a different path"
+    keep_g, keep_r = same[got["ray"]], same[ref["ray"]]
+    for f in abi.SEG_FIELDS:
+        np.testing.assert_allclose(got[f][keep_g], ref[f][keep_r], rtol=1e-7, atol=1e-7, err_msg=f)
