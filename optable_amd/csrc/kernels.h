@@ -206,9 +206,8 @@ template <class T, uint32_t F> constexpr int blocked_minw() { return (F & F_FLAT
 // largest workgroup an instantiation may be launched with.  Waves of k_trace_rolling never synchronise after the scene
 // image is staged, so the workgroup size only decides how many waves share one image: 512 threads = 2 waves per SIMD =
 // 256 VGPRs fit every instantiation except the all-features fp64 one (it would spill 44 bytes per lane).  The fp32
-// curved-surface preset (cfg 5) is allowed 1024 threads = 4 waves per SIMD on one 54 KB image: at the 128-register cap it
-// spills 6 of the 138 registers it would like (28 bytes of scratch per lane, deliberately: 16 instead of 12 waves per CU
-// took cfg 5 from 20.97 to 19.68 ms, A/B in one run).
+// curved-surface preset (cfg 5) is allowed 1024 threads = 4 waves per SIMD on one 74 KB image (16 instead of 12 waves per
+// CU took cfg 5 from 20.97 to 19.68 ms, A/B in one run; 119 registers under -ffp-contract=on, no spills).
 template <class T, uint32_t F> constexpr int blocked_threads() {
     return ((sizeof(T) == 8 && F == F_ALL) || (F & F_FLAT)) ? 256 : ((sizeof(T) == 4 && F == (F_AABB | F_REFRACT | F_CURVED | F_GRID)) ? 1024 : 512);
 }
