@@ -25,6 +25,17 @@ batch = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=1j * np.pi * scenes.W
 eng = get_engine()
 eng.upload(table.compile())
 out = SegmentBatch(n * K, prec, batch.device)
+ROT = int(os.environ.get("ROT", 1))  # ROT=4: rotate four input batches as bench.py does (reads come from HBM, not the Infinity Cache)
+batches = [batch]
+for seed in range(1, ROT):
+    o2, d2 = scenes.cfg2_rays(n, seed)
+    batches.append(RayBatch.from_arrays(o2, d2, wavelength=scenes.WL, q=1j * np.pi * scenes.W0**2 / scenes.WL, precision=prec))
+_turn = [0]
+
+
+def next_batch():
+    _turn[0] += 1
+    return batches[_turn[0] % len(batches)]
 bytes_alg = n * (104 if prec == "f64" else 56) * (1 + K)
 
 
@@ -52,12 +63,12 @@ for rnd in range(5):
         eng.set_option(abi.OPT_NT_STORES, nt)
         eng.set_option(abi.OPT_MIN_WAVES, mw)
         eng.set_option(abi.OPT_BLOCKS_PER_CU, bpc)
-        results[v].append(timed(lambda: eng.trace(batch, K, out=out)))
+        results[v].append(timed(lambda: eng.trace(next_batch(), K, out=out)))
     if prec == "f64":
         for nt in (0, 1):
             eng.set_option(abi.OPT_NT_STORES, nt)
             eng.set_option(abi.OPT_BLOCKS_PER_CU, 0)
-            ceil[nt].append(timed(lambda: eng.stream_ceiling(batch, K, out)))
+            ceil[nt].append(timed(lambda: eng.stream_ceiling(next_batch(), K, out)))
 print(f"workload cfg2 n={n} K={K} {prec}; algorithmic bytes/launch {bytes_alg}")
 for v in variants:
     med = statistics.median(results[v])
