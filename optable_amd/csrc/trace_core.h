@@ -830,7 +830,7 @@ __device__ __forceinline__ void root_grid_hit(const Scene<T>& sc, const RayState
 // the node index voted in a second table by the lanes at the minimum — and is bit-identical too, but cfg 3 fp64 takes
 // 5.51-5.54 ms with it and without it (139 registers, 3 waves per SIMD): not kept.
 #ifndef OT_FLAT_CELLS
-#define OT_FLAT_CELLS 3
+#define OT_FLAT_CELLS 2  // cells per round; cfg 3 fp32 with the final slot: 1 / 2 / 3 / 4 cells = 3.81 / 3.42-3.50 / 3.64 / 3.71 ms
 #endif
 static constexpr int FLAT_CELLS = OT_FLAT_CELLS;
 template <class T> struct FlatLds {
