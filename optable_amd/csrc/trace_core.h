@@ -907,15 +907,20 @@ __device__ __forceinline__ Hit<float> flat_grid_hit(const Scene<float>& sc, cons
     const T slack = T(4) * margin;
     const int max_items = L.queue_cap / (64 * FLAT_CELLS);  // the host sizes the queue for 64 lanes x FLAT_CELLS x the fullest cell
     bool first_round = true;
-    while (__any(walking)) {  // rounds (wave-uniform)
-        // ---- walk: up to FLAT_CELLS cells, item ranges only
-        int kb[FLAT_CELLS], ke[FLAT_CELLS], cnt = 0;
+    while (true) {  // rounds (wave-uniform)
+        const unsigned long long wmask = __ballot(walking);
+        if (wmask == 0ull) break;
+        // ---- walk: item ranges only.  A round walks FLAT_CELLS cells per lane; once at most half of the lanes are still
+        // walking it takes twice as many — their pairs fit the same queue, the slots of such a round are half empty
+        // anyway, and a round less is a scan, two fences and a partly filled slot less.
+        const int ncell = 2 * __popcll(wmask) <= 64 ? 2 * FLAT_CELLS : FLAT_CELLS;
+        int kb[2 * FLAT_CELLS], ke[2 * FLAT_CELLS], cnt = 0;
         T covered = T(0);
         bool left = !walking;
 #pragma unroll
-        for (int w = 0; w < FLAT_CELLS; ++w) {
+        for (int w = 0; w < 2 * FLAT_CELLS; ++w) {
             kb[w] = ke[w] = 0;
-            if (!left) {
+            if (w < ncell && !left) {  // (w < ncell: wave-uniform)
                 const int cidx = c1 * g0 + c0;
                 kb[w] = (int)start[cidx];
                 ke[w] = (int)start[cidx + 1];
@@ -943,7 +948,8 @@ __device__ __forceinline__ Hit<float> flat_grid_hit(const Scene<float>& sc, cons
         int total;
         int off = wave_excl_scan_i32(cnt, total);
 #pragma unroll
-        for (int w = 0; w < FLAT_CELLS; ++w) {
+        for (int w = 0; w < 2 * FLAT_CELLS; ++w) {
+            if (w >= ncell) break;  // wave-uniform
             const int c = ke[w] - kb[w];
             if (w == 0) {
                 for (int j = 0; j < max_items; ++j)
