@@ -285,8 +285,8 @@ enum ot_option {
     OT_OPT_LIST_CAP = 6,       /* heavy scenes: live rays per wave in the rolling list: a power of two (default 128) */
     OT_OPT_PAIR_STORES = 7,    /* lane-per-ray kernel: lane pairs write two fields per 16-byte store (0/1) */
     OT_OPT_MIX_GENERATIONS = 8,/* heavy scenes: -1 auto, 0 generation-pure lists even under a top-level grid */
-    OT_OPT_FLAT_QUEUE = 9,     /* fp32 planar scenes under a top-level grid: wave-wide candidate queue (0/1) */
-    OT_OPT_LDS_RECORDS = 10    /* ... with the records of the live rays in LDS: -1 auto, 0 never, 1 whenever it fits */
+    OT_OPT_FLAT_QUEUE = 9,     /* planar scenes under a top-level grid: wave-wide candidate queue (0/1) */
+    OT_OPT_LDS_RECORDS = 10    /* ... with the records of the live rays in LDS (fp32): -1 auto, 0 never, 1 whenever it fits */
 };
 int ot_set_option(ot_ctx* ctx, int32_t option, int32_t value);
 

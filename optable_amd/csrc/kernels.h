@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256, MINW) void k_trace_fused(SceneBlob blob, T uni
 
 // workgroups per CU the compiler has to leave room for (registers).  The pair-queue kernel is compiled for five 256-thread
 // workgroups = 5 waves per SIMD (96 registers: it uses 95).
-template <class T, uint32_t F> constexpr int blocked_minw() { return (F & F_FLAT) ? 5 : 1; }
+template <class T, uint32_t F> constexpr int blocked_minw() { return (F & F_FLAT) ? (sizeof(T) == 4 ? 5 : 3) : 1; }
 // largest workgroup an instantiation may be launched with.  Waves of k_trace_rolling never synchronise after the scene
 // image is staged, so the workgroup size only decides how many waves share one image: 512 threads = 2 waves per SIMD =
 // 256 VGPRs fit every instantiation except the all-features fp64 one (it would spill 44 bytes per lane).  The fp32
@@ -269,19 +269,20 @@ __global__ __launch_bounds__((REC_LDS ? 768 : blocked_threads<T, F>()), (REC_LDS
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long* ring = reinterpret_cast<unsigned long long*>(lds_tail) + wave * CAP;  // wave-private list (a ring of CAP entries)
     // F_FLAT: per-wave key table and pair queue of flat_grid_hit, behind the lists of all waves
-    FlatLds<T> flat = {nullptr, nullptr, nullptr, 0};
+    FlatLds<T> flat = {nullptr, nullptr, nullptr, nullptr, 0};
     if constexpr ((F & F_FLAT) != 0) {
-        const int per_wave = (64 * 24 + flat_cap * 2 + 15) & ~15;
+        const int per_wave = (FlatLds<T>::fixed_bytes + flat_cap * 2 + 15) & ~15;
         uint8_t* fb = reinterpret_cast<uint8_t*>(reinterpret_cast<unsigned long long*>(lds_tail) + (blockDim.x >> 6) * CAP) + wave * per_wave;
         flat.key = reinterpret_cast<unsigned long long*>(fb);
-        flat.point = reinterpret_cast<float4*>(fb + 64 * 8);
-        flat.queue = reinterpret_cast<uint16_t*>(fb + 64 * 24);
+        flat.point = reinterpret_cast<T*>(fb + 64 * 8);
+        if constexpr (sizeof(T) == 8) flat.node = reinterpret_cast<int32_t*>(fb + 64 * (8 + 24));
+        flat.queue = reinterpret_cast<uint16_t*>(fb + FlatLds<T>::fixed_bytes);
         flat.queue_cap = flat_cap;
     }
     // REC_LDS: [waves][12 reals + 3 words][CAP] behind the lists and the pair-queue areas of all waves
     uint32_t* lds_rec = nullptr;
     if constexpr (REC_LDS) {
-        const int per_wave_flat = (F & F_FLAT) ? ((64 * 24 + flat_cap * 2 + 15) & ~15) : 0;
+        const int per_wave_flat = (F & F_FLAT) ? ((FlatLds<T>::fixed_bytes + flat_cap * 2 + 15) & ~15) : 0;
         uint8_t* rb = reinterpret_cast<uint8_t*>(reinterpret_cast<unsigned long long*>(lds_tail) + (blockDim.x >> 6) * CAP) + (blockDim.x >> 6) * per_wave_flat;
         lds_rec = reinterpret_cast<uint32_t*>(rb) + wave * (12 * (int)(sizeof(T) / 4) + 3) * CAP;
     }
@@ -369,7 +370,7 @@ __global__ __launch_bounds__((REC_LDS ? 768 : blocked_threads<T, F>()), (REC_LDS
             }
             const GateCtx gate = {counts, n_classes, cls, nullptr, nullptr, 0, 0};
             Hit<T> h;
-            if constexpr ((F & F_FLAT) != 0 && sizeof(T) == 4) h = flat_grid_hit<F, GATE_PLAIN>(sc, r, active, gate, flat, lane OT_FLAT_STAMP_ARGS);
+            if constexpr ((F & F_FLAT) != 0) h = flat_grid_hit<T, F, GATE_PLAIN>(sc, r, active, gate, flat, lane OT_FLAT_STAMP_ARGS);
             else h = nearest_hit<T, F, GATE_PLAIN>(sc, r, active, gate);
             OT_STAMP_AT(1);
             RayState<T> child = {};

@@ -483,8 +483,7 @@ template <class T, bool L>
 static auto rolling_flat_ptr() {
     using KernR = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, SegsT<T>, int32_t*, int32_t*, int32_t, WaveScratch<T>, int32_t,
                            unsigned long long*, int32_t, int32_t);
-    if constexpr (sizeof(T) == 4) return (KernR)k_trace_rolling<T, (F_AABB | F_LENS | F_REFRACT | F_ROOT | F_FLAT), L, false>;
-    else return (KernR) nullptr;
+    return (KernR)k_trace_rolling<T, (F_AABB | F_LENS | F_REFRACT | F_ROOT | F_FLAT), L, false>;
 }
 // ... and with the records of the live rays in LDS next to the scene image
 template <class T>
@@ -560,9 +559,9 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
         static const KernR tr[4][2][2] = {OT_R(FR), OT_R(FC), OT_R(FD), OT_R(F_ALL)};
 #undef OT_R
         const int nt_r = (mix || !c->opt_nt) ? 0 : 1;
-        // fp32 planar scenes under a top-level grid of leaves: candidates through a wave-wide pair queue (flat_grid_hit)
+        // planar scenes under a top-level grid of leaves: candidates through a wave-wide pair queue (flat_grid_hit)
         const int32_t flat_cap = 64 * FLAT_CELLS * (c->root_max_items > 0 ? c->root_max_items : 1);
-        const bool flat_ok = !f64 && c->opt_flat && mix && (need & ~FR) == 0 && c->root_n_items <= 1024 && flat_cap <= 8192;  // queue entry = lane << 10 | index into the grid's item list
+        const bool flat_ok = c->opt_flat && mix && (need & ~FR) == 0 && c->root_n_items <= 1024 && flat_cap <= 8192;  // queue entry = lane << 10 | index into the grid's item list
         static const KernR flat_k[2] = {rolling_flat_ptr<T, false>(), rolling_flat_ptr<T, true>()};
         static const int max_threads[4] = {blocked_threads<T, FR>(), blocked_threads<T, FC>(), blocked_threads<T, FD>(), blocked_threads<T, F_ALL>()};
         // Where the scene image lives and how many waves share it.  The waves never synchronise after staging, so the
@@ -571,10 +570,10 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
         // = 8 waves).  Images beyond what LDS holds next to the lists are read from L2.
         const size_t img = ((bytes + 15) / 16) * 16;
         const size_t entry = sizeof(unsigned long long);
-        const size_t flat_bytes = ((size_t)(64 * 24 + (size_t)flat_cap * 2) + 15) & ~(size_t)15;  // per wave (kernels.h)
+        const size_t flat_bytes = ((size_t)(FlatLds<T>::fixed_bytes + (size_t)flat_cap * 2) + 15) & ~(size_t)15;  // per wave (kernels.h)
         constexpr int REC_LDS_MIN_WAVES = 12;
         const size_t rec_bytes = 12 * sizeof(T) + 12;  // per record of a live ray
-        const KernR kl = flat_ok ? rolling_flat_lds_ptr<T>() : (KernR) nullptr;  // pair queue + records in LDS
+        const KernR kl = (flat_ok && !f64) ? rolling_flat_lds_ptr<T>() : (KernR) nullptr;  // pair queue + records in LDS (fp32: a record is 60 bytes)
         int32_t cap0 = mix ? c->opt_list_cap : (c->opt_list_cap_pure > 0 ? c->opt_list_cap_pure : 256);
         int best_wpb = 4, best_waves = 0, best_per_cu = 1, best_cap = cap0;
         bool best_lds = false, rec_lds = false;

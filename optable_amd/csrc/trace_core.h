@@ -49,7 +49,7 @@ enum : uint32_t {
     F_MISC = 256,    // the rarer curved shapes: cylinder walls, polygons in a tilted plane (needs F_CURVED)
     F_SUBTREE = 512, // cells of the top-level grid may list whole groups (stale boxes, gridded groups) besides leaves
     F_ALL = 1023,
-    F_FLAT = 1024    // (not part of F_ALL) fp32 planar scenes under a top-level grid: candidates go through a wave-wide
+    F_FLAT = 1024    // (not part of F_ALL) planar scenes under a top-level grid: candidates go through a wave-wide
                      // queue of (ray, leaf) pairs and are tested with full lanes (flat_grid_hit)
 };
 
@@ -825,19 +825,22 @@ __device__ __forceinline__ void root_grid_hit(const Scene<T>& sc, const RayState
 //          the grid; the others walk on (second and later rounds have few lanes, but also few pairs).
 // The lane that holds a ray's minimum after a slot leaves the hit point next to the key (computed from the ray's own
 // values: the same bits as a test in the ray's own lane).
-// Single precision only and planar leaves only (preset FR): results are bit-identical to root_grid_hit
-// (test_pair_queue_walk_equals_per_lane_walk).  A double-precision form was built and measured — t alone in the key,
-// the node index voted in a second table by the lanes at the minimum — and is bit-identical too, but cfg 3 fp64 takes
-// 5.51-5.54 ms with it and without it (139 registers, 3 waves per SIMD): not kept.
+// Planar leaves only (preset FR); results are bit-identical to root_grid_hit in both precisions
+// (test_pair_queue_walk_equals_per_lane_walk, test_random_planar_scene_pair_queue_variants_agree).  In double precision
+// t does not fit a 64-bit key next to the index: the key is t alone and the node index lives in a second table (see
+// commit below).  cfg 3 fp64 gains 3 % from it (139 registers, 3 waves per SIMD), random planar scenes 12-29 %.
 #ifndef OT_FLAT_CELLS
 #define OT_FLAT_CELLS 2  // cells per round; cfg 3 fp32 with the final slot: 1 / 2 / 3 / 4 cells = 3.81 / 3.42-3.50 / 3.64 / 3.71 ms
 #endif
 static constexpr int FLAT_CELLS = OT_FLAT_CELLS;
 template <class T> struct FlatLds {
-    unsigned long long* key;   // [64]
-    float4* point;             // [64] hit point of the key's candidate
+    unsigned long long* key;   // [64]  fp32: t bits << 32 | node; fp64: t bits
+    int32_t* node;             // [64]  fp64 only: lowest node index among the candidates at the key's t
+    T* point;                  // [64][4 (fp32) / 3 (fp64)] hit point of the winning candidate
     uint16_t* queue;           // [queue_cap]
     int32_t queue_cap;
+    // bytes per wave, without the queue (kernels.h and the host size the LDS with this)
+    static constexpr int fixed_bytes = sizeof(T) == 4 ? 64 * 24 : 64 * (8 + 4 + 24);
 };
 // exclusive add-scan over the 64 lanes in six DPP adds (row_shr 1 / 2 / 4 / 8 inside the rows of 16, then row_bcast 15 /
 // 31 across the rows) — no LDS crossbar round trips; the wave total comes back in a scalar register.  Called with all 64
@@ -872,14 +875,15 @@ __device__ __forceinline__ int wave_incl_max_i32(int v) {
 #define OT_FLAT_AT(k) do {} while (0)
 #define OT_FLAT_COUNT(k) do {} while (0)
 #endif
-template <uint32_t F, int GATE>
-__device__ __forceinline__ Hit<float> flat_grid_hit(const Scene<float>& sc, const RayState<float>& r, bool active, const GateCtx& gate,
-                                                    const FlatLds<float>& L, int lane OT_FLAT_STAMP_PARAMS) {
-    typedef float T;
+template <class T, uint32_t F, int GATE>
+__device__ __forceinline__ Hit<T> flat_grid_hit(const Scene<T>& sc, const RayState<T>& r, bool active, const GateCtx& gate,
+                                                const FlatLds<T>& L, int lane OT_FLAT_STAMP_PARAMS) {
+    constexpr bool F32 = sizeof(T) == 4;
     Hit<T> best;
     best.t = Num<T>::inf(); best.node = -1; best.px = best.py = best.pz = T(0);
     const RayInv<T> ri = make_inv(r.dx, r.dy, r.dz);
     L.key[lane] = ~0ull;
+    if constexpr (!F32) L.node[lane] = 0x7fffffff;
     // grid header and DDA start (root_grid_hit's, per lane)
     const T* g = sc.aux + sc.root;
     const int a0 = (int)g[0], a1 = (int)g[1], g0 = (int)g[2], g1 = (int)g[3];
@@ -980,9 +984,14 @@ __device__ __forceinline__ Hit<float> flat_grid_hit(const Scene<float>& sc, cons
             const T slen = __shfl(r.len, src, 64);
             const int slast = __shfl(r.last, src, 64);
             const DNode<T>& nd = sc.nodes[item];
-            const unsigned long long cur = L.key[src];  // the ray's best so far (may be stale: it only prunes)
-            const T best_t = cur == ~0ull ? Num<T>::inf() : __uint_as_float((unsigned)(cur >> 32));
-            const int best_node = cur == ~0ull ? -1 : (int)(cur & 0xffffffffull);
+            const unsigned long long cur = L.key[src];  // the ray's best so far (read between slots: it only prunes)
+            T best_t = Num<T>::inf();
+            int best_node = -1;
+            if constexpr (F32) {
+                if (cur != ~0ull) { best_t = __uint_as_float((unsigned)(cur >> 32)); best_node = (int)(cur & 0xffffffffull); }
+            } else {
+                if (cur != ~0ull) { best_t = __longlong_as_double((long long)cur); best_node = L.node[src]; }
+            }
             const T rx = sx - nd.org[0], ry = sy - nd.org[1], rz = sz - nd.org[2];
             const T lox = dot3_t(nd.M[0], rx, nd.M[3], ry, nd.M[6], rz);
             const T ldx = dot3_t(nd.M[0], sdx, nd.M[3], sdy, nd.M[6], sdz);
@@ -1007,11 +1016,28 @@ __device__ __forceinline__ Hit<float> flat_grid_hit(const Scene<float>& sc, cons
         };
         auto commit = [&](const Cand& cd) {
             if (cd.ok) {  // the candidate beat what this lane saw: let the table decide
-                const unsigned long long mine = ((unsigned long long)__float_as_uint(cd.t) << 32) | (unsigned long long)(unsigned)cd.item;
-                atomicMin(&L.key[cd.src], mine);
-                // whoever holds the minimum after the atomics of this slot leaves its hit point next to the key (the same
-                // pair can sit in the queue twice when a leaf is listed in two cells: same key, same point)
-                if (L.key[cd.src] == mine) L.point[cd.src] = make_float4(cd.Px, cd.Py, cd.Pz, 0.f);
+                if constexpr (F32) {
+                    const unsigned long long mine = ((unsigned long long)__float_as_uint(cd.t) << 32) | (unsigned long long)(unsigned)cd.item;
+                    atomicMin(&L.key[cd.src], mine);
+                    // whoever holds the minimum after the atomics of this slot leaves its hit point next to the key (the same
+                    // pair can sit in the queue twice when a leaf is listed in two cells: same key, same point)
+                    if (L.key[cd.src] == mine) {
+                        T* pt = L.point + 4 * cd.src;
+                        pt[0] = cd.Px; pt[1] = cd.Py; pt[2] = cd.Pz;
+                    }
+                } else {
+                    // double precision: t does not fit a 64-bit key next to the index.  The key is t alone; a lane that
+                    // LOWERS the minimum clears the node table's entry, then every lane whose t equals the minimum takes part
+                    // in an atomic minimum over the node indices (instructions of one wave run in order: clear before vote)
+                    const unsigned long long mine = (unsigned long long)__double_as_longlong(cd.t);  // t > 0: bits order like values
+                    const unsigned long long old = atomicMin(&L.key[cd.src], mine);
+                    if (mine < old) L.node[cd.src] = 0x7fffffff;
+                    if (L.key[cd.src] == mine) atomicMin(&L.node[cd.src], cd.item);
+                    if (L.key[cd.src] == mine && L.node[cd.src] == cd.item) {
+                        T* pt = L.point + 3 * cd.src;
+                        pt[0] = cd.Px; pt[1] = cd.Py; pt[2] = cd.Pz;
+                    }
+                }
             }
         };
         // (Two slots evaluated before either commits, so that their LDS round trips overlap inside the wave, and the next
@@ -1024,13 +1050,16 @@ __device__ __forceinline__ Hit<float> flat_grid_hit(const Scene<float>& sc, cons
         OT_FLAT_AT(7);
         // ---- verdict: done when the best hit lies inside the covered part of the ray, or the walk left the grid
         const unsigned long long mine = L.key[lane];
-        if (mine != ~0ull) { best.t = __uint_as_float((unsigned)(mine >> 32)); best.node = (int)(mine & 0xffffffffull); }
+        if (mine != ~0ull) {
+            if constexpr (F32) { best.t = __uint_as_float((unsigned)(mine >> 32)); best.node = (int)(mine & 0xffffffffull); }
+            else { best.t = __longlong_as_double((long long)mine); best.node = L.node[lane]; }
+        }
         if (walking) walking = !left && !(best.t + slack < covered);
         OT_FLAT_AT(8);
     }
     // the hit point of the winner was computed by the lane that tested it, from this ray's own values: same bits as a
     // test in the ray's own lane
-    if (active && best.node >= 0) { const float4 pt = L.point[lane]; best.px = pt.x; best.py = pt.y; best.pz = pt.z; }
+    if (active && best.node >= 0) { const T* pt = L.point + (F32 ? 4 : 3) * lane; best.px = pt[0]; best.py = pt[1]; best.pz = pt[2]; }
     else { best.t = Num<T>::inf(); best.node = -1; }
     return best;
 }

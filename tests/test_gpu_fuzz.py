@@ -266,7 +266,7 @@ def random_planar_scene(oa, rng):
 
 @pytest.mark.parametrize("seed", range(6))
 def test_random_planar_scene_pair_queue_variants_agree(seed, oracle):
-    """fp32 heavy-scene kernel on random planar scenes in its three forms — every lane walking its own cells, the wave-wide
+    """The heavy-scene kernel on random planar scenes, in both precisions, in its three forms — every lane walking its own cells, the wave-wide
     pair queue over global records, the pair queue with the records in LDS — and the lane-per-ray kernel: the same bits
     from all four (ragged ray counts, dead rays, finite lengths, dispersive glass, a different wavelength per ray, mirrors
     tilted out of the table plane), and the fp64 trace of the same scene against the oracle."""
@@ -284,30 +284,32 @@ def test_random_planar_scene_pair_queue_variants_agree(seed, oracle):
     o = np.stack([np.zeros(n), rng.uniform(-6, 6, n), rng.uniform(-0.3, 0.3, n)], 1)
     d = np.stack([np.ones(n), rng.uniform(-0.15, 0.15, n), rng.uniform(-0.03, 0.03, n)], 1)
     wl = rng.uniform(400e-7, 1100e-7, n)
-    batch = RayBatch.from_arrays(o, d, wavelength=wl, q=1j * np.pi * scenes.W0**2 / wl, precision="f32")
-    batch.flags[::11] |= abi.RAY_DEAD
-    length = torch.full((n,), float("inf"), dtype=batch.ox.dtype, device=batch.device)
-    length[3::7] = 9.0
-    batch.length = length
     eng = get_engine()
-    outs, shapes = [], []
-    try:
-        for kern, flat, rec in ((2, 0, 0), (2, 1, 0), (2, 1, 1), (1, 0, 0)):  # the last one: the lane-per-ray kernel
-            eng.set_option(abi.OPT_KERNEL, kern)
-            eng.set_option(abi.OPT_FLAT_QUEUE, flat)
-            eng.set_option(abi.OPT_LDS_RECORDS, rec)
-            outs.append(table.trace_batch(batch, max_segments=K))
-            shapes.append(eng.last_launch()["pair_queue"])
-    finally:
-        eng.set_option(abi.OPT_KERNEL, 0)
-        eng.set_option(abi.OPT_FLAT_QUEUE, 1)
-        eng.set_option(abi.OPT_LDS_RECORDS, -1)
-    assert shapes[:2] == [0, 1] and shapes[2] in (1, 3) and shapes[3] == 0  # (3 unless the image leaves no room for the records)
-    valid = outs[0].valid_mask()
-    for other in outs[1:]:
-        assert torch.equal(outs[0].count, other.count)
-        for f in abi.SEG_FIELDS + ("ray", "surface"):
-            assert torch.equal(outs[0].field(f)[valid], other.field(f)[valid]), f
+    for prec in ("f32", "f64"):
+        batch = RayBatch.from_arrays(o, d, wavelength=wl, q=1j * np.pi * scenes.W0**2 / wl, precision=prec)
+        batch.flags[::11] |= abi.RAY_DEAD
+        length = torch.full((n,), float("inf"), dtype=batch.ox.dtype, device=batch.device)
+        length[3::7] = 9.0
+        batch.length = length
+        outs, shapes = [], []
+        try:
+            for kern, flat, rec in ((2, 0, 0), (2, 1, 0), (2, 1, 1), (1, 0, 0)):  # the last one: the lane-per-ray kernel
+                eng.set_option(abi.OPT_KERNEL, kern)
+                eng.set_option(abi.OPT_FLAT_QUEUE, flat)
+                eng.set_option(abi.OPT_LDS_RECORDS, rec)
+                outs.append(table.trace_batch(batch, max_segments=K))
+                shapes.append(eng.last_launch()["pair_queue"])
+        finally:
+            eng.set_option(abi.OPT_KERNEL, 0)
+            eng.set_option(abi.OPT_FLAT_QUEUE, 1)
+            eng.set_option(abi.OPT_LDS_RECORDS, -1)
+        # (records in LDS: single precision only, and only when the image leaves room for them)
+        assert shapes[:2] == [0, 1] and shapes[2] in ((1, 3) if prec == "f32" else (1,)) and shapes[3] == 0
+        valid = outs[0].valid_mask()
+        for other in outs[1:]:
+            assert torch.equal(outs[0].count, other.count)
+            for f in abi.SEG_FIELDS + ("ray", "surface"):
+                assert torch.equal(outs[0].field(f)[valid], other.field(f)[valid]), (prec, f)
     # and the scene itself, in double precision, against the oracle
     b64 = RayBatch.from_arrays(o, d, wavelength=wl, q=1j * np.pi * scenes.W0**2 / wl)
     got = table.trace_batch(b64, max_segments=K).to_host(reference_order=True)
