@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Not collected by pytest (run by hand: python tests/extended_fuzz.py).  Extended differential fuzzing on the GPU box (HIP path vs the C oracle): 90 more seeds of the three scene
-families of tests/test_gpu_fuzz.py (small, large with grids/arrays/dispersion, branching).  Prints the fraction
+"""Not collected by pytest (run by hand: python tests/extended_fuzz.py).  Extended differential fuzzing on the GPU box (HIP path vs the C oracle): more seeds of the scene
+families of tests/test_gpu_fuzz.py (small, large with grids/arrays/dispersion, branching, planar = pair-queue kernel).  Prints the fraction
 of rays whose surface sequence differs and the worst relative field error per seed; flags anything beyond
 0.2 % / 1e-7.  Last runs: 90 seeds and `SEEDS=600` (1800 scenes, 5.5e6 rays): see DESIGN.md §5."""
 import os, sys
@@ -54,6 +54,16 @@ for seed in range(100, 100 + (N_SEEDS or 20)):
     o = np.stack([np.zeros(n), rng.uniform(-3, 3, n), rng.uniform(-0.3, 0.3, n)], 1)
     d = np.stack([np.ones(n), rng.uniform(-0.12, 0.12, n), rng.uniform(-0.02, 0.02, n)], 1)
     compare(t, RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=1j*np.pi*scenes.W0**2/scenes.WL), cap, n, f"branch {seed}")
+# planar family: 14-48 overlapping, tilted planar components — the scenes that go through the pair queue of the heavy-scene
+# kernel (fp64 here: t in the key, node index voted), with dispersive glass and a wavelength per ray
+for seed in range(100, 100 + (N_SEEDS or 30)):
+    rng = np.random.default_rng(6000 + seed)
+    t = oa.OpticalTable(); t.add_components(F.random_planar_scene(oa, rng))
+    n, K = 4000, 14
+    o = np.stack([np.zeros(n), rng.uniform(-6, 6, n), rng.uniform(-0.3, 0.3, n)], 1)
+    d = np.stack([np.ones(n), rng.uniform(-0.15, 0.15, n), rng.uniform(-0.03, 0.03, n)], 1)
+    wl = rng.uniform(400e-7, 1100e-7, n)
+    compare(t, RayBatch.from_arrays(o, d, wavelength=wl, q=1j*np.pi*scenes.W0**2/wl), K, n, f"planar {seed}")
 # fourth family: interact-count limits (optical_component.py:140-149) with unique and with shared ray ids
 for seed in range(100, 100 + (N_SEEDS or 20)):
     rng = np.random.default_rng(4000 + seed)
