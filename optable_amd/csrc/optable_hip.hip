@@ -478,19 +478,20 @@ static auto fused_ptr() {
     else return (Kern)k_trace_fused<T, FM, L, W, N>;
 }
 
-// the pair-queue variant of the heavy-scene kernel exists in single precision only (trace_core.h flat_grid_hit)
-template <class T, bool L>
+// the pair-queue variants of the heavy-scene kernel (trace_core.h flat_grid_hit): planar scenes under a top-level grid
+// of leaves, with circular / rectangular apertures only (FM = FR) or with polygon / boolean ones as well (FR | F_POLY)
+template <class T, uint32_t FM, bool L>
 static auto rolling_flat_ptr() {
     using KernR = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, SegsT<T>, int32_t*, int32_t*, int32_t, WaveScratch<T>, int32_t,
                            unsigned long long*, int32_t, int32_t);
-    return (KernR)k_trace_rolling<T, (F_AABB | F_LENS | F_REFRACT | F_ROOT | F_FLAT), L, false>;
+    return (KernR)k_trace_rolling<T, (FM | F_FLAT), L, false>;
 }
-// ... and with the records of the live rays in LDS next to the scene image
-template <class T>
+// ... and with the records of the live rays in LDS next to the scene image (single precision)
+template <class T, uint32_t FM>
 static auto rolling_flat_lds_ptr() {
     using KernR = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, SegsT<T>, int32_t*, int32_t*, int32_t, WaveScratch<T>, int32_t,
                            unsigned long long*, int32_t, int32_t);
-    if constexpr (sizeof(T) == 4) return (KernR)k_trace_rolling<T, (F_AABB | F_LENS | F_REFRACT | F_ROOT | F_FLAT), true, false, true>;
+    if constexpr (sizeof(T) == 4) return (KernR)k_trace_rolling<T, (FM | F_FLAT), true, false, true>;
     else return (KernR) nullptr;
 }
 
@@ -536,6 +537,7 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
     // smallest instantiation that covers the scene's features, then the launch options
     constexpr uint32_t FA = F_AABB | F_LENS, FB = F_AABB | F_LENS | F_REFRACT, FC = FB | F_GRID | F_ROOT | F_SUBTREE,
                        FR = FB | F_ROOT,  // planar scenes under a top-level grid that lists leaves only (cfg 3)
+                       FRP = FR | F_POLY,  // ... with polygon / boolean apertures (prisms with polygonal caps, blocks with holes)
                        FD = F_AABB | F_REFRACT | F_CURVED | F_GRID;  // spherical / aspheric optics in gridded groups (cfg 5)
     const uint32_t need = c->features;
     // Heavy scenes (many nodes per segment => VALU-bound, uneven path lengths) use the blocked
@@ -550,20 +552,23 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
         // of surfaces (cfg 5) keep generation-pure lists: mixing costs them more than the tails do (cfg 5 fp32:
         // 36.6 vs 31.6 ms; cfg 3 fp32: 5.1 vs 5.5 ms).
         const bool mix = c->opt_mix < 0 ? c->root_grid >= 0 : (c->opt_mix != 0 && c->root_grid >= 0);
-        const int fr = (c->root_grid >= 0 && (need & ~FR) == 0) ? 0 : ((need & ~FC) == 0 ? 1 : ((need & ~FD) == 0 ? 2 : 3));
+        const int fr = (c->root_grid >= 0 && (need & ~FR) == 0) ? 0 : ((c->root_grid >= 0 && (need & ~FRP) == 0) ? 4 : ((need & ~FC) == 0 ? 1 : ((need & ~FD) == 0 ? 2 : 3)));
         // [preset][image in LDS][non-temporal segment stores].  Mixed lists write the [k][ray] slots of a pass in fragments
         // of several tickets: partial lines that the L2 can merge with what neighbouring passes write if the stores are
         // PLAIN (cfg 3 fp32: 5.62 ms with non-temporal stores, 4.38 ms with plain ones, interleaved A/B); generation-pure
         // lists write longer runs and keep the non-temporal stores (cfg 5: 19.3 vs 19.6 ms).
 #define OT_R(FM) {{k_trace_rolling<T, FM, false, false>, k_trace_rolling<T, FM, false, true>}, {k_trace_rolling<T, FM, true, false>, k_trace_rolling<T, FM, true, true>}}
-        static const KernR tr[4][2][2] = {OT_R(FR), OT_R(FC), OT_R(FD), OT_R(F_ALL)};
+        static const KernR tr[5][2][2] = {OT_R(FR), OT_R(FC), OT_R(FD), OT_R(F_ALL), OT_R(FRP)};
 #undef OT_R
         const int nt_r = (mix || !c->opt_nt) ? 0 : 1;
         // planar scenes under a top-level grid of leaves: candidates through a wave-wide pair queue (flat_grid_hit)
         const int32_t flat_cap = 64 * FLAT_CELLS * (c->root_max_items > 0 ? c->root_max_items : 1);
-        const bool flat_ok = c->opt_flat && mix && (need & ~FR) == 0 && c->root_n_items <= 1024 && flat_cap <= 8192;  // queue entry = lane << 10 | index into the grid's item list
-        static const KernR flat_k[2] = {rolling_flat_ptr<T, false>(), rolling_flat_ptr<T, true>()};
-        static const int max_threads[4] = {blocked_threads<T, FR>(), blocked_threads<T, FC>(), blocked_threads<T, FD>(), blocked_threads<T, F_ALL>()};
+        const bool flat_ok = c->opt_flat && mix && (fr == 0 || fr == 4) && c->root_n_items <= 1024 && flat_cap <= 8192;  // queue entry = lane << 10 | index into the grid's item list
+        static const KernR flat_k[2][2] = {{rolling_flat_ptr<T, FR, false>(), rolling_flat_ptr<T, FR, true>()},
+                                           {rolling_flat_ptr<T, FRP, false>(), rolling_flat_ptr<T, FRP, true>()}};
+        const int fp = fr == 4 ? 1 : 0;
+        static const int max_threads[5] = {blocked_threads<T, FR>(), blocked_threads<T, FC>(), blocked_threads<T, FD>(), blocked_threads<T, F_ALL>(),
+                                           blocked_threads<T, FRP>()};
         // Where the scene image lives and how many waves share it.  The waves never synchronise after staging, so the
         // workgroup size is only packaging: take the one that keeps most waves resident per CU (registers and LDS
         // decide; cfg 5 fp32: 54 KB image, 152 VGPRs -> one 768-thread workgroup = 12 waves, against 2 x 256 threads
@@ -573,7 +578,7 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
         const size_t flat_bytes = ((size_t)(FlatLds<T>::fixed_bytes + (size_t)flat_cap * 2) + 15) & ~(size_t)15;  // per wave (kernels.h)
         constexpr int REC_LDS_MIN_WAVES = 12;
         const size_t rec_bytes = 12 * sizeof(T) + 12;  // per record of a live ray
-        const KernR kl = (flat_ok && !f64) ? rolling_flat_lds_ptr<T>() : (KernR) nullptr;  // pair queue + records in LDS (fp32: a record is 60 bytes)
+        const KernR kl = (flat_ok && !f64) ? (fp ? rolling_flat_lds_ptr<T, FRP>() : rolling_flat_lds_ptr<T, FR>()) : (KernR) nullptr;  // pair queue + records in LDS (fp32: a record is 60 bytes)
         int32_t cap0 = mix ? c->opt_list_cap : (c->opt_list_cap_pure > 0 ? c->opt_list_cap_pure : 256);
         int best_wpb = 4, best_waves = 0, best_per_cu = 1, best_cap = cap0;
         bool best_lds = false, rec_lds = false;
@@ -589,7 +594,7 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
                     while (CAP > 128 && lds_img && img + (size_t)wpb * CAP * entry > 156 * 1024) CAP >>= 1;
                     const size_t lds_b = (lds_img ? img : 0) + (size_t)wpb * CAP * entry + (flat_ok ? (size_t)wpb * flat_bytes : 0);
                     if (lds_b > 158 * 1024) continue;
-                    KernR kq = flat_ok ? flat_k[lds_img ? 1 : 0] : tr[fr][lds_img ? 1 : 0][nt_r];
+                    KernR kq = flat_ok ? flat_k[fp][lds_img ? 1 : 0] : tr[fr][lds_img ? 1 : 0][nt_r];
                     if (lds_b > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
                     int per_cu = 0;
                     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kq, 64 * wpb, lds_b) != hipSuccess) per_cu = 0;
@@ -625,7 +630,7 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
         }
         const int wpb = best_wpb;
         const int32_t CAP = best_cap;
-        KernR kr = rec_lds ? kl : (flat_ok ? flat_k[best_lds ? 1 : 0] : tr[fr][best_lds ? 1 : 0][nt_r]);
+        KernR kr = rec_lds ? kl : (flat_ok ? flat_k[fp][best_lds ? 1 : 0] : tr[fr][best_lds ? 1 : 0][nt_r]);
         const size_t lds_r = (best_lds ? img : 0) + (size_t)wpb * CAP * entry + (flat_ok ? (size_t)wpb * flat_bytes : 0) + (rec_lds ? (size_t)wpb * rec_bytes * CAP : 0);
         if (lds_r > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
         int per_cu_r = best_per_cu;

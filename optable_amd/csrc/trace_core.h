@@ -1001,11 +1001,15 @@ __device__ __forceinline__ Hit<T> flat_grid_hit(const Scene<T>& sc, const RaySta
             const T ldy = dot3_t(nd.M[1], sdx, nd.M[4], sdy, nd.M[7], sdz), ldz = dot3_t(nd.M[2], sdx, nd.M[5], sdy, nd.M[8], sdz);
             const T Px = fma_t(t, ldx, lox), Py = fma_t(t, ldy, loy), Pz = fma_t(t, ldz, loz);
             const int sh = nd.shape;
-            const bool inside = sh == OT_SHAPE_CIRCLE ? (dot3_t(Px, Px, Py, Py, Pz, Pz) <= nd.r2)
-                                                      : (sh == OT_SHAPE_RECT && abs_t(Py) <= nd.p[0] && abs_t(Pz) <= nd.p[1]);
+            bool inside = sh == OT_SHAPE_CIRCLE ? (dot3_t(Px, Px, Py, Py, Pz, Pz) <= nd.r2)
+                                                : (sh == OT_SHAPE_RECT && abs_t(Py) <= nd.p[0] && abs_t(Pz) <= nd.p[1]);
             bool ok = q < total && item != slast && ldx != T(0) && s != T(0) && ((s > T(0)) == (ldx > T(0)));
             ok = ok && !(abs_t(t) < Num<T>::eps_t() || t < T(0) || t > slen);
-            ok = ok && (t < best_t || (t == best_t && item < best_node)) && inside;
+            ok = ok && (t < best_t || (t == best_t && item < best_node));
+            if constexpr (F & F_POLY) {  // polygon / boolean apertures: only for the few pairs that got this far
+                if (ok && sh != OT_SHAPE_CIRCLE && sh != OT_SHAPE_RECT) inside = planar_boundary<T, F>(sc, nd, Px, Py, Pz);
+            }
+            ok = ok && inside;
             if (ok && (nd.flags & OT_NODE_CHECK_AABB)) {  // the leaf's own AABB test (component_group.py:104-107), for would-be hits
                 const RayInv<T> rinv = make_inv(sdx, sdy, sdz);
                 T u1, u2;

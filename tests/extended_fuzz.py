@@ -58,7 +58,7 @@ for seed in range(100, 100 + (N_SEEDS or 20)):
 # kernel (fp64 here: t in the key, node index voted), with dispersive glass and a wavelength per ray
 for seed in range(100, 100 + (N_SEEDS or 30)):
     rng = np.random.default_rng(6000 + seed)
-    t = oa.OpticalTable(); t.add_components(F.random_planar_scene(oa, rng))
+    t = oa.OpticalTable(); t.add_components(F.random_planar_scene(oa, rng, irises=seed % 2 == 1))  # odd seeds: irises (boolean apertures)
     n, K = 4000, 14
     o = np.stack([np.zeros(n), rng.uniform(-6, 6, n), rng.uniform(-0.3, 0.3, n)], 1)
     d = np.stack([np.ones(n), rng.uniform(-0.15, 0.15, n), rng.uniform(-0.03, 0.03, n)], 1)

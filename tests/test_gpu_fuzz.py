@@ -240,15 +240,20 @@ def test_random_large_scene_fp32_tracks_fp64(seed):
         assert err.max() < 2e-3, (f, err.max())
 
 
-def random_planar_scene(oa, rng):
-    """14-48 planar components with circular / rectangular apertures only, overlapping and tilted out of the plane at
-    random: the scenes the pair-queue kernel is launched for (preset FR: planar leaves directly under a top-level grid)."""
+def random_planar_scene(oa, rng, irises=False):
+    """14-48 planar components, overlapping and tilted out of the plane at random: the scenes the pair-queue kernel is
+    launched for (planar leaves directly under a top-level grid).  Circular / rectangular apertures only, or with
+    `irises` also absorbing plates with a hole (boolean apertures: the F_POLY preset of the same kernel)."""
     comps = []
     glasses = [oa.Glass_NBK7, oa.Glass_UVFS, oa.Glass_NSF57]
     for _ in range(int(rng.integers(14, 49))):
         pos = [rng.uniform(3, 40), rng.uniform(-6, 6), rng.uniform(-0.4, 0.4)]
         ang = rng.uniform(-np.pi, np.pi)
-        kind = int(rng.integers(0, 5))
+        kind = int(rng.integers(0, 7 if irises else 5))
+        if kind >= 5:
+            comps.append(oa.Block(pos, hole=oa.Circle(rng.uniform(0.2, 0.7)) if kind == 5 else oa.Rectangle(rng.uniform(0.3, 1.2), rng.uniform(0.3, 1.0)),
+                                  width=rng.uniform(1.5, 2.5), height=2).RotZ(0.4 * ang))
+            continue
         glass = glasses[int(rng.integers(0, len(glasses)))]()
         if kind == 0:
             c = oa.Mirror(pos, radius=rng.uniform(0.5, 1.6)).RotZ(ang)
@@ -264,7 +269,7 @@ def random_planar_scene(oa, rng):
     return comps
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(8))
 def test_random_planar_scene_pair_queue_variants_agree(seed, oracle):
     """The heavy-scene kernel on random planar scenes, in both precisions, in its three forms — every lane walking its own cells, the wave-wide
     pair queue over global records, the pair queue with the records in LDS — and the lane-per-ray kernel: the same bits
@@ -277,7 +282,7 @@ def test_random_planar_scene_pair_queue_variants_agree(seed, oracle):
 
     rng = np.random.default_rng(5000 + seed)
     table = oa.OpticalTable()
-    table.add_components(random_planar_scene(oa, rng))
+    table.add_components(random_planar_scene(oa, rng, irises=seed >= 6))  # the last seeds: boolean apertures as well
     scene = table.compile()
     assert scene.root_grid >= 0
     n, K = 20_000 + 37 * seed, 12
