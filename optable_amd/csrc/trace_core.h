@@ -918,7 +918,7 @@ __device__ __forceinline__ Hit<T> flat_grid_hit(const Scene<T>& sc, const RaySta
         // walking it takes twice as many — their pairs fit the same queue, the slots of such a round are half empty
         // anyway, and a round less is a scan, two fences and a partly filled slot less.
         const int ncell = 2 * __popcll(wmask) <= 64 ? 2 * FLAT_CELLS : FLAT_CELLS;
-        int kb[2 * FLAT_CELLS], ke[2 * FLAT_CELLS], cnt = 0;
+        int kb[2 * FLAT_CELLS], ke[2 * FLAT_CELLS], cnt = 0, cm = 0;
         T covered = T(0);
         bool left = !walking;
 #pragma unroll
@@ -929,6 +929,7 @@ __device__ __forceinline__ Hit<T> flat_grid_hit(const Scene<T>& sc, const RaySta
                 kb[w] = (int)start[cidx];
                 ke[w] = (int)start[cidx + 1];
                 cnt += ke[w] - kb[w];
+                cm = max(cm, ke[w] - kb[w]);
                 covered = min_t(tmax0, tmax1);
                 if (tmax0 < tmax1) { c0 += s0; tmax0 += dt0; if (c0 < 0 || c0 >= g0) left = true; }
                 else { c1 += s1; tmax1 += dt1; if (c1 < 0 || c1 >= g1) left = true; }
@@ -936,19 +937,23 @@ __device__ __forceinline__ Hit<T> flat_grid_hit(const Scene<T>& sc, const RaySta
         }
         // The leaf a ray starts on lies in the first cell of its walk and can never be hit (test_leaf: idx == r.last): it is
         // taken out here, before it costs a pair — one candidate in six on cfg 3.
+        // (loops over the items of a cell run to the fullest cell of the grid or, in grids with crowded cells, to the
+        // fullest cell any lane walked this round — wave-uniform either way, so the writes below are predicated stores in
+        // straight-line code)
+        int cmax = max_items;
+        if (max_items > 4) cmax = min(__builtin_amdgcn_readlane(wave_incl_max_i32(cm), 63), max_items);  // (scene-uniform branch)
         unsigned long long skip0 = 0ull;
         if (first_round) {
             const int c = ke[0] - kb[0];
-            for (int j = 0; j < max_items; ++j)
+            for (int j = 0; j < cmax; ++j)
                 if (j < c && (int)items[kb[0] + j] == r.last) skip0 |= 1ull << j;
             cnt -= __popcll(skip0);
             first_round = false;
         }
         OT_FLAT_AT(5);
         OT_FLAT_COUNT(10);
-        // ---- queue: one scan of the counts, every lane writes its pairs (lane << 10 | index into the grid's item list).
-        // The trip count of the inner loop is the fullest cell of the grid — the same for every lane, so the writes are
-        // predicated stores in straight-line code; the item itself is looked up by the lane that tests the pair.
+        // ---- queue: one scan of the counts, every lane writes its pairs (lane << 10 | index into the grid's item list);
+        // the item itself is looked up by the lane that tests the pair.
         int total;
         int off = wave_excl_scan_i32(cnt, total);
 #pragma unroll
@@ -956,10 +961,10 @@ __device__ __forceinline__ Hit<T> flat_grid_hit(const Scene<T>& sc, const RaySta
             if (w >= ncell) break;  // wave-uniform
             const int c = ke[w] - kb[w];
             if (w == 0) {
-                for (int j = 0; j < max_items; ++j)
+                for (int j = 0; j < cmax; ++j)
                     if (j < c && !((skip0 >> j) & 1ull)) L.queue[off++] = (uint16_t)((lane << 10) | (kb[w] + j));
             } else {
-                for (int j = 0; j < max_items; ++j)
+                for (int j = 0; j < cmax; ++j)
                     if (j < c) L.queue[off + j] = (uint16_t)((lane << 10) | (kb[w] + j));
                 off += c;
             }
