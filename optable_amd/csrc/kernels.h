@@ -220,13 +220,15 @@ template <class T, uint32_t F> constexpr int blocked_threads() {
 // interaction + waiting for its stores — gfx9 counts loads and stores in ONE in-order counter (vmcnt), so the
 // state loads of a pass wait for the 25 record / state stores of the pass before it to be acknowledged.
 // Here every wave owns ONE list of up to CAP live rays: a ring in LDS (entry = ray index | segment index << 32).
-// A pass takes the 64 OLDEST entries, its survivors go to the tail, and whenever 64 slots are free the wave draws a
-// ticket of 64 consecutive fresh rays from a device-wide queue and appends it: with mixed lists every pass is full
-// until the queue is empty (FIFO: no ray waits behind younger ones), rays of different generations share a pass, and
-// no wave waits for the slowest chunk of its workgroup (workgroups are persistent: every wave runs until queue and
-// list are empty).  (Before the ring a list was worked off in rounds — passes of 64 and a remainder, 44 lanes per
-// pass on average; holding the remainder back in that scheme meant moving its records and lost, 5.19 vs 4.88 ms;
-// the ring needs no move: cfg 3 fp32 4.22 -> 4.02 ms, cfg 5 fp64 40.2 -> 36.0 ms, cfg 5 fp32 19.3 -> 19.6 ms.)
+// A pass takes the 64 OLDEST entries and its survivors go to the tail; whenever 64 slots are free the wave draws a ticket
+// of 64 consecutive fresh rays from a device-wide queue.  Mixed lists trace the ticket at once, as a pass of its own
+// (coalesced loads of the caller's arrays, and a batch's rays usually start alike: a coherent pass), and append its
+// survivors; generation-pure lists append the ticket itself.  With mixed lists every pass is full until the queue is
+// empty (FIFO: no ray waits behind younger ones), rays of different generations share a pass, and no wave waits for
+// the slowest chunk of its workgroup (workgroups are persistent: every wave runs until queue and list are empty).
+// (Before the ring a list was worked off in rounds — passes of 64 and a remainder, 44 lanes per pass on average;
+// holding the remainder back in that scheme meant moving its records and lost, 5.19 vs 4.88 ms; the ring needs no
+// move: cfg 3 fp32 4.22 -> 4.02 ms, cfg 5 fp64 40.2 -> 36.0 ms, cfg 5 fp32 19.3 -> 19.6 ms.)
 // Output slots are [k][ray] as in the other kernels: the result does not depend on which wave traced a ray or when.
 // Tried on top and dropped (cfg 3, fp32, 1e7 rays; 4.9 ms as it stands): a ring buffer with the next pass's records
 // prefetched before this pass's stores, with and without forcing the wait ahead of the stores (5.9 - 6.2 ms: 19 more
@@ -311,7 +313,27 @@ __global__ __launch_bounds__((REC_LDS ? 768 : blocked_threads<T, F>()), (REC_LDS
         // the queue is empty; otherwise only an EMPTY list is refilled, CAP rays at once, and the list is worked off in
         // rounds that are pure in their generation (scenes whose rays all run through the same sequence of surfaces: a
         // pass then tests one kind of surface, cfg 5)
-        if (mix || (round_left == 0 && alive == 0)) {
+        // Mixed lists: a ticket is traced AS SOON AS IT IS DRAWN, as a pass of its own — 64 consecutive rays of the caller's
+        // arrays on their first segment (coalesced loads, and the rays of a batch usually start alike: a coherent pass) —
+        // and only its survivors enter the ring.  The ring then holds no first segments: its passes read records only.
+        bool fresh = false;
+        unsigned long long fresh_first = 0;
+        int fresh_cnt = 0;
+        if (mix) {
+            if (!exhausted && alive + 64 <= CAP) {
+                unsigned long long first = 0;
+                if (lane == 0) first = atomicAdd(queue, 64ull);
+                first = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(first >> 32)) << 32) |
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(first & 0xffffffffull));
+                if (first >= (unsigned long long)n) {
+                    exhausted = true;
+                } else {
+                    fresh = true;
+                    fresh_first = first;
+                    fresh_cnt = (int)((unsigned long long)n - first < 64ull ? (unsigned long long)n - first : 64ull);
+                }
+            }
+        } else if (round_left == 0 && alive == 0) {
             while (!exhausted && alive + 64 <= CAP) {
                 unsigned long long first = 0;
                 if (lane == 0) first = atomicAdd(queue, 64ull);
@@ -324,22 +346,23 @@ __global__ __launch_bounds__((REC_LDS ? 768 : blocked_threads<T, F>()), (REC_LDS
                 alive += cnt;
             }
         }
-        if (alive == 0) break;  // queue and list are empty
-        if (round_left == 0) {
+        if (!fresh && alive == 0) break;  // queue and list are empty
+        if (!fresh && round_left == 0) {
             round_left = alive;
             // generation-pure lists start every round at position 0 and compact IN PLACE (survivors go to positions
             // already read): the records a round touches are the shrinking prefix the last round wrote, which stays in L2
             if (!mix) tail = head;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        // One pass: the 64 oldest entries (FIFO: no ray waits behind younger ones).  Survivors and fresh tickets go to
-        // the tail, so a pass never has to wait for a remainder: with mixed lists it is full whenever 64 rays are alive.
+        // One pass: a fresh ticket, or the 64 oldest entries of the ring (FIFO: no ray waits behind younger ones).
+        // Survivors go to the tail, so a pass never has to wait for a remainder: with mixed lists a ring pass is full
+        // whenever 64 rays are alive (a ticket is drawn whenever fewer are).
         const int avail = mix ? alive : round_left;
-        const int take = avail < 64 ? avail : 64;
+        const int take = fresh ? fresh_cnt : (avail < 64 ? avail : 64);
         {
             const int p = (head + lane) & M;
             bool active = lane < take;
-            const unsigned long long entry = active ? ring[p] : 0ull;
+            const unsigned long long entry = fresh ? fresh_first + (unsigned long long)lane : (active ? ring[p] : 0ull);
             const int64_t i = (int64_t)(entry & 0x7fffffffull);
             const int32_t k = (int32_t)(entry >> 32);
             RayState<T> r = {};
@@ -404,10 +427,14 @@ __global__ __launch_bounds__((REC_LDS ? 768 : blocked_threads<T, F>()), (REC_LDS
                 sint[q + CAP] = cls;
                 sint[q + 2 * CAP] = child.last;
             }
-            head = (head + take) & M;
             tail = (tail + __popcll(mk)) & M;
-            alive += __popcll(mk) - take;
-            round_left -= take;
+            if (fresh) {
+                alive += __popcll(mk);
+            } else {
+                head = (head + take) & M;
+                alive += __popcll(mk) - take;
+                round_left -= take;
+            }
             if (!mix && round_left == 0) head = (tail - alive) & M;  // the next round reads what this one wrote
             OT_STAMP_AT(2);
 #ifdef OT_STAMP
