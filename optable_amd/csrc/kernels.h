@@ -52,7 +52,7 @@ template <class T> static SegsT<T> view(const ot_segments* s) {
 // scene blob: [DNode<T> x n_nodes][DMat<T> x n_mats][T x n_aux], staged into LDS word by word
 struct SceneBlob {
     const uint32_t* words;
-    int32_t n_words, n_nodes, n_mats, root, cache_mat;
+    int32_t n_words, n_nodes, n_mats, root, cache_mat, root_pack;
 };
 
 template <class T> __device__ __forceinline__ Scene<T> bind_scene(const uint32_t* base, const SceneBlob& b, T unit) {
@@ -64,6 +64,7 @@ template <class T> __device__ __forceinline__ Scene<T> bind_scene(const uint32_t
     sc.n_mats = b.n_mats;
     sc.cache_mat = b.cache_mat;
     sc.root = b.root;
+    sc.root_pack = b.root_pack;
     sc.unit = unit;
     return sc;
 }

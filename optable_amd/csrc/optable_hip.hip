@@ -57,6 +57,7 @@ struct ot_ctx {
     uint32_t features = 0;
     int32_t root_max_items = 0;  // most items in one cell of the top-level grid
     int64_t root_n_items = 0;    // entries of all its cells together
+    int32_t root_pack = -1;      // aux offset of the packed cells (fill_blob), -1 when not built
     int32_t root_grid = -1;  // aux offset of the top-level grid
     int32_t cache_mat = -1;  // first Sellmeier material
     int32_t* slot_max = nullptr;  // device [n_slots]: max_interact_count per count slot
@@ -147,8 +148,21 @@ static int timing_end(ot_ctx* c) {
 }
 
 // host -> device node conversion
+// Cells of the top-level grid in one word each (first item | count << 11) behind the caller's aux array, for the pair-queue
+// walk (trace_core.h flat_grid_hit): possible when the item list has at most 1024 entries and no cell more than 42.
+// Returns the number of cells to append, 0 when the grid is absent or too large for the packing.
+static int64_t packable_cells(const ot_scene_desc* s) {
+    if (s->root_grid < 0) return 0;
+    const double* g = s->aux + s->root_grid;
+    const int64_t cells = (int64_t)g[2] * (int64_t)g[3];
+    if ((int64_t)g[11 + cells] > 1024) return 0;
+    for (int64_t k = 0; k < cells; ++k)
+        if (g[11 + k + 1] - g[11 + k] > 42) return 0;
+    return cells;
+}
 template <class T> static void fill_blob(const ot_scene_desc* s, std::vector<uint8_t>& out) {
-    const size_t nb = sizeof(DNode<T>) * s->n_nodes, mb = sizeof(DMat<T>) * s->n_materials, ab = sizeof(T) * s->n_aux;
+    const int64_t pack = packable_cells(s);
+    const size_t nb = sizeof(DNode<T>) * s->n_nodes, mb = sizeof(DMat<T>) * s->n_materials, ab = sizeof(T) * (s->n_aux + pack);
     out.assign(((nb + mb + ab + 15) / 16) * 16, 0);
     DNode<T>* nodes = reinterpret_cast<DNode<T>*>(out.data());
     for (int i = 0; i < s->n_nodes; ++i) {
@@ -188,6 +202,10 @@ template <class T> static void fill_blob(const ot_scene_desc* s, std::vector<uin
     }
     T* aux = reinterpret_cast<T*>(out.data() + nb + mb);
     for (int i = 0; i < s->n_aux; ++i) aux[i] = (T)s->aux[i];
+    for (int64_t k = 0; k < pack; ++k) {
+        const double* start = s->aux + s->root_grid + 11;
+        aux[s->n_aux + k] = (T)(start[k] + 2048.0 * (start[k + 1] - start[k]));
+    }
 }
 
 // which code paths the scene needs (trace_core.h feature mask)
@@ -404,6 +422,7 @@ int ot_scene_upload(ot_ctx* c, const ot_scene_desc* s) {
     c->n_slots = s->n_count_slots; c->max_children = s->max_children; c->unit = s->unit;
     c->features = scene_features(s);
     c->root_grid = s->root_grid;
+    c->root_pack = packable_cells(s) > 0 ? s->n_aux : -1;
     c->cache_mat = -1;
     for (int i = 0; i < s->n_materials; ++i)
         if (s->materials[i].kind == OT_MAT_SELLMEIER) { c->cache_mat = i; break; }
@@ -518,6 +537,7 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
     blob.n_nodes = c->n_nodes;
     blob.n_mats = c->n_mats;
     blob.root = c->root_grid;
+    blob.root_pack = c->root_pack;
     blob.cache_mat = c->cache_mat;
     const int block = 256;
     const bool in_lds = bytes <= (size_t)c->opt_lds_limit_kb * 1024;
@@ -563,7 +583,7 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
         const int nt_r = (mix || !c->opt_nt) ? 0 : 1;
         // planar scenes under a top-level grid of leaves: candidates through a wave-wide pair queue (flat_grid_hit)
         const int32_t flat_cap = 64 * FLAT_CELLS * (c->root_max_items > 0 ? c->root_max_items : 1);
-        const bool flat_ok = c->opt_flat && mix && (fr == 0 || fr == 4) && c->root_n_items <= 1024 && flat_cap <= 8192;  // queue entry = lane << 10 | index into the grid's item list
+        const bool flat_ok = c->opt_flat && mix && (fr == 0 || fr == 4) && c->root_pack >= 0 && flat_cap <= 8192;  // queue entry = lane << 10 | index into the grid's item list
         static const KernR flat_k[2][2] = {{rolling_flat_ptr<T, FR, false>(), rolling_flat_ptr<T, FR, true>()},
                                            {rolling_flat_ptr<T, FRP, false>(), rolling_flat_ptr<T, FRP, true>()}};
         const int fp = fr == 4 ? 1 : 0;
@@ -760,6 +780,7 @@ static int trace_generation(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
     blob.n_nodes = c->n_nodes;
     blob.n_mats = c->n_mats;
     blob.root = c->root_grid;
+    blob.root_pack = c->root_pack;
     blob.cache_mat = c->cache_mat;
     const bool in_lds = bytes <= (size_t)c->opt_lds_limit_kb * 1024;
     const size_t lds_bytes = in_lds ? bytes : 0;

@@ -99,6 +99,7 @@ template <class T> struct Scene {
     int32_t n_mats;
     int32_t cache_mat;  // first Sellmeier material, -1 when every material is a constant
     int32_t root;  // aux offset of the top-level grid, -1 when the scene has none
+    int32_t root_pack;  // aux offset of its cells as (first item | count << 11), one word per cell; -1 when not built
     T unit;
 };
 
@@ -906,8 +907,8 @@ __device__ __forceinline__ Hit<T> flat_grid_hit(const Scene<T>& sc, const RaySta
     T tmax0 = par0 ? Num<T>::inf() : (org0 + size0 * T(c0 + (s0 > 0 ? 1 : 0)) - o0) * i0;
     T tmax1 = par1 ? Num<T>::inf() : (org1 + size1 * T(c1 + (s1 > 0 ? 1 : 0)) - o1) * i1;
     const T dt0 = par0 ? Num<T>::inf() : size0 * abs_t(i0), dt1 = par1 ? Num<T>::inf() : size1 * abs_t(i1);
-    const T* start = g + 11;
-    const T* items = start + (g0 * g1 + 1);
+    const T* items = g + 11 + (g0 * g1 + 1);
+    const T* cellpack = sc.aux + sc.root_pack;  // (the host launches this walk only when the packed cells exist)
     const T slack = T(4) * margin;
     const int max_items = L.queue_cap / (64 * FLAT_CELLS);  // the host sizes the queue for 64 lanes x FLAT_CELLS x the fullest cell
     bool first_round = true;
@@ -925,11 +926,11 @@ __device__ __forceinline__ Hit<T> flat_grid_hit(const Scene<T>& sc, const RaySta
         for (int w = 0; w < 2 * FLAT_CELLS; ++w) {
             kb[w] = ke[w] = 0;
             if (w < ncell && !left) {  // (w < ncell: wave-uniform)
-                const int cidx = c1 * g0 + c0;
-                kb[w] = (int)start[cidx];
-                ke[w] = (int)start[cidx + 1];
-                cnt += ke[w] - kb[w];
-                cm = max(cm, ke[w] - kb[w]);
+                const int pk = (int)cellpack[c1 * g0 + c0];  // first item | count << 11: one LDS word per cell instead of two
+                kb[w] = pk & 2047;
+                ke[w] = kb[w] + (pk >> 11);
+                cnt += pk >> 11;
+                cm = max(cm, pk >> 11);
                 covered = min_t(tmax0, tmax1);
                 if (tmax0 < tmax1) { c0 += s0; tmax0 += dt0; if (c0 < 0 || c0 >= g0) left = true; }
                 else { c1 += s1; tmax1 += dt1; if (c1 < 0 || c1 >= g1) left = true; }
