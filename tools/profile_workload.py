@@ -18,7 +18,7 @@ from optable_amd.batch import RayBatch, SegmentBatch
 from optable_amd.engine import get_engine
 
 name = sys.argv[1]
-reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else (20 if name == "cfg3" else 5)  # cfg3: enough launches that the clock ramp of the first ones does not carry the average
 SIZES = {"cfg2": 1_000_000, "cfg3": 10_000_000, "cfg4": 160_000_000, "cfg5": 12_500_000, "cfg4b": 12_800_000, "monitor": 1_000_000}
 n = int(os.environ.get("RAYS", SIZES[name]))
 eng = get_engine()
