@@ -25,6 +25,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -151,6 +152,32 @@ def make_batch(oa, wl, n, rank, device, seed_shift=0):
         return base.multiplexed_in_wavelength(np.linspace(400e-7, 1100e-7, W.CFG4_WAVELENGTHS))
     o, d, lam = wl.rays(n, rank + seed_shift)
     return RayBatch.from_arrays(o, d, wavelength=lam, q=1j * np.pi * W.W0**2 / lam, precision=wl.precision, device=device)
+
+
+def sample_device_clocks(out):
+    """`rocm-smi --showclocks --showpower --json` of the first card, from a child process, into `out` (best effort: a
+    diagnostic next to the sustained figure, never a reason for the bench to fail)."""
+    import subprocess
+    try:
+        time.sleep(0.3)  # let the loop get going
+        res = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--json"], capture_output=True, text=True, timeout=2.5)
+        text = res.stdout[res.stdout.index("{"):]
+        card = next(iter(json.loads(text).values()))
+        for key, val in card.items():
+            k = key.lower()
+            digits = "".join(ch for ch in str(val) if ch.isdigit() or ch == ".")
+            if not digits:
+                continue
+            if k.startswith("sclk clock speed"):
+                out["sclk_mhz"] = float(digits)
+            elif k.startswith("mclk clock speed"):
+                out["mclk_mhz"] = float(digits)
+            elif k.startswith("fclk clock speed"):
+                out["fclk_mhz"] = float(digits)
+            elif "power (w)" in k:
+                out["package_power_w"] = float(digits)
+    except Exception:  # noqa: BLE001 - diagnostic only
+        pass
 
 
 def kernel_name(scene, wl):
@@ -384,6 +411,9 @@ def main():
         if world == 1 and not args.no_sustained:
             # >= 1 s of back-to-back launches: long enough for any outside sampler to see the GPU busy, and the
             # figure a long job gets
+            clocks = {}
+            sampler = threading.Thread(target=sample_device_clocks, args=(clocks,), daemon=True)
+            sampler.start()  # reads the clocks the chip runs at WHILE this loop keeps it busy (boxes of a pool differ)
             t_s = time.perf_counter()
             done = 0
             chunk = max(1, int(0.02 / max(dt / args.steps, 1e-6)))  # ~20 ms of launches between host syncs
@@ -394,6 +424,9 @@ def main():
                 torch.cuda.synchronize()
             dt_s = time.perf_counter() - t_s
             extra["sustained"] = {"seconds": dt_s, "steps": done, "ms_per_step": dt_s / done * 1e3}
+            sampler.join(timeout=3.0)
+            if clocks:
+                extra["sustained"]["device_clocks_under_load"] = clocks
         step(0)  # leave real results in outs[0]
         torch.cuda.synchronize()
         segs_step = int(outs[0].count.abs().sum().item())
