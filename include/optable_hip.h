@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define OT_ABI_VERSION 6  /* 3: ot_trace_generation_f32; 4: ot_bench_stream_f32; 5: OT_OPT_LIST_CAP, ray flags bits 8..31, ot_debug_generation_mismatches; 6: ot_debug_last_launch, OT_OPT_FLAT_QUEUE, OT_OPT_LDS_RECORDS */
+#define OT_ABI_VERSION 7  /* 3: ot_trace_generation_f32; 4: ot_bench_stream_f32; 5: OT_OPT_LIST_CAP, ray flags bits 8..31, ot_debug_generation_mismatches; 6: ot_debug_last_launch, OT_OPT_FLAT_QUEUE, OT_OPT_LDS_RECORDS; 7: ot_trace_append_*, ot_segment_block, OT_OPT_APPEND_CHUNK, OT_OPT_INSTANCING */
 
 /* ---- status codes ------------------------------------------------------------------- */
 enum ot_status {
@@ -225,6 +225,33 @@ int ot_trace_f32(ot_ctx* ctx, const ot_rays* rays, int64_t n_rays, int32_t max_s
                  const ot_segments* out, int32_t* seg_count, int32_t* counts,
                  int32_t n_count_classes);
 
+/* The same trace with the APPEND layout: a dense list of segment records instead of max_segments * n_rays slots.
+ * The reference returns a list with one entry per processed segment (optical_table.py:125-134); the [k][ray] slots of
+ * ot_trace_* hold that list with a hole for every segment a ray did not live to (cfg 3: 11 GB of slots for 2.8 GB of
+ * records; cfg 5: 35 GB for 17 GB), and their late planes are written a few elements per cache line.  Here the output is
+ * ONE allocation of 14 planes of `capacity` slots each — the 12 real fields in the order of ot_segments, then int32
+ * ray[capacity], int32 surface[capacity] — filled in append order: every wave of the kernel claims chunks of slots from
+ * a device-wide cursor and writes 64 consecutive records per pass.
+ *   - *n_slots (device int64) receives the number of slots claimed.  Slots [0, *n_slots) hold records, except that the
+ *     unused tail of each wave's last chunk is marked ray = -1 (at most OT_OPT_APPEND_CHUNK - 1 slots per wave).
+ *   - order: the records of one ray lie at increasing slot numbers in segment order, so a STABLE sort by `ray` yields the
+ *     reference's order (input ray major, then segment order) — the contract of ot_trace_generation_*'s flat list.  The
+ *     order of rays among each other is not deterministic.  seg_count[i] is written as by ot_trace_*.
+ *   - capacity (a multiple of 64; base 16-byte aligned): if *n_slots > capacity the records that did not fit are lost
+ *     (nothing is written outside the block); *n_slots is still exact, so the caller can retry with enough room.
+ *     sum(seg_count) + chunk * (number of waves launched) always suffices; max_segments * n_rays + that slack never fails.
+ * Works for every scene ot_trace_* accepts, always on the rolling-list kernel. */
+typedef struct ot_segment_block {
+    void* base;        /* device pointer: 12 planes of `real`[capacity], then int32 ray[capacity], int32 surface[capacity] */
+    int64_t capacity;  /* slots per plane */
+} ot_segment_block;
+int ot_trace_append_f64(ot_ctx* ctx, const ot_rays* rays, int64_t n_rays, int32_t max_segments,
+                        const ot_segment_block* out, int64_t* n_slots, int32_t* seg_count, int32_t* counts,
+                        int32_t n_count_classes);
+int ot_trace_append_f32(ot_ctx* ctx, const ot_rays* rays, int64_t n_rays, int32_t max_segments,
+                        const ot_segment_block* out, int64_t* n_slots, int32_t* seg_count, int32_t* counts,
+                        int32_t n_count_classes);
+
 /* Branching trace, one generation of the breadth-first ray tree per call
  * (optical_table.py:115-134).  Input: the generation's alive rays with their tree index
  * (rays_tree) in BFS order.  budget[i] = how many more segments tree i may still process
@@ -251,7 +278,8 @@ int ot_debug_generation_mismatches(ot_ctx* ctx, int64_t* count);
 /* Diagnostic: the shape of the last ot_trace_* launch on this ctx, for profiles and tuning notes.
  * info[0] kernel (1 lane per ray, 2 rolling lists), [1] threads per workgroup, [2] workgroups per CU the occupancy
  * query allowed, [3] workgroups launched, [4] dynamic LDS bytes per workgroup, [5] list capacity per wave (rolling),
- * [6] 1 = mixed generations, [7] bit 0 = candidate pair queue (OT_OPT_FLAT_QUEUE took effect), bit 1 = records in LDS. */
+ * [6] 1 = mixed generations, [7] bit 0 = candidate pair queue (OT_OPT_FLAT_QUEUE took effect), bit 1 = records in LDS,
+ * bit 2 = append layout. */
 int ot_debug_last_launch(ot_ctx* ctx, int32_t info[8]);
 
 /* Monitor.record (monitor.py:183-193): intersect finished segments with a rectangular
@@ -286,7 +314,9 @@ enum ot_option {
     OT_OPT_PAIR_STORES = 7,    /* lane-per-ray kernel: lane pairs write two fields per 16-byte store (0/1) */
     OT_OPT_MIX_GENERATIONS = 8,/* heavy scenes: -1 auto, 0 generation-pure lists even under a top-level grid */
     OT_OPT_FLAT_QUEUE = 9,     /* planar scenes under a top-level grid: wave-wide candidate queue (0/1) */
-    OT_OPT_LDS_RECORDS = 10    /* ... with the records of the live rays in LDS (fp32): -1 auto, 0 never, 1 whenever it fits */
+    OT_OPT_LDS_RECORDS = 10,   /* heavy scenes, fp32: records of the live rays in LDS: -1 auto, 0 never, 1 whenever it fits */
+    OT_OPT_APPEND_CHUNK = 11,  /* ot_trace_append_*: slots a wave claims per atomic (multiple of 64, default 512) */
+    OT_OPT_INSTANCING = 12     /* fold identical lattice children (MMA / MLA / DMD) into one record + per-member pose at upload (0/1) */
 };
 int ot_set_option(ot_ctx* ctx, int32_t option, int32_t value);
 

@@ -7,7 +7,7 @@ __graft_entry__ as g; g.build()"` or `make -C optable_amd/csrc`).
 import ctypes as C
 import os
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "liboptable_hip.so")
 
@@ -56,6 +56,11 @@ class OtSegments(C.Structure):
     _fields_ = [(f, C.c_void_p) for f in SEG_FIELDS] + [("ray", C.c_void_p), ("surface", C.c_void_p)]
 
 
+class OtSegmentBlock(C.Structure):
+    """Append layout: one allocation of 14 planes of `capacity` slots (12 reals in SEG_FIELDS order, int32 ray, int32 surface)."""
+    _fields_ = [("base", C.c_void_p), ("capacity", C.c_int64)]
+
+
 class OtMonitor(C.Structure):
     _fields_ = [("M", C.c_double * 9), ("origin", C.c_double * 3),
                 ("half_width", C.c_double), ("half_height", C.c_double)]
@@ -67,6 +72,7 @@ NODE_CHECK_AABB, NODE_GRID = 1, 2
 MAT_CONST, MAT_SELLMEIER = 0, 1
 RAY_HAS_Q, RAY_DEAD = 1, 2
 OPT_NT_STORES, OPT_MIN_WAVES, OPT_BLOCKS_PER_CU, OPT_KERNEL, OPT_LDS_LIMIT_KB, OPT_LIST_CAP, OPT_PAIR_STORES, OPT_MIX_GENERATIONS, OPT_FLAT_QUEUE, OPT_LDS_RECORDS = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+OPT_APPEND_CHUNK, OPT_INSTANCING = 11, 12
 
 # every symbol the header declares, with its ctypes signature
 _vp, _i32, _i64 = C.c_void_p, C.c_int32, C.c_int64
@@ -81,6 +87,8 @@ SYMBOLS = {
     "ot_scene_upload": (C.c_int, [_vp, C.POINTER(OtSceneDesc)]),
     "ot_trace_f64": (C.c_int, _TRACE_ARGS),
     "ot_trace_f32": (C.c_int, _TRACE_ARGS),
+    "ot_trace_append_f64": (C.c_int, [_vp, C.POINTER(OtRays), _i64, _i32, C.POINTER(OtSegmentBlock), _vp, _vp, _vp, _i32]),
+    "ot_trace_append_f32": (C.c_int, [_vp, C.POINTER(OtRays), _i64, _i32, C.POINTER(OtSegmentBlock), _vp, _vp, _vp, _i32]),
     "ot_trace_generation_f64": (C.c_int, [_vp, C.POINTER(OtRays), _vp, _i64, _vp, C.POINTER(OtSegments), _i64,
                                           _vp, C.POINTER(OtRays), _vp, _i64, _vp, _vp, _i32]),
     "ot_trace_generation_f32": (C.c_int, [_vp, C.POINTER(OtRays), _vp, _i64, _vp, C.POINTER(OtSegments), _i64,

@@ -215,22 +215,62 @@ class RayBatch:
 
 
 class SegmentBatch:
-    """`capacity` segment slots (reference: the List[Ray] `ray_tracing` returns).
+    """`capacity` segment slots (reference: the List[Ray] `ray_tracing` returns).  Three layouts:
 
-    Non-branching trace: slot k*n_rays + i = k-th segment of ray i, valid for k < count[i].
+    slots   non-branching trace (ot_trace_*): slot k*n_rays + i = k-th segment of ray i, valid for k < count[i];
+    list    breadth-first trace (ot_trace_generation_*): the first `n_valid` slots, in generation order;
+    append  non-branching trace, dense (ot_trace_append_*): the first `n_valid` slots are records in append order or
+            holes (`ray == -1`, the unused tail of a wave's last chunk); `count[i]` as for slots.
+    For `list` and `append` a STABLE sort by `ray` gives the reference's order (input ray major, then segment order).
     """
 
-    def __init__(self, capacity, precision="f64", device="cuda"):
+    def __init__(self, capacity, precision="f64", device="cuda", block=False):
         self.capacity, self.precision, self.device = int(capacity), precision, torch.device(device)
         dt = _REAL[precision]
-        for f in abi.SEG_FIELDS:
-            name = "n_index" if f == "n" else f
-            setattr(self, name, torch.empty(self.capacity, dtype=dt, device=self.device))
-        self.ray = torch.empty(self.capacity, dtype=torch.int32, device=self.device)
-        self.surface = torch.empty(self.capacity, dtype=torch.int32, device=self.device)
-        self.count = None      # int32 [n_rays] (non-branching layout)
+        self.block = None
+        if block:  # ONE allocation of 14 planes (include/optable_hip.h: ot_segment_block); the fields are its rows
+            self.capacity = cap = (self.capacity + 63) // 64 * 64
+            width = 8 if precision == "f64" else 4
+            self.block = torch.empty(12 * cap * width + 2 * cap * 4, dtype=torch.uint8, device=self.device)
+            reals = self.block[: 12 * cap * width].view(dt).view(12, cap)
+            ints = self.block[12 * cap * width:].view(torch.int32).view(2, cap)
+            for k, f in enumerate(abi.SEG_FIELDS):
+                setattr(self, "n_index" if f == "n" else f, reals[k])
+            self.ray, self.surface = ints[0], ints[1]
+        else:
+            for f in abi.SEG_FIELDS:
+                name = "n_index" if f == "n" else f
+                setattr(self, name, torch.empty(self.capacity, dtype=dt, device=self.device))
+            self.ray = torch.empty(self.capacity, dtype=torch.int32, device=self.device)
+            self.surface = torch.empty(self.capacity, dtype=torch.int32, device=self.device)
+        self.count = None      # int32 [n_rays] (slots and append layouts)
         self.n_rays = None
-        self.n_valid = None    # number of valid slots when the layout is a flat list
+        self._n_valid = None   # number of slots in use when the layout is a list (list, append)
+        self.cursor = None     # append layout: device scalar the kernel leaves the slot count in (read on first use)
+        self.append = False
+
+    @property
+    def n_valid(self):
+        if self._n_valid is None and self.cursor is not None:
+            claimed = int(self.cursor.item())  # synchronises with the trace
+            if claimed > self.capacity:
+                raise RuntimeError(f"append layout: the trace needed {claimed} slots, the block holds {self.capacity}; "
+                                   f"records beyond it were dropped — trace again with capacity >= {claimed}")
+            self._n_valid = claimed
+        return self._n_valid
+
+    @n_valid.setter
+    def n_valid(self, value):
+        self._n_valid = value
+
+    @property
+    def layout(self):
+        return "append" if self.append else ("slots" if self.count is not None else "list")
+
+    def block_struct(self):
+        s = abi.OtSegmentBlock()
+        s.base, s.capacity = self.block.data_ptr(), self.capacity
+        return s
 
     def field(self, name):
         return self.n_index if name == "n" else getattr(self, name)
@@ -252,7 +292,8 @@ class SegmentBatch:
         for f in abi.SEG_FIELDS:
             setattr(out, "n_index" if f == "n" else f, self.field(f).to(dt))
         out.ray, out.surface = self.ray, self.surface
-        out.count, out.n_rays, out.n_valid = self.count, self.n_rays, self.n_valid
+        out.count, out.n_rays, out._n_valid, out.cursor = self.count, self.n_rays, self.n_valid, None
+        out.append, out.block = self.append, None
         for extra in ("capped", "counts_table", "count_ids"):
             if hasattr(self, extra):
                 setattr(out, extra, getattr(self, extra))
@@ -260,11 +301,13 @@ class SegmentBatch:
 
     def valid_mask(self):
         """Boolean mask over slots (device)."""
-        if self.count is not None:
+        if self.layout == "slots":
             k = torch.arange(self.capacity // self.n_rays, device=self.device, dtype=torch.int32).unsqueeze(1)
-            return (k < self.count.unsqueeze(0)).reshape(-1)
+            return (k < self.count.abs().unsqueeze(0)).reshape(-1)
         m = torch.zeros(self.capacity, dtype=torch.bool, device=self.device)
         m[: self.n_valid] = True
+        if self.append:
+            m[: self.n_valid] &= self.ray[: self.n_valid] >= 0
         return m
 
     def _columns_to_host(self, m):
@@ -285,6 +328,15 @@ class SegmentBatch:
         if self.count is not None and self.n_rays == 0:
             out = {f: np.zeros(0) for f in abi.SEG_FIELDS}
             out.update(ray=np.zeros(0, np.int32), surface=np.zeros(0, np.int32), count=np.zeros(0, np.int32))
+            return out
+        if self.append:  # records in append order with holes: drop the holes, then as for a list
+            out = self._columns_to_host(self.n_valid)
+            keep = out["ray"] >= 0
+            out = {k: v[keep] for k, v in out.items()}
+            if reference_order:
+                order = np.argsort(out["ray"], kind="stable")
+                out = {k: v[order] for k, v in out.items()}
+            out["count"] = np.abs(self.count.cpu().numpy())
             return out
         if self.count is not None:
             K = self.capacity // self.n_rays

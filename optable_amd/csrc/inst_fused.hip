@@ -1,0 +1,23 @@
+// inst_fused.hip — the k_trace_fused instantiations of one precision (-DOT_REAL=double | float) and their lookup.
+#include "tables.h"
+
+using T = OT_REAL;
+using namespace preset;
+
+// The 128-register cap (MINW = 4) pays for the mirror / lens kernel and for the fp32 Snell kernel; the fp64 Snell kernel
+// wants 145 registers and would spill: that combination is not compiled.  The all-features kernel exists in single
+// precision only (in double it needs more than 256 registers; those scenes take the rolling lists), with non-temporal
+// stores only, and is also the one that reads images beyond the LDS limit from L2.
+template <uint32_t FM, int W, bool N> static FusedKern<T> one() {
+    if constexpr (W == 4 && sizeof(T) == 8 && (FM & F_REFRACT) != 0) return nullptr;
+    else return k_trace_fused<T, FM, true, W, N>;
+}
+template <uint32_t FM> static FusedKern<T> pick(bool minw4, bool nt) {
+    return minw4 ? (nt ? one<FM, 4, true>() : one<FM, 4, false>()) : (nt ? one<FM, 1, true>() : one<FM, 1, false>());
+}
+template <> FusedKern<T> fused_kernel<T>(int fi, bool lds, bool minw4, bool nt) {
+    if (lds && fi == 0) return pick<FA>(minw4, nt);
+    if (lds && fi == 1) return pick<FB>(minw4, nt);
+    if constexpr (sizeof(T) == 4) return lds ? k_trace_fused<T, F_ALL, true, 1, true> : k_trace_fused<T, F_ALL, false, 1, true>;
+    else return nullptr;
+}

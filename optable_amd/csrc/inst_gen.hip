@@ -1,0 +1,14 @@
+// inst_gen.hip — the generation kernels (k_gen_pass count / emit, k_gen_probe) of one precision and their lookup.
+#include "tables.h"
+
+using T = OT_REAL;
+using namespace preset;
+
+template <uint32_t FM> static GenKern<T> pick(bool lds, bool emit) {
+    if (lds) return emit ? k_gen_pass<T, FM, true, true> : k_gen_pass<T, FM, true, false>;
+    return emit ? k_gen_pass<T, FM, false, true> : k_gen_pass<T, FM, false, false>;
+}
+// beam splitters and partially reflecting slabs are planar scenes: they get the small instantiation (145 instead of 255
+// registers in fp64); count gates, curved shapes and polygons need the full one
+template <> GenKern<T> gen_kernel<T>(bool small, bool lds, bool emit) { return small ? pick<FB>(lds, emit) : pick<F_ALL>(lds, emit); }
+template <> ProbeKern<T> probe_kernel<T>(bool lds) { return lds ? k_gen_probe<T, F_ALL, true> : k_gen_probe<T, F_ALL, false>; }

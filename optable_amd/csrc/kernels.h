@@ -15,6 +15,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "trace_core.h"
 
 using namespace ot;
@@ -49,18 +51,21 @@ template <class T> static SegsT<T> view(const ot_segments* s) {
 }
 
 // ------------------------------------------------------------------------------------------
-// scene blob: [DNode<T> x n_nodes][DMat<T> x n_mats][T x n_aux], staged into LDS word by word
+// scene blob: [DNode<T> x n_phys][DMat<T> x n_mats][T x n_aux][int32 x 4 n_runs], staged into LDS word by word.
+// n_nodes counts the caller's (virtual) nodes, n_phys the records kept after instanced runs were folded (trace_core.h NodeRef).
 struct SceneBlob {
     const uint32_t* words;
-    int32_t n_words, n_nodes, n_mats, root, cache_mat, root_pack;
+    int32_t n_words, n_nodes, n_phys, n_mats, root, cache_mat, root_pack, n_runs, runs_word;
 };
 
 template <class T> __device__ __forceinline__ Scene<T> bind_scene(const uint32_t* base, const SceneBlob& b, T unit) {
     Scene<T> sc;
     sc.nodes = reinterpret_cast<const DNode<T>*>(base);
-    sc.mats = reinterpret_cast<const DMat<T>*>(sc.nodes + b.n_nodes);
+    sc.mats = reinterpret_cast<const DMat<T>*>(sc.nodes + b.n_phys);
     sc.aux = reinterpret_cast<const T*>(sc.mats + b.n_mats);
+    sc.runs = reinterpret_cast<const int32_t*>(base + b.runs_word);
     sc.n_nodes = b.n_nodes;
+    sc.n_runs = b.n_runs;
     sc.n_mats = b.n_mats;
     sc.cache_mat = b.cache_mat;
     sc.root = b.root;
@@ -85,6 +90,28 @@ __device__ __forceinline__ void store_segment(const SegsT<T>& out, int64_t slot,
     st<NT>(out.n + slot, r.n); st<NT>(out.pl + slot, r.pl);
     st<NT>(out.ray + slot, tree); st<NT>(out.surface + slot, surface);
 }
+
+// Append layout (ot_trace_append_*): ONE allocation of 14 planes of `cap` slots — the 12 real fields in ot_segments order,
+// then int32 ray[cap], int32 surface[cap] — instead of 14 independent arrays: two scalar registers instead of 28 live
+// across the pass loop of a kernel that has 102 of them.
+template <class T> struct SegPlanes {
+    uint8_t* base;
+    int64_t cap;
+};
+template <class T, bool NT = false>
+__device__ __forceinline__ void store_segment(const SegPlanes<T>& out, int64_t slot, const RayState<T>& r, T len, int32_t tree,
+                                              int32_t surface) {
+    T* p = reinterpret_cast<T*>(out.base) + slot;
+    const int64_t cap = out.cap;
+    st<NT>(p, r.ox); p += cap; st<NT>(p, r.oy); p += cap; st<NT>(p, r.oz); p += cap;
+    st<NT>(p, r.dx); p += cap; st<NT>(p, r.dy); p += cap; st<NT>(p, r.dz); p += cap;
+    st<NT>(p, len); p += cap; st<NT>(p, r.I); p += cap;
+    st<NT>(p, r.qr); p += cap; st<NT>(p, r.qi); p += cap;
+    st<NT>(p, r.n); p += cap; st<NT>(p, r.pl);
+    int32_t* q = reinterpret_cast<int32_t*>(reinterpret_cast<T*>(out.base) + 12 * cap) + slot;
+    st<NT>(q, tree); st<NT>(q + cap, surface);
+}
+template <class T> __device__ __forceinline__ int32_t* ray_plane(const SegPlanes<T>& out) { return reinterpret_cast<int32_t*>(reinterpret_cast<T*>(out.base) + 12 * out.cap); }
 
 // Paired stores: lanes 2j and 2j+1 hold records for two ADJACENT slots.  Instead of fourteen stores of one element
 // per lane, the pair takes the fields two at a time: after one DPP exchange the even lane holds both lanes' values of
@@ -159,6 +186,7 @@ __global__ __launch_bounds__(256, MINW) void k_trace_fused(SceneBlob blob, T uni
         if (active) {
             const int32_t fl = in.flags[i];
             r = load_ray(in, i, fl);
+            if ((uint32_t)r.last >= (uint32_t)sc.n_nodes) r.last = -1;  // bits 8.. of a caller's flags that name no node of this scene
             if constexpr (F & F_REFRACT) mc = make_matcache(sc, r.wl);
             cls = in.id[i];
             if (fl & OT_RAY_DEAD) {  // optical_component.py:349: a dead ray hits nothing and is returned as is
@@ -176,7 +204,7 @@ __global__ __launch_bounds__(256, MINW) void k_trace_fused(SceneBlob blob, T uni
             const bool both = pair && ((storing >> (threadIdx.x & 62)) & 3ull) == 3ull;
             if (both) {
                 const bool hit = h.node >= 0;
-                store_segment_paired<T, NT>(out, (int64_t)k * n + i, r, hit ? h.t : r.len, (int32_t)i, hit ? sc.nodes[h.node].leaf_id : -1,
+                store_segment_paired<T, NT>(out, (int64_t)k * n + i, r, hit ? h.t : r.len, (int32_t)i, hit ? leaf_id_of<T, F>(sc, h.node) : -1,
                                             (threadIdx.x & 1) != 0);
             }
             if (active) {
@@ -186,7 +214,7 @@ __global__ __launch_bounds__(256, MINW) void k_trace_fused(SceneBlob blob, T uni
                     if (!both) store_segment<T, NT>(out, slot, r, r.len, (int32_t)i, -1);
                     active = false;
                 } else {
-                    if (!both) store_segment<T, NT>(out, slot, r, h.t, (int32_t)i, sc.nodes[h.node].leaf_id);
+                    if (!both) store_segment<T, NT>(out, slot, r, h.t, (int32_t)i, leaf_id_of<T, F>(sc, h.node));
                     RayState<T> child;
                     const int nk = interact<T, F, 1>(sc, r, h, &child, mc);
                     if (nk == 1) r = child;
@@ -201,66 +229,73 @@ __global__ __launch_bounds__(256, MINW) void k_trace_fused(SceneBlob blob, T uni
     }
 }
 
-// workgroups per CU the compiler has to leave room for (registers).  The pair-queue kernel is compiled for five 256-thread
-// workgroups = 5 waves per SIMD (96 registers: it uses 95).
-template <class T, uint32_t F> constexpr int blocked_minw() { return (F & F_FLAT) ? (sizeof(T) == 4 ? 5 : 3) : 1; }
-// largest workgroup an instantiation may be launched with.  Waves of k_trace_rolling never synchronise after the scene
-// image is staged, so the workgroup size only decides how many waves share one image: 512 threads = 2 waves per SIMD =
-// 256 VGPRs fit every instantiation except the all-features fp64 one (it would spill 44 bytes per lane).  The fp32
-// curved-surface preset (cfg 5) is allowed 1024 threads = 4 waves per SIMD on one 74 KB image (16 instead of 12 waves per
-// CU took cfg 5 from 20.97 to 19.68 ms, A/B in one run; 119 registers under -ffp-contract=on, no spills).
-template <class T, uint32_t F> constexpr int blocked_threads() {
-    return ((sizeof(T) == 8 && F == F_ALL) || (F & F_FLAT)) ? 256 : ((sizeof(T) == 4 && F == (F_AABB | F_REFRACT | F_CURVED | F_GRID)) ? 1024 : 512);
-}
-
 // ------------------------------------------------------------------------------------------
-// k_trace_rolling: heavy scenes whose rays are unrelated after the first bounce (top-level grid: cfg 3).
-// k_trace_blocked gives every wave a fixed chunk that lives as long as its longest ray, so its late passes run with
-// a handful of lanes, and a pass costs about the same whether 64 lanes work in it or 3.  Stamps inside the kernel
-// (tools/stamp_phases.py) show where a pass goes: ~50 % nearest hit, ~20 % waiting for its loads, ~27 % record +
-// interaction + waiting for its stores — gfx9 counts loads and stores in ONE in-order counter (vmcnt), so the
-// state loads of a pass wait for the 25 record / state stores of the pass before it to be acknowledged.
-// Here every wave owns ONE list of up to CAP live rays: a ring in LDS (entry = ray index | segment index << 32).
-// A pass takes the 64 OLDEST entries and its survivors go to the tail; whenever 64 slots are free the wave draws a ticket
-// of 64 consecutive fresh rays from a device-wide queue.  Mixed lists trace the ticket at once, as a pass of its own
-// (coalesced loads of the caller's arrays, and a batch's rays usually start alike: a coherent pass), and append its
-// survivors; generation-pure lists append the ticket itself.  With mixed lists every pass is full until the queue is
-// empty (FIFO: no ray waits behind younger ones), rays of different generations share a pass, and no wave waits for
-// the slowest chunk of its workgroup (workgroups are persistent: every wave runs until queue and list are empty).
-// (Before the ring a list was worked off in rounds — passes of 64 and a remainder, 44 lanes per pass on average;
-// holding the remainder back in that scheme meant moving its records and lost, 5.19 vs 4.88 ms; the ring needs no
-// move: cfg 3 fp32 4.22 -> 4.02 ms, cfg 5 fp64 40.2 -> 36.0 ms, cfg 5 fp32 19.3 -> 19.6 ms.)
-// Output slots are [k][ray] as in the other kernels: the result does not depend on which wave traced a ray or when.
-// Tried on top and dropped (cfg 3, fp32, 1e7 rays; 4.9 ms as it stands): a ring buffer with the next pass's records
-// prefetched before this pass's stores, with and without forcing the wait ahead of the stores (5.9 - 6.2 ms: 19 more
-// live registers and per-lane source selects cost more than the hidden latency returns); a branch-free planar test
-// in the cell loop (5.5 ms: the early exits do pay, whole waves leave a candidate together more often than not);
-// a resumable grid walk that visits at most 1 / 2 / 4 cells per pass and parks long walks for the next pass
-// (14.4 / 11.1 / 8.7 ms: every extra pass pays the pass's load -> trace -> store latency again).
-// Per-wave scratch of k_trace_rolling: the records of the wave's live rays, stored by LIST POSITION (not by ray
-// index), one allocation for the launch: wave w owns [w][field][CAP].  A pass reads 64 consecutive ring positions
-// and writes its survivors to the tail (generation-pure lists: to the start of the round's range, all read already,
-// so the compaction happens in place): every access is 64 consecutive elements (two runs where the ring wraps), and
-// a few MB per XCD of such records stay in L2 between the pass that writes them and the pass that reads them.  (Round 2 first kept the records by ray index in 11 arrays of n: the
-// rays of a pass are scattered over those, wavelength / flags / id were gathered from the caller's arrays on every
-// pass, and rocprofv3 showed 18 GB of HBM traffic for 3.3 GB of algorithmic bytes on cfg 3.)
+// k_trace_rolling: heavy scenes (many nodes per segment: VALU- and latency-bound, uneven path lengths).
+// A fixed chunk of rays per wave lives as long as its longest ray, so its late passes run with a handful of lanes, and
+// a pass costs about the same whether 64 lanes work in it or 3.  Here every wave owns ONE list of up to CAP live rays: a
+// ring in LDS (entry = ray index | segment index << 32).  A pass takes the 64 OLDEST entries and its survivors go to the
+// tail; fresh rays come in tickets of 64 consecutive rays from a device-wide queue (one atomic per ticket).
+//   mixed lists (scenes under a top-level grid: the rays of a wave are unrelated after the first bounce — cfg 3): a ticket
+//     is drawn whenever 64 slots are free and traced at once, as a pass of its own (coalesced loads of the caller's arrays,
+//     and a batch's rays usually start alike: a coherent pass); only its survivors enter the ring.  Every pass is full
+//     until the queue is empty, rays of all generations share a pass.
+//   generation-pure lists (scenes whose rays all run through the same sequence of surfaces — cfg 5): only an EMPTY list is
+//     refilled, CAP rays at once, and worked off in rounds; a pass then tests one kind of surface (mixing cost cfg 5 16 %).
+// Workgroups are persistent and their waves never synchronise after the scene image is staged: no wave waits for the
+// slowest chunk of its workgroup.
+// The records of the live rays (12 reals + one word of flags and start node, + the count class in scenes with limited
+// surfaces) are kept BY LIST POSITION, [field][CAP] per wave: a pass reads 64 consecutive ring positions and writes its
+// survivors to the tail (generation-pure lists: to the start of the round's range, all read already, so the compaction
+// happens in place).  REC_LDS puts them in LDS next to the scene image — a pass then touches global memory only for a
+// ray's first load and for the segment records it writes, nothing it has to wait for (gfx9 retires loads and stores
+// through ONE in-order counter, so with the records in global memory every pass's loads queue behind the stores of
+// the pass before); otherwise they live in a per-wave global scratch that stays in L2 between the pass that writes it
+// and the pass that reads it (fp64, large images).
+// Output, by the type of `out`:
+//   SegsT<T>      the [k][ray] slots of ot_trace_*: segment k of ray i at k * n + i.  Survivors of different tickets are
+//                 scattered over the late planes: 4-byte stores into lines whose other elements belong to dead rays
+//                 (cfg 3: 6.3 GB written for 2.8 GB of records, and a store instruction that touches 64 lines).
+//   SegPlanes<T>  the append layout of ot_trace_append_*: every wave claims chunks of `chunk` slots from a device-wide
+//                 cursor (one atomic per chunk) and fills them pass by pass, 64 records = whole lines per field.  A ray
+//                 stays with its wave and chunks are claimed in address order, so the records of one ray lie at
+//                 increasing addresses: a stable sort by `ray` is the reference's order (optical_table.py:125-134), as for
+//                 the breadth-first trace.  The unused tail of a wave's last chunk is marked ray = -1.
+// Tried and dropped (cfg 3, fp32, 1e7 rays): a ring buffer with the next pass's records prefetched before this pass's
+// stores (19 more live registers and per-lane source selects cost more than the hidden latency returns); a branch-free
+// planar test in the per-lane cell loop (the early exits do pay there); a resumable grid walk that visits at most 1 / 2 /
+// 4 cells per pass (every extra pass pays the pass's load -> trace -> store latency again); lists worked off in rounds
+// with a remainder pass instead of the FIFO ring (44 instead of 62 lanes per pass).
+struct AppendCtl {
+    unsigned long long* cursor;  // slots claimed so far (device); the caller reads it back as *n_slots
+    int64_t capacity;
+    int32_t chunk;               // slots per claim, a multiple of 64
+};
 template <class T> struct WaveScratch {
     uint8_t* base;
-    int64_t wave_bytes;  // bytes per wave: CAP * (12 * sizeof(T) + 12)
-    int32_t cap;
-    // fields 0..11: ox oy oz dx dy dz qr qi I n pl wavelength; then int32 flags, int32 id, int32 node the ray starts on
-    __device__ __forceinline__ T* f(int64_t wave, int k) const { return reinterpret_cast<T*>(base + wave * wave_bytes) + (int64_t)k * cap; }
-    __device__ __forceinline__ int32_t* flags(int64_t wave) const { return reinterpret_cast<int32_t*>(base + wave * wave_bytes + (int64_t)12 * cap * sizeof(T)); }
-    __device__ __forceinline__ int32_t* id(int64_t wave) const { return flags(wave) + cap; }
-    __device__ __forceinline__ int32_t* last(int64_t wave) const { return flags(wave) + 2 * cap; }
+    int64_t wave_bytes;  // bytes per wave: CAP * record bytes, rounded up
 };
+template <uint32_t F> constexpr int rec_int_words() { return (F & F_LIMIT) ? 2 : 1; }
 
-// REC_LDS: the records of the live rays live in LDS instead of the per-wave global scratch (the pair-queue variant for
-// planar scenes: small image, 95 registers — LDS, not registers, decides how many waves fit).
-template <class T, uint32_t F, bool SCENE_IN_LDS, bool NT, bool REC_LDS = false>
-__global__ __launch_bounds__((REC_LDS ? 768 : blocked_threads<T, F>()), (REC_LDS ? 1 : blocked_minw<T, F>())) void k_trace_rolling(
-    SceneBlob blob, T unit, RaysT<T> in, int64_t n, int32_t K, SegsT<T> out, int32_t* __restrict__ seg_count, int32_t* counts,
+// Largest workgroup an instantiation may be launched with, and the workgroups per CU the compiler has to leave registers
+// for.  The waves never synchronise after staging, so the workgroup size only decides how many waves share one image:
+//   pair queue, records in LDS: LDS decides the occupancy — one 768-thread workgroup per CU (170 registers allowed, ~100 used);
+//   pair queue, records in global memory: five 256-thread workgroups = 5 waves per SIMD (96 registers: it uses 95), fp64 three;
+//   curved-surface preset (cfg 5) in fp32: one 1024-thread workgroup = 4 waves per SIMD on one image (128 registers);
+//   all features in fp64: 256 threads (255 registers); everything else 512 = 2 waves per SIMD.
+template <class T, uint32_t F, bool REC_LDS> constexpr int rolling_threads() {
+    if ((F & F_FLAT) != 0) return REC_LDS ? 768 : 256;
+    if (sizeof(T) == 8 && F == F_ALL) return 256;
+    if (sizeof(T) == 4 && F == (F_AABB | F_REFRACT | F_CURVED | F_GRID)) return 1024;
+    return 512;
+}
+template <class T, uint32_t F, bool REC_LDS> constexpr int rolling_minw() { return ((F & F_FLAT) != 0 && !REC_LDS) ? (sizeof(T) == 4 ? 5 : 3) : 1; }
+
+template <class T, uint32_t F, bool SCENE_IN_LDS, bool NT, bool REC_LDS, class OUT>
+__global__ __launch_bounds__((rolling_threads<T, F, REC_LDS>()), (rolling_minw<T, F, REC_LDS>())) void k_trace_rolling(
+    SceneBlob blob, T unit, RaysT<T> in, int64_t n, int32_t K, OUT out, AppendCtl ac, int32_t* __restrict__ seg_count, int32_t* counts,
     int32_t n_classes, WaveScratch<T> ws, int32_t CAP, unsigned long long* queue, int32_t mix, int32_t flat_cap) {
+    constexpr bool APPEND = std::is_same<OUT, SegPlanes<T>>::value;
+    constexpr int W = (int)(sizeof(T) / 4), RI = rec_int_words<F>();
     extern __shared__ __align__(16) uint32_t lds[];
     const uint32_t* base = blob.words;
     uint32_t* lds_tail = lds;
@@ -269,37 +304,34 @@ __global__ __launch_bounds__((REC_LDS ? 768 : blocked_threads<T, F>()), (REC_LDS
         base = lds;
         lds_tail = lds + ((blob.n_words + 3) & ~3);
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
     unsigned long long* ring = reinterpret_cast<unsigned long long*>(lds_tail) + wave * CAP;  // wave-private list (a ring of CAP entries)
+    uint8_t* lds_next = reinterpret_cast<uint8_t*>(reinterpret_cast<unsigned long long*>(lds_tail) + n_waves * CAP);
     // F_FLAT: per-wave key table and pair queue of flat_grid_hit, behind the lists of all waves
     FlatLds<T> flat = {nullptr, nullptr, nullptr, nullptr, 0};
     if constexpr ((F & F_FLAT) != 0) {
         const int per_wave = (FlatLds<T>::fixed_bytes + flat_cap * 2 + 15) & ~15;
-        uint8_t* fb = reinterpret_cast<uint8_t*>(reinterpret_cast<unsigned long long*>(lds_tail) + (blockDim.x >> 6) * CAP) + wave * per_wave;
+        uint8_t* fb = lds_next + wave * per_wave;
         flat.key = reinterpret_cast<unsigned long long*>(fb);
         flat.point = reinterpret_cast<T*>(fb + 64 * 8);
         if constexpr (sizeof(T) == 8) flat.node = reinterpret_cast<int32_t*>(fb + 64 * (8 + 24));
         flat.queue = reinterpret_cast<uint16_t*>(fb + FlatLds<T>::fixed_bytes);
         flat.queue_cap = flat_cap;
-    }
-    // REC_LDS: [waves][12 reals + 3 words][CAP] behind the lists and the pair-queue areas of all waves
-    uint32_t* lds_rec = nullptr;
-    if constexpr (REC_LDS) {
-        const int per_wave_flat = (F & F_FLAT) ? ((FlatLds<T>::fixed_bytes + flat_cap * 2 + 15) & ~15) : 0;
-        uint8_t* rb = reinterpret_cast<uint8_t*>(reinterpret_cast<unsigned long long*>(lds_tail) + (blockDim.x >> 6) * CAP) + (blockDim.x >> 6) * per_wave_flat;
-        lds_rec = reinterpret_cast<uint32_t*>(rb) + wave * (12 * (int)(sizeof(T) / 4) + 3) * CAP;
+        lds_next += n_waves * per_wave;
     }
     __syncthreads();  // the only workgroup barrier: the scene image is staged
     const Scene<T> sc = bind_scene<T>(base, blob, unit);
-    const int64_t gw = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;  // this wave's scratch
-    // ONE base pointer per wave; field f of ring position p is element p + f * CAP (twelve reals, then flags / id / node
-    // as 32-bit words behind them).  Fourteen separate base pointers cost 28 scalar registers that the kernel does not
-    // have (106 of 102 in use: the compiler was spilling scalars into vector lanes).
-    T* const srec = REC_LDS ? reinterpret_cast<T*>(lds_rec) : ws.f(gw, 0);
-    int32_t* const sint = REC_LDS ? reinterpret_cast<int32_t*>(lds_rec) + 12 * (int)(sizeof(T) / 4) * CAP : ws.flags(gw);
+    // ONE base pointer per wave; field f of ring position p is element p + f * CAP (twelve reals, then the integer words
+    // behind them).  Separate base pointers per field cost scalar registers that the kernel does not have.
+    const int64_t gw = (int64_t)blockIdx.x * n_waves + wave;
+    T* const srec = REC_LDS ? reinterpret_cast<T*>(lds_next) + (int64_t)wave * ((12 * W + RI) * CAP) / W
+                            : reinterpret_cast<T*>(ws.base + gw * ws.wave_bytes);
+    int32_t* const sint = reinterpret_cast<int32_t*>(srec + 12 * CAP);
     const int M = CAP - 1;  // CAP is a power of two (host)
     int head = 0, tail = 0, alive = 0, round_left = 0;  // wave-uniform: `alive` entries from ring position `head`; survivors and tickets go to `tail`
     bool exhausted = false;
+    int64_t chunk_pos = 0;  // append layout: next free slot of this wave's chunk, and how many are left in it
+    int32_t chunk_left = 0;
 #ifdef OT_STAMP
     unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define OT_STAMP_AT(k) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long _t = __builtin_amdgcn_s_memtime(); st_acc[k] += _t - st_last; st_last = _t; } while (0)
@@ -309,23 +341,19 @@ __global__ __launch_bounds__((REC_LDS ? 768 : blocked_threads<T, F>()), (REC_LDS
 #define OT_STAMP_AT(k) do {} while (0)
 #define OT_FLAT_STAMP_ARGS
 #endif
+    auto draw_ticket = [&]() -> unsigned long long {
+        unsigned long long first = 0;
+        if (lane == 0) first = atomicAdd(queue, 64ull);
+        return ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(first >> 32)) << 32) |
+               (uint32_t)__builtin_amdgcn_readfirstlane((int)(first & 0xffffffffull));
+    };
     for (;;) {
-        // mix: top up whenever 64 slots are free (rays of all generations share the list), so every pass is full until
-        // the queue is empty; otherwise only an EMPTY list is refilled, CAP rays at once, and the list is worked off in
-        // rounds that are pure in their generation (scenes whose rays all run through the same sequence of surfaces: a
-        // pass then tests one kind of surface, cfg 5)
-        // Mixed lists: a ticket is traced AS SOON AS IT IS DRAWN, as a pass of its own — 64 consecutive rays of the caller's
-        // arrays on their first segment (coalesced loads, and the rays of a batch usually start alike: a coherent pass) —
-        // and only its survivors enter the ring.  The ring then holds no first segments: its passes read records only.
         bool fresh = false;
         unsigned long long fresh_first = 0;
         int fresh_cnt = 0;
         if (mix) {
             if (!exhausted && alive + 64 <= CAP) {
-                unsigned long long first = 0;
-                if (lane == 0) first = atomicAdd(queue, 64ull);
-                first = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(first >> 32)) << 32) |
-                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(first & 0xffffffffull));
+                const unsigned long long first = draw_ticket();
                 if (first >= (unsigned long long)n) {
                     exhausted = true;
                 } else {
@@ -336,10 +364,7 @@ __global__ __launch_bounds__((REC_LDS ? 768 : blocked_threads<T, F>()), (REC_LDS
             }
         } else if (round_left == 0 && alive == 0) {
             while (!exhausted && alive + 64 <= CAP) {
-                unsigned long long first = 0;
-                if (lane == 0) first = atomicAdd(queue, 64ull);
-                first = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(first >> 32)) << 32) |
-                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(first & 0xffffffffull));
+                const unsigned long long first = draw_ticket();
                 if (first >= (unsigned long long)n) { exhausted = true; break; }
                 const int cnt = (int)((unsigned long long)n - first < 64ull ? (unsigned long long)n - first : 64ull);
                 if (lane < cnt) ring[(tail + lane) & M] = first + (unsigned long long)lane;  // segment index 0
@@ -351,65 +376,77 @@ __global__ __launch_bounds__((REC_LDS ? 768 : blocked_threads<T, F>()), (REC_LDS
         if (!fresh && round_left == 0) {
             round_left = alive;
             // generation-pure lists start every round at position 0 and compact IN PLACE (survivors go to positions
-            // already read): the records a round touches are the shrinking prefix the last round wrote, which stays in L2
+            // already read): the records a round touches are the shrinking prefix the last round wrote
             if (!mix) tail = head;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         // One pass: a fresh ticket, or the 64 oldest entries of the ring (FIFO: no ray waits behind younger ones).
-        // Survivors go to the tail, so a pass never has to wait for a remainder: with mixed lists a ring pass is full
-        // whenever 64 rays are alive (a ticket is drawn whenever fewer are).
         const int avail = mix ? alive : round_left;
         const int take = fresh ? fresh_cnt : (avail < 64 ? avail : 64);
         {
             const int p = (head + lane) & M;
-            bool active = lane < take;
-            const unsigned long long entry = fresh ? fresh_first + (unsigned long long)lane : (active ? ring[p] : 0ull);
-            const int64_t i = (int64_t)(entry & 0x7fffffffull);
-            const int32_t k = (int32_t)(entry >> 32);
+            const bool entry = lane < take;
+            const unsigned long long e = fresh ? fresh_first + (unsigned long long)lane : (entry ? ring[p] : 0ull);
+            const int64_t i = (int64_t)(e & 0x7fffffffull);
+            const int32_t k = (int32_t)(e >> 32);
             RayState<T> r = {};
             int32_t cls = 0, fl = 0;
-            if (active) {
+            if (entry) {
                 if (k == 0) {  // first segment: the caller's arrays (a ticket is 64 consecutive rays)
                     fl = in.flags[i];
-                    cls = in.id[i];
+                    if constexpr ((F & F_LIMIT) != 0) cls = in.id[i];
                     r = load_ray(in, i, fl);
-                } else {  // later ones: this wave's scratch, by ring position
+                    if ((uint32_t)r.last >= (uint32_t)sc.n_nodes) r.last = -1;  // bits 8.. of a caller's flags that name no node
+                    fl &= 0xff;
+                } else {  // later ones: this wave's records, by ring position
                     r.ox = srec[p]; r.oy = srec[p + CAP]; r.oz = srec[p + 2 * CAP];
                     r.dx = srec[p + 3 * CAP]; r.dy = srec[p + 4 * CAP]; r.dz = srec[p + 5 * CAP];
                     r.qr = srec[p + 6 * CAP]; r.qi = srec[p + 7 * CAP]; r.I = srec[p + 8 * CAP];
                     r.n = srec[p + 9 * CAP]; r.pl = srec[p + 10 * CAP]; r.wl = srec[p + 11 * CAP];
-                    fl = sint[p];
-                    cls = sint[p + CAP];
-                    r.last = sint[p + 2 * CAP];
+                    const int32_t meta = sint[p];
+                    fl = meta & 0xff;
+                    r.last = (meta >> 8) - 1;
+                    if constexpr ((F & F_LIMIT) != 0) cls = sint[p + CAP];
                     r.len = Num<T>::inf();
                     r.has_q = (fl & OT_RAY_HAS_Q) != 0;
                 }
             }
             OT_STAMP_AT(0);
-            bool survive = false;
-            if (active && (fl & OT_RAY_DEAD)) {  // optical_component.py:349: returned as it came
-                store_segment<T, NT>(out, i, r, r.len, (int32_t)i, -2);
-                seg_count[i] = 1;
-                active = false;
-            }
+            const bool active = entry && !(fl & OT_RAY_DEAD);  // optical_component.py:349: a dead ray is returned as it came
             const GateCtx gate = {counts, n_classes, cls, nullptr, nullptr, 0, 0};
             Hit<T> h;
             if constexpr ((F & F_FLAT) != 0) h = flat_grid_hit<T, F, GATE_PLAIN>(sc, r, active, gate, flat, lane OT_FLAT_STAMP_ARGS);
             else h = nearest_hit<T, F, GATE_PLAIN>(sc, r, active, gate);
             OT_STAMP_AT(1);
+            // the segment record: every entry of the pass writes exactly one
+            const bool hit = active && h.node >= 0;
+            int64_t slot = (int64_t)k * n + i;
+            bool room = true;
+            if constexpr (APPEND) {
+                const unsigned long long writers = __ballot(entry);
+                const int need = __popcll(writers), rank = __popcll(writers & ((1ull << lane) - 1ull));
+                int64_t fresh_pos = 0;
+                if (need > chunk_left) {  // wave-uniform: claim the next chunk; the pass may straddle the two
+                    const unsigned long long c0 = lane == 0 ? atomicAdd(ac.cursor, (unsigned long long)ac.chunk) : 0ull;
+                    fresh_pos = (int64_t)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(c0 >> 32)) << 32) |
+                                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(c0 & 0xffffffffull)));
+                }
+                slot = rank < chunk_left ? chunk_pos + rank : fresh_pos + (rank - chunk_left);
+                if (need > chunk_left) { chunk_pos = fresh_pos + (need - chunk_left); chunk_left = ac.chunk - (need - chunk_left); }
+                else { chunk_pos += need; chunk_left -= need; }
+                room = slot < ac.capacity;  // an output that is too small loses records, never writes outside (the cursor tells)
+            }
+            if (entry && room) store_segment<T, NT>(out, slot, r, hit ? h.t : r.len, (int32_t)i, hit ? leaf_id_of<T, F>(sc, h.node) : (active ? -1 : -2));
+            bool survive = false;
             RayState<T> child = {};
-            if (active) {
-                const int64_t slot = (int64_t)k * n + i;
+            if (entry) {
                 int32_t used = k + 1;
-                if (h.node < 0) {
-                    store_segment<T, NT>(out, slot, r, r.len, (int32_t)i, -1);
-                } else {
-                    store_segment<T, NT>(out, slot, r, h.t, (int32_t)i, sc.nodes[h.node].leaf_id);
+                if (hit) {
                     MatCache<T> mc = {T(1)};
                     if constexpr (F & F_REFRACT) mc = make_matcache(sc, r.wl);
                     const int nk = interact<T, F, 1>(sc, r, h, &child, mc);
                     if (nk == 1) survive = k + 1 < K;
-                    else if (nk > 1) used = -(k + 1);
+                    else if (nk > 1) used = -(k + 1);  // the tree branches here: the caller re-traces it generation by generation
                 }
                 if (!survive) seg_count[i] = used;
             }
@@ -424,9 +461,8 @@ __global__ __launch_bounds__((REC_LDS ? 768 : blocked_threads<T, F>()), (REC_LDS
                 srec[q + 3 * CAP] = child.dx; srec[q + 4 * CAP] = child.dy; srec[q + 5 * CAP] = child.dz;
                 srec[q + 6 * CAP] = child.qr; srec[q + 7 * CAP] = child.qi; srec[q + 8 * CAP] = child.I;
                 srec[q + 9 * CAP] = child.n; srec[q + 10 * CAP] = child.pl; srec[q + 11 * CAP] = r.wl;
-                sint[q] = fl;
-                sint[q + CAP] = cls;
-                sint[q + 2 * CAP] = child.last;
+                sint[q] = fl | ((child.last + 1) << 8);
+                if constexpr ((F & F_LIMIT) != 0) sint[q + CAP] = cls;
             }
             tail = (tail + __popcll(mk)) & M;
             if (fresh) {
@@ -442,9 +478,14 @@ __global__ __launch_bounds__((REC_LDS ? 768 : blocked_threads<T, F>()), (REC_LDS
             st_acc[4] += 1;
 #endif
         }
-        // the ring and the scratch records written above are read by other lanes of this wave in a later pass: LDS and
-        // global accesses of one wave complete in issue order, the fence only stops the compiler from moving them
+        // the ring and the records written above are read by other lanes of this wave in a later pass: LDS and global
+        // accesses of one wave complete in issue order, the fence only stops the compiler from moving them
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+    if constexpr (APPEND) {  // the unused tail of this wave's last chunk: holes
+        int32_t* rp = ray_plane(out);
+        for (int64_t s = chunk_pos + lane; s < chunk_pos + chunk_left; s += 64)
+            if (s < ac.capacity) rp[s] = -1;
     }
 #ifdef OT_STAMP
     if (lane == 0) for (int q = 0; q < 12; ++q) atomicAdd(&queue[8 + q], st_acc[q]);
@@ -519,6 +560,7 @@ __global__ __launch_bounds__(256) void k_gen_probe(SceneBlob blob, T unit, RaysT
     if (active) {
         fl = in.flags[i];
         r = load_ray(in, i, fl);
+        if ((uint32_t)r.last >= (uint32_t)sc.n_nodes) r.last = -1;
         cls = in.id[i];
     }
     const GateCtx gate = {counts, n_classes, cls, nullptr, probe, n, i};
@@ -591,6 +633,7 @@ __global__ __launch_bounds__(256) void k_gen_pass(SceneBlob blob, T unit, RaysT<
     if (active) {
         fl = in.flags[i];
         r = load_ray(in, i, fl);
+        if ((uint32_t)r.last >= (uint32_t)sc.n_nodes) r.last = -1;
         cls = in.id[i];
     }
     const bool dead = active && (fl & OT_RAY_DEAD);
@@ -623,7 +666,7 @@ __global__ __launch_bounds__(256) void k_gen_pass(SceneBlob blob, T unit, RaysT<
             const int32_t t = my_tree;
             if (dead) store_segment<T, GEN_NT>(out, slot, r, r.len, t, -2);
             else if (h.node < 0) store_segment<T, GEN_NT>(out, slot, r, r.len, t, -1);
-            else store_segment<T, GEN_NT>(out, slot, r, h.t, t, sc.nodes[h.node].leaf_id);
+            else store_segment<T, GEN_NT>(out, slot, r, h.t, t, leaf_id_of<T, F>(sc, h.node));
         }
     }
     const int64_t d0 = (int64_t)(before & 0xffffffffull) + kid_excl;
@@ -640,84 +683,3 @@ __global__ __launch_bounds__(256) void k_gen_pass(SceneBlob blob, T unit, RaysT<
     if (c_nk > 0) put(nk > 0 ? ch[0] : r, d0, nk > 0);
     if (c_nk > 1) put(nk > 1 ? ch[1] : r, d0 + 1, nk > 1);
 }
-
-// totals of a generation from the scanned wave totals: segments written and rays of the next generation.  Runs between
-// the two passes: the emit pass takes its first slot from totals[2] (the cursor as it stood), so the caller's cursor
-// and next-generation count can be published here and the generation needs no closing kernel.
-__global__ void k_gen_totals(const unsigned long long* wave_total, const unsigned long long* wave_prefix, int64_t n_waves, int64_t* totals,
-                             int64_t* cursor, int64_t* n_next) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const unsigned long long all = wave_prefix[n_waves - 1] + wave_total[n_waves - 1];
-        totals[0] = (int64_t)(all >> 32);
-        totals[1] = (int64_t)(all & 0xffffffffull);
-        totals[2] = *cursor;
-        *cursor += totals[0];
-        *n_next = totals[1];
-    }
-}
-
-// rank[slot][i] = how many earlier rays of i's tree (this generation) hit limited leaf `slot`
-__global__ void k_gen_rank(const int32_t* tree, int64_t n, int32_t n_slots, const int32_t* ex, int32_t* rank) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int64_t head = tree_head(tree, i);
-    for (int s = 0; s < n_slots; ++s) rank[(int64_t)s * n + i] = ex[(int64_t)s * n + i] - ex[(int64_t)s * n + head];
-}
-// after the trace: each tree's last ray of the generation folds the generation's hits into the table
-__global__ void k_gen_counts(const int32_t* tree, const int32_t* ids, int64_t n, int32_t n_slots, const int32_t* rank,
-                             const int32_t* probe, const int32_t* slot_max, int32_t* counts, int32_t n_classes) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (i == n - 1 || tree[i + 1] != tree[i]) {
-        for (int s = 0; s < n_slots; ++s) {
-            if ((uint32_t)ids[i] >= (uint32_t)n_classes) break;  // id outside the table: not counted (count_gate's rule)
-            int32_t* c = counts + (int64_t)s * n_classes + ids[i];
-            const int32_t total = *c + rank[(int64_t)s * n + i] + probe[(int64_t)s * n + i];
-            *c = total < slot_max[s] ? total : (*c > slot_max[s] ? *c : slot_max[s]);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Monitor.record
-__global__ void k_mon_test(ot_monitor mon, SegsT<double> s, int64_t n, const int32_t* seg_count, int64_t n_rays, int32_t* hit,
-                           double* P, double* tt) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (seg_count) {  // [k][ray] layout of ot_trace_*: slot i is valid iff k < |seg_count[ray]|
-        const int32_t c = seg_count[i % n_rays];
-        if (i / n_rays >= (c < 0 ? -c : c)) { hit[i] = 0; return; }
-    }
-    const double rx = s.ox[i] - mon.origin[0], ry = s.oy[i] - mon.origin[1], rz = s.oz[i] - mon.origin[2];
-    const double* M = mon.M;
-    const double ox = M[0] * rx + M[3] * ry + M[6] * rz, oy = M[1] * rx + M[4] * ry + M[7] * rz,
-                 oz = M[2] * rx + M[5] * ry + M[8] * rz;
-    double dx = M[0] * s.dx[i] + M[3] * s.dy[i] + M[6] * s.dz[i], dy = M[1] * s.dx[i] + M[4] * s.dy[i] + M[7] * s.dz[i],
-           dz = M[2] * s.dx[i] + M[5] * s.dy[i] + M[8] * s.dz[i];
-    const double inv = 1.0 / sqrt(dx * dx + dy * dy + dz * dz);  // ray_to_local_coordinates renormalises
-    dx *= inv; dy *= inv; dz *= inv;
-    int32_t ok = 0;
-    if (dx != 0.0) {
-        const double t = -ox / dx;
-        if (!(fabs(t) < 1e-9 || t < 0.0 || t > s.len[i])) {
-            const double Px = ox + t * dx, Py = oy + t * dy, Pz = oz + t * dz;
-            if (fabs(Py) <= mon.half_width && fabs(Pz) <= mon.half_height) {
-                ok = 1;
-                P[3 * i] = Px; P[3 * i + 1] = Py; P[3 * i + 2] = Pz;
-                tt[i] = t;
-            }
-        }
-    }
-    hit[i] = ok;
-}
-__global__ void k_mon_compact(const int32_t* hit, const int64_t* off, const double* P, const double* tt, int64_t n,
-                              int64_t* hit_index, double* Px, double* Py, double* Pz, double* t, int64_t* n_hits) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (hit[i]) {
-        const int64_t d = off[i];
-        hit_index[d] = i; Px[d] = P[3 * i]; Py[d] = P[3 * i + 1]; Pz[d] = P[3 * i + 2]; t[d] = tt[i];
-    }
-    if (i == n - 1) *n_hits = off[i] + hit[i];
-}
-

@@ -3,7 +3,6 @@
 // No CPU fallback lives here: without a GPU every entry point fails with OT_ERR_HIP.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
-#include <hipcub/hipcub.hpp>
 
 #include <cmath>
 #include <cstdio>
@@ -12,6 +11,8 @@
 #include <vector>
 
 #include "kernels.h"
+#include "misc_kernels.h"
+#include "tables.h"
 
 // ------------------------------------------------------------------------------------------
 // error plumbing
@@ -53,6 +54,9 @@ struct ot_ctx {
     void *blob64 = nullptr, *blob32 = nullptr;
     size_t bytes64 = 0, bytes32 = 0;
     int32_t n_nodes = 0, n_mats = 0, n_aux = 0, n_slots = 0, max_children = 0;
+    int32_t n_phys = 0, n_runs = 0, runs_word64 = 0, runs_word32 = 0;  // instanced runs folded by fill_blob (trace_core.h NodeRef)
+    int32_t opt_append_chunk = 512;  // append layout: slots per claim
+    int32_t opt_instancing = 1;      // fold lattice children into instanced runs at upload
     double unit = 1e-2;
     uint32_t features = 0;
     int32_t root_max_items = 0;  // most items in one cell of the top-level grid
@@ -74,8 +78,8 @@ struct ot_ctx {
     int32_t opt_kernel = 0;  // 0 auto, 1 fused (lane per ray), 2 rolling lists (the heavy-scene kernel)
     int32_t last_launch[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // ot_debug_last_launch
     // heavy-scene launch plan per precision (a dozen occupancy queries): recomputed after an upload or an option change
-    struct RollingPlan { uint64_t epoch = 0; int wpb = 4, per_cu = 1; int32_t cap = 128; bool lds = false, rec_lds = false; };
-    RollingPlan plan[2];
+    struct RollingPlan { uint64_t epoch = 0; int wpb = 4, per_cu = 1; int32_t cap = 128; bool lds = false, rec_lds = false; size_t lds_bytes = 0; };
+    RollingPlan plan[2][2];  // [precision][output layout]
     uint64_t plan_epoch = 1;
     int32_t opt_rec_lds = -1;    // pair-queue scenes: records of the live rays in LDS (-1 auto, 0 never, 1 whenever it fits)
     int32_t opt_list_cap = 128;  // k_trace_rolling: live rays per wave (cfg 3: 128 beats 256 and 512)
@@ -160,14 +164,55 @@ static int64_t packable_cells(const ot_scene_desc* s) {
         if (g[11 + k + 1] - g[11 + k] > 42) return 0;
     return cells;
 }
-template <class T> static void fill_blob(const ot_scene_desc* s, std::vector<uint8_t>& out) {
+// Instanced runs: consecutive leaf children of a gridded group that differ only in origin, lab AABB and leaf id — the caps
+// of an MMA, the lenslets of an MLA, the mirrors of a DMD (component_group.py:228-304, 367).  The device image keeps one
+// record per run plus 9 reals per member (trace_core.h NodeRef); everything is compared bit for bit, so a lattice with
+// per-element drift (roc_drift, focal_drift) simply has no runs.  Children of gridded groups are only ever reached
+// through the group's grid, never by the linear walk, which is what makes folding them safe.
+struct NodeRun { int32_t first, count, pnode, geo; };
+static bool same_but_pose(const ot_node& a, const ot_node& b) {
+    return !memcmp(a.M, b.M, sizeof a.M) && !memcmp(a.lbox, b.lbox, sizeof a.lbox) && !memcmp(a.p, b.p, sizeof a.p) &&
+           !memcmp(&a.reflectivity, &b.reflectivity, 4 * sizeof(double)) && a.kind == b.kind && a.flags == b.flags && a.shape == b.shape &&
+           a.interaction == b.interaction && a.mat1 == b.mat1 && a.mat2 == b.mat2 && a.roc_kind == b.roc_kind &&
+           a.max_interact_count < 0 && b.max_interact_count < 0 && a.aux < 0 && b.aux < 0 && b.leaf_id == a.leaf_id + 1;
+}
+static std::vector<NodeRun> find_runs(const ot_scene_desc* s) {
+    std::vector<NodeRun> runs;
+    constexpr int MIN_RUN = 8, MAX_RUNS = 8;
+    for (int g = 0; g < s->n_nodes; ++g) {
+        const ot_node& grp = s->nodes[g];
+        if (grp.kind != OT_NODE_GROUP || !(grp.flags & OT_NODE_GRID)) continue;
+        for (int j = g + 1; j < grp.end;) {  // (validate_scene: every child of a gridded group is a leaf)
+            int e = j + 1;
+            while (e < grp.end && s->nodes[e].kind == OT_NODE_LEAF && s->nodes[e - 1].kind == OT_NODE_LEAF && same_but_pose(s->nodes[e - 1], s->nodes[e])) ++e;
+            if (e - j >= MIN_RUN && (int)runs.size() < MAX_RUNS) runs.push_back({j, e - j, 0, 0});
+            j = e;
+        }
+    }
+    return runs;  // ascending in `first` (groups are visited in node order, children in order)
+}
+
+template <class T> static void fill_blob(const ot_scene_desc* s, const std::vector<NodeRun>& runs_in, std::vector<uint8_t>& out, int32_t& n_phys,
+                                         int32_t& runs_word) {
+    std::vector<NodeRun> runs = runs_in;
     const int64_t pack = packable_cells(s);
-    const size_t nb = sizeof(DNode<T>) * s->n_nodes, mb = sizeof(DMat<T>) * s->n_materials, ab = sizeof(T) * (s->n_aux + pack);
-    out.assign(((nb + mb + ab + 15) / 16) * 16, 0);
+    int folded = 0, geo_reals = 0;
+    for (const NodeRun& r : runs) { folded += r.count - 1; geo_reals += 9 * r.count; }
+    n_phys = s->n_nodes - folded;
+    const size_t nb = sizeof(DNode<T>) * n_phys, mb = sizeof(DMat<T>) * s->n_materials, ab = sizeof(T) * (s->n_aux + pack + geo_reals);
+    const size_t rb = sizeof(int32_t) * 4 * runs.size();
+    out.assign(((nb + mb + ab + rb + 15) / 16) * 16, 0);
     DNode<T>* nodes = reinterpret_cast<DNode<T>*>(out.data());
+    size_t next_run = 0;
+    int phys = 0;
     for (int i = 0; i < s->n_nodes; ++i) {
+        if (next_run < runs.size() && i == runs[next_run].first) runs[next_run].pnode = phys;
+        if (next_run < runs.size() && i > runs[next_run].first) {  // a folded member
+            if (i == runs[next_run].first + runs[next_run].count - 1) ++next_run;
+            continue;
+        }
         const ot_node& h = s->nodes[i];
-        DNode<T>& d = nodes[i];
+        DNode<T>& d = nodes[phys++];
         for (int k = 0; k < 9; ++k) d.M[k] = (T)h.M[k];
         for (int k = 0; k < 3; ++k) d.org[k] = (T)h.origin[k];
         for (int k = 0; k < 6; ++k) { d.aabb[k] = (T)h.aabb[k]; d.lbox[k] = (T)h.lbox[k]; }
@@ -202,10 +247,35 @@ template <class T> static void fill_blob(const ot_scene_desc* s, std::vector<uin
     }
     T* aux = reinterpret_cast<T*>(out.data() + nb + mb);
     for (int i = 0; i < s->n_aux; ++i) aux[i] = (T)s->aux[i];
+    if (sizeof(T) == 4) {
+        // The cell lookup of a gridded group widens the ray's footprint by the grid's margin (trace_core.h grid_children);
+        // in single precision the footprint itself carries a few ulp of the coordinates, far above the 1e-7 the host
+        // chose for double: widen to 64 ulp of the group's largest coordinate (a fraction of a percent of a cell).
+        for (int i = 0; i < s->n_nodes; ++i) {
+            const ot_node& g = s->nodes[i];
+            if (g.kind != OT_NODE_GROUP || !(g.flags & OT_NODE_GRID)) continue;
+            double big = 0.0;
+            for (int k = 0; k < 6; ++k) big = std::fmax(big, std::fabs(g.aabb[k]));
+            const double m = 64.0 * 1.1920929e-7 * big;
+            if ((double)aux[g.aux + 8] < m) aux[g.aux + 8] = (T)m;
+        }
+    }
     for (int64_t k = 0; k < pack; ++k) {
         const double* start = s->aux + s->root_grid + 11;
         aux[s->n_aux + k] = (T)(start[k] + 2048.0 * (start[k + 1] - start[k]));
     }
+    int32_t geo = (int32_t)(s->n_aux + pack);
+    for (NodeRun& r : runs) {  // per member: origin[3], lab AABB[6]
+        r.geo = geo;
+        for (int m = 0; m < r.count; ++m) {
+            const ot_node& h = s->nodes[r.first + m];
+            for (int k = 0; k < 3; ++k) aux[geo++] = (T)h.origin[k];
+            for (int k = 0; k < 6; ++k) aux[geo++] = (T)h.aabb[k];
+        }
+    }
+    runs_word = (int32_t)((nb + mb + ab) / 4);
+    int32_t* rt = reinterpret_cast<int32_t*>(out.data() + nb + mb + ab);
+    for (size_t k = 0; k < runs.size(); ++k) { rt[4 * k] = runs[k].first; rt[4 * k + 1] = runs[k].count; rt[4 * k + 2] = runs[k].pnode; rt[4 * k + 3] = runs[k].geo; }
 }
 
 // which code paths the scene needs (trace_core.h feature mask)
@@ -408,8 +478,12 @@ int ot_scene_upload(ot_ctx* c, const ot_scene_desc* s) {
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
     std::vector<uint8_t> b64, b32;
-    fill_blob<double>(s, b64);
-    fill_blob<float>(s, b32);
+    const std::vector<NodeRun> runs = c->opt_instancing ? find_runs(s) : std::vector<NodeRun>();
+    int32_t n_phys = 0;
+    fill_blob<double>(s, runs, b64, n_phys, c->runs_word64);
+    fill_blob<float>(s, runs, b32, n_phys, c->runs_word32);
+    c->n_phys = n_phys;
+    c->n_runs = (int32_t)runs.size();
     HIP_TRY(hipStreamSynchronize(c->stream));  // previous launches may still read the old scene
     if (c->blob64) { (void)hipFree(c->blob64); c->blob64 = nullptr; }
     if (c->blob32) { (void)hipFree(c->blob32); c->blob32 = nullptr; }
@@ -488,59 +562,169 @@ template <class T> static int32_t pair_ok(const ot_ctx* c, const ot_segments* s,
     return 1;
 }
 
-// Address of one k_trace_fused instantiation, or nullptr for the combinations the launch logic never selects: the
-// 128-register cap (MINW = 4) on the fp64 Snell kernel would spill (145 VGPRs wanted), so it is not even compiled.
-template <class T, uint32_t FM, bool L, int W, bool N>
-static auto fused_ptr() {
-    using Kern = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, SegsT<T>, int32_t*, int32_t*, int32_t, int32_t);
-    if constexpr (sizeof(T) == 8 && W == 4 && (FM & F_REFRACT) != 0) return (Kern) nullptr;
-    else return (Kern)k_trace_fused<T, FM, L, W, N>;
+template <class T> static SceneBlob make_blob(const ot_ctx* c) {
+    constexpr bool f64 = sizeof(T) == 8;
+    SceneBlob blob;
+    blob.words = (const uint32_t*)(f64 ? c->blob64 : c->blob32);
+    blob.n_words = (int32_t)((f64 ? c->bytes64 : c->bytes32) / 4);
+    blob.n_nodes = c->n_nodes;
+    blob.n_phys = c->n_phys;
+    blob.n_mats = c->n_mats;
+    blob.root = c->root_grid;
+    blob.root_pack = c->root_pack;
+    blob.cache_mat = c->cache_mat;
+    blob.n_runs = c->n_runs;
+    blob.runs_word = f64 ? c->runs_word64 : c->runs_word32;
+    return blob;
 }
 
-// the pair-queue variants of the heavy-scene kernel (trace_core.h flat_grid_hit): planar scenes under a top-level grid
-// of leaves, with circular / rectangular apertures only (FM = FR) or with polygon / boolean ones as well (FR | F_POLY)
-template <class T, uint32_t FM, bool L>
-static auto rolling_flat_ptr() {
-    using KernR = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, SegsT<T>, int32_t*, int32_t*, int32_t, WaveScratch<T>, int32_t,
-                           unsigned long long*, int32_t, int32_t);
-    return (KernR)k_trace_rolling<T, (FM | F_FLAT), L, false>;
-}
-// ... and with the records of the live rays in LDS next to the scene image (single precision)
-template <class T, uint32_t FM>
-static auto rolling_flat_lds_ptr() {
-    using KernR = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, SegsT<T>, int32_t*, int32_t*, int32_t, WaveScratch<T>, int32_t,
-                           unsigned long long*, int32_t, int32_t);
-    if constexpr (sizeof(T) == 4) return (KernR)k_trace_rolling<T, (FM | F_FLAT), true, false, true>;
-    else return (KernR) nullptr;
+// Heavy scenes: persistent waves with their own lists of live rays (k_trace_rolling).  OUT = SegsT<T>: the [k][ray] slots of
+// ot_trace_*; SegPlanes<T>: the append layout of ot_trace_append_*.
+template <class T, class OUT>
+static int launch_rolling(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, const OUT& out, const AppendCtl& ac, int32_t* seg_count,
+                          int32_t* counts, int32_t n_classes) {
+    using namespace preset;  // tables.h
+    constexpr bool f64 = sizeof(T) == 8, append = std::is_same<OUT, SegPlanes<T>>::value;
+    const SceneBlob blob = make_blob<T>(c);
+    const size_t bytes = f64 ? c->bytes64 : c->bytes32;
+    const uint32_t need = c->features;
+    // Scenes under a top-level grid (many separate components, rays of a wave unrelated after the first bounce)
+    // mix generations in a list and top it up continuously.  Scenes whose rays all run through the same sequence
+    // of surfaces (cfg 5) keep generation-pure lists: mixing costs them more than the tails do (cfg 5 fp32:
+    // 36.6 vs 31.6 ms; cfg 3 fp32: 5.1 vs 5.5 ms).
+    const bool mix = c->opt_mix < 0 ? c->root_grid >= 0 : (c->opt_mix != 0 && c->root_grid >= 0);
+    const size_t img = ((bytes + 15) / 16) * 16;
+    const bool img_fits = c->opt_lds_limit_kb != 0 && img <= 140 * 1024;  // else: read from L2, by the all-features preset
+    const int fr = !img_fits ? 3 : ((c->root_grid >= 0 && (need & ~FR) == 0) ? 0 : ((c->root_grid >= 0 && (need & ~FRP) == 0) ? 4 : ((need & ~FC) == 0 ? 1 : ((need & ~FD) == 0 ? 2 : 3))));
+    // planar scenes under a top-level grid of leaves: candidates through a wave-wide pair queue (flat_grid_hit)
+    const int32_t flat_cap = 64 * FLAT_CELLS * (c->root_max_items > 0 ? c->root_max_items : 1);
+    const bool flat_ok = c->opt_flat && mix && (fr == 0 || fr == 4) && c->root_pack >= 0 && flat_cap <= 8192 && c->n_runs == 0;  // queue entry = lane << 10 | index into the grid's item list
+    // Where the scene image and the records of the live rays live, and how many waves share an image.  The waves never
+    // synchronise after staging, so the workgroup size is only packaging: take what keeps most waves resident per CU
+    // (registers and LDS decide).  Preference: image + records in LDS (a pass then waits for nothing in global memory)
+    // when enough waves still fit; else image in LDS, records in the per-wave global scratch (L2); images beyond what
+    // LDS holds next to the lists are read from L2 (all-features preset only).
+    const size_t entry = sizeof(unsigned long long);
+    const size_t flat_bytes = flat_ok ? (((size_t)(FlatLds<T>::fixed_bytes + (size_t)flat_cap * 2) + 15) & ~(size_t)15) : 0;  // per wave (kernels.h)
+    const size_t rec_bytes = 12 * sizeof(T) + 4 * ((need & F_LIMIT) && fr == 3 ? 2 : 1);  // per record of a live ray (kernels.h rec_int_words)
+    const int32_t cap0 = mix ? c->opt_list_cap : (c->opt_list_cap_pure > 0 ? c->opt_list_cap_pure : 256);
+    ot_ctx::RollingPlan& plan = c->plan[f64 ? 1 : 0][append ? 1 : 0];
+    if (plan.epoch != c->plan_epoch) {
+        struct Try { int waves = 0, wpb = 0, per_cu = 0; int32_t cap = 0; size_t lds = 0; };
+        auto evaluate = [&](bool lds_img, bool rec_lds, int32_t CAP, Try& best) -> int {
+            const void* k = (const void*)rolling_kernel<T, OUT>(fr, flat_ok, lds_img, rec_lds);
+            if (!k) return 0;
+            const size_t per_wave = (size_t)CAP * entry + flat_bytes + (rec_lds ? rec_bytes * CAP : 0);
+            for (int wpb = 4; wpb * 64 <= rolling_max_threads<T>(fr, flat_ok, rec_lds); wpb += 4) {
+                const size_t lds_b = (lds_img ? img : 0) + (size_t)wpb * per_wave;
+                if (lds_b > 158 * 1024) continue;
+                if (lds_b > 48 * 1024) HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
+                int per_cu = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 64 * wpb, lds_b) != hipSuccess) per_cu = 0;
+                if (per_cu * wpb > best.waves) { best.waves = per_cu * wpb; best.wpb = wpb; best.per_cu = per_cu; best.cap = CAP; best.lds = lds_b; }
+            }
+            return 0;
+        };
+        Try chosen;
+        bool lds_img = false, rec_lds = false;
+        // (1) image and records in LDS: the largest list that still gives REC_LDS_MIN_WAVES waves per CU
+        const int rec_lds_min_waves = c->opt_rec_lds > 0 ? 4 : 12;  // OT_OPT_LDS_RECORDS = 1: whenever it fits at all
+        if (img_fits && c->opt_rec_lds != 0) {
+            Try t;
+            for (int32_t CAP = cap0; CAP >= 128; CAP >>= 1) {  // (a list holds at least two tickets)
+                t = Try();
+                const int rc = evaluate(true, true, CAP, t);
+                if (rc) return rc;
+                if (t.waves >= rec_lds_min_waves) break;
+            }
+            if (t.waves >= rec_lds_min_waves) { chosen = t; lds_img = rec_lds = true; }
+        }
+        // (2) image in LDS, records in global scratch
+        if (!chosen.waves && img_fits) {
+            for (int32_t CAP = cap0; CAP >= 128 && !chosen.waves; CAP >>= 1) {
+                const int rc = evaluate(true, false, CAP, chosen);
+                if (rc) return rc;
+            }
+            lds_img = chosen.waves > 0;
+        }
+        // (3) image read from L2
+        if (!chosen.waves) {
+            const int rc = evaluate(false, false, cap0, chosen);
+            if (rc) return rc;
+        }
+        if (!chosen.waves) return fail(OT_ERR_UNSUPPORTED, "no k_trace_rolling launch configuration fits this scene image");
+        plan.epoch = c->plan_epoch; plan.wpb = chosen.wpb; plan.per_cu = chosen.per_cu; plan.cap = chosen.cap; plan.lds = lds_img;
+        plan.rec_lds = rec_lds; plan.lds_bytes = chosen.lds;
+    }
+    const int wpb = plan.wpb;
+    const int32_t CAP = plan.cap;
+    const auto kr = rolling_kernel<T, OUT>(fr, flat_ok, plan.lds, plan.rec_lds);
+    if (!kr) return fail(OT_ERR_UNSUPPORTED, "no k_trace_rolling instantiation for this scene / option combination");
+    const size_t lds_r = plan.lds_bytes;
+    if (lds_r > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
+    int per_cu_r = plan.per_cu;
+    if (c->opt_blocks_per_cu > 0) per_cu_r = c->opt_blocks_per_cu;
+    const int64_t want = (n + 64 * (int64_t)wpb - 1) / (64 * (int64_t)wpb);  // one ticket per wave at least
+    const int64_t capr = (int64_t)c->n_cus * per_cu_r;
+    const int gridr = (int)(want < capr ? want : capr);
+    // per-wave record scratch (by list position) + the ticket counter
+    const size_t wave_bytes = plan.rec_lds ? 0 : align_up((size_t)CAP * rec_bytes);
+    const size_t scratch_bytes = wave_bytes * (size_t)gridr * wpb;
+    if (c->blocked.ensure(scratch_bytes + 256)) return fail(OT_ERR_HIP, "hipMalloc of rolling-trace scratch failed");
+    c->blocked_queue_off = scratch_bytes;
+    WaveScratch<T> ws = {(uint8_t*)c->blocked.p, (int64_t)wave_bytes};
+    unsigned long long* queue = (unsigned long long*)((uint8_t*)c->blocked.p + scratch_bytes);
+#ifdef OT_STAMP
+    HIP_TRY(hipMemsetAsync(queue, 0, 24 * sizeof(unsigned long long), c->stream));
+#else
+    HIP_TRY(hipMemsetAsync(queue, 0, sizeof(unsigned long long), c->stream));
+#endif
+    if (append) HIP_TRY(hipMemsetAsync(ac.cursor, 0, sizeof(unsigned long long), c->stream));
+    hipEvent_t ev0, ev1;
+    int rc = timing_pair(c, &ev0, &ev1);
+    if (rc) return rc;
+    hipExtLaunchKernelGGL(kr, dim3(gridr), dim3(64 * wpb), (uint32_t)lds_r, c->stream, ev0, ev1, 0u, blob, (T)c->unit, view<T>(rays), n,
+                          K, out, ac, seg_count, counts, n_classes, ws, CAP, queue, mix ? 1 : 0, flat_ok ? flat_cap : 0);
+    HIP_TRY(hipGetLastError());
+    const int32_t shape[8] = {2, 64 * wpb, per_cu_r, gridr, (int32_t)lds_r, CAP, mix ? 1 : 0, (flat_ok ? 1 : 0) | (plan.rec_lds ? 2 : 0) | (append ? 4 : 0)};
+    for (int q = 0; q < 8; ++q) c->last_launch[q] = shape[q];
+    return 0;
 }
 
-template <class T>
-static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, const ot_segments* out, int32_t* seg_count,
-                       int32_t* counts, int32_t n_classes) {
+static int check_trace_args(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, const int32_t* seg_count, const int32_t* counts, int32_t n_classes) {
     if (!c) return fail(OT_ERR_INVALID, "ctx is NULL");
     if (!c->has_scene) return fail(OT_ERR_NOSCENE, "ot_scene_upload has not been called");
     if (c->max_children > 2) return fail(OT_ERR_UNSUPPORTED, "more than two children per hit");
     int rc = check_rays(rays, "rays");
     if (rc) return rc;
-    rc = check_segs(out);
-    if (rc) return rc;
     if (n < 0 || K < 1 || !seg_count) return fail(OT_ERR_INVALID, "bad n / max_segments / seg_count");
     if (n >= (int64_t)1 << 31) return fail(OT_ERR_INVALID, "n must be < 2^31 per launch (int32 ray index)");
     if (c->n_slots > 0 && (!counts || n_classes < 1)) return fail(OT_ERR_INVALID, "scene has limited surfaces: counts table required");
+    return 0;
+}
+
+template <class T>
+static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, const ot_segments* out, int32_t* seg_count,
+                       int32_t* counts, int32_t n_classes) {
+    int rc = check_trace_args(c, rays, n, K, seg_count, counts, n_classes);
+    if (rc) return rc;
+    rc = check_segs(out);
+    if (rc) return rc;
     if (n == 0) return 0;
     HIP_TRY(hipSetDevice(c->device));
+    using namespace preset;  // tables.h
     const bool f64 = sizeof(T) == 8;
-    SceneBlob blob;
-    blob.words = (const uint32_t*)(f64 ? c->blob64 : c->blob32);
+    const uint32_t need = c->features;
+    const int fi = (need & ~FA) == 0 ? 0 : ((need & ~FB) == 0 ? 1 : 2);
+    // Heavy scenes (many nodes per segment => VALU-bound, uneven path lengths) use the rolling lists; light ones are
+    // HBM-bound and keep one lane per ray with perfectly coalesced streams.  The all-features preset has no lane-per-ray
+    // form in double precision (it would need more than 256 registers): those scenes always take the lists.
     const size_t bytes = f64 ? c->bytes64 : c->bytes32;
-    blob.n_words = (int32_t)(bytes / 4);
-    blob.n_nodes = c->n_nodes;
-    blob.n_mats = c->n_mats;
-    blob.root = c->root_grid;
-    blob.root_pack = c->root_pack;
-    blob.cache_mat = c->cache_mat;
-    const int block = 256;
     const bool in_lds = bytes <= (size_t)c->opt_lds_limit_kb * 1024;
+    const bool use_rolling = c->opt_kernel == 2 || (c->opt_kernel == 0 && c->n_nodes >= 24 && K > 2) || (f64 && (fi == 2 || !in_lds));
+    if (use_rolling) return launch_rolling<T, SegsT<T>>(c, rays, n, K, view<T>(out), AppendCtl{nullptr, 0, 0}, seg_count, counts, n_classes);
+    const SceneBlob blob = make_blob<T>(c);
+    const int block = 256;
     const int64_t blocks_needed = (n + block - 1) / block;
     // Grid: small scenes (staging the blob costs nothing) get up to 256 blocks per CU, i.e. one ray per
     // lane up to 1.7e7 rays and a short grid-stride loop beyond: fresh blocks replace finished ones, which
@@ -554,148 +738,13 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
     if (c->opt_blocks_per_cu > 0) per_cu = c->opt_blocks_per_cu;
     const int64_t cap = (int64_t)c->n_cus * per_cu;
     const int grid = (int)(blocks_needed < cap ? blocks_needed : cap);
-    // smallest instantiation that covers the scene's features, then the launch options
-    constexpr uint32_t FA = F_AABB | F_LENS, FB = F_AABB | F_LENS | F_REFRACT, FC = FB | F_GRID | F_ROOT | F_SUBTREE,
-                       FR = FB | F_ROOT,  // planar scenes under a top-level grid that lists leaves only (cfg 3)
-                       FRP = FR | F_POLY,  // ... with polygon / boolean apertures (prisms with polygonal caps, blocks with holes)
-                       FD = F_AABB | F_REFRACT | F_CURVED | F_GRID;  // spherical / aspheric optics in gridded groups (cfg 5)
-    const uint32_t need = c->features;
-    // Heavy scenes (many nodes per segment => VALU-bound, uneven path lengths) use the blocked
-    // kernel; light ones are HBM-bound and keep one lane per ray with perfectly coalesced streams.
-    const bool use_blocked = c->opt_kernel == 2 || (c->opt_kernel == 0 && c->n_nodes >= 24 && K > 2);
-    if (use_blocked) {
-        // Heavy scenes: persistent waves with their own lists of live rays (k_trace_rolling).
-        using KernR = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, SegsT<T>, int32_t*, int32_t*, int32_t, WaveScratch<T>, int32_t,
-                               unsigned long long*, int32_t, int32_t);
-        // Scenes under a top-level grid (many separate components, rays of a wave unrelated after the first bounce)
-        // mix generations in a list and top it up continuously.  Scenes whose rays all run through the same sequence
-        // of surfaces (cfg 5) keep generation-pure lists: mixing costs them more than the tails do (cfg 5 fp32:
-        // 36.6 vs 31.6 ms; cfg 3 fp32: 5.1 vs 5.5 ms).
-        const bool mix = c->opt_mix < 0 ? c->root_grid >= 0 : (c->opt_mix != 0 && c->root_grid >= 0);
-        const int fr = (c->root_grid >= 0 && (need & ~FR) == 0) ? 0 : ((c->root_grid >= 0 && (need & ~FRP) == 0) ? 4 : ((need & ~FC) == 0 ? 1 : ((need & ~FD) == 0 ? 2 : 3)));
-        // [preset][image in LDS][non-temporal segment stores].  Mixed lists write the [k][ray] slots of a pass in fragments
-        // of several tickets: partial lines that the L2 can merge with what neighbouring passes write if the stores are
-        // PLAIN (cfg 3 fp32: 5.62 ms with non-temporal stores, 4.38 ms with plain ones, interleaved A/B); generation-pure
-        // lists write longer runs and keep the non-temporal stores (cfg 5: 19.3 vs 19.6 ms).
-#define OT_R(FM) {{k_trace_rolling<T, FM, false, false>, k_trace_rolling<T, FM, false, true>}, {k_trace_rolling<T, FM, true, false>, k_trace_rolling<T, FM, true, true>}}
-        static const KernR tr[5][2][2] = {OT_R(FR), OT_R(FC), OT_R(FD), OT_R(F_ALL), OT_R(FRP)};
-#undef OT_R
-        const int nt_r = (mix || !c->opt_nt) ? 0 : 1;
-        // planar scenes under a top-level grid of leaves: candidates through a wave-wide pair queue (flat_grid_hit)
-        const int32_t flat_cap = 64 * FLAT_CELLS * (c->root_max_items > 0 ? c->root_max_items : 1);
-        const bool flat_ok = c->opt_flat && mix && (fr == 0 || fr == 4) && c->root_pack >= 0 && flat_cap <= 8192;  // queue entry = lane << 10 | index into the grid's item list
-        static const KernR flat_k[2][2] = {{rolling_flat_ptr<T, FR, false>(), rolling_flat_ptr<T, FR, true>()},
-                                           {rolling_flat_ptr<T, FRP, false>(), rolling_flat_ptr<T, FRP, true>()}};
-        const int fp = fr == 4 ? 1 : 0;
-        static const int max_threads[5] = {blocked_threads<T, FR>(), blocked_threads<T, FC>(), blocked_threads<T, FD>(), blocked_threads<T, F_ALL>(),
-                                           blocked_threads<T, FRP>()};
-        // Where the scene image lives and how many waves share it.  The waves never synchronise after staging, so the
-        // workgroup size is only packaging: take the one that keeps most waves resident per CU (registers and LDS
-        // decide; cfg 5 fp32: 54 KB image, 152 VGPRs -> one 768-thread workgroup = 12 waves, against 2 x 256 threads
-        // = 8 waves).  Images beyond what LDS holds next to the lists are read from L2.
-        const size_t img = ((bytes + 15) / 16) * 16;
-        const size_t entry = sizeof(unsigned long long);
-        const size_t flat_bytes = ((size_t)(FlatLds<T>::fixed_bytes + (size_t)flat_cap * 2) + 15) & ~(size_t)15;  // per wave (kernels.h)
-        constexpr int REC_LDS_MIN_WAVES = 12;
-        const size_t rec_bytes = 12 * sizeof(T) + 12;  // per record of a live ray
-        const KernR kl = (flat_ok && !f64) ? (fp ? rolling_flat_lds_ptr<T, FRP>() : rolling_flat_lds_ptr<T, FR>()) : (KernR) nullptr;  // pair queue + records in LDS (fp32: a record is 60 bytes)
-        int32_t cap0 = mix ? c->opt_list_cap : (c->opt_list_cap_pure > 0 ? c->opt_list_cap_pure : 256);
-        int best_wpb = 4, best_waves = 0, best_per_cu = 1, best_cap = cap0;
-        bool best_lds = false, rec_lds = false;
-        ot_ctx::RollingPlan& plan = c->plan[f64 ? 1 : 0];
-        if (plan.epoch == c->plan_epoch) {
-            best_wpb = plan.wpb; best_per_cu = plan.per_cu; best_cap = plan.cap; best_lds = plan.lds; rec_lds = plan.rec_lds; best_waves = 1;
-        } else {
-            for (int pass = 0; pass < 2 && best_waves == 0; ++pass) {  // pass 0: image in LDS; pass 1: image in L2
-                const bool lds_img = pass == 0;
-                if (lds_img && (c->opt_lds_limit_kb == 0 || img > 140 * 1024)) continue;
-                for (int wpb = 4; wpb * 64 <= (flat_ok ? blocked_threads<T, FR | F_FLAT>() : max_threads[fr]); wpb += 4) {
-                    int32_t CAP = cap0;
-                    while (CAP > 128 && lds_img && img + (size_t)wpb * CAP * entry > 156 * 1024) CAP >>= 1;
-                    const size_t lds_b = (lds_img ? img : 0) + (size_t)wpb * CAP * entry + (flat_ok ? (size_t)wpb * flat_bytes : 0);
-                    if (lds_b > 158 * 1024) continue;
-                    KernR kq = flat_ok ? flat_k[fp][lds_img ? 1 : 0] : tr[fr][lds_img ? 1 : 0][nt_r];
-                    if (lds_b > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
-                    int per_cu = 0;
-                    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kq, 64 * wpb, lds_b) != hipSuccess) per_cu = 0;
-                    if (per_cu * wpb > best_waves) { best_waves = per_cu * wpb; best_wpb = wpb; best_per_cu = per_cu; best_cap = CAP; best_lds = lds_img; }
-                }
-            }
-            // Pair-queue scenes: the records of the live rays (15 words x CAP per wave) in LDS as well, when at least
-            // REC_LDS_MIN_WAVES waves per CU still fit.  A pass then touches global memory only for a ray's first load and
-            // for the segment records it writes — nothing it has to wait for (gfx9 retires loads and stores in order, so with
-            // the records in global memory every pass's loads queue behind the 29 stores of the pass before).
-            // (Offered to the curved-surface preset too, cfg 5 fp32: its 74 KB image leaves room for 8 such waves only —
-            // 31.2 instead of 19.7 ms — so the variant is compiled for the pair-queue preset alone.)
-            if (kl && c->opt_rec_lds != 0 && c->opt_lds_limit_kb != 0 && img <= 140 * 1024) {
-                int rw = 0, rwpb = 0, rcap = 0, rper = 0;
-                for (int32_t capl = cap0; capl >= 128; capl >>= 1) {
-                    const size_t per_wave = (size_t)capl * entry + (flat_ok ? flat_bytes : 0) + rec_bytes * capl;
-                    for (int wpb = 4; wpb <= 12; wpb += 4) {
-                        const size_t lds_b = img + (size_t)wpb * per_wave;
-                        if (lds_b > 158 * 1024) continue;
-                        HIP_TRY(hipFuncSetAttribute((const void*)kl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
-                        int per_cu = 0;
-                        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kl, 64 * wpb, lds_b) != hipSuccess) per_cu = 0;
-                        if (per_cu * wpb > rw) { rw = per_cu * wpb; rwpb = wpb; rcap = capl; rper = per_cu; }
-                    }
-                    if (rw >= REC_LDS_MIN_WAVES) break;  // the largest list that still gives the waves
-                }
-                if (rw >= (c->opt_rec_lds > 0 ? 4 : REC_LDS_MIN_WAVES)) {
-                    rec_lds = true; best_wpb = rwpb; best_cap = rcap; best_lds = true; best_waves = rw; best_per_cu = rper;
-                }
-            }
-            if (best_waves == 0) return fail(OT_ERR_HIP, "no launch configuration fits this scene image");
-            plan.epoch = c->plan_epoch; plan.wpb = best_wpb; plan.per_cu = best_per_cu; plan.cap = best_cap; plan.lds = best_lds; plan.rec_lds = rec_lds;
-        }
-        const int wpb = best_wpb;
-        const int32_t CAP = best_cap;
-        KernR kr = rec_lds ? kl : (flat_ok ? flat_k[fp][best_lds ? 1 : 0] : tr[fr][best_lds ? 1 : 0][nt_r]);
-        const size_t lds_r = (best_lds ? img : 0) + (size_t)wpb * CAP * entry + (flat_ok ? (size_t)wpb * flat_bytes : 0) + (rec_lds ? (size_t)wpb * rec_bytes * CAP : 0);
-        if (lds_r > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r));
-        int per_cu_r = best_per_cu;
-        if (c->opt_blocks_per_cu > 0) per_cu_r = c->opt_blocks_per_cu;
-        const int64_t want = (n + 64 * (int64_t)wpb - 1) / (64 * (int64_t)wpb);  // one ticket per wave at least
-        const int64_t capr = (int64_t)c->n_cus * per_cu_r;
-        const int gridr = (int)(want < capr ? want : capr);
-        // per-wave record scratch (by list position) + the ticket counter
-        const size_t wave_bytes = align_up((size_t)CAP * (12 * sizeof(T) + 12));
-        const size_t scratch_bytes = wave_bytes * (size_t)gridr * wpb;
-        if (c->blocked.ensure(scratch_bytes + 256)) return fail(OT_ERR_HIP, "hipMalloc of rolling-trace scratch failed");
-        c->blocked_queue_off = scratch_bytes;
-        WaveScratch<T> ws = {(uint8_t*)c->blocked.p, (int64_t)wave_bytes, CAP};
-        unsigned long long* queue = (unsigned long long*)((uint8_t*)c->blocked.p + scratch_bytes);
-#ifdef OT_STAMP
-        HIP_TRY(hipMemsetAsync(queue, 0, 24 * sizeof(unsigned long long), c->stream));
-#else
-        HIP_TRY(hipMemsetAsync(queue, 0, sizeof(unsigned long long), c->stream));
-#endif
-        hipEvent_t ev0, ev1;
-        rc = timing_pair(c, &ev0, &ev1);
-        if (rc) return rc;
-        hipExtLaunchKernelGGL(kr, dim3(gridr), dim3(64 * wpb), (uint32_t)lds_r, c->stream, ev0, ev1, 0u, blob, (T)c->unit, view<T>(rays), n,
-                              K, view<T>(out), seg_count, counts, n_classes, ws, CAP, queue, mix ? 1 : 0, flat_ok ? flat_cap : 0);
-        HIP_TRY(hipGetLastError());
-        const int32_t shape[8] = {2, 64 * wpb, per_cu_r, gridr, (int32_t)lds_r, CAP, mix ? 1 : 0, (flat_ok ? 1 : 0) | (rec_lds ? 2 : 0)};
-        for (int q = 0; q < 8; ++q) c->last_launch[q] = shape[q];
-        return 0;
-    }
     hipEvent_t ev0, ev1;
     rc = timing_pair(c, &ev0, &ev1);
     if (rc) return rc;
-    using Kern = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, SegsT<T>, int32_t*, int32_t*, int32_t, int32_t);
-    const int fi = (need & ~FA) == 0 ? 0 : ((need & ~FB) == 0 ? 1 : 2);
-    // the 128-register cap pays for the mirror/lens kernel only; the Snell kernel would spill (fp64: 145 VGPRs)
-    const int mw = (c->opt_minw == 4 && (fi == 0 || (fi == 1 && !f64))) ? 1 : 0, nt = c->opt_nt ? 1 : 0;
-#define OT_K(FM, L, W, N) fused_ptr<T, FM, L, W, N>()
-#define OT_ROW(FM) {{{OT_K(FM, false, 1, false), OT_K(FM, false, 1, true)}, {OT_K(FM, false, 4, false), OT_K(FM, false, 4, true)}}, \
-                    {{OT_K(FM, true, 1, false), OT_K(FM, true, 1, true)}, {OT_K(FM, true, 4, false), OT_K(FM, true, 4, true)}}}
-    static const Kern table[3][2][2][2] = {OT_ROW(FA), OT_ROW(FB),
-                                           {{{OT_K(F_ALL, false, 1, false), OT_K(F_ALL, false, 1, true)}, {nullptr, nullptr}},
-                                            {{OT_K(F_ALL, true, 1, false), OT_K(F_ALL, true, 1, true)}, {nullptr, nullptr}}}};
-#undef OT_ROW
-#undef OT_K
-    Kern kern = table[fi][in_lds ? 1 : 0][mw][nt];
+    // smallest instantiation that covers the scene's features; the 128-register cap pays for the mirror / lens kernel
+    // and the fp32 Snell kernel only (the fp64 Snell kernel would spill: 145 VGPRs)
+    const bool mw = c->opt_minw == 4 && (fi == 0 || (fi == 1 && !f64));
+    FusedKern<T> kern = fused_kernel<T>(fi, in_lds, mw, c->opt_nt != 0);
     if (!kern) return fail(OT_ERR_UNSUPPORTED, "no kernel instantiation for this scene / option combination");
     const size_t lds_bytes = in_lds ? bytes : 0;
     if (lds_bytes > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -707,6 +756,26 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
     return 0;
 }
 
+// Append layout: always the rolling lists (a light scene takes the planar preset FC).
+template <class T>
+static int trace_append(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, const ot_segment_block* out, int64_t* n_slots,
+                        int32_t* seg_count, int32_t* counts, int32_t n_classes) {
+    int rc = check_trace_args(c, rays, n, K, seg_count, counts, n_classes);
+    if (rc) return rc;
+    if (!out || !out->base || out->capacity < 0 || !n_slots) return fail(OT_ERR_INVALID, "bad segment block / n_slots");
+    if ((uintptr_t)out->base % 16 || out->capacity % 64) return fail(OT_ERR_INVALID, "segment block: base must be 16-byte aligned, capacity a multiple of 64");
+    HIP_TRY(hipSetDevice(c->device));
+    if (n == 0) {
+        HIP_TRY(hipMemsetAsync(n_slots, 0, sizeof(int64_t), c->stream));
+        return 0;
+    }
+    // slots per claim: one device-wide atomic per chunk.  512 keeps a cfg 3 trace (5e7 records) at 1e5 claims per launch;
+    // the price is the unused tail of every wave's last chunk (holes, ray = -1: half a chunk per wave on average).
+    const int32_t chunk = c->opt_append_chunk;
+    const SegPlanes<T> planes = {(uint8_t*)out->base, out->capacity};
+    const AppendCtl ac = {(unsigned long long*)n_slots, out->capacity, chunk};
+    return launch_rolling<T, SegPlanes<T>>(c, rays, n, K, planes, ac, seg_count, counts, n_classes);
+}
 
 extern "C" {
 
@@ -717,6 +786,14 @@ int ot_trace_f64(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, const ot_
 int ot_trace_f32(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, const ot_segments* out, int32_t* seg_count,
                  int32_t* counts, int32_t n_classes) {
     return trace_fused<float>(c, rays, n, K, out, seg_count, counts, n_classes);
+}
+int ot_trace_append_f64(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, const ot_segment_block* out, int64_t* n_slots,
+                        int32_t* seg_count, int32_t* counts, int32_t n_classes) {
+    return trace_append<double>(c, rays, n, K, out, n_slots, seg_count, counts, n_classes);
+}
+int ot_trace_append_f32(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, const ot_segment_block* out, int64_t* n_slots,
+                        int32_t* seg_count, int32_t* counts, int32_t n_classes) {
+    return trace_append<float>(c, rays, n, K, out, n_slots, seg_count, counts, n_classes);
 }
 
 }  // extern "C"
@@ -759,9 +836,7 @@ static int trace_generation(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
     int32_t* probe = (int32_t*)p; p += sz_slot;
     int32_t* probe_ex = (int32_t*)p; p += sz_slot;
     int32_t* rank = (int32_t*)p;
-    size_t tmp = 0, tmp_w = 0;
-    if (ns > 0) hipcub::DeviceScan::ExclusiveSum((void*)nullptr, tmp, probe, probe_ex, (int)n, c->stream);
-    hipcub::DeviceScan::ExclusiveSum((void*)nullptr, tmp_w, wave_total, wave_prefix, (int)n_waves, c->stream);
+    const size_t tmp = ns > 0 ? scan_tmp_bytes<int32_t>(n) : 0, tmp_w = scan_tmp_bytes<unsigned long long>(n_waves);
     if (c->scan_tmp.ensure((tmp > tmp_w ? tmp : tmp_w) + 256)) return fail(OT_ERR_HIP, "hipMalloc of scan scratch failed");
     const int block = 256;
     const int g1 = (int)((n + block - 1) / block);
@@ -772,27 +847,14 @@ static int trace_generation(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
         HIP_TRY(hipMemsetAsync(c->gen_mismatch, 0, sizeof(unsigned long long), c->stream));
     }
     mismatch = c->gen_mismatch;  // lives with the ctx: accumulated over all generations (ot_debug_generation_mismatches)
-    SceneBlob blob;
     constexpr bool f64 = sizeof(T) == 8;
     const size_t bytes = f64 ? c->bytes64 : c->bytes32;
-    blob.words = (const uint32_t*)(f64 ? c->blob64 : c->blob32);
-    blob.n_words = (int32_t)(bytes / 4);
-    blob.n_nodes = c->n_nodes;
-    blob.n_mats = c->n_mats;
-    blob.root = c->root_grid;
-    blob.root_pack = c->root_pack;
-    blob.cache_mat = c->cache_mat;
+    const SceneBlob blob = make_blob<T>(c);
     const bool in_lds = bytes <= (size_t)c->opt_lds_limit_kb * 1024;
     const size_t lds_bytes = in_lds ? bytes : 0;
-    // beam splitters and partially reflecting slabs are planar scenes: they get the small instantiation
-    // (145 instead of 255 VGPRs, 3 waves/SIMD instead of 1); count gates need the full one
-    constexpr uint32_t FG = F_AABB | F_LENS | F_REFRACT;
-    const bool small = (c->features & ~FG) == 0;
-    auto k_probe = in_lds ? k_gen_probe<T, F_ALL, true> : k_gen_probe<T, F_ALL, false>;
-    auto k_count = small ? (in_lds ? k_gen_pass<T, FG, true, false> : k_gen_pass<T, FG, false, false>)
-                         : (in_lds ? k_gen_pass<T, F_ALL, true, false> : k_gen_pass<T, F_ALL, false, false>);
-    auto k_emit = small ? (in_lds ? k_gen_pass<T, FG, true, true> : k_gen_pass<T, FG, false, true>)
-                        : (in_lds ? k_gen_pass<T, F_ALL, true, true> : k_gen_pass<T, F_ALL, false, true>);
+    const bool small = (c->features & ~preset::FB) == 0;  // planar scenes without count gates: the small instantiation (tables.h)
+    const ProbeKern<T> k_probe = probe_kernel<T>(in_lds);
+    const GenKern<T> k_count = gen_kernel<T>(small, in_lds, false), k_emit = gen_kernel<T>(small, in_lds, true);
     if (lds_bytes > 48 * 1024) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         HIP_TRY(hipFuncSetAttribute((const void*)k_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -803,14 +865,14 @@ static int trace_generation(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
         hipLaunchKernelGGL(k_probe, dim3(g1), dim3(block), lds_bytes, c->stream, blob, (T)c->unit, view<T>(rays), tree, n, budget,
                            counts, n_classes, probe);
         for (int s = 0; s < ns; ++s)
-            HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->scan_tmp.p, tmp, probe + (int64_t)s * n, probe_ex + (int64_t)s * n, (int)n, c->stream));
+            exclusive_scan<int32_t, int32_t>(c->scan_tmp.p, probe + (int64_t)s * n, probe_ex + (int64_t)s * n, n, c->stream);
         hipLaunchKernelGGL(k_gen_rank, dim3(g1), dim3(block), 0, c->stream, tree, n, ns, probe_ex, rank);
     }
     // count -> scan of the wave totals -> emit (kernels.h: k_gen_pass)
     hipLaunchKernelGGL(k_count, dim3(g1), dim3(block), lds_bytes, c->stream, blob, (T)c->unit, view<T>(rays), tree, n, budget,
                        (const int64_t*)seg_cursor, view<T>(out), out_capacity, view_out<T>(next), next_tree, next_capacity, code, wave_total,
                        (const unsigned long long*)wave_prefix, counts, n_classes, (const int32_t*)rank, mismatch);
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->scan_tmp.p, tmp_w, wave_total, wave_prefix, (int)n_waves, c->stream));
+    exclusive_scan<unsigned long long, unsigned long long>(c->scan_tmp.p, wave_total, wave_prefix, n_waves, c->stream);
     hipLaunchKernelGGL(k_gen_totals, dim3(1), dim3(64), 0, c->stream, (const unsigned long long*)wave_total,
                        (const unsigned long long*)wave_prefix, n_waves, totals, seg_cursor, n_next);
     hipLaunchKernelGGL(k_emit, dim3(g1), dim3(block), lds_bytes, c->stream, blob, (T)c->unit, view<T>(rays), tree, n, budget,
@@ -860,12 +922,10 @@ int ot_monitor_record_f64(ot_ctx* c, const ot_monitor* mon, const ot_segments* s
     int64_t* off = (int64_t*)p; p += sz_off;
     double* P = (double*)p; p += sz_P;
     double* tt = (double*)p;
-    size_t tmp = 0;
-    hipcub::DeviceScan::ExclusiveSum((void*)nullptr, tmp, hit, off, (int)n, c->stream);
-    if (c->scan_tmp.ensure(tmp + 256)) return fail(OT_ERR_HIP, "hipMalloc of scan scratch failed");
+    if (c->scan_tmp.ensure(scan_tmp_bytes<int64_t>(n) + 256)) return fail(OT_ERR_HIP, "hipMalloc of scan scratch failed");
     const int block = 256, grid = (int)((n + block - 1) / block);
     hipLaunchKernelGGL(k_mon_test, dim3(grid), dim3(block), 0, c->stream, *mon, view<double>(segs), n, seg_count, n_rays, hit, P, tt);
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(c->scan_tmp.p, tmp, hit, off, (int)n, c->stream));
+    exclusive_scan<int32_t, int64_t>(c->scan_tmp.p, hit, off, n, c->stream);
     hipLaunchKernelGGL(k_mon_compact, dim3(grid), dim3(block), 0, c->stream, hit, off, P, tt, n, hit_index, (double*)Px, (double*)Py,
                        (double*)Pz, (double*)t, n_hits);
     HIP_TRY(hipGetLastError());
@@ -912,6 +972,10 @@ int ot_set_option(ot_ctx* c, int32_t option, int32_t value) {
         case OT_OPT_LDS_RECORDS:
             if (value < -1 || value > 1) return fail(OT_ERR_INVALID, "OT_OPT_LDS_RECORDS takes -1 (auto), 0 or 1");
             c->opt_rec_lds = value; return 0;
+        case OT_OPT_APPEND_CHUNK:
+            if (value < 64 || value > (1 << 20) || value % 64) return fail(OT_ERR_INVALID, "OT_OPT_APPEND_CHUNK takes a multiple of 64, 64..1048576");
+            c->opt_append_chunk = value; return 0;
+        case OT_OPT_INSTANCING: c->opt_instancing = value != 0; return 0;  // takes effect at the next ot_scene_upload
         case OT_OPT_BLOCKS_PER_CU:
             if (value < 0 || value > 65536) return fail(OT_ERR_INVALID, "OT_OPT_BLOCKS_PER_CU out of range");
             c->opt_blocks_per_cu = value; return 0;

@@ -1,0 +1,53 @@
+// tables.h — which kernel instantiations exist, and the lookups the launch code (optable_hip.hip) uses to get them.
+// The instantiations are compiled in their own translation units, one per kernel family and precision
+// (inst_fused.hip, inst_rolling.hip, inst_gen.hip, each built with -DOT_REAL=double and -DOT_REAL=float), so the
+// library builds in parallel and the launch code only ever sees function pointers.  A lookup returns nullptr for a
+// combination that is not compiled; the launch code never asks for one.
+#pragma once
+
+#include "kernels.h"
+
+// scene feature presets (trace_core.h feature mask): the launch code picks the smallest one that covers the scene
+namespace preset {
+constexpr uint32_t FA = F_AABB | F_LENS;                       // mirrors + thin lenses (cfg 2)
+constexpr uint32_t FB = FA | F_REFRACT;                        // + Snell interfaces, materials (cfg 4)
+constexpr uint32_t FC = FB | F_GRID | F_ROOT | F_SUBTREE;      // planar scenes with gridded groups / subtrees under a top-level grid
+constexpr uint32_t FR = FB | F_ROOT;                           // planar scenes under a top-level grid that lists leaves only (cfg 3)
+constexpr uint32_t FRP = FR | F_POLY;                          // ... with polygon / boolean apertures
+constexpr uint32_t FD = F_AABB | F_REFRACT | F_CURVED | F_GRID;  // spherical / aspheric optics in gridded groups (cfg 5)
+}  // namespace preset
+
+template <class T>
+using FusedKern = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, SegsT<T>, int32_t*, int32_t*, int32_t, int32_t);
+template <class T, class OUT>
+using RollingKern = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, OUT, AppendCtl, int32_t*, int32_t*, int32_t, WaveScratch<T>, int32_t,
+                             unsigned long long*, int32_t, int32_t);
+template <class T>
+using GenKern = void (*)(SceneBlob, T, RaysT<T>, const int32_t*, int64_t, int32_t*, const int64_t*, SegsT<T>, int64_t, RaysOutT<T>, int32_t*,
+                         int64_t, uint8_t*, unsigned long long*, const unsigned long long*, int32_t*, int32_t, const int32_t*,
+                         unsigned long long*);
+template <class T>
+using ProbeKern = void (*)(SceneBlob, T, RaysT<T>, const int32_t*, int64_t, const int32_t*, int32_t*, int32_t, int32_t*);
+
+// k_trace_fused: fi = 0 FA, 1 FB, 2 F_ALL; image in LDS; 128-register cap (4 waves per SIMD); non-temporal segment stores
+template <class T> FusedKern<T> fused_kernel(int fi, bool lds, bool minw4, bool nt);
+// k_trace_rolling: fr = 0 FR, 1 FC, 2 FD, 3 F_ALL, 4 FRP; flat = the pair-queue walk (FR / FRP only); image in LDS or read
+// from L2 (all-features preset only); records of the live rays in LDS (fp32: pair queue and FD) or in the global scratch.
+// OUT = SegsT<T> ([k][ray] slots) or SegPlanes<T> (append layout).  Non-temporal segment stores are part of the choice:
+// the sparse [k][ray] slots of mixed lists want plain stores (partial lines merge in L2), everything else streams.
+template <class T, class OUT> RollingKern<T, OUT> rolling_kernel(int fr, bool flat, bool lds, bool rec_lds);
+template <class T> int rolling_max_threads(int fr, bool flat, bool rec_lds);
+// k_gen_pass / k_gen_probe: small = the planar preset FB instead of F_ALL
+template <class T> GenKern<T> gen_kernel(bool small, bool lds, bool emit);
+template <class T> ProbeKern<T> probe_kernel(bool lds);
+
+#define OT_DECLARE_TABLES(T)                                                       \
+    template <> FusedKern<T> fused_kernel<T>(int, bool, bool, bool);               \
+    template <> RollingKern<T, SegsT<T>> rolling_kernel<T, SegsT<T>>(int, bool, bool, bool);          \
+    template <> RollingKern<T, SegPlanes<T>> rolling_kernel<T, SegPlanes<T>>(int, bool, bool, bool);  \
+    template <> int rolling_max_threads<T>(int, bool, bool);                       \
+    template <> GenKern<T> gen_kernel<T>(bool, bool, bool);                        \
+    template <> ProbeKern<T> probe_kernel<T>(bool);
+OT_DECLARE_TABLES(double)
+OT_DECLARE_TABLES(float)
+#undef OT_DECLARE_TABLES

@@ -92,10 +92,12 @@ template <class T> struct DMat {
 };
 
 template <class T> struct Scene {
-    const DNode<T>* nodes;
+    const DNode<T>* nodes;  // PHYSICAL records: every node once, except that a run of instanced leaves keeps one prototype
     const DMat<T>* mats;
     const T* aux;
-    int32_t n_nodes;
+    const int32_t* runs;    // [n_runs][4]: first virtual index, count, physical index of the prototype, aux offset of the geo table
+    int32_t n_nodes;        // VIRTUAL node count: the caller's depth-first list (indices in hits, ties, skip lists, grid items)
+    int32_t n_runs;
     int32_t n_mats;
     int32_t cache_mat;  // first Sellmeier material, -1 when every material is a constant
     int32_t root;  // aux offset of the top-level grid, -1 when the scene has none
@@ -116,6 +118,47 @@ template <class T> struct Hit {
     T px, py, pz;  // local hit point
     int32_t node;  // -1: none
 };
+
+// A node as the kernels see it: the record (shared by all members of an instanced run) and the pose that is the member's
+// own — origin[3] and lab AABB[6], contiguous — plus its leaf id.  Instanced runs: the children of a lattice group (MMA caps,
+// MLA lenslets, DMD mirrors: component_group.py:228-304, 367) differ only in origin, box and leaf id, so the device image
+// keeps ONE record per run and a 9-real table entry per member instead of 53 / 94 words each (cfg 5: 74 KB -> 16 KB, which is
+// what lets the records of the live rays sit in LDS next to the image).  The virtual index space is the caller's: hits,
+// tie-breaks, `last` and grid items never see the compression.
+template <class T> struct NodeRef {
+    const DNode<T>* nd;
+    const T* geo;      // org[0..2], aabb[3..8]
+    int32_t inst;      // member number inside its run, 0 for ordinary nodes
+};
+template <class T, uint32_t F> __device__ __forceinline__ NodeRef<T> node_ref(const Scene<T>& sc, int v) {
+    NodeRef<T> r;
+    r.inst = 0;
+    if constexpr ((F & F_GRID) != 0) {  // runs only exist below gridded groups
+        int shift = 0;
+        for (int k = 0; k < sc.n_runs; ++k) {  // scene-uniform trip count (0 for most scenes, 1 for cfg 5)
+            const int first = sc.runs[4 * k], cnt = sc.runs[4 * k + 1];
+            if (v < first) break;
+            if (v < first + cnt) {
+                r.nd = sc.nodes + sc.runs[4 * k + 2];
+                r.inst = v - first;
+                r.geo = sc.aux + sc.runs[4 * k + 3] + 9 * r.inst;
+                return r;
+            }
+            shift += cnt - 1;
+        }
+        r.nd = sc.nodes + (v - shift);
+    } else {
+        r.nd = sc.nodes + v;
+    }
+    r.geo = r.nd->org;  // org[3] and aabb[6] are adjacent in the record
+    return r;
+}
+
+// what ot_segments.surface reports for a hit on virtual node v (the members of a run are consecutive leaves)
+template <class T, uint32_t F> __device__ __forceinline__ int32_t leaf_id_of(const Scene<T>& sc, int v) {
+    const NodeRef<T> nr = node_ref<T, F>(sc, v);
+    return nr.nd->leaf_id + nr.inst;
+}
 
 template <class T> __device__ __forceinline__ T sqrt_t(T x);
 template <> __device__ __forceinline__ double sqrt_t<double>(double x) { return sqrt(x); }
@@ -606,10 +649,11 @@ template <int GATE> __device__ __forceinline__ bool count_gate(const GateCtx& g,
 // A planar leaf is cheaper to reject by its sign/distance tests than by the slab test, and a hit
 // needs both, so the slab test runs last and only for leaves that would otherwise be hits.
 template <class T, uint32_t F, int GATE, bool ORDERED, bool DEFER_AABB = false>
-__device__ __forceinline__ void test_leaf(const Scene<T>& sc, const DNode<T>& nd, int idx, const RayState<T>& r, Hit<T>& best,
+__device__ __forceinline__ void test_leaf(const Scene<T>& sc, const NodeRef<T>& nr, int idx, const RayState<T>& r, Hit<T>& best,
                                           const GateCtx& gate, const RayInv<T>* ri = nullptr) {
+    const DNode<T>& nd = *nr.nd;
     if (GATE == GATE_PROBE && nd.max_count < 0) return;  // the probe pass only looks at limited leaves
-    const T rx = r.ox - nd.org[0], ry = r.oy - nd.org[1], rz = r.oz - nd.org[2];
+    const T rx = r.ox - nr.geo[0], ry = r.oy - nr.geo[1], rz = r.oz - nr.geo[2];
     const int sh = nd.shape;
     const bool planar = sh == OT_SHAPE_CIRCLE || sh == OT_SHAPE_RECT || sh == OT_SHAPE_POLYGON2D || sh == OT_SHAPE_CSG;
     const bool limited = (F & F_LIMIT) && nd.max_count >= 0;
@@ -636,7 +680,7 @@ __device__ __forceinline__ void test_leaf(const Scene<T>& sc, const DNode<T>& nd
         if (!limited && !(t < best.t || (!ORDERED && t == best.t && idx < best.node))) return;
         if (DEFER_AABB && (nd.flags & OT_NODE_CHECK_AABB)) {  // the leaf's own AABB test, after the cheap rejections
             T u1, u2;
-            if (!slab_inv(r.ox, r.oy, r.oz, *ri, nd.aabb, u1, u2)) return;
+            if (!slab_inv(r.ox, r.oy, r.oz, *ri, nr.geo + 3, u1, u2)) return;
         }
         const T loy = dot3_t(nd.M[1], rx, nd.M[4], ry, nd.M[7], rz), loz = dot3_t(nd.M[2], rx, nd.M[5], ry, nd.M[8], rz);
         const T ldy = dot3_t(nd.M[1], r.dx, nd.M[4], r.dy, nd.M[7], r.dz), ldz = dot3_t(nd.M[2], r.dx, nd.M[5], r.dy, nd.M[8], r.dz);
@@ -646,7 +690,7 @@ __device__ __forceinline__ void test_leaf(const Scene<T>& sc, const DNode<T>& nd
         const T prune_t = limited ? Num<T>::inf() : best.t;
         if (DEFER_AABB && (nd.flags & OT_NODE_CHECK_AABB)) {  // curved leaves: the slab test is the cheap one
             T u1, u2;
-            if (!slab_inv(r.ox, r.oy, r.oz, *ri, nd.aabb, u1, u2)) return;
+            if (!slab_inv(r.ox, r.oy, r.oz, *ri, nr.geo + 3, u1, u2)) return;
             if (beyond_best(u1, prune_t)) return;
         }
         T ox, oy, oz, dx, dy, dz;
@@ -704,9 +748,9 @@ __device__ __forceinline__ void grid_children(const Scene<T>& sc, const DNode<T>
             for (int k = kb; k < ke; ++k) {
                 const int ci = (int)items[k];
                 if (ci == cand0 || ci == cand1 || ci == cand2 || ci == cand3) continue;  // listed in several cells
-                const DNode<T>& ch = sc.nodes[ci];
+                const NodeRef<T> ch = node_ref<T, F>(sc, ci);
                 T u1, u2;
-                if (!slab_inv(r.ox, r.oy, r.oz, ri, ch.aabb, u1, u2)) continue;  // the child's own AABB test, unchanged
+                if (!slab_inv(r.ox, r.oy, r.oz, ri, ch.geo + 3, u1, u2)) continue;  // the child's own AABB test, unchanged
                 if (beyond_best(u1, best.t)) continue;  // (gridded groups hold no count-limited child)
                 if (ncand == 0) cand0 = ci;
                 else if (ncand == 1) cand1 = ci;
@@ -719,7 +763,7 @@ __device__ __forceinline__ void grid_children(const Scene<T>& sc, const DNode<T>
 #pragma unroll 1
     for (int c = 0; c < 4; ++c) {  // one copy of the leaf test in the instruction stream
         const int ci = c == 0 ? cand0 : (c == 1 ? cand1 : (c == 2 ? cand2 : cand3));
-        if (c < ncand) test_leaf<T, F, GATE, false>(sc, sc.nodes[ci], ci, r, best, gate);
+        if (c < ncand) test_leaf<T, F, GATE, false>(sc, node_ref<T, F>(sc, ci), ci, r, best, gate);
     }
 }
 
@@ -728,12 +772,13 @@ __device__ __forceinline__ void grid_children(const Scene<T>& sc, const DNode<T>
 template <class T, uint32_t F, int GATE>
 __device__ __forceinline__ void walk_subtree(const Scene<T>& sc, int first, const RayState<T>& r, const RayInv<T>& ri, Hit<T>& best,
                                              const GateCtx& gate) {
-    const int last = sc.nodes[first].end;
+    const int last = node_ref<T, F>(sc, first).nd->end;
     for (int j = first; j < last;) {
-        const DNode<T>& nd = sc.nodes[j];
+        const NodeRef<T> nr = node_ref<T, F>(sc, j);
+        const DNode<T>& nd = *nr.nd;
         T t1 = T(0), t2 = T(0);
         if (nd.flags & OT_NODE_CHECK_AABB) {
-            if (!slab_inv(r.ox, r.oy, r.oz, ri, nd.aabb, t1, t2)) { j = nd.end; continue; }
+            if (!slab_inv(r.ox, r.oy, r.oz, ri, nr.geo + 3, t1, t2)) { j = nd.end; continue; }
             if (!(F & F_LIMIT) && beyond_best(t1, best.t)) { j = nd.end; continue; }
         }
         if (nd.kind == OT_NODE_GROUP) {
@@ -747,7 +792,7 @@ __device__ __forceinline__ void walk_subtree(const Scene<T>& sc, int first, cons
             ++j;
             continue;
         }
-        test_leaf<T, F, GATE, false>(sc, nd, j, r, best, gate);
+        test_leaf<T, F, GATE, false>(sc, nr, j, r, best, gate);
         ++j;
     }
 }
@@ -791,16 +836,16 @@ __device__ __forceinline__ void root_grid_hit(const Scene<T>& sc, const RayState
         const int kb = (int)start[cidx], ke = (int)start[cidx + 1];
         for (int k = kb; k < ke; ++k) {
             const int item = (int)items[k];
-            const DNode<T>& nd = sc.nodes[item];
+            const NodeRef<T> nr = node_ref<T, F>(sc, item);
             // the compiler lists leaves directly wherever it can (scene.py:_root_grid): cheap planar rejections
             // first, the leaf's own AABB test last; subtrees (stale boxes, gridded groups) take the general walk.
             // (A branch-free planar test was measured here, cfg 3 fp32: 5.54 against 5.09 ms with the early exits —
             // in a per-lane walk whole waves leave a candidate together often enough; in the slots of flat_grid_hit,
             // where 64 lanes hold 64 unrelated pairs, it is the other way round.)
             if constexpr (F & F_SUBTREE) {
-                if (nd.kind != OT_NODE_LEAF) { walk_subtree<T, F, GATE>(sc, item, r, ri, best, gate); continue; }
+                if (nr.nd->kind != OT_NODE_LEAF) { walk_subtree<T, F, GATE>(sc, item, r, ri, best, gate); continue; }
             }
-            test_leaf<T, F, GATE, false, true>(sc, nd, item, r, best, gate, &ri);
+            test_leaf<T, F, GATE, false, true>(sc, nr, item, r, best, gate, &ri);
         }
         const T texit = min_t(tmax0, tmax1);
         if (best.t + slack < texit) return;  // nothing in later cells can be nearer (or tie)
@@ -1093,14 +1138,15 @@ __device__ __forceinline__ Hit<T> nearest_hit(const Scene<T>& sc, const RayState
             return best;
         }
     }
-    for (int i = 0; i < sc.n_nodes; ++i) {
-        const DNode<T>& nd = sc.nodes[i];
+    for (int i = 0; i < sc.n_nodes; ++i) {  // virtual indices; the children of an instanced run are only ever reached through their group's grid
+        const NodeRef<T> nr = node_ref<T, F>(sc, i);
+        const DNode<T>& nd = *nr.nd;
         if constexpr (F & F_AABB) {
             bool inside = false;
             T t1 = T(0), t2 = T(0);
             if (nd.kind == OT_NODE_GROUP && (nd.flags & OT_NODE_CHECK_AABB)) {
                 if (i >= skip_until) {
-                    inside = slab_inv(r.ox, r.oy, r.oz, ri, nd.aabb, t1, t2);
+                    inside = slab_inv(r.ox, r.oy, r.oz, ri, nr.geo + 3, t1, t2);
                     if (!(F & F_LIMIT) && beyond_best(t1, best.t)) inside = false;  // nothing in this group can be nearer
                     if (!inside) skip_until = nd.end;
                 }
@@ -1121,7 +1167,7 @@ __device__ __forceinline__ Hit<T> nearest_hit(const Scene<T>& sc, const RayState
             }
         }
         if (i < skip_until) continue;
-        test_leaf<T, F, GATE, true, (F & F_AABB) != 0>(sc, nd, i, r, best, gate, &ri);
+        test_leaf<T, F, GATE, true, (F & F_AABB) != 0>(sc, nr, i, r, best, gate, &ri);
     }
     return best;
 }
@@ -1175,7 +1221,8 @@ __device__ __forceinline__ void surf_normal(const Scene<T>& sc, const DNode<T>& 
 template <class T, uint32_t F, int MAXK>
 __device__ __forceinline__ int interact(const Scene<T>& sc, const RayState<T>& r, const Hit<T>& h, RayState<T>* kids,
                                         const MatCache<T>& mc) {
-    const DNode<T>& nd = sc.nodes[h.node];
+    const NodeRef<T> nr = node_ref<T, F>(sc, h.node);
+    const DNode<T>& nd = *nr.nd;
     if (nd.inter == OT_INT_BLOCK) return 0;
     T dx, dy, dz;  // incoming direction in the leaf frame
     to_local(nd, r.dx, r.dy, r.dz, dx, dy, dz);
@@ -1184,7 +1231,7 @@ __device__ __forceinline__ int interact(const Scene<T>& sc, const RayState<T>& r
     const T pl_hit = r.pl + t * r.n;     // Ray.pathlength(t) (ray.py:145-147)
     T Ox, Oy, Oz;
     to_lab(nd, h.px, h.py, h.pz, Ox, Oy, Oz);
-    Ox += nd.org[0]; Oy += nd.org[1]; Oz += nd.org[2];
+    Ox += nr.geo[0]; Oy += nr.geo[1]; Oz += nr.geo[2];
     int nk = 0;
     auto emit = [&](T lx, T ly, T lz, T I, T qr, T qi, T n, T pl) {
         if (nk < MAXK) {

@@ -31,8 +31,15 @@ def shard_indices_by_id(ids, rank, world):
 def final_state(segs):
     """[12, n_rays] tensor: each ray's last segment (non-branching [k][ray] layout)."""
     if segs.count is None:
-        raise ValueError("final_state needs the [segment][ray] layout of a non-branching trace; a ray tree has no single last segment")
+        raise ValueError("final_state needs a non-branching trace (slots or append layout); a ray tree has no single last segment")
     n = segs.n_rays
+    if segs.append:  # the records of a ray lie at increasing slots: its last segment is its highest slot
+        m = segs.n_valid
+        ray = segs.ray[:m].long()
+        slot = torch.arange(m, device=segs.device)
+        keep = ray >= 0
+        last = torch.zeros(n, dtype=torch.int64, device=segs.device).scatter_reduce_(0, ray[keep], slot[keep], "amax", include_self=False)
+        return torch.stack([segs.field(f)[last] for f in FINAL_FIELDS])
     last = (segs.count.long().abs() - 1).clamp_(min=0) * n + torch.arange(n, device=segs.device)
     return torch.stack([segs.field(f)[last] for f in FINAL_FIELDS])
 

@@ -49,11 +49,19 @@ class Engine:
         self.scene = scene
 
     # -- non-branching trace ---------------------------------------------------------------
-    def trace(self, rays: RayBatch, max_segments, out: SegmentBatch = None, counts=None):
-        """All segments of every ray in one launch; returns the SegmentBatch ([k][ray] slots)."""
+    def trace(self, rays: RayBatch, max_segments, out: SegmentBatch = None, counts=None, layout="slots", capacity=None):
+        """All segments of every ray in one launch; returns the SegmentBatch.
+        layout="slots": [k][ray] slots (ot_trace_*).  layout="append": a dense list in append order
+        (ot_trace_append_*, include/optable_hip.h) — `capacity` slots (default: max_segments * n_rays plus the
+        chunk slack, which always suffices; pass what the job needs to save memory: if it turns out too small a
+        RuntimeError names the size that fits)."""
         if self.scene is None:
             raise RuntimeError("upload a scene first")
         n, K = rays.n, int(max_segments)
+        if layout == "append":
+            return self._trace_append(rays, K, out, counts, capacity)
+        if layout != "slots":
+            raise ValueError(f"unknown layout {layout!r}")
         if out is None:
             out = SegmentBatch(n * K, rays.precision, rays.device)
         elif out.capacity < n * K or out.precision != rays.precision:
@@ -72,6 +80,35 @@ class Engine:
         rs, ss = rays.c_struct(), out.c_struct()
         abi.check(fn(self._ctx, C.byref(rs), n, K, C.byref(ss), out.count.data_ptr(),
                      None if counts is None else counts.data_ptr(), n_classes), self.lib)
+        out.counts_table = counts
+        return out
+
+    APPEND_SLACK = 1 << 23  # slots beyond the records: chunk (512) x waves of the launch (at most 256 CUs x 16 x 2)
+
+    def _trace_append(self, rays, K, out, counts, capacity):
+        n = rays.n
+        if capacity is None:
+            capacity = n * K + min(self.APPEND_SLACK, 512 * ((n + 63) // 64 + 1))
+        if out is None:
+            out = SegmentBatch(capacity, rays.precision, rays.device, block=True)
+        elif out.block is None or out.precision != rays.precision:
+            raise ValueError("append layout needs a SegmentBatch(block=True) of the rays' precision")
+        if out.count is None or out.count.numel() != n:
+            out.count = torch.empty(n, dtype=torch.int32, device=rays.device)
+        out.n_rays, out.append, out.n_valid, out.counts_table = n, True, 0, counts
+        if n == 0:
+            return out
+        n_slots_table = len(self.scene.limited)
+        if n_slots_table and counts is None:
+            counts = torch.zeros((n_slots_table, n), dtype=torch.int32, device=rays.device)
+        n_classes = 0 if counts is None else counts.shape[1]
+        fn = self.lib.ot_trace_append_f64 if rays.precision == "f64" else self.lib.ot_trace_append_f32
+        cursor = torch.zeros(1, dtype=torch.int64, device=rays.device)
+        rs, blk = rays.c_struct(), out.block_struct()
+        abi.check(fn(self._ctx, C.byref(rs), n, K, C.byref(blk), cursor.data_ptr(), out.count.data_ptr(),
+                     None if counts is None else counts.data_ptr(), n_classes), self.lib)
+        out.cursor = cursor  # device scalar: read lazily (n_valid) so that back-to-back launches do not synchronise
+        out.n_valid = None
         out.counts_table = counts
         return out
 
@@ -188,7 +225,7 @@ class Engine:
         dev = segs.device
         if segs.precision != "f64":  # the monitor pass is fp64: widen an fp32 history once
             segs = segs.astype("f64")
-        if segs.count is not None:
+        if segs.layout == "slots":
             n_segments, count_ptr, n_rays = segs.capacity // segs.n_rays * segs.n_rays, segs.count.data_ptr(), segs.n_rays
         else:
             n_segments = segs.n_valid if n_segments is None else n_segments

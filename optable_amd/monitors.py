@@ -186,7 +186,7 @@ class MonitorHits:
 
         self.monitor, self.segs = monitor, segs
         ray = segs.ray[slot].long()
-        if segs.count is not None:  # [k][ray] slots: reference order is ray-major, then k
+        if segs.layout == "slots":  # [k][ray] slots: reference order is ray-major, then k
             order = torch.argsort(ray * (segs.capacity // max(segs.n_rays, 1)) + slot // max(segs.n_rays, 1))
         else:
             order = torch.argsort(ray, stable=True)

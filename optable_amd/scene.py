@@ -117,9 +117,22 @@ class _Builder:
         """Large flat groups (MLA / MMA / DMD ...): a 2-D grid over the children's lab AABBs so the
         kernel visits only the children near the ray instead of all of them.  Pure acceleration:
         every child found through the grid still passes its own AABB test, and a child the grid
-        misses could not have passed it (boxes are binned with a margin far above the slab test's
-        1e-12 / 1e-8 tolerances).  Not built when a child is itself a group or count-limited
-        (its gate must see every geometric hit)."""
+        misses could not have passed it.  Not built when a child is itself a group or count-limited
+        (its gate must see every geometric hit).
+
+        Superset argument.  A child is listed in the cells its box overlaps after SHRINKING the box by delta =
+        margin / 4 on every side (a box thinner than that: the cell of its centre); the kernel looks up the cells
+        the ray's footprint inside the group box overlaps after WIDENING it by 2 * margin (fp32: by 64 ulp of the
+        group's largest coordinate, set at upload).  A child whose slab test passes has a box that the footprint
+        reaches to within the test's 1e-12 / 1e-8 tolerances, so the widened footprint and the shrunken box share
+        a point, and the cell of that point is both listed and looked up.  Shrinking instead of widening the boxes
+        matters for lattices: their children end exactly on cell borders, and a widened box would be listed in all
+        eight neighbouring cells as well.
+
+        Lattices (equal boxes on a regular raster: MMA caps, MLA lenslets, DMD mirrors, component_group.py:228-304,
+        367) get the raster itself as their grid — one member per cell, found in O(1) — and the device folds their
+        members into one record plus a pose per member (optable_hip.hip find_runs).  Other groups get cells about
+        half the size of a typical child, at most 64 x 64."""
         kids = list(range(slot + 1, node.end))
         if not self.accelerate or len(kids) < self.GRID_MIN_CHILDREN:
             return
@@ -131,24 +144,35 @@ class _Builder:
         if extent[a0] <= 0 or extent[a1] <= 0:
             return
         boxes = np.array([self.nodes[k].aabb[:] for k in kids], dtype=float).reshape(-1, 3, 2)
-        # cells about half the size of a typical child (children of a lattice touch cell borders), at most 64 x 64
-        typical = np.median(boxes[:, [a0, a1], 1] - boxes[:, [a0, a1], 0], axis=0)
-        dims = [int(min(64, max(1, np.floor(extent[a] / max(typical[j] / 2, extent[a] / 64))))) for j, a in enumerate((a0, a1))]
+        if not np.all(np.isfinite(boxes)) or not np.all(np.isfinite(gbox)):
+            return
         margin = 1e-7 + 1e-9 * float(extent.max())
-        # The children of a lattice end exactly on cell borders, and binning them with a margin would put each
-        # one into the neighbouring cells as well (MMA 16x16: 4 caps per cell instead of 1-2).  Start the grid a
-        # quarter cell early (one more cell per axis) so that child borders fall inside cells.
-        size = [extent[a0] / dims[0], extent[a1] / dims[1]]
-        org = [gbox[a0, 0] - 0.25 * size[0], gbox[a1, 0] - 0.25 * size[1]]
-        dims = [min(dims[0] + 1, 64), min(dims[1] + 1, 64)]
+        raster = _lattice_raster(boxes[:, [a0, a1], :], gbox[[a0, a1], :])
+        if raster is not None:
+            org, size, dims = raster
+        else:
+            typical = np.median(boxes[:, [a0, a1], 1] - boxes[:, [a0, a1], 0], axis=0)
+            dims = [int(min(64, max(1, np.floor(extent[a] / max(typical[j] / 2, extent[a] / 64))))) for j, a in enumerate((a0, a1))]
+            size = [extent[a0] / dims[0], extent[a1] / dims[1]]
+            org = [gbox[a0, 0], gbox[a1, 0]]
+        # cover the group box with a margin to spare on the high side (the low side starts at or before the box)
+        for j, a in enumerate((a0, a1)):
+            while org[j] + dims[j] * size[j] < gbox[a, 1] + 4 * margin:
+                dims[j] += 1
         inv = [1.0 / size[0], 1.0 / size[1]]
-        if org[0] + dims[0] * size[0] < gbox[a0, 1] + margin or org[1] + dims[1] * size[1] < gbox[a1, 1] + margin:
-            size = [(gbox[a0, 1] + 2 * margin - org[0]) / dims[0], (gbox[a1, 1] + 2 * margin - org[1]) / dims[1]]  # 64-cell cap: stretch
-            inv = [1.0 / size[0], 1.0 / size[1]]
+        delta = margin / 4
         cells = [[] for _ in range(dims[0] * dims[1])]
-        span = lambda col, pad, o, i, n: np.clip(np.floor((col + pad - o) * i), 0, n - 1).astype(int).tolist()
-        lo0s, hi0s = span(boxes[:, a0, 0], -margin, org[0], inv[0], dims[0]), span(boxes[:, a0, 1], margin, org[0], inv[0], dims[0])
-        lo1s, hi1s = span(boxes[:, a1, 0], -margin, org[1], inv[1], dims[1]), span(boxes[:, a1, 1], margin, org[1], inv[1], dims[1])
+
+        def span(lo, hi, o, i, n):
+            lo, hi = lo + delta, hi - delta
+            mid = 0.5 * (lo + hi)
+            thin = hi < lo
+            lo, hi = np.where(thin, mid, lo), np.where(thin, mid, hi)
+            return (np.clip(np.floor((lo - o) * i), 0, n - 1).astype(int).tolist(),
+                    np.clip(np.floor((hi - o) * i), 0, n - 1).astype(int).tolist())
+
+        lo0s, hi0s = span(boxes[:, a0, 0], boxes[:, a0, 1], org[0], inv[0], dims[0])
+        lo1s, hi1s = span(boxes[:, a1, 0], boxes[:, a1, 1], org[1], inv[1], dims[1])
         for k, lo0, hi0, lo1, hi1 in zip(kids, lo0s, hi0s, lo1s, hi1s):
             for c1 in range(lo1, hi1 + 1):
                 for c0 in range(lo0, hi0 + 1):
@@ -211,6 +235,35 @@ class _Builder:
         self.max_children = max(self.max_children, _fanout(kind, node.reflectivity, node.transmission))
         if kind in (MIRROR, REFRACT) and node.reflectivity > 0 and node.transmission > 0:
             self.always_branches = True  # every ordinary hit on this leaf emits two rays
+
+
+LATTICE_MAX_CELLS = 128  # per axis
+
+
+def _lattice_raster(boxes, gbox):
+    """(origin, cell size, cells per axis) of the raster on which the children of a lattice group lie, or None.
+    `boxes` [n, 2, 2] and `gbox` [2, 2] are the children's and the group's extents along the two grid axes.  A
+    raster exists when at least 90 % of the children have the same extents (the others — an MMA's back plate —
+    are simply listed in every cell they cover) and those members start on multiples of their size; the raster is
+    continued in whole cells to the group's low edges."""
+    width = boxes[:, :, 1] - boxes[:, :, 0]
+    med = np.median(width, axis=0)
+    if not np.all(med > 0):
+        return None
+    member = np.all(np.abs(width - med) <= 1e-9 * med, axis=1)
+    if member.sum() < 0.9 * len(boxes):
+        return None
+    lo = boxes[member][:, :, 0]
+    first = lo.min(axis=0)
+    steps = (lo - first) / med
+    if np.any(np.abs(steps - np.round(steps)) > 1e-6):
+        return None
+    below = np.maximum(np.ceil((first - gbox[:, 0]) / med - 1e-9), 0)
+    org = first - below * med
+    dims = np.maximum(np.ceil((np.maximum(gbox[:, 1], boxes[:, :, 1].max(axis=0)) - org) / med - 1e-9), 1)
+    if np.any(dims > LATTICE_MAX_CELLS):
+        return None
+    return [float(org[0]), float(org[1])], [float(med[0]), float(med[1])], [int(dims[0]), int(dims[1])]
 
 
 def _fanout(kind, refl, trans):

@@ -106,13 +106,15 @@ class OpticalTable:
             print(f"Ray tracing time exceeds the maximum tracing time after 0 traces. ({len(rays)} ray tree(s) truncated)")
         return _clone_rays(self.rays)
 
-    def trace_batch(self, batch, max_segments=None, counts=None, scene=None):
+    def trace_batch(self, batch, max_segments=None, counts=None, scene=None, layout="slots", capacity=None):
         """Scalable entry: `RayBatch` in, `SegmentBatch` out, no Python objects.  Non-branching
         scenes run as one launch with [segment][ray] output slots; branching scenes run generation by
         generation; both in the batch's precision.
         `scene`: a `table.compile()` result to reuse when the components have not changed since (flattening
         a few hundred components in Python costs milliseconds — 10 ms for cfg 5 — and the engine skips the
-        upload when it already holds that very scene); default: compile now, poses are read at call time."""
+        upload when it already holds that very scene); default: compile now, poses are read at call time.
+        `layout`: "slots" ([segment][ray] slots) or "append" (a dense list in append order, `capacity` slots: see
+        Engine.trace) for the non-branching launch; ray trees always come back as a list in generation order."""
         eng = _engine()
         if scene is None:
             scene = self.compile()
@@ -125,7 +127,7 @@ class OpticalTable:
             if max_segments is not None and (scene.max_children <= 1 or speculate):
                 # max_children == 2: speculate that no tree actually branches (e.g. mirror-coated
                 # interfaces only split on total internal reflection); fall back when one does.
-                segs = eng.trace(batch, cap)
+                segs = eng.trace(batch, cap, layout=layout, capacity=capacity)
                 if scene.max_children <= 1 or not bool((segs.count < 0).any()):
                     return segs
             return eng.trace_tree(batch, cap)

@@ -1,0 +1,164 @@
+"""GPU (MI355X): the append layout of ot_trace_append_* (a dense list of segment records, include/optable_hip.h) and
+the instanced lattice runs of the device image against the [k][ray] slots, the oracle and the un-accelerated scene.
+Everything here is bit-exact: the layouts and the instancing change where records are kept, not what is computed."""
+import numpy as np
+import pytest
+import torch
+
+import scenes
+from optable_amd import abi
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(o, d, precision="f64"):
+    from optable_amd.batch import RayBatch
+
+    q = 1j * np.pi * scenes.W0**2 / scenes.WL
+    return RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=q, precision=precision, device="cuda")
+
+
+def _table(components, accelerate=True):
+    import optable_amd as oa
+
+    t = oa.OpticalTable()
+    t.accelerate = accelerate
+    t.add_components(components)
+    return t
+
+
+CASES = {
+    "cfg2": (scenes.cfg2_components, lambda n: scenes.cfg2_rays(n, 0), 20000, 5),
+    "cfg3": (scenes.cfg3_components, lambda n: scenes.cfg3_rays(n, 2), 30000, 20),
+    "cfg5": (scenes.cfg5_components, lambda n: scenes.cfg5_rays(n, 3), 6000, 50),
+}
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_append_layout_equals_slots(case, precision):
+    """Same records, bit for bit, in the reference's order; holes only at chunk tails; final states agree."""
+    import optable_amd as oa
+    from optable_amd import dist
+    from optable_amd.engine import get_engine
+
+    comps, gen, n, K = CASES[case]
+    table = _table(comps(oa))
+    batch = _batch(*gen(n), precision=precision)
+    eng = get_engine()
+    eng.set_option(abi.OPT_KERNEL, 2)  # the slots through the same (rolling-list) kernel family
+    try:
+        slots = table.trace_batch(batch, max_segments=K)
+    finally:
+        eng.set_option(abi.OPT_KERNEL, 0)
+    app = table.trace_batch(batch, max_segments=K, layout="append")
+    assert app.layout == "append" and eng.last_launch()["pair_queue"] & 4
+    a, b = slots.to_host(reference_order=True), app.to_host(reference_order=True)
+    for f in abi.SEG_FIELDS + ("ray", "surface", "count"):
+        np.testing.assert_array_equal(a[f], b[f], err_msg=f)
+    # slots in use = records + holes; holes are marked ray == -1 and number less than one chunk per wave
+    used = app.n_valid
+    ray = app.ray[:used].cpu().numpy()
+    assert (ray >= 0).sum() == len(a["ray"]) == int(np.abs(a["count"]).sum())
+    info = eng.last_launch()
+    waves = info["workgroups"] * info["threads"] // 64
+    assert (ray < 0).sum() < 512 * waves
+    # a stable sort by ray is the reference's order: within a ray the records lie at increasing slots in segment order
+    keep = ray >= 0
+    order = np.argsort(ray[keep], kind="stable")
+    np.testing.assert_array_equal(app.length[:used].cpu().numpy()[keep][order], a["length"])
+    np.testing.assert_array_equal(dist.final_state(app).cpu().numpy(), dist.final_state(slots).cpu().numpy())
+
+
+def test_append_capacity_too_small_reports_the_size_that_fits():
+    import optable_amd as oa
+
+    table = _table(scenes.cfg3_components(oa))
+    batch = _batch(*scenes.cfg3_rays(20000, 2), precision="f32")
+    full = table.trace_batch(batch, max_segments=20, layout="append")
+    need = full.n_valid
+    small = table.trace_batch(batch, max_segments=20, layout="append", capacity=need // 2)
+    with pytest.raises(RuntimeError, match=f"capacity >= {need}"):
+        _ = small.n_valid
+    np.testing.assert_array_equal(small.count.cpu().numpy(), full.count.cpu().numpy())  # the trace itself is complete
+    fits = table.trace_batch(batch, max_segments=20, layout="append", capacity=int(np.abs(full.count.cpu().numpy()).sum()) + 512 * 256 * 16)
+    assert fits.n_valid > 0
+
+
+def test_append_monitor_and_export_follow_the_list_contract(tmp_path):
+    """Monitor.record and the CSV export over an append-layout history equal those over the slots."""
+    import optable_amd as oa
+
+    comps = scenes.cfg2_components(oa)
+    table = _table(comps)
+    mon = oa.Monitor(origin=[7.5, 0, 0], width=6, height=6)
+    batch = _batch(*scenes.cfg2_rays(5000, 0))
+    slots = table.trace_batch(batch, max_segments=5)
+    app = table.trace_batch(batch, max_segments=5, layout="append")
+    h0, h1 = table.record_batch(mon, slots), table.record_batch(mon, app)
+    assert len(h0) == len(h1) > 0
+    for acc in ("yList", "zList", "tYList", "IList", "tList"):
+        np.testing.assert_array_equal(getattr(h0, acc)(None).cpu().numpy(), getattr(h1, acc)(None).cpu().numpy(), err_msg=acc)
+    a, b = tmp_path / "a.csv", tmp_path / "b.csv"
+    table.export_batch_csv(slots, str(a), batch)
+    table.export_batch_csv(app, str(b), batch)
+    assert a.read_text() == b.read_text()
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+@pytest.mark.parametrize("family", ["mma", "mla", "dmd"])
+def test_instanced_lattices_equal_the_plain_scene(family, precision, oracle):
+    """MMA / MLA / DMD children folded into one record + a pose per member, found through the lattice's own raster:
+    bit-identical to the same scene without instancing and without any grid, and (fp64) equal to the oracle."""
+    import optable_amd as oa
+    from optable_amd.engine import get_engine
+
+    if family == "mma":
+        comps = lambda: scenes.cfg5_components(oa)
+        o, d = scenes.cfg5_rays(4000, 3)
+        K = 50
+    elif family == "mla":
+        comps = lambda: [oa.MLA([6, 0, 0], N=(9, 7), pitch=0.4, focal_length=3.0, radius=0.2).RotZ(0.2), oa.Mirror([9, 0, 0], radius=3).RotZ(np.pi)]
+        rng = np.random.default_rng(7)
+        n = 4000
+        o = np.stack([np.zeros(n), rng.uniform(-1.8, 1.8, n), rng.uniform(-1.4, 1.4, n)], 1)
+        d = np.stack([np.ones(n), rng.uniform(-.03, .03, n), rng.uniform(-.03, .03, n)], 1)
+        K = 8
+    else:
+        comps = lambda: [oa.DMD([5, 0, 0], N=(8, 6), pitch=0.5, tilt_angle=np.pi / 5), oa.SquareMirror([0, 4, 0], 12, 12).RotZ(-np.pi / 2)]
+        rng = np.random.default_rng(8)
+        n = 4000
+        o = np.stack([np.zeros(n), rng.uniform(-2.0, 2.0, n), rng.uniform(-1.5, 1.5, n)], 1)
+        d = np.stack([np.ones(n), rng.uniform(-.02, .02, n), rng.uniform(-.02, .02, n)], 1)
+        K = 8
+    batch = _batch(o, d, precision=precision)
+    eng = get_engine()
+    got = {}
+    for label, inst, accel in (("instanced", 1, True), ("plain nodes", 0, True), ("no grid", 0, False)):
+        eng.set_option(abi.OPT_INSTANCING, inst)
+        try:
+            table = _table(comps(), accelerate=accel)
+            got[label] = table.trace_batch(batch, max_segments=K).to_host(reference_order=True)
+        finally:
+            eng.set_option(abi.OPT_INSTANCING, 1)
+    for label in ("plain nodes", "no grid"):
+        for f in abi.SEG_FIELDS + ("ray", "surface", "count"):
+            np.testing.assert_array_equal(got["instanced"][f], got[label][f], err_msg=f"{label} {f}")
+    assert len(got["instanced"]["ray"]) > len(o)
+    if precision == "f64":
+        ref = oracle.trace(_table(comps()).compile(), batch.to_host(), max_trace_num=K)
+        np.testing.assert_array_equal(got["instanced"]["surface"], ref["surface"])
+        for f in ("ox", "oy", "oz", "dx", "dy", "dz", "length", "pathlength"):
+            np.testing.assert_allclose(got["instanced"][f], ref[f], rtol=1e-9, atol=1e-9, err_msg=f)
+
+
+def test_instancing_shrinks_the_cfg5_image_and_moves_the_records_to_lds():
+    import optable_amd as oa
+    from optable_amd.engine import get_engine
+
+    table = _table(scenes.cfg5_components(oa))
+    batch = _batch(*scenes.cfg5_rays(20000, 3), precision="f32")
+    table.trace_batch(batch, max_segments=50)
+    info = get_engine().last_launch()
+    assert info["kernel"] == 2 and info["pair_queue"] & 2, info  # rolling lists, records of the live rays in LDS
+    assert info["threads"] * info["workgroups_per_cu"] >= 12 * 64, info

@@ -39,6 +39,11 @@ if os.environ.get('KERNEL'):
     eng.set_option(abi.OPT_KERNEL, int(os.environ['KERNEL']))
 if os.environ.get('MINW'):
     eng.set_option(abi.OPT_MIN_WAVES, int(os.environ['MINW']))
+if os.environ.get('INST'):
+    eng.set_option(abi.OPT_INSTANCING, int(os.environ['INST']))
+if os.environ.get('CHUNK'):
+    eng.set_option(abi.OPT_APPEND_CHUNK, int(os.environ['CHUNK']))
+LAYOUTS = os.environ.get('LAYOUT', 'slots').split(',')  # slots, append or both ("slots,append")
 if os.environ.get('BPC'):
     eng.set_option(abi.OPT_BLOCKS_PER_CU, int(os.environ['BPC']))
 Q = lambda wl: 1j * np.pi * scenes.W0**2 / wl
@@ -69,18 +74,32 @@ def _run(name, comps, o, d, wl, K, prec, reps=5):
         eng.trace(batch, K, out=out)
         fused = not bool((out.count < 0).any())
     if fused:
-        out = SegmentBatch(n * K, prec, batch.device)
-        eng.trace(batch, K, out=out)
-        eng.timing(True)
-        for _ in range(reps):
-            eng.trace(batch, K, out=out)
-        ms, cnt = eng.timing_read()
-        eng.timing(False)
-        segs = int(out.count.sum().item())
-        t = ms / cnt / 1e3
-        mode = "fused"
-        if os.environ.get("SHAPE"):
-            print("   launch:", eng.last_launch(), flush=True)
+        for layout in LAYOUTS:
+            out = None
+            torch.cuda.empty_cache()
+            if layout == "append":  # sized by the records of a first trace, like a caller who knows the job
+                probe = eng.trace(batch, K, layout="append")
+                cap = probe.n_valid + 4096
+                del probe
+                torch.cuda.empty_cache()
+                out = SegmentBatch(cap, prec, batch.device, block=True)
+            else:
+                out = SegmentBatch(n * K, prec, batch.device)
+            eng.trace(batch, K, out=out, layout=layout)
+            eng.timing(True)
+            for _ in range(reps):
+                eng.trace(batch, K, out=out, layout=layout)
+            ms, cnt = eng.timing_read()
+            eng.timing(False)
+            segs = int(out.count.abs().sum().item())
+            t = ms / cnt / 1e3
+            mode = "fused" if layout == "slots" else "append"
+            if os.environ.get("SHAPE"):
+                print("   launch:", eng.last_launch(), flush=True)
+            if layout != LAYOUTS[-1]:
+                gbs = (n * b + segs * b) / t / 1e9
+                print(f"{name:28s} {prec} {mode:11s} n={n:9d} S={S:3d} K={K:2d} segs/ray={segs / n:5.2f} time={t * 1e3:9.3f} ms "
+                      f"{segs / t:10.3e} seg/s {segs * S / t:10.3e} isect/s  {gbs:7.1f} GB/s ({gbs / 80:4.1f}% of 8 TB/s)", flush=True)
         if os.environ.get("CEILING"):  # the same streams with no tracing (fixed K records per ray)
             eng.timing(True)
             for _ in range(reps):
