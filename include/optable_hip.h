@@ -286,7 +286,8 @@ int ot_debug_last_launch(ot_ctx* ctx, int32_t info[8]);
  * monitor plane, honouring segment length.  hit_index receives the slot indices of the segments
  * that hit (ascending), P the local hit point, t the distance; *n_hits the count.
  * seg_count/n_rays: pass ot_trace_*'s seg_count and n_rays to scan a [k][ray] slot array
- * (n_segments = max_segments*n_rays; unused slots are skipped); NULL/0 for a flat list. */
+ * (n_segments = max_segments*n_rays; unused slots are skipped); NULL/0 for a flat list (ot_trace_generation_*);
+ * NULL/-1 for a list with holes (ot_trace_append_*: slots whose `ray` is negative are skipped). */
 typedef struct ot_monitor {
     double M[9];
     double origin[3];

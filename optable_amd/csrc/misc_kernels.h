@@ -140,7 +140,7 @@ __global__ void k_mon_test(ot_monitor mon, SegsT<double> s, int64_t n, const int
     if (seg_count) {  // [k][ray] layout of ot_trace_*: slot i is valid iff k < |seg_count[ray]|
         const int32_t c = seg_count[i % n_rays];
         if (i / n_rays >= (c < 0 ? -c : c)) { hit[i] = 0; return; }
-    } else if (s.ray[i] < 0) {  // flat lists: a hole of the append layout (ot_trace_append_*)
+    } else if (n_rays < 0 && s.ray[i] < 0) {  // a list with holes: the append layout of ot_trace_append_*
         hit[i] = 0;
         return;
     }

@@ -164,6 +164,46 @@ static int64_t packable_cells(const ot_scene_desc* s) {
         if (g[11 + k + 1] - g[11 + k] > 42) return 0;
     return cells;
 }
+// Aspheres whose implicit function g = x + F(r) is convex (or concave) along every line through the local box — F convex and
+// non-decreasing on [0, box diagonal] (or -F) — get a device flag: a ray that starts on such a surface can skip the root
+// scan in the two cases trace_core.h hit_leaf spells out.  Checked numerically on 512 samples of the reference's own F
+// (component_group.py:1061-1064, 1092-1097); anything not clearly convex gets no flag and the full scan.
+static double host_sag(const ot_node& h, double r) {
+    const double r2 = r * r;
+    if (h.shape == OT_SHAPE_ASPHERE_PARAM) {
+        const double R = h.p[1], k = h.p[2], r4 = r2 * r2;
+        return r2 / (R * (1.0 + std::sqrt(1.0 - (1.0 + k) * r2 / (R * R)))) + h.p[3] * r4 + h.p[4] * r4 * r2 + h.p[5] * r4 * r4;
+    }
+    const double EFL = h.p[1], n = h.p[2];
+    return (EFL / (n + 1.0)) * (-1.0 + std::sqrt(1.0 + (n + 1.0) / (n - 1.0) * r2 / (EFL * EFL)));
+}
+static int32_t asphere_convexity(const ot_node& h) {
+    if (h.kind != OT_NODE_LEAF || (h.shape != OT_SHAPE_ASPHERE_PARAM && h.shape != OT_SHAPE_ASPHERE_EXACT)) return 0;
+    constexpr int N = 512;
+    const double rmax = 1.4143 * h.p[0] * 1.001, dr = rmax / N;
+    if (!(rmax > 0)) return 0;
+    double f[N + 1];
+    for (int j = 0; j <= N; ++j) {
+        f[j] = host_sag(h, j * dr);
+        if (!std::isfinite(f[j])) return 0;
+    }
+    double scale = 0.0;
+    for (int j = 0; j <= N; ++j) scale = std::fmax(scale, std::fabs(f[j]));
+    const double tol = 1e-13 * (scale + 1e-300);
+    bool pos = true, neg = true;  // F (resp. -F) non-decreasing and convex
+    for (int j = 1; j <= N; ++j) {
+        const double d1 = f[j] - f[j - 1];
+        if (d1 < -tol) pos = false;
+        if (d1 > tol) neg = false;
+        if (j < N) {
+            const double d2 = f[j + 1] - 2.0 * f[j] + f[j - 1];
+            if (d2 < -tol) pos = false;
+            if (d2 > tol) neg = false;
+        }
+    }
+    return pos ? DN_CONVEX_POS : (neg ? DN_CONVEX_NEG : 0);
+}
+
 // Instanced runs: consecutive leaf children of a gridded group that differ only in origin, lab AABB and leaf id — the caps
 // of an MMA, the lenslets of an MLA, the mirrors of a DMD (component_group.py:228-304, 367).  The device image keeps one
 // record per run plus 9 reals per member (trace_core.h NodeRef); everything is compared bit for bit, so a lattice with
@@ -233,7 +273,7 @@ template <class T> static void fill_blob(const ot_scene_desc* s, const std::vect
             d.p[7] = (T)(h.p[1] / (h.p[2] + 1.0));
         }
         d.pad1 = (T)0;
-        d.kind = h.kind; d.end = h.end; d.flags = h.flags; d.shape = h.shape; d.inter = h.interaction;
+        d.kind = h.kind; d.end = h.end; d.flags = h.flags | asphere_convexity(h); d.shape = h.shape; d.inter = h.interaction;
         d.mat1 = h.mat1; d.mat2 = h.mat2; d.roc_kind = h.roc_kind; d.max_count = h.max_interact_count;
         d.slot = h.count_slot; d.aux = h.aux; d.leaf_id = h.leaf_id;
     }
@@ -909,6 +949,7 @@ int ot_monitor_record_f64(ot_ctx* c, const ot_monitor* mon, const ot_segments* s
     if (rc) return rc;
     if (n < 0 || n >= (int64_t)1 << 31) return fail(OT_ERR_INVALID, "bad segment count");
     if (seg_count && (n_rays < 1 || n % n_rays != 0)) return fail(OT_ERR_INVALID, "n_segments must be a multiple of n_rays");
+    if (!seg_count && n_rays > 0) return fail(OT_ERR_INVALID, "n_rays without seg_count: pass 0 for a list, -1 for a list with holes");
     HIP_TRY(hipSetDevice(c->device));
     if (n == 0) {
         HIP_TRY(hipMemsetAsync(n_hits, 0, sizeof(int64_t), c->stream));

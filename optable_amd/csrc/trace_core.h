@@ -73,6 +73,11 @@ template <> struct Num<float> {
 // the LDS bank of lane l is (stride * node_l + field) mod 32: an odd stride (53) sends different nodes to different banks,
 // where the natural 52 dwords (a multiple of 4) left only 8 distinct banks — 21 % of the LDS cycles of cfg 3 were bank
 // conflicts, 4 % with the pad (tools/lds_probe.sh); cfg 3 +1 %, cfg 5 fp32 19.65 -> 19.2 ms.
+// flags of a device record beyond ot_node_flags (set at upload, optable_hip.hip fill_blob)
+enum : int32_t {
+    DN_CONVEX_POS = 256,  // asphere: g(t) = x + F(r) is convex along every line inside the local box (F convex and non-decreasing there)
+    DN_CONVEX_NEG = 512   // ... -g is
+};
 template <class T> struct DNode {
     T M[9];
     T org[3];
@@ -162,7 +167,10 @@ template <class T, uint32_t F> __device__ __forceinline__ int32_t leaf_id_of(con
 
 template <class T> __device__ __forceinline__ T sqrt_t(T x);
 template <> __device__ __forceinline__ double sqrt_t<double>(double x) { return sqrt(x); }
-template <> __device__ __forceinline__ float sqrt_t<float>(float x) { return sqrtf(x); }
+// fp32: the bare v_sqrt_f32 (1 ulp).  sqrtf() wraps it in a scaling sequence for denormal arguments (a compare, a multiply,
+// two selects and an ldexp per call: ~150 of the 6000 instructions of the curved-surface kernel); every argument here is a
+// squared length or 1 +- something of order one.
+template <> __device__ __forceinline__ float sqrt_t<float>(float x) { return __builtin_amdgcn_sqrtf(x); }
 template <class T> __device__ __forceinline__ T abs_t(T x) { return x < T(0) ? -x : x; }
 template <class T> __device__ __forceinline__ T min_t(T a, T b) { return a < b ? a : b; }
 template <class T> __device__ __forceinline__ T max_t(T a, T b) { return a < b ? b : a; }
@@ -199,6 +207,11 @@ __device__ __forceinline__ double div_t(double a, double b) {
 // stream ceiling), and their contract is a tolerance against fp64, not correctly rounded quotients.
 __device__ __forceinline__ float rcp_t(float b) { return __builtin_amdgcn_rcpf(b); }
 __device__ __forceinline__ float div_t(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+// a / b as the build's precision wants it where the source of the reference has a plain division: IEEE in double (the
+// oracle's bits), the hardware reciprocal in single — the compiler's fp32 "/" guards against denormal and huge operands
+// with a frexp / ldexp sequence of ~8 instructions, and the kernels divide lengths and indices of order one.
+__device__ __forceinline__ double qd(double a, double b) { return a / b; }
+__device__ __forceinline__ float qd(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 // a0*b0 + a1*b1 + a2*b2 with the roundings WRITTEN DOWN (one product rounded, two fused steps).  Left to the compiler's
 // contraction the same source expression fuses differently in different surroundings, and the planar leaf test exists in
 // two shapes (test_leaf with early exits, the branch-free slot of flat_grid_hit) whose results must agree bit for bit.
@@ -255,10 +268,10 @@ template <class T> __device__ __forceinline__ bool beyond_best(T t1, T best_t) {
 template <class T> __device__ __forceinline__ T material_index(const DMat<T>& m, T wavelength_m) {
     if (m.kind == OT_MAT_CONST) return m.n;
     // 1 + sum_i B_i L^2/(L^2 - C_i) over a common denominator: one division instead of three
-    const T um = wavelength_m / T(1e-6), um2 = um * um;
+    const T um = qd(wavelength_m, T(1e-6)), um2 = um * um;
     const T p0 = um2 - m.C[0], p1 = um2 - m.C[1], p2 = um2 - m.C[2];
     const T num = m.B[0] * p1 * p2 + m.B[1] * p0 * p2 + m.B[2] * p0 * p1;
-    return sqrt_t(T(1) + um2 * num / (p0 * p1 * p2));
+    return sqrt_t(T(1) + qd(um2 * num, p0 * p1 * p2));
 }
 
 // n(lambda) depends only on the ray's wavelength and the material, and a ray keeps its wavelength
@@ -338,11 +351,11 @@ template <class T> __device__ __forceinline__ T sag_d1(const DNode<T>& nd, T r) 
     if (sizeof(T) == 4) {
         const T r2 = r * r;
         if (nd.shape == OT_SHAPE_ASPHERE_PARAM) {
-            const T R = nd.p[1], sq = sqrt_t(T(1) - (T(1) + nd.p[2]) * r2 / (R * R));
-            return r / (R * sq) + r * r2 * (T(4) * nd.p[3] + r2 * (T(6) * nd.p[4] + r2 * T(8) * nd.p[5]));
+            const T R = nd.p[1], sq = sqrt_t(T(1) - qd((T(1) + nd.p[2]) * r2, R * R));
+            return qd(r, R * sq) + r * r2 * (T(4) * nd.p[3] + r2 * (T(6) * nd.p[4] + r2 * T(8) * nd.p[5]));
         }
-        const T E = nd.p[1], n = nd.p[2], A = (n + T(1)) / (n - T(1));
-        return A * r / ((n + T(1)) * E * sqrt_t(T(1) + A * r2 / (E * E)));
+        const T E = nd.p[1], n = nd.p[2], A = qd(n + T(1), n - T(1));
+        return qd(A * r, (n + T(1)) * E * sqrt_t(T(1) + qd(A * r2, E * E)));
     }
     const T h = T(1e-4) * nd.p[0];
     return (sag(nd, r + h) - sag(nd, r - h)) / (T(2) * h);
@@ -351,12 +364,12 @@ template <class T> __device__ __forceinline__ T sag_d2(const DNode<T>& nd, T r) 
     if (sizeof(T) == 4) {
         const T r2 = r * r;
         if (nd.shape == OT_SHAPE_ASPHERE_PARAM) {
-            const T R = nd.p[1], k1 = T(1) + nd.p[2], sq = sqrt_t(T(1) - k1 * r2 / (R * R));
-            return T(1) / (R * sq) + k1 * r2 / (R * R * R * sq * sq * sq) +
+            const T R = nd.p[1], k1 = T(1) + nd.p[2], sq = sqrt_t(T(1) - qd(k1 * r2, R * R));
+            return qd(T(1), R * sq) + qd(k1 * r2, R * R * R * sq * sq * sq) +
                    r2 * (T(12) * nd.p[3] + r2 * (T(30) * nd.p[4] + r2 * T(56) * nd.p[5]));
         }
-        const T E = nd.p[1], n = nd.p[2], A = (n + T(1)) / (n - T(1)), u = sqrt_t(T(1) + A * r2 / (E * E));
-        return A / ((n + T(1)) * E) * (T(1) / u - A * r2 / (E * E * u * u * u));
+        const T E = nd.p[1], n = nd.p[2], A = qd(n + T(1), n - T(1)), u = sqrt_t(T(1) + qd(A * r2, E * E));
+        return qd(A, (n + T(1)) * E) * (qd(T(1), u) - qd(A * r2, E * E * u * u * u));
     }
     const T h = T(1e-4) * nd.p[0];
     return (sag(nd, r + h) - T(2) * sag(nd, r) + sag(nd, r - h)) / (h * h);
@@ -379,7 +392,7 @@ template <class T> __device__ __forceinline__ bool poly_inside(const T* rec, T P
             py <= max_t(y1, y2) + tol)
             on_edge = true;
         if ((y1 > py) != (y2 > py)) {
-            const T xc = x1 + (py - y1) * (x2 - x1) / (y2 - y1);
+            const T xc = x1 + qd((py - y1) * (x2 - x1), y2 - y1);
             if (xc >= px) inside = !inside;
         }
     }
@@ -482,14 +495,14 @@ __device__ __forceinline__ T surf_g(const Scene<T>& sc, const DNode<T>& nd, T ox
 template <class T, uint32_t F>
 __device__ __forceinline__ T polish_root(const Scene<T>& sc, const DNode<T>& nd, T ox, T oy, T oz, T dx, T dy, T dz, T a, T b,
                                          T ga, T gb) {
-    T t = a - ga * (b - a) / (gb - ga);  // false-position start
+    T t = a - qd(ga * (b - a), gb - ga);  // false-position start
     if (!(t > a && t < b)) t = T(0.5) * (a + b);
     for (int it = 0; it < 48; ++it) {
         T dg;
         const T g = surf_g<T, F>(sc, nd, ox, oy, oz, dx, dy, dz, t, &dg);
         if (g == T(0)) return t;
         if ((g < T(0)) == (ga < T(0))) { a = t; ga = g; } else { b = t; gb = g; }
-        T tn = t - g / dg;
+        T tn = t - qd(g, dg);
         // converged Newton step: accept BEFORE the bracket safeguard — a converged iterate sits on the
         // bracket end it has just moved (tn == a), and bisecting there would throw the root away and
         // spend the remaining iterations halving the interval
@@ -518,7 +531,7 @@ __device__ __forceinline__ bool hit_leaf(const Scene<T>& sc, const DNode<T>& nd,
         t1 = max_t(t1, T(0));
         t2 = min_t(t2, T(100));
         // np.linspace(t1 - EPS, t2 + EPS, 10): sign change per sub-interval, roots ascending
-        const T a = t1 - EPS, b = t2 + EPS, step = (b - a) / T(9);
+        const T a = t1 - EPS, b = t2 + EPS, step = qd(b - a, T(9));
         if (nd.shape == OT_SHAPE_SPHERE) {
             // Closed form of the same search.  g(t) = |o + t d| - R is negative exactly between the two
             // intersections r0 < r1 of the line with the sphere, so sample interval i of the scan shows a sign
@@ -533,7 +546,7 @@ __device__ __forceinline__ bool hit_leaf(const Scene<T>& sc, const DNode<T>& nd,
             if (!(disc > T(0))) return false;  // the line stays outside: g never changes sign
             const T hc = sqrt_t(disc);
             const T r0 = tca - hc, r1 = tca + hc;
-            const T inv_step = T(9) / (b - a);
+            const T inv_step = qd(T(9), b - a);
             const bool in0 = r0 > a && r0 < b, in1 = r1 > a && r1 < b;
             const int i0 = min((int)((r0 - a) * inv_step), 8), i1 = min((int)((r1 - a) * inv_step), 8);
             if (in0 && in1 && i0 == i1) return false;  // both inside one interval: equal signs at its ends
@@ -561,6 +574,20 @@ __device__ __forceinline__ bool hit_leaf(const Scene<T>& sc, const DNode<T>& nd,
             }
             return surf_g<T, F>(sc, nd, ox, oy, oz, dx, dy, dz, t, (T*)nullptr);
         };
+        // A ray that STARTS on a convex asphere needs no scan in two cases (both exact in real arithmetic, and what the scan
+        // below would find): g is convex along the ray with g(0) = 0, so (i) leaving to the positive side, g'(0) > 0, it
+        // never returns; (ii) going to the negative side it returns at most once, and not before the end of the search
+        // interval if g is still negative there.  The only crossing the reference's samples can then show is the one at the
+        // start point, which its |t| < EPS filter throws away (optical_component.py:221-227).  Grazing starts (|g'| small,
+        // where rounding of the start point could move that root beyond EPS) take the scan.  cfg 5: the rays leaving the
+        // lens front towards the mirror and those entering the glass — two of six segments per round trip.
+        if (own && asph && (nd.flags & (DN_CONVEX_POS | DN_CONVEX_NEG))) {
+            const T sgn = (nd.flags & DN_CONVEX_POS) ? T(1) : T(-1);
+            const T r20 = oy * oy + oz * oz;
+            const T dg0 = sgn * (dx + sag_slope_over_r(nd, r20) * (oy * dy + oz * dz));
+            if (dg0 > T(0.25)) return false;
+            if (dg0 < T(-0.25) && sgn * sample(b) < T(0)) return false;
+        }
         T tl = a, gl = sample(a);
         for (int i = 1; i < 10; ++i) {
             const T tr = (i == 9) ? b : a + T(i) * step;
@@ -648,7 +675,9 @@ template <int GATE> __device__ __forceinline__ bool count_gate(const GateCtx& g,
 // DEFER_AABB: the caller has NOT yet applied this leaf's own AABB test (component_group.py:104-107).
 // A planar leaf is cheaper to reject by its sign/distance tests than by the slab test, and a hit
 // needs both, so the slab test runs last and only for leaves that would otherwise be hits.
-template <class T, uint32_t F, int GATE, bool ORDERED, bool DEFER_AABB = false>
+// KIND: 0 any leaf; 1 / 2: the caller has sorted planar from curved leaves itself and this call site only ever sees planar /
+// curved ones (the other half of the function is not compiled into it).
+template <class T, uint32_t F, int GATE, bool ORDERED, bool DEFER_AABB = false, int KIND = 0>
 __device__ __forceinline__ void test_leaf(const Scene<T>& sc, const NodeRef<T>& nr, int idx, const RayState<T>& r, Hit<T>& best,
                                           const GateCtx& gate, const RayInv<T>* ri = nullptr) {
     const DNode<T>& nd = *nr.nd;
@@ -658,7 +687,7 @@ __device__ __forceinline__ void test_leaf(const Scene<T>& sc, const NodeRef<T>& 
     const bool planar = sh == OT_SHAPE_CIRCLE || sh == OT_SHAPE_RECT || sh == OT_SHAPE_POLYGON2D || sh == OT_SHAPE_CSG;
     const bool limited = (F & F_LIMIT) && nd.max_count >= 0;
     T t, Px, Py, Pz;
-    if (!(F & F_CURVED) || planar) {
+    if (KIND != 2 && (!(F & F_CURVED) || KIND == 1 || planar)) {
         // A ray cannot meet the plane it starts on a second time: the only root is t = 0, which the reference's
         // |t| < 1e-9 guard rejects (optical_component.py:184).  Saying so by identity instead of by distance is
         // the same rule in exact arithmetic and immune to rounding of the start point — in single precision a
@@ -686,7 +715,7 @@ __device__ __forceinline__ void test_leaf(const Scene<T>& sc, const NodeRef<T>& 
         const T ldy = dot3_t(nd.M[1], r.dx, nd.M[4], r.dy, nd.M[7], r.dz), ldz = dot3_t(nd.M[2], r.dx, nd.M[5], r.dy, nd.M[8], r.dz);
         Px = fma_t(t, ldx, lox); Py = fma_t(t, ldy, loy); Pz = fma_t(t, ldz, loz);
         if (!planar_boundary<T, F>(sc, nd, Px, Py, Pz)) return;
-    } else {
+    } else if (KIND != 1) {
         const T prune_t = limited ? Num<T>::inf() : best.t;
         if (DEFER_AABB && (nd.flags & OT_NODE_CHECK_AABB)) {  // curved leaves: the slab test is the cheap one
             T u1, u2;
@@ -1138,6 +1167,24 @@ __device__ __forceinline__ Hit<T> nearest_hit(const Scene<T>& sc, const RayState
             return best;
         }
     }
+    // Curved leaves wait until the planar ones have been tested (scenes without count gates: the order of the tests is
+    // free there, exact ties go to the lower node index either way).  A planar test costs ~50 instructions, an asphere
+    // search ~400, and behind a nearer planar hit the curved leaf's AABB entry lies beyond the best hit: it is pruned
+    // without a search (cfg 5: a ray coming back from the micro-mirrors meets the flat back of the lens before its
+    // aspheric front, which the list names first).  The pending leaves are wave-uniform node indices with a per-lane
+    // membership mask.
+    constexpr bool DEFER_CURVED = (F & F_CURVED) != 0 && (F & F_LIMIT) == 0;
+    int pend_node[4] = {0, 0, 0, 0}, n_pend = 0;
+    uint32_t my_pend = 0;
+    auto flush_pending = [&]() {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c < n_pend && ((my_pend >> c) & 1u))
+                test_leaf<T, F, GATE, false, (F & F_AABB) != 0, 2>(sc, node_ref<T, F>(sc, pend_node[c]), pend_node[c], r, best, gate, &ri);
+        }
+        n_pend = 0;
+        my_pend = 0;
+    };
     for (int i = 0; i < sc.n_nodes; ++i) {  // virtual indices; the children of an instanced run are only ever reached through their group's grid
         const NodeRef<T> nr = node_ref<T, F>(sc, i);
         const DNode<T>& nd = *nr.nd;
@@ -1166,9 +1213,26 @@ __device__ __forceinline__ Hit<T> nearest_hit(const Scene<T>& sc, const RayState
                 continue;
             }
         }
-        if (i < skip_until) continue;
-        test_leaf<T, F, GATE, true, (F & F_AABB) != 0>(sc, nr, i, r, best, gate, &ri);
+        if constexpr (DEFER_CURVED) {
+            const int sh = nd.shape;
+            if (!(sh == OT_SHAPE_CIRCLE || sh == OT_SHAPE_RECT || sh == OT_SHAPE_POLYGON2D || sh == OT_SHAPE_CSG)) {  // wave-uniform
+                const bool want = i >= skip_until;
+                if (__any(want)) {
+                    if (n_pend == 4) flush_pending();
+                    if (n_pend == 0) pend_node[0] = i; else if (n_pend == 1) pend_node[1] = i; else if (n_pend == 2) pend_node[2] = i; else pend_node[3] = i;
+                    if (want) my_pend |= 1u << n_pend;
+                    ++n_pend;
+                }
+                continue;
+            }
+            if (i < skip_until) continue;
+            test_leaf<T, F, GATE, false, (F & F_AABB) != 0, 1>(sc, nr, i, r, best, gate, &ri);
+        } else {
+            if (i < skip_until) continue;
+            test_leaf<T, F, GATE, true, (F & F_AABB) != 0>(sc, nr, i, r, best, gate, &ri);
+        }
     }
+    if constexpr (DEFER_CURVED) flush_pending();
     return best;
 }
 
@@ -1190,9 +1254,9 @@ __device__ __forceinline__ void surf_normal(const Scene<T>& sc, const DNode<T>& 
     }
     if constexpr (F & F_CURVED) {
         switch (nd.shape) {
-            case OT_SHAPE_SPHERE: nx = Px / nd.p[0]; ny = Py / nd.p[0]; nz = Pz / nd.p[0]; return;
+            case OT_SHAPE_SPHERE: nx = qd(Px, nd.p[0]); ny = qd(Py, nd.p[0]); nz = qd(Pz, nd.p[0]); return;
             case OT_SHAPE_CYLINDER:
-                if constexpr (F & F_MISC) { nx = Px / nd.p[0]; ny = Py / nd.p[0]; nz = T(0); }
+                if constexpr (F & F_MISC) { nx = qd(Px, nd.p[0]); ny = qd(Py, nd.p[0]); nz = T(0); }
                 return;
             case OT_SHAPE_POLYGON3D:
                 if constexpr (F & F_MISC) {
@@ -1205,7 +1269,7 @@ __device__ __forceinline__ void surf_normal(const Scene<T>& sc, const DNode<T>& 
                 const T r = sqrt_t(Py * Py + Pz * Pz);
                 if (r < T(1e-12)) return;
                 const T s = sag_d1(nd, r);
-                const T ay = s * (Py / r), az = s * (Pz / r);
+                const T ay = s * qd(Py, r), az = s * qd(Pz, r);
                 const T inv = rsqrt_t(T(1) + ay * ay + az * az);
                 nx = inv; ny = ay * inv; nz = az * inv;
                 return;
@@ -1273,7 +1337,7 @@ __device__ __forceinline__ int interact(const Scene<T>& sc, const RayState<T>& r
             if (nd.roc_kind == OT_ROC_ASPHERE) {  // surfaces.py:362-373
                 const T rr = sqrt_t(h.py * h.py + h.pz * h.pz), s = sag_d1(nd, rr);
                 const T w = T(1) + s * s;
-                ROC = w * sqrt_t(w) / sag_d2(nd, rr);
+                ROC = qd(w * sqrt_t(w), sag_d2(nd, rr));
             }
         }
         T nin = n1, nout = n2;
@@ -1285,7 +1349,7 @@ __device__ __forceinline__ int interact(const Scene<T>& sc, const RayState<T>& r
                 const T back = rcp_t(ratio);
                 qtr = q1r * back; qti = q1i * back; qrr = q1r; qri = q1i;
             } else {
-                const T Cc = (nin - nout) / (ROC * nout), Cr = T(2) / ROC;
+                const T Cc = qd(nin - nout, ROC * nout), Cr = qd(T(2), ROC);
                 cdiv(q1r, q1i, Cc * q1r + ratio, Cc * q1i, qtr, qti);
                 cdiv(q1r, q1i, Cr * q1r + T(1), Cr * q1i, qrr, qri);
             }

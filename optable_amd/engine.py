@@ -229,7 +229,7 @@ class Engine:
             n_segments, count_ptr, n_rays = segs.capacity // segs.n_rays * segs.n_rays, segs.count.data_ptr(), segs.n_rays
         else:
             n_segments = segs.n_valid if n_segments is None else n_segments
-            count_ptr, n_rays = None, 0
+            count_ptr, n_rays = None, (-1 if segs.append else 0)
         idx = torch.empty(n_segments, dtype=torch.int64, device=dev)
         P = [torch.empty(n_segments, dtype=torch.float64, device=dev) for _ in range(3)]
         t = torch.empty(n_segments, dtype=torch.float64, device=dev)
