@@ -311,7 +311,7 @@ enum ot_option {
     OT_OPT_BLOCKS_PER_CU = 3,  /* persistent-grid size in 256-thread blocks per CU (0 = auto)  */
     OT_OPT_KERNEL = 4,         /* 0 auto; 1 lane-per-ray kernel; 2 rolling-list kernel (heavy scenes) */
     OT_OPT_LDS_LIMIT_KB = 5,   /* scene images above this many KB are read from global memory   */
-    OT_OPT_LIST_CAP = 6,       /* heavy scenes: live rays per wave in the rolling list: a power of two (default 128) */
+    OT_OPT_LIST_CAP = 6,       /* heavy scenes: live rays per wave in the rolling list: a multiple of 64, 128..1024 (mixed lists use it only if it is a power of two) */
     OT_OPT_PAIR_STORES = 7,    /* lane-per-ray kernel: lane pairs write two fields per 16-byte store (0/1) */
     OT_OPT_MIX_GENERATIONS = 8,/* heavy scenes: -1 auto, 0 generation-pure lists even under a top-level grid */
     OT_OPT_FLAT_QUEUE = 9,     /* planar scenes under a top-level grid: wave-wide candidate queue (0/1) */

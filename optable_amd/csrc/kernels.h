@@ -66,6 +66,7 @@ template <class T> __device__ __forceinline__ Scene<T> bind_scene(const uint32_t
     sc.runs = reinterpret_cast<const int32_t*>(base + b.runs_word);
     sc.n_nodes = b.n_nodes;
     sc.n_runs = b.n_runs;
+    for (int k = 0; k < 4; ++k) sc.run0[k] = b.n_runs > 0 ? __builtin_amdgcn_readfirstlane(sc.runs[k]) : 0;
     sc.n_mats = b.n_mats;
     sc.cache_mat = b.cache_mat;
     sc.root = b.root;
@@ -327,7 +328,7 @@ __global__ __launch_bounds__((rolling_threads<T, F, REC_LDS>()), (rolling_minw<T
     T* const srec = REC_LDS ? reinterpret_cast<T*>(lds_next) + (int64_t)wave * ((12 * W + RI) * CAP) / W
                             : reinterpret_cast<T*>(ws.base + gw * ws.wave_bytes);
     int32_t* const sint = reinterpret_cast<int32_t*>(srec + 12 * CAP);
-    const int M = CAP - 1;  // CAP is a power of two (host)
+    const int M = mix ? CAP - 1 : -1;  // mixed lists: a ring, CAP is a power of two (host); generation-pure lists always start at position 0 and never wrap: any multiple of 64
     int head = 0, tail = 0, alive = 0, round_left = 0;  // wave-uniform: `alive` entries from ring position `head`; survivors and tickets go to `tail`
     bool exhausted = false;
     int64_t chunk_pos = 0;  // append layout: next free slot of this wave's chunk, and how many are left in it
@@ -416,7 +417,13 @@ __global__ __launch_bounds__((rolling_threads<T, F, REC_LDS>()), (rolling_minw<T
             const GateCtx gate = {counts, n_classes, cls, nullptr, nullptr, 0, 0};
             Hit<T> h;
             if constexpr ((F & F_FLAT) != 0) h = flat_grid_hit<T, F, GATE_PLAIN>(sc, r, active, gate, flat, lane OT_FLAT_STAMP_ARGS);
-            else h = nearest_hit<T, F, GATE_PLAIN>(sc, r, active, gate);
+            else {
+#ifdef OT_STAMP
+                h = nearest_hit<T, F, GATE_PLAIN>(sc, r, active, gate, st_acc, &st_last);
+#else
+                h = nearest_hit<T, F, GATE_PLAIN>(sc, r, active, gate);
+#endif
+            }
             OT_STAMP_AT(1);
             // the segment record: every entry of the pass writes exactly one
             const bool hit = active && h.node >= 0;

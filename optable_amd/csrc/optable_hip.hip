@@ -646,7 +646,7 @@ static int launch_rolling(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, 
     // LDS holds next to the lists are read from L2 (all-features preset only).
     const size_t entry = sizeof(unsigned long long);
     const size_t flat_bytes = flat_ok ? (((size_t)(FlatLds<T>::fixed_bytes + (size_t)flat_cap * 2) + 15) & ~(size_t)15) : 0;  // per wave (kernels.h)
-    const size_t rec_bytes = 12 * sizeof(T) + 4 * ((need & F_LIMIT) && fr == 3 ? 2 : 1);  // per record of a live ray (kernels.h rec_int_words)
+    const size_t rec_bytes = 12 * sizeof(T) + 4 * (fr == 3 ? 2 : 1);  // per record of a live ray (kernels.h rec_int_words: the all-features preset keeps the count class)
     const int32_t cap0 = mix ? c->opt_list_cap : (c->opt_list_cap_pure > 0 ? c->opt_list_cap_pure : 256);
     ot_ctx::RollingPlan& plan = c->plan[f64 ? 1 : 0][append ? 1 : 0];
     if (plan.epoch != c->plan_epoch) {
@@ -671,7 +671,7 @@ static int launch_rolling(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, 
         const int rec_lds_min_waves = c->opt_rec_lds > 0 ? 4 : 12;  // OT_OPT_LDS_RECORDS = 1: whenever it fits at all
         if (img_fits && c->opt_rec_lds != 0) {
             Try t;
-            for (int32_t CAP = cap0; CAP >= 128; CAP >>= 1) {  // (a list holds at least two tickets)
+            for (int32_t CAP = cap0; CAP >= 128; CAP = mix ? CAP >> 1 : CAP - 64) {  // (a list holds at least two tickets)
                 t = Try();
                 const int rc = evaluate(true, true, CAP, t);
                 if (rc) return rc;
@@ -1007,9 +1007,10 @@ int ot_set_option(ot_ctx* c, int32_t option, int32_t value) {
         case OT_OPT_LDS_LIMIT_KB:
             if (value < 0 || value > 150) return fail(OT_ERR_INVALID, "OT_OPT_LDS_LIMIT_KB takes 0..150");
             c->opt_lds_limit_kb = value; return 0;
-        case OT_OPT_LIST_CAP:
-            if (value < 64 || value > 1024 || (value & (value - 1))) return fail(OT_ERR_INVALID, "OT_OPT_LIST_CAP takes a power of two, 64..1024");
-            c->opt_list_cap = value; c->opt_list_cap_pure = value; return 0;
+        case OT_OPT_LIST_CAP:  // generation-pure lists never wrap: any multiple of 64; mixed lists are rings: powers of two only
+            if (value < 128 || value > 1024 || value % 64) return fail(OT_ERR_INVALID, "OT_OPT_LIST_CAP takes a multiple of 64, 128..1024");
+            if (!(value & (value - 1))) c->opt_list_cap = value;
+            c->opt_list_cap_pure = value; return 0;
         case OT_OPT_LDS_RECORDS:
             if (value < -1 || value > 1) return fail(OT_ERR_INVALID, "OT_OPT_LDS_RECORDS takes -1 (auto), 0 or 1");
             c->opt_rec_lds = value; return 0;

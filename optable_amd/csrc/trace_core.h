@@ -101,6 +101,7 @@ template <class T> struct Scene {
     const DMat<T>* mats;
     const T* aux;
     const int32_t* runs;    // [n_runs][4]: first virtual index, count, physical index of the prototype, aux offset of the geo table
+    int32_t run0[4];        // the first run, read once per workgroup: node_ref is called a dozen times per pass and an LDS round trip each adds up
     int32_t n_nodes;        // VIRTUAL node count: the caller's depth-first list (indices in hits, ties, skip lists, grid items)
     int32_t n_runs;
     int32_t n_mats;
@@ -140,16 +141,28 @@ template <class T, uint32_t F> __device__ __forceinline__ NodeRef<T> node_ref(co
     r.inst = 0;
     if constexpr ((F & F_GRID) != 0) {  // runs only exist below gridded groups
         int shift = 0;
-        for (int k = 0; k < sc.n_runs; ++k) {  // scene-uniform trip count (0 for most scenes, 1 for cfg 5)
-            const int first = sc.runs[4 * k], cnt = sc.runs[4 * k + 1];
-            if (v < first) break;
-            if (v < first + cnt) {
-                r.nd = sc.nodes + sc.runs[4 * k + 2];
-                r.inst = v - first;
-                r.geo = sc.aux + sc.runs[4 * k + 3] + 9 * r.inst;
-                return r;
+        if (sc.n_runs > 0) {  // scene-uniform
+            const int first = sc.run0[0], cnt = sc.run0[1];
+            if (v >= first) {
+                if (v < first + cnt) {
+                    r.nd = sc.nodes + sc.run0[2];
+                    r.inst = v - first;
+                    r.geo = sc.aux + sc.run0[3] + 9 * r.inst;
+                    return r;
+                }
+                shift = cnt - 1;
+                for (int k = 1; k < sc.n_runs; ++k) {  // further runs: rare
+                    const int f2 = sc.runs[4 * k], c2 = sc.runs[4 * k + 1];
+                    if (v < f2) break;
+                    if (v < f2 + c2) {
+                        r.nd = sc.nodes + sc.runs[4 * k + 2];
+                        r.inst = v - f2;
+                        r.geo = sc.aux + sc.runs[4 * k + 3] + 9 * r.inst;
+                        return r;
+                    }
+                    shift += c2 - 1;
+                }
             }
-            shift += cnt - 1;
         }
         r.nd = sc.nodes + (v - shift);
     } else {
@@ -1151,8 +1164,16 @@ __device__ __forceinline__ Hit<T> flat_grid_hit(const Scene<T>& sc, const RaySta
 // Nearest hit over the whole scene for one ray (all lanes of the wave walk the node list with
 // the same index; a lane that pruned a group idles until the list leaves that group, and when
 // every lane of the wave pruned it the wave jumps ahead to the smallest skip target).
+#ifdef OT_STAMP  // diagnostic build: where the linear pass spends its cycles — st_acc[5] group boxes and loop, [6] planar leaves, [7] gridded
+                 // groups (cell lookup + children), [8] deferred curved leaves
+#define OT_NH_STAMP_PARAMS , unsigned long long* st_acc = nullptr, unsigned long long* st_last = nullptr
+#define OT_NH_AT(k) do { if (st_acc) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long _t = __builtin_amdgcn_s_memtime(); st_acc[k] += _t - *st_last; *st_last = _t; } } while (0)
+#else
+#define OT_NH_STAMP_PARAMS
+#define OT_NH_AT(k) do {} while (0)
+#endif
 template <class T, uint32_t F, int GATE>
-__device__ __forceinline__ Hit<T> nearest_hit(const Scene<T>& sc, const RayState<T>& r, bool active, const GateCtx& gate) {
+__device__ __forceinline__ Hit<T> nearest_hit(const Scene<T>& sc, const RayState<T>& r, bool active, const GateCtx& gate OT_NH_STAMP_PARAMS) {
     Hit<T> best;
     best.t = Num<T>::inf();
     best.node = -1;
@@ -1201,15 +1222,19 @@ __device__ __forceinline__ Hit<T> nearest_hit(const Scene<T>& sc, const RayState
             if (nd.kind == OT_NODE_GROUP) {
                 if constexpr (F & F_GRID) {
                     if (nd.flags & OT_NODE_GRID) {  // wave-uniform branch; lanes that missed the box idle inside
+                        OT_NH_AT(5);
                         if (inside) {
                             grid_children<T, F, GATE>(sc, nd, r, ri, t1, t2, best, gate);
                             skip_until = nd.end;
                         }
+                        OT_NH_AT(7);
                     }
                 }
-                // every lane of the wave takes this branch (nd is wave-uniform); inactive lanes hold INT_MAX
-                const int target = __builtin_amdgcn_readfirstlane(wave_min_i32(skip_until));
-                if (target > i + 1) i = (target < sc.n_nodes ? target : sc.n_nodes) - 1;
+                // Every lane of the wave takes this branch (nd is wave-uniform).  If no lane wants the group's first child the
+                // wave jumps over the group: a lane that is skipping holds the end of this group or of one that encloses it
+                // (inactive lanes INT_MAX), so none of them has business before nd.end.  One ballot; the first version took
+                // the wave-wide minimum of skip_until here, six dependent cross-lane steps per group node.
+                if (!__any(skip_until <= i + 1)) i = nd.end - 1;
                 continue;
             }
         }
@@ -1226,13 +1251,17 @@ __device__ __forceinline__ Hit<T> nearest_hit(const Scene<T>& sc, const RayState
                 continue;
             }
             if (i < skip_until) continue;
+            OT_NH_AT(5);
             test_leaf<T, F, GATE, false, (F & F_AABB) != 0, 1>(sc, nr, i, r, best, gate, &ri);
+            OT_NH_AT(6);
         } else {
             if (i < skip_until) continue;
             test_leaf<T, F, GATE, true, (F & F_AABB) != 0>(sc, nr, i, r, best, gate, &ri);
         }
     }
+    OT_NH_AT(5);
     if constexpr (DEFER_CURVED) flush_pending();
+    OT_NH_AT(8);
     return best;
 }
 

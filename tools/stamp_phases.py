@@ -23,7 +23,7 @@ prec = sys.argv[2] if len(sys.argv) > 2 else "f32"
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 3_000_000
 wl = W.baseline_workloads(oa)[name]
 eng = get_engine()
-for k, v in (("CAP", abi.OPT_LIST_CAP), ("KERNEL", abi.OPT_KERNEL), ("RECLDS", abi.OPT_LDS_RECORDS), ("FLAT", abi.OPT_FLAT_QUEUE)):
+for k, v in (("CAP", abi.OPT_LIST_CAP), ("KERNEL", abi.OPT_KERNEL), ("RECLDS", abi.OPT_LDS_RECORDS), ("FLAT", abi.OPT_FLAT_QUEUE), ("INST", abi.OPT_INSTANCING)):
     if os.environ.get(k):
         eng.set_option(v, int(os.environ[k]))
 table = oa.OpticalTable()
@@ -48,6 +48,9 @@ segs = int(out.count.abs().sum().item())
 print(f"{name} {prec} n={n}: {ms / cnt:.3f} ms (stamped build), {passes} passes for {segs} segments = {segs / passes:.1f} lanes per pass")
 for label, v in (("list + loads (waited)", load), ("nearest hit", hit), ("record + interact + state (waited)", inter), ("compaction", comp)):
     print(f"   {label:36s} {v / passes:9.0f} cycles per pass  {100 * v / tot:5.1f} %")
+if not rounds and walk + queue + test + verdict:  # the linear pass (nearest_hit): its phases are part of "nearest hit" above
+    for label, v in (("  group boxes + loop", walk), ("  planar leaves", queue), ("  gridded groups", test), ("  deferred curved leaves", verdict)):
+        print(f"   {label:36s} {v / passes:9.0f} cycles per pass  {100 * v / tot:5.1f} %")
 if rounds:  # the pair-queue walk (flat_grid_hit): its phases are part of none of the above ("nearest hit" holds only the setup)
     tot2 = tot + walk + queue + test + verdict
     print(f"   pair queue: {rounds / passes:.2f} rounds and {slots / passes:.2f} slots of 64 pairs per pass")
