@@ -315,7 +315,8 @@ enum ot_option {
     OT_OPT_PAIR_STORES = 7,    /* lane-per-ray kernel: lane pairs write two fields per 16-byte store (0/1) */
     OT_OPT_MIX_GENERATIONS = 8,/* heavy scenes: -1 auto, 0 generation-pure lists even under a top-level grid */
     OT_OPT_FLAT_QUEUE = 9,     /* planar scenes under a top-level grid: wave-wide candidate queue (0/1) */
-    OT_OPT_LDS_RECORDS = 10,   /* heavy scenes, fp32: records of the live rays in LDS: -1 auto, 0 never, 1 whenever it fits */
+    OT_OPT_LDS_RECORDS = 10,   /* heavy scenes, fp32: records of the live rays in LDS (the first 128 positions of every wave's list; the rest
+                                  of a generation-pure list of OT_OPT_LIST_CAP entries spills to global scratch): -1 auto, 0 never, 1 whenever it fits */
     OT_OPT_APPEND_CHUNK = 11,  /* ot_trace_append_*: slots a wave claims per atomic (multiple of 64, default 512) */
     OT_OPT_INSTANCING = 12     /* fold identical lattice children (MMA / MLA / DMD) into one record + per-member pose at upload (0/1) */
 };

@@ -15,6 +15,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <type_traits>
 
 #include "trace_core.h"
@@ -266,6 +267,7 @@ __global__ __launch_bounds__(256, MINW) void k_trace_fused(SceneBlob blob, T uni
 // planar test in the per-lane cell loop (the early exits do pay there); a resumable grid walk that visits at most 1 / 2 /
 // 4 cells per pass (every extra pass pays the pass's load -> trace -> store latency again); lists worked off in rounds
 // with a remainder pass instead of the FIFO ring (44 instead of 62 lanes per pass).
+static constexpr int REC_LDS_POSITIONS = 128;  // REC_LDS kernels: the first 128 positions of every wave's list keep their records in LDS
 struct AppendCtl {
     unsigned long long* cursor;  // slots claimed so far (device); the caller reads it back as *n_slots
     int64_t capacity;
@@ -294,9 +296,28 @@ template <class T, uint32_t F, bool REC_LDS> constexpr int rolling_minw() { retu
 template <class T, uint32_t F, bool SCENE_IN_LDS, bool NT, bool REC_LDS, class OUT>
 __global__ __launch_bounds__((rolling_threads<T, F, REC_LDS>()), (rolling_minw<T, F, REC_LDS>())) void k_trace_rolling(
     SceneBlob blob, T unit, RaysT<T> in, int64_t n, int32_t K, OUT out, AppendCtl ac, int32_t* __restrict__ seg_count, int32_t* counts,
-    int32_t n_classes, WaveScratch<T> ws, int32_t CAP, unsigned long long* queue, int32_t mix, int32_t flat_cap) {
+    int32_t n_classes, WaveScratch<T> ws, int32_t CAP, int32_t capl_arg, unsigned long long* queue, int32_t mix, int32_t flat_cap) {
+    // list positions whose records live in LDS: a compile-time constant, so that the twelve field planes of a record are
+    // immediate offsets of one ds_read / ds_write address instead of twelve scalar registers and an add each
+    constexpr int CAPL = REC_LDS ? REC_LDS_POSITIONS : 0;
+    (void)capl_arg;  // the host passes the same number (optable_hip.hip checks it against REC_LDS_POSITIONS)
     constexpr bool APPEND = std::is_same<OUT, SegPlanes<T>>::value;
     constexpr int W = (int)(sizeof(T) / 4), RI = rec_int_words<F>();
+    // Where the records of the live rays are: list positions below CAPL in LDS (REC_LDS), the others in this wave's global
+    // scratch.  Mixed lists with REC_LDS keep everything in LDS (CAPL == CAP; the pair-queue kernels are only ever mixed
+    // and do not compile the overflow path); generation-pure lists keep the FRONT of the list there: they compact in place
+    // towards position 0, so a long list (full passes: 58 lanes per pass at 512 entries, 45 at 128) spills its far end to
+    // global memory only while it is young, and once it has thinned out to CAPL rays every pass is LDS only.
+    constexpr bool OVERFLOW = !REC_LDS || (F & F_FLAT) == 0;
+    // The caller's 15 array pointers are needed once per ray, for its first segment — and as a by-value kernel argument
+    // they would sit in 30 of the 102 scalar registers for the whole pass loop (the kernel spills scalars into vector lanes
+    // as it is).  They are read from the kernel-argument segment where they are used instead; `in` itself is never touched.
+    // (The segment is laid out like a struct of the parameters in order, each at its natural alignment: LeadArgs below;
+    // tools/kernel_resources.sh --args prints the offsets the code object records.)
+    struct LeadArgs { SceneBlob blob; T unit; RaysT<T> in; };
+    typedef const __attribute__((address_space(4))) RaysT<T>* RaysArgPtr;
+    const RaysArgPtr in_arg = (RaysArgPtr)((uintptr_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(LeadArgs, in));
+    (void)in;
     extern __shared__ __align__(16) uint32_t lds[];
     const uint32_t* base = blob.words;
     uint32_t* lds_tail = lds;
@@ -306,8 +327,12 @@ __global__ __launch_bounds__((rolling_threads<T, F, REC_LDS>()), (rolling_minw<T
         lds_tail = lds + ((blob.n_words + 3) & ~3);
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
-    unsigned long long* ring = reinterpret_cast<unsigned long long*>(lds_tail) + wave * CAP;  // wave-private list (a ring of CAP entries)
-    uint8_t* lds_next = reinterpret_cast<uint8_t*>(reinterpret_cast<unsigned long long*>(lds_tail) + n_waves * CAP);
+    // wave-private list of CAP entries: mixed lists a ring of (ray index | segment index << 32); generation-pure lists the ray
+    // indices alone (every ray of the list is on the same segment: the list is refilled only when it is empty)
+    const int ring_bytes = CAP * (mix ? 8 : 4);
+    unsigned long long* ring64 = reinterpret_cast<unsigned long long*>(reinterpret_cast<uint8_t*>(lds_tail) + wave * ring_bytes);
+    uint32_t* ring32 = reinterpret_cast<uint32_t*>(ring64);
+    uint8_t* lds_next = reinterpret_cast<uint8_t*>(lds_tail) + n_waves * ring_bytes;
     // F_FLAT: per-wave key table and pair queue of flat_grid_hit, behind the lists of all waves
     FlatLds<T> flat = {nullptr, nullptr, nullptr, nullptr, 0};
     if constexpr ((F & F_FLAT) != 0) {
@@ -325,9 +350,12 @@ __global__ __launch_bounds__((rolling_threads<T, F, REC_LDS>()), (rolling_minw<T
     // ONE base pointer per wave; field f of ring position p is element p + f * CAP (twelve reals, then the integer words
     // behind them).  Separate base pointers per field cost scalar registers that the kernel does not have.
     const int64_t gw = (int64_t)blockIdx.x * n_waves + wave;
-    T* const srec = REC_LDS ? reinterpret_cast<T*>(lds_next) + (int64_t)wave * ((12 * W + RI) * CAP) / W
-                            : reinterpret_cast<T*>(ws.base + gw * ws.wave_bytes);
-    int32_t* const sint = reinterpret_cast<int32_t*>(srec + 12 * CAP);
+    T* const lrec = reinterpret_cast<T*>(lds_next) + (int64_t)wave * ((12 * W + RI) * CAPL) / W;  // REC_LDS: field stride CAPL
+    int32_t* const lint = reinterpret_cast<int32_t*>(lrec + 12 * CAPL);
+    const int CAPG = CAP - (REC_LDS ? CAPL : 0);                                                   // global part: field stride CAPG
+    T* const grec = reinterpret_cast<T*>(ws.base + gw * ws.wave_bytes);
+    int32_t* const gint = reinterpret_cast<int32_t*>(grec + 12 * CAPG);
+    int32_t kround = 0;  // generation-pure lists: the segment index of every ray in the list
     const int M = mix ? CAP - 1 : -1;  // mixed lists: a ring, CAP is a power of two (host); generation-pure lists always start at position 0 and never wrap: any multiple of 64
     int head = 0, tail = 0, alive = 0, round_left = 0;  // wave-uniform: `alive` entries from ring position `head`; survivors and tickets go to `tail`
     bool exhausted = false;
@@ -368,10 +396,11 @@ __global__ __launch_bounds__((rolling_threads<T, F, REC_LDS>()), (rolling_minw<T
                 const unsigned long long first = draw_ticket();
                 if (first >= (unsigned long long)n) { exhausted = true; break; }
                 const int cnt = (int)((unsigned long long)n - first < 64ull ? (unsigned long long)n - first : 64ull);
-                if (lane < cnt) ring[(tail + lane) & M] = first + (unsigned long long)lane;  // segment index 0
-                tail = (tail + cnt) & M;
+                if (lane < cnt) ring32[tail + lane] = (uint32_t)first + (uint32_t)lane;  // segment index 0
+                tail += cnt;
                 alive += cnt;
             }
+            kround = 0;
         }
         if (!fresh && alive == 0) break;  // queue and list are empty
         if (!fresh && round_left == 0) {
@@ -387,31 +416,82 @@ __global__ __launch_bounds__((rolling_threads<T, F, REC_LDS>()), (rolling_minw<T
         {
             const int p = (head + lane) & M;
             const bool entry = lane < take;
-            const unsigned long long e = fresh ? fresh_first + (unsigned long long)lane : (entry ? ring[p] : 0ull);
-            const int64_t i = (int64_t)(e & 0x7fffffffull);
-            const int32_t k = (int32_t)(e >> 32);
-            RayState<T> r = {};
-            int32_t cls = 0, fl = 0;
-            if (entry) {
-                if (k == 0) {  // first segment: the caller's arrays (a ticket is 64 consecutive rays)
-                    fl = in.flags[i];
-                    if constexpr ((F & F_LIMIT) != 0) cls = in.id[i];
-                    r = load_ray(in, i, fl);
-                    if ((uint32_t)r.last >= (uint32_t)sc.n_nodes) r.last = -1;  // bits 8.. of a caller's flags that name no node
-                    fl &= 0xff;
-                } else {  // later ones: this wave's records, by ring position
-                    r.ox = srec[p]; r.oy = srec[p + CAP]; r.oz = srec[p + 2 * CAP];
-                    r.dx = srec[p + 3 * CAP]; r.dy = srec[p + 4 * CAP]; r.dz = srec[p + 5 * CAP];
-                    r.qr = srec[p + 6 * CAP]; r.qi = srec[p + 7 * CAP]; r.I = srec[p + 8 * CAP];
-                    r.n = srec[p + 9 * CAP]; r.pl = srec[p + 10 * CAP]; r.wl = srec[p + 11 * CAP];
-                    const int32_t meta = sint[p];
-                    fl = meta & 0xff;
-                    r.last = (meta >> 8) - 1;
-                    if constexpr ((F & F_LIMIT) != 0) cls = sint[p + CAP];
-                    r.len = Num<T>::inf();
-                    r.has_q = (fl & OT_RAY_HAS_Q) != 0;
+            // (ray index, segment index): 32 bits each — n < 2^31 per launch
+            int32_t i = (int32_t)(uint32_t)fresh_first + lane, k = 0;
+            if (!fresh) {
+                i = 0;
+                k = kround;
+                if (entry) {
+                    if (mix) { const unsigned long long e = ring64[p]; i = (int32_t)(e & 0x7fffffffull); k = (int32_t)(e >> 32); }
+                    else i = (int32_t)ring32[p];
                 }
             }
+            RayState<T> r = {};
+            int32_t cls = 0, fl = 0;
+            // A ray's record in two parts: what the nearest-hit search needs (origin, direction, length, start node) and
+            // what only rides along to the interaction and the next record (q, intensity, index, path length, wavelength).
+            // Kernels with their records in LDS fetch the second part AFTER the search: six registers less at the search's
+            // peak (the curved-surface kernel has 128 at 16 waves per CU), for LDS reads that cost the same either way.
+            constexpr bool LATE = REC_LDS;
+            auto load_part = [&](const bool geom) {
+                if (!entry) return;
+                if (k == 0) {  // first segment: the caller's arrays (a ticket is 64 consecutive rays)
+                    RaysArgPtr ip = in_arg;
+                    asm volatile("" : "+s"(ip));  // opaque here: the pointers are loaded now, not hoisted out of the pass loop
+                    RaysT<T> in_now;
+                    {
+                        static_assert(sizeof(RaysT<T>) == 15 * sizeof(uint64_t), "RaysT is fifteen pointers");
+                        const __attribute__((address_space(4))) uint64_t* src = (const __attribute__((address_space(4))) uint64_t*)ip;
+                        uint64_t words[15];
+#pragma unroll
+                        for (int w = 0; w < 15; ++w) words[w] = src[w];
+                        __builtin_memcpy(&in_now, words, sizeof(in_now));
+                    }
+                    if (geom) {
+                        fl = in_now.flags[i];
+                        if constexpr ((F & F_LIMIT) != 0) cls = in_now.id[i];
+                        r.ox = ld_once(in_now.ox + i); r.oy = ld_once(in_now.oy + i); r.oz = ld_once(in_now.oz + i);
+                        r.dx = ld_once(in_now.dx + i); r.dy = ld_once(in_now.dy + i); r.dz = ld_once(in_now.dz + i);
+                        r.len = in_now.len ? in_now.len[i] : Num<T>::inf();
+                        r.has_q = (fl & OT_RAY_HAS_Q) != 0;
+                        r.last = (int32_t)((uint32_t)fl >> 8) - 1;  // bits 8..31: node the ray was emitted on, plus one (generation buffers; 0 for a caller's ray)
+                        if ((uint32_t)r.last >= (uint32_t)sc.n_nodes) r.last = -1;  // ... that name no node of this scene
+                        fl &= 0xff;
+                    } else {
+                        r.wl = ld_once(in_now.wl + i); r.qr = ld_once(in_now.qr + i); r.qi = ld_once(in_now.qi + i);
+                        r.I = ld_once(in_now.I + i); r.n = ld_once(in_now.n + i); r.pl = ld_once(in_now.pl + i);
+                    }
+                } else if (REC_LDS && (!OVERFLOW || head < CAPL)) {  // later ones: this wave's records, by list position (a pass lies in one region: wave-uniform branch)
+                    if (geom) {
+                        r.ox = lrec[p]; r.oy = lrec[p + CAPL]; r.oz = lrec[p + 2 * CAPL];
+                        r.dx = lrec[p + 3 * CAPL]; r.dy = lrec[p + 4 * CAPL]; r.dz = lrec[p + 5 * CAPL];
+                        const int32_t meta = lint[p];
+                        if constexpr ((F & F_LIMIT) != 0) cls = lint[p + CAPL];
+                        r.last = (meta >> 8) - 1;
+                        r.has_q = meta & OT_RAY_HAS_Q;  // (a dead ray never gets a record: the flag word of a record is HAS_Q or nothing)
+                        r.len = Num<T>::inf();
+                    } else {
+                        r.qr = lrec[p + 6 * CAPL]; r.qi = lrec[p + 7 * CAPL]; r.I = lrec[p + 8 * CAPL];
+                        r.n = lrec[p + 9 * CAPL]; r.pl = lrec[p + 10 * CAPL]; r.wl = lrec[p + 11 * CAPL];
+                    }
+                } else if constexpr (OVERFLOW) {
+                    const int g = p - (REC_LDS ? CAPL : 0);
+                    if (geom) {
+                        r.ox = grec[g]; r.oy = grec[g + CAPG]; r.oz = grec[g + 2 * CAPG];
+                        r.dx = grec[g + 3 * CAPG]; r.dy = grec[g + 4 * CAPG]; r.dz = grec[g + 5 * CAPG];
+                        const int32_t meta = gint[g];
+                        if constexpr ((F & F_LIMIT) != 0) cls = gint[g + CAPG];
+                        r.last = (meta >> 8) - 1;
+                        r.has_q = meta & OT_RAY_HAS_Q;
+                        r.len = Num<T>::inf();
+                    } else {
+                        r.qr = grec[g + 6 * CAPG]; r.qi = grec[g + 7 * CAPG]; r.I = grec[g + 8 * CAPG];
+                        r.n = grec[g + 9 * CAPG]; r.pl = grec[g + 10 * CAPG]; r.wl = grec[g + 11 * CAPG];
+                    }
+                }
+            };
+            load_part(true);
+            if constexpr (!LATE) load_part(false);
             OT_STAMP_AT(0);
             const bool active = entry && !(fl & OT_RAY_DEAD);  // optical_component.py:349: a dead ray is returned as it came
             const GateCtx gate = {counts, n_classes, cls, nullptr, nullptr, 0, 0};
@@ -424,10 +504,11 @@ __global__ __launch_bounds__((rolling_threads<T, F, REC_LDS>()), (rolling_minw<T
                 h = nearest_hit<T, F, GATE_PLAIN>(sc, r, active, gate);
 #endif
             }
+            if constexpr (LATE) load_part(false);
             OT_STAMP_AT(1);
             // the segment record: every entry of the pass writes exactly one
             const bool hit = active && h.node >= 0;
-            int64_t slot = (int64_t)k * n + i;
+            int64_t slot = (int64_t)k * n + (int64_t)i;
             bool room = true;
             if constexpr (APPEND) {
                 const unsigned long long writers = __ballot(entry);
@@ -463,13 +544,28 @@ __global__ __launch_bounds__((rolling_threads<T, F, REC_LDS>()), (rolling_minw<T
                 // them: alive <= CAP and survivors <= take); every record load of the pass was issued before these stores
                 // and accesses of one wave complete in issue order
                 const int q = (tail + __popcll(mk & ((1ull << lane) - 1ull))) & M;
-                ring[q] = ((unsigned long long)(k + 1) << 32) | (unsigned long long)i;
-                srec[q] = child.ox; srec[q + CAP] = child.oy; srec[q + 2 * CAP] = child.oz;
-                srec[q + 3 * CAP] = child.dx; srec[q + 4 * CAP] = child.dy; srec[q + 5 * CAP] = child.dz;
-                srec[q + 6 * CAP] = child.qr; srec[q + 7 * CAP] = child.qi; srec[q + 8 * CAP] = child.I;
-                srec[q + 9 * CAP] = child.n; srec[q + 10 * CAP] = child.pl; srec[q + 11 * CAP] = r.wl;
-                sint[q] = fl | ((child.last + 1) << 8);
-                if constexpr ((F & F_LIMIT) != 0) sint[q + CAP] = cls;
+                if (mix) ring64[q] = ((unsigned long long)(uint32_t)(k + 1) << 32) | (unsigned long long)(uint32_t)i;
+                else ring32[q] = (uint32_t)i;
+                const int32_t meta = (r.has_q ? OT_RAY_HAS_Q : 0) | ((child.last + 1) << 8);
+                if (REC_LDS && (!OVERFLOW || q < CAPL)) {
+                    lrec[q] = child.ox; lrec[q + CAPL] = child.oy; lrec[q + 2 * CAPL] = child.oz;
+                    lrec[q + 3 * CAPL] = child.dx; lrec[q + 4 * CAPL] = child.dy; lrec[q + 5 * CAPL] = child.dz;
+                    lrec[q + 6 * CAPL] = child.qr; lrec[q + 7 * CAPL] = child.qi; lrec[q + 8 * CAPL] = child.I;
+                    lrec[q + 9 * CAPL] = child.n; lrec[q + 10 * CAPL] = child.pl; lrec[q + 11 * CAPL] = r.wl;
+                    lint[q] = meta;
+                    if constexpr ((F & F_LIMIT) != 0) lint[q + CAPL] = cls;
+                }
+                if constexpr (OVERFLOW) {
+                    if (!REC_LDS || q >= CAPL) {
+                        const int g = q - (REC_LDS ? CAPL : 0);
+                        grec[g] = child.ox; grec[g + CAPG] = child.oy; grec[g + 2 * CAPG] = child.oz;
+                        grec[g + 3 * CAPG] = child.dx; grec[g + 4 * CAPG] = child.dy; grec[g + 5 * CAPG] = child.dz;
+                        grec[g + 6 * CAPG] = child.qr; grec[g + 7 * CAPG] = child.qi; grec[g + 8 * CAPG] = child.I;
+                        grec[g + 9 * CAPG] = child.n; grec[g + 10 * CAPG] = child.pl; grec[g + 11 * CAPG] = r.wl;
+                        gint[g] = meta;
+                        if constexpr ((F & F_LIMIT) != 0) gint[g + CAPG] = cls;
+                    }
+                }
             }
             tail = (tail + __popcll(mk)) & M;
             if (fresh) {
@@ -479,7 +575,7 @@ __global__ __launch_bounds__((rolling_threads<T, F, REC_LDS>()), (rolling_minw<T
                 alive += __popcll(mk) - take;
                 round_left -= take;
             }
-            if (!mix && round_left == 0) head = (tail - alive) & M;  // the next round reads what this one wrote
+            if (!mix && round_left == 0) { head = (tail - alive) & M; ++kround; }  // the next round reads what this one wrote
             OT_STAMP_AT(2);
 #ifdef OT_STAMP
             st_acc[4] += 1;

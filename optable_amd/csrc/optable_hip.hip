@@ -78,7 +78,7 @@ struct ot_ctx {
     int32_t opt_kernel = 0;  // 0 auto, 1 fused (lane per ray), 2 rolling lists (the heavy-scene kernel)
     int32_t last_launch[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // ot_debug_last_launch
     // heavy-scene launch plan per precision (a dozen occupancy queries): recomputed after an upload or an option change
-    struct RollingPlan { uint64_t epoch = 0; int wpb = 4, per_cu = 1; int32_t cap = 128; bool lds = false, rec_lds = false; size_t lds_bytes = 0; };
+    struct RollingPlan { uint64_t epoch = 0; int wpb = 4, per_cu = 1; int32_t cap = 128, capl = 0; bool lds = false, rec_lds = false; size_t lds_bytes = 0; };
     RollingPlan plan[2][2];  // [precision][output layout]
     uint64_t plan_epoch = 1;
     int32_t opt_rec_lds = -1;    // pair-queue scenes: records of the live rays in LDS (-1 auto, 0 never, 1 whenever it fits)
@@ -644,57 +644,62 @@ static int launch_rolling(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, 
     // (registers and LDS decide).  Preference: image + records in LDS (a pass then waits for nothing in global memory)
     // when enough waves still fit; else image in LDS, records in the per-wave global scratch (L2); images beyond what
     // LDS holds next to the lists are read from L2 (all-features preset only).
-    const size_t entry = sizeof(unsigned long long);
+    const size_t entry = mix ? 8 : 4;  // list entry: (ray index | segment index << 32), or the ray index alone (kernels.h)
     const size_t flat_bytes = flat_ok ? (((size_t)(FlatLds<T>::fixed_bytes + (size_t)flat_cap * 2) + 15) & ~(size_t)15) : 0;  // per wave (kernels.h)
     const size_t rec_bytes = 12 * sizeof(T) + 4 * (fr == 3 ? 2 : 1);  // per record of a live ray (kernels.h rec_int_words: the all-features preset keeps the count class)
+    // List capacity.  Mixed lists (rings, a power of two): 128 (256: +4 %, 512: +25 % on cfg 3).  Generation-pure lists: the
+    // longer the better for the lanes (a list shrinks as its rays die and every round ends in a partial pass: 45 lanes per
+    // pass at 128 entries, 53 at 256, 58 at 512 on cfg 5), but only the first 128 positions keep their records in LDS and a
+    // pass over the global part waits for its loads behind the segment stores of the pass before (one in-order counter):
+    // cfg 5 fp32, append layout, 16 waves per CU: 14.9 ms at 128, 13.5 at 256, 16+ at 384 and beyond.
     const int32_t cap0 = mix ? c->opt_list_cap : (c->opt_list_cap_pure > 0 ? c->opt_list_cap_pure : 256);
     ot_ctx::RollingPlan& plan = c->plan[f64 ? 1 : 0][append ? 1 : 0];
     if (plan.epoch != c->plan_epoch) {
-        struct Try { int waves = 0, wpb = 0, per_cu = 0; int32_t cap = 0; size_t lds = 0; };
-        auto evaluate = [&](bool lds_img, bool rec_lds, int32_t CAP, Try& best) -> int {
-            const void* k = (const void*)rolling_kernel<T, OUT>(fr, flat_ok, lds_img, rec_lds);
+        struct Try { int waves = 0, wpb = 0, per_cu = 0; int32_t cap = 0, capl = 0; size_t lds = 0; };
+        // most waves per CU for one placement: image in LDS or not, the first `capl` records of every list in LDS
+        auto evaluate = [&](bool lds_img, int32_t CAP, int32_t CAPL, Try& best) -> int {
+            const void* k = (const void*)rolling_kernel<T, OUT>(fr, flat_ok, lds_img, CAPL > 0);
             if (!k) return 0;
-            const size_t per_wave = (size_t)CAP * entry + flat_bytes + (rec_lds ? rec_bytes * CAP : 0);
-            for (int wpb = 4; wpb * 64 <= rolling_max_threads<T>(fr, flat_ok, rec_lds); wpb += 4) {
+            const size_t per_wave = (size_t)CAP * entry + flat_bytes + rec_bytes * CAPL;
+            for (int wpb = 4; wpb * 64 <= rolling_max_threads<T>(fr, flat_ok, CAPL > 0); wpb += 4) {
                 const size_t lds_b = (lds_img ? img : 0) + (size_t)wpb * per_wave;
                 if (lds_b > 158 * 1024) continue;
                 if (lds_b > 48 * 1024) HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b));
                 int per_cu = 0;
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 64 * wpb, lds_b) != hipSuccess) per_cu = 0;
-                if (per_cu * wpb > best.waves) { best.waves = per_cu * wpb; best.wpb = wpb; best.per_cu = per_cu; best.cap = CAP; best.lds = lds_b; }
+                if (per_cu * wpb > best.waves) { best.waves = per_cu * wpb; best.wpb = wpb; best.per_cu = per_cu; best.cap = CAP; best.capl = CAPL; best.lds = lds_b; }
             }
             return 0;
         };
         Try chosen;
-        bool lds_img = false, rec_lds = false;
-        // (1) image and records in LDS: the largest list that still gives REC_LDS_MIN_WAVES waves per CU
-        const int rec_lds_min_waves = c->opt_rec_lds > 0 ? 4 : 12;  // OT_OPT_LDS_RECORDS = 1: whenever it fits at all
+        bool lds_img = false;
+        // (1) image in LDS, records in LDS: all of them (mixed lists) or the front of the list (generation-pure lists).
+        //     Taken when at least 12 waves per CU still fit (OT_OPT_LDS_RECORDS = 1: whenever it fits at all).
+        const int rec_lds_min_waves = c->opt_rec_lds > 0 ? 4 : 12;
         if (img_fits && c->opt_rec_lds != 0) {
             Try t;
-            for (int32_t CAP = cap0; CAP >= 128; CAP = mix ? CAP >> 1 : CAP - 64) {  // (a list holds at least two tickets)
-                t = Try();
-                const int rc = evaluate(true, true, CAP, t);
-                if (rc) return rc;
-                if (t.waves >= rec_lds_min_waves) break;
-            }
-            if (t.waves >= rec_lds_min_waves) { chosen = t; lds_img = rec_lds = true; }
+            // (the LDS part of a list is REC_LDS_POSITIONS = 128 entries, a compile-time constant of the kernels: a mixed list
+            // is then exactly that long, a generation-pure one keeps the rest of its cap0 entries in global scratch)
+            const int rc = evaluate(true, mix || cap0 < REC_LDS_POSITIONS ? REC_LDS_POSITIONS : cap0, REC_LDS_POSITIONS, t);
+            if (rc) return rc;
+            if (t.waves >= rec_lds_min_waves) { chosen = t; lds_img = true; }
         }
         // (2) image in LDS, records in global scratch
         if (!chosen.waves && img_fits) {
             for (int32_t CAP = cap0; CAP >= 128 && !chosen.waves; CAP >>= 1) {
-                const int rc = evaluate(true, false, CAP, chosen);
+                const int rc = evaluate(true, CAP, 0, chosen);
                 if (rc) return rc;
             }
             lds_img = chosen.waves > 0;
         }
         // (3) image read from L2
         if (!chosen.waves) {
-            const int rc = evaluate(false, false, cap0, chosen);
+            const int rc = evaluate(false, cap0, 0, chosen);
             if (rc) return rc;
         }
         if (!chosen.waves) return fail(OT_ERR_UNSUPPORTED, "no k_trace_rolling launch configuration fits this scene image");
-        plan.epoch = c->plan_epoch; plan.wpb = chosen.wpb; plan.per_cu = chosen.per_cu; plan.cap = chosen.cap; plan.lds = lds_img;
-        plan.rec_lds = rec_lds; plan.lds_bytes = chosen.lds;
+        plan.epoch = c->plan_epoch; plan.wpb = chosen.wpb; plan.per_cu = chosen.per_cu; plan.cap = chosen.cap; plan.capl = chosen.capl; plan.lds = lds_img;
+        plan.rec_lds = chosen.capl > 0; plan.lds_bytes = chosen.lds;
     }
     const int wpb = plan.wpb;
     const int32_t CAP = plan.cap;
@@ -708,7 +713,8 @@ static int launch_rolling(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, 
     const int64_t capr = (int64_t)c->n_cus * per_cu_r;
     const int gridr = (int)(want < capr ? want : capr);
     // per-wave record scratch (by list position) + the ticket counter
-    const size_t wave_bytes = plan.rec_lds ? 0 : align_up((size_t)CAP * rec_bytes);
+    const int32_t CAPL = plan.capl;
+    const size_t wave_bytes = align_up((size_t)(CAP - CAPL) * rec_bytes);  // what the lists keep outside LDS
     const size_t scratch_bytes = wave_bytes * (size_t)gridr * wpb;
     if (c->blocked.ensure(scratch_bytes + 256)) return fail(OT_ERR_HIP, "hipMalloc of rolling-trace scratch failed");
     c->blocked_queue_off = scratch_bytes;
@@ -724,7 +730,7 @@ static int launch_rolling(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, 
     int rc = timing_pair(c, &ev0, &ev1);
     if (rc) return rc;
     hipExtLaunchKernelGGL(kr, dim3(gridr), dim3(64 * wpb), (uint32_t)lds_r, c->stream, ev0, ev1, 0u, blob, (T)c->unit, view<T>(rays), n,
-                          K, out, ac, seg_count, counts, n_classes, ws, CAP, queue, mix ? 1 : 0, flat_ok ? flat_cap : 0);
+                          K, out, ac, seg_count, counts, n_classes, ws, CAP, CAPL, queue, mix ? 1 : 0, flat_ok ? flat_cap : 0);
     HIP_TRY(hipGetLastError());
     const int32_t shape[8] = {2, 64 * wpb, per_cu_r, gridr, (int32_t)lds_r, CAP, mix ? 1 : 0, (flat_ok ? 1 : 0) | (plan.rec_lds ? 2 : 0) | (append ? 4 : 0)};
     for (int q = 0; q < 8; ++q) c->last_launch[q] = shape[q];

@@ -21,7 +21,7 @@ template <class T>
 using FusedKern = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, SegsT<T>, int32_t*, int32_t*, int32_t, int32_t);
 template <class T, class OUT>
 using RollingKern = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, OUT, AppendCtl, int32_t*, int32_t*, int32_t, WaveScratch<T>, int32_t,
-                             unsigned long long*, int32_t, int32_t);
+                             int32_t, unsigned long long*, int32_t, int32_t);
 template <class T>
 using GenKern = void (*)(SceneBlob, T, RaysT<T>, const int32_t*, int64_t, int32_t*, const int64_t*, SegsT<T>, int64_t, RaysOutT<T>, int32_t*,
                          int64_t, uint8_t*, unsigned long long*, const unsigned long long*, int32_t*, int32_t, const int32_t*,

@@ -601,31 +601,42 @@ __device__ __forceinline__ bool hit_leaf(const Scene<T>& sc, const DNode<T>& nd,
             if (dg0 > T(0.25)) return false;
             if (dg0 < T(-0.25) && sgn * sample(b) < T(0)) return false;
         }
-        T tl = a, gl = sample(a);
-        for (int i = 1; i < 10; ++i) {
-            const T tr = (i == 9) ? b : a + T(i) * step;
-            const T gr = sample(tr);
-            // fp64: the reference's strict product test (optical_component.py:131).  fp32: |P| - R is
-            // quantised to ~2e-6 at R ~ 30, so a sample lands on g == 0 exactly for several percent of
-            // the rays and the product test would drop those roots; compare signs instead.
-            const bool crossing = sizeof(T) == 4 ? ((gl < T(0)) != (gr < T(0))) : (gl * gr < T(0));
+        // Two steps, so that the instruction stream holds the ten samples once and ONE copy of the root polish: (1) the
+        // ten samples, unrolled, leave a mask of the intervals with a sign change; (2) the marked intervals in ascending
+        // order — almost always one — are polished and filtered as the reference does.  (Written as one loop, the compiler
+        // unrolled nine polishes into every inlined copy of this function: 14000 instructions in the curved-surface kernel.)
+        uint32_t crossings = 0;
+        {
+            T gl = sample(a);
+#pragma unroll
+            for (int i = 1; i < 10; ++i) {
+                const T gr = sample((i == 9) ? b : a + T(i) * step);
+                // fp64: the reference's strict product test (optical_component.py:131).  fp32: |P| - R is
+                // quantised to ~2e-6 at R ~ 30, so a sample lands on g == 0 exactly for several percent of
+                // the rays and the product test would drop those roots; compare signs instead.
+                const bool crossing = sizeof(T) == 4 ? ((gl < T(0)) != (gr < T(0))) : (gl * gr < T(0));
+                if (crossing) crossings |= 1u << i;
+                gl = gr;
+            }
+        }
+#pragma unroll 1
+        while (crossings) {
+            const int i = __builtin_ctz(crossings);
+            crossings &= crossings - 1;
+            const T tl = (i == 1) ? a : a + T(i - 1) * step, tr = (i == 9) ? b : a + T(i) * step;
             // A ray that was emitted ON this surface (own) has a root at its start point: the bracket that holds t = 0
             // shows a sign change, brentq converges to that root and the |t| < EPS filter throws it away
             // (optical_component.py:221-227).  The samples are taken as always — a second crossing further along still
             // shows in its own interval — but polishing the root at the start point only to discard it is skipped.
-            if (crossing && own && tl <= T(0) && tr >= T(0)) { tl = tr; gl = gr; continue; }
-            if (crossing) {
-                const T t = polish_root<T, F>(sc, nd, ox, oy, oz, dx, dy, dz, tl, tr, gl, gr);
-                if (t >= T(0) && abs_t(t) >= EPS && t <= len) {
-                    const T X = ox + t * dx, Y = oy + t * dy, Z = oz + t * dz;
-                    if (curved_boundary<T, F>(sc, nd, X, Y, Z)) {
-                        t_out = t; Px = X; Py = Y; Pz = Z;
-                        return true;
-                    }
+            if (own && tl <= T(0) && tr >= T(0)) continue;
+            const T t = polish_root<T, F>(sc, nd, ox, oy, oz, dx, dy, dz, tl, tr, sample(tl), sample(tr));
+            if (t >= T(0) && abs_t(t) >= EPS && t <= len) {
+                const T X = ox + t * dx, Y = oy + t * dy, Z = oz + t * dz;
+                if (curved_boundary<T, F>(sc, nd, X, Y, Z)) {
+                    t_out = t; Px = X; Py = Y; Pz = Z;
+                    return true;
                 }
             }
-            tl = tr;
-            gl = gr;
         }
     }
     return false;
@@ -782,30 +793,42 @@ __device__ __forceinline__ void grid_children(const Scene<T>& sc, const DNode<T>
     // Phase 2 (expensive, lock-step): every lane runs the leaf test of its c-th candidate at the same
     // time.  Testing a curved leaf the moment a lane finds it would serialise the 10-point scans of
     // the 64 lanes behind each other (measured on cfg 5: ~15k VALU instructions per wave-segment).
-    int cand0 = -1, cand1 = -1, cand2 = -1, cand3 = -1, ncand = 0;
-    for (int c1 = c1lo; c1 <= c1hi; ++c1)
-        for (int c0 = c0lo; c0 <= c0hi; ++c0) {
-            const int cidx = c1 * g0 + c0;
-            const int kb = (int)start[cidx], ke = (int)start[cidx + 1];
-            for (int k = kb; k < ke; ++k) {
-                const int ci = (int)items[k];
-                if (ci == cand0 || ci == cand1 || ci == cand2 || ci == cand3) continue;  // listed in several cells
-                const NodeRef<T> ch = node_ref<T, F>(sc, ci);
-                T u1, u2;
-                if (!slab_inv(r.ox, r.oy, r.oz, ri, ch.geo + 3, u1, u2)) continue;  // the child's own AABB test, unchanged
-                if (beyond_best(u1, best.t)) continue;  // (gridded groups hold no count-limited child)
-                if (ncand == 0) cand0 = ci;
-                else if (ncand == 1) cand1 = ci;
-                else if (ncand == 2) cand2 = ci;
-                else if (ncand == 3) cand3 = ci;
-                else test_leaf<T, F, GATE, false>(sc, ch, ci, r, best, gate);  // overflow: rare, test in place
-                ++ncand;
+    // The walk is one flat loop with its position (cell, item) in registers, so that a lane whose four candidate slots
+    // are full tests them and walks on — rare; a lattice lists one member and perhaps a back plate per cell — and the
+    // instruction stream holds the leaf test once.
+    int c1 = c1lo, c0 = c0lo;
+    int k = (int)start[c1 * g0 + c0], ke = (int)start[c1 * g0 + c0 + 1];
+    bool walking = true;
+#pragma unroll 1
+    while (__any(walking)) {  // rounds of up to four candidates per lane: almost always one
+        int cand0 = -1, cand1 = -1, cand2 = -1, cand3 = -1, ncand = 0;
+        while (walking && ncand < 4) {
+            if (k >= ke) {  // next cell of the footprint
+                if (++c0 > c0hi) {
+                    c0 = c0lo;
+                    if (++c1 > c1hi) { walking = false; break; }
+                }
+                k = (int)start[c1 * g0 + c0];
+                ke = (int)start[c1 * g0 + c0 + 1];
+                continue;
             }
+            const int ci = (int)items[k++];
+            if (ci == cand0 || ci == cand1 || ci == cand2 || ci == cand3) continue;  // listed in several cells
+            const NodeRef<T> ch = node_ref<T, F>(sc, ci);
+            T u1, u2;
+            if (!slab_inv(r.ox, r.oy, r.oz, ri, ch.geo + 3, u1, u2)) continue;  // the child's own AABB test, unchanged
+            if (beyond_best(u1, best.t)) continue;  // (gridded groups hold no count-limited child)
+            if (ncand == 0) cand0 = ci;
+            else if (ncand == 1) cand1 = ci;
+            else if (ncand == 2) cand2 = ci;
+            else cand3 = ci;
+            ++ncand;
         }
 #pragma unroll 1
-    for (int c = 0; c < 4; ++c) {  // one copy of the leaf test in the instruction stream
-        const int ci = c == 0 ? cand0 : (c == 1 ? cand1 : (c == 2 ? cand2 : cand3));
-        if (c < ncand) test_leaf<T, F, GATE, false>(sc, node_ref<T, F>(sc, ci), ci, r, best, gate);
+        for (int c = 0; c < 4; ++c) {  // one copy of the leaf test in the instruction stream
+            const int ci = c == 0 ? cand0 : (c == 1 ? cand1 : (c == 2 ? cand2 : cand3));
+            if (c < ncand) test_leaf<T, F, GATE, false>(sc, node_ref<T, F>(sc, ci), ci, r, best, gate);
+        }
     }
 }
 
@@ -1195,18 +1218,11 @@ __device__ __forceinline__ Hit<T> nearest_hit(const Scene<T>& sc, const RayState
     // aspheric front, which the list names first).  The pending leaves are wave-uniform node indices with a per-lane
     // membership mask.
     constexpr bool DEFER_CURVED = (F & F_CURVED) != 0 && (F & F_LIMIT) == 0;
-    int pend_node[4] = {0, 0, 0, 0}, n_pend = 0;
+    int pend0 = 0, pend1 = 0, pend2 = 0, pend3 = 0, n_pend = 0;  // (four scalars: an array indexed by a loop variable would live in scratch)
     uint32_t my_pend = 0;
-    auto flush_pending = [&]() {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (c < n_pend && ((my_pend >> c) & 1u))
-                test_leaf<T, F, GATE, false, (F & F_AABB) != 0, 2>(sc, node_ref<T, F>(sc, pend_node[c]), pend_node[c], r, best, gate, &ri);
-        }
-        n_pend = 0;
-        my_pend = 0;
-    };
-    for (int i = 0; i < sc.n_nodes; ++i) {  // virtual indices; the children of an instanced run are only ever reached through their group's grid
+    int i = 0;
+  more_nodes:
+    for (; i < sc.n_nodes; ++i) {  // virtual indices; the children of an instanced run are only ever reached through their group's grid
         const NodeRef<T> nr = node_ref<T, F>(sc, i);
         const DNode<T>& nd = *nr.nd;
         if constexpr (F & F_AABB) {
@@ -1243,8 +1259,8 @@ __device__ __forceinline__ Hit<T> nearest_hit(const Scene<T>& sc, const RayState
             if (!(sh == OT_SHAPE_CIRCLE || sh == OT_SHAPE_RECT || sh == OT_SHAPE_POLYGON2D || sh == OT_SHAPE_CSG)) {  // wave-uniform
                 const bool want = i >= skip_until;
                 if (__any(want)) {
-                    if (n_pend == 4) flush_pending();
-                    if (n_pend == 0) pend_node[0] = i; else if (n_pend == 1) pend_node[1] = i; else if (n_pend == 2) pend_node[2] = i; else pend_node[3] = i;
+                    if (n_pend == 4) break;  // (wave-uniform) test what is pending first: ONE call site of the curved-leaf test
+                    if (n_pend == 0) pend0 = i; else if (n_pend == 1) pend1 = i; else if (n_pend == 2) pend2 = i; else pend3 = i;
                     if (want) my_pend |= 1u << n_pend;
                     ++n_pend;
                 }
@@ -1260,7 +1276,16 @@ __device__ __forceinline__ Hit<T> nearest_hit(const Scene<T>& sc, const RayState
         }
     }
     OT_NH_AT(5);
-    if constexpr (DEFER_CURVED) flush_pending();
+    if constexpr (DEFER_CURVED) {
+#pragma unroll 1
+        for (int c = 0; c < n_pend; ++c) {  // one copy of the curved-leaf test in the instruction stream
+            const int pn = c == 0 ? pend0 : (c == 1 ? pend1 : (c == 2 ? pend2 : pend3));
+            if ((my_pend >> c) & 1u) test_leaf<T, F, GATE, false, (F & F_AABB) != 0, 2>(sc, node_ref<T, F>(sc, pn), pn, r, best, gate, &ri);
+        }
+        n_pend = 0;
+        my_pend = 0;
+        if (i < sc.n_nodes) goto more_nodes;  // (the list was full: the walk stopped before pushing node i)
+    }
     OT_NH_AT(8);
     return best;
 }
