@@ -186,12 +186,14 @@ def kernel_name(scene, wl):
 
 
 def committed_counters(name):
-    """SQ-counter summary of this workload committed under profiles/ (tools/profile_configs.sh), or None."""
-    path = os.path.join(ROOT, "profiles", f"r02_{name}_counters.json")
-    if os.path.exists(path):
-        rec = json.load(open(path))
-        rec["source"] = os.path.relpath(path, ROOT)
-        return rec
+    """SQ-counter summary of this workload committed under profiles/ (tools/profile_r03.sh; the newest round that has
+    one), or None."""
+    for rnd in ("r03", "r02"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_{name}_counters.json")
+        if os.path.exists(path):
+            rec = json.load(open(path))
+            rec["source"] = os.path.relpath(path, ROOT)
+            return rec
     return None
 
 
@@ -210,30 +212,55 @@ def survey_config(oa, eng, name, device):
     eng.upload(scene)
     batch = make_batch(oa, wl, n, 0, device)
     n = batch.n
-    out = SegmentBatch(n * wl.max_segments, wl.precision, batch.device)
-    t_load = time.perf_counter()
-    while time.perf_counter() - t_load < 0.06:  # clocks up
-        eng.trace(batch, wl.max_segments, out=out)
-        torch.cuda.synchronize()
-    reps = 5 if name == "cfg3" else 3
-    eng.timing(True)
-    for _ in range(reps):
-        eng.trace(batch, wl.max_segments, out=out)
-    ms, cnt = eng.timing_read()
-    eng.timing(False)
-    segs = int(out.count.abs().sum().item())
-    t = ms / cnt / 1e3
+    heavy = scene.n_nodes >= 24
     b = BYTES[wl.precision]
+    reps = 5 if name == "cfg3" else 3
+
+    def measure(layout):
+        """device time per trace with the output in `layout`: [k][ray] slots (ot_trace_*) or the dense append-order list
+        (ot_trace_append_*, sized like a caller who knows the job: by the records of a first trace)"""
+        torch.cuda.empty_cache()
+        if layout == "append":
+            probe = eng.trace(batch, wl.max_segments, layout="append")
+            cap = probe.n_valid + 4096
+            del probe
+            torch.cuda.empty_cache()
+            out = SegmentBatch(cap, wl.precision, batch.device, block=True)
+        else:
+            out = SegmentBatch(n * wl.max_segments, wl.precision, batch.device)
+        t_load = time.perf_counter()
+        while time.perf_counter() - t_load < 0.06:  # clocks up
+            eng.trace(batch, wl.max_segments, out=out, layout=layout)
+            torch.cuda.synchronize()
+        eng.timing(True)
+        for _ in range(reps):
+            eng.trace(batch, wl.max_segments, out=out, layout=layout)
+        ms, cnt = eng.timing_read()
+        eng.timing(False)
+        segs = int(out.count.abs().sum().item())
+        slots = out.capacity if layout == "slots" else int(out.n_valid)
+        launch = eng.last_launch()
+        del out
+        return ms / cnt / 1e3, cnt, segs, slots, launch
+
+    t, cnt, segs, slots, launch = measure("slots")
     alg = n * b + segs * b
     rec = {"workload": wl.label, "rays": n, "dtype": wl.precision, "kernel": kernel_name(scene, wl), "leaf_surfaces": scene.n_leaves,
+           "layout": "slots: segment k of ray i at k * n_rays + i (ot_trace_*)", "output_slots": slots,
            "launches": cnt, "ms_per_trace": t * 1e3, "segments_per_ray": segs / n, "segments_per_s": segs / t,
            "intersections_per_s": segs * scene.n_leaves / t, "algorithmic_gbs": alg / t / 1e9,
-           "hbm_frac": alg / t / 1e9 / HBM_PEAK_GBS,
-           "bound": "hbm" if scene.n_nodes < 24 else "valu/latency (S >= 24, SURVEY.md §8d): the HBM fraction is for comparison"}
+           "hbm_frac": alg / t / 1e9 / HBM_PEAK_GBS, "launch": launch,
+           "bound": "hbm" if not heavy else "valu/latency (S >= 24, SURVEY.md §8d): the HBM fraction is for comparison"}
+    if heavy:  # the same trace with the dense output: same records (tests/test_gpu_append.py), written in whole lines
+        ta, cnta, segsa, slotsa, launcha = measure("append")
+        rec["append_layout"] = {"layout": "append: dense list in append order, a stable sort by ray is the reference's order (ot_trace_append_*)",
+                                "output_slots": slotsa, "holes": slotsa - segsa, "launches": cnta, "ms_per_trace": ta * 1e3,
+                                "segments_per_s": segsa / ta, "intersections_per_s": segsa * scene.n_leaves / ta,
+                                "algorithmic_gbs": alg / ta / 1e9, "hbm_frac": alg / ta / 1e9 / HBM_PEAK_GBS, "launch": launcha}
     counters = committed_counters(name)
     if counters:
         rec["sq_counters"] = counters
-    del out, batch
+    del batch
     torch.cuda.empty_cache()
     return rec
 
@@ -313,7 +340,9 @@ def main():
     from optable_amd import workloads as W
 
     wl = W.baseline_workloads(oa)[args.workload]
-    n = min(wl.rays_per_rank(world, args.rays), MAX_PER_RANK[wl.name])
+    n_wanted = wl.rays_per_rank(world, args.rays)
+    n = min(n_wanted, MAX_PER_RANK[wl.name])
+    clamped = n < n_wanted  # a rank takes at most what fits its HBM with the full history: the total then grows with N
     if wl.name == "cfg4":
         n = max(n // W.CFG4_WAVELENGTHS, 1) * W.CFG4_WAVELENGTHS
     MAX_SEG, prec, bytes_rec = wl.max_segments, wl.precision, BYTES[wl.precision]
@@ -433,7 +462,17 @@ def main():
         local_final = None
 
     gather_ms = gather_error = None
+    ranks_info = gather_split = None
     if distributed:
+        # every rank's own time and work next to the maximum `value` is computed from: a straggler shows by rank
+        mine = torch.tensor([dt, float(segs_step), float(n)], dtype=torch.float64, device=comm_dev)
+        everyone = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(everyone, mine)
+        per_rank = [[float(x) for x in t.tolist()] for t in everyone]
+        ms_steps = sorted(r[0] / args.steps * 1e3 for r in per_rank)
+        ranks_info = {"ms_per_step": {"min": ms_steps[0], "median": ms_steps[len(ms_steps) // 2], "max": ms_steps[-1],
+                                      "by_rank": [r[0] / args.steps * 1e3 for r in per_rank]},
+                      "segments_per_step_by_rank": [int(r[1]) for r in per_rank], "rays_by_rank": [int(r[2]) for r in per_rank]}
         tmax = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -449,7 +488,8 @@ def main():
                 torch.cuda.synchronize()
             dist.barrier()
             g0 = time.perf_counter()
-            gathered = odist.gather_final_state(local, dst=0)
+            gather_split = {}
+            gathered = odist.gather_final_state(local, dst=0, timings=gather_split)
             if not args.dry_run:
                 torch.cuda.synchronize()
             dist.barrier()
@@ -479,7 +519,8 @@ def main():
         line = {
             "metric": "ray-surface intersections/sec", "value": value, "unit": "intersections/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": wl.scaling, "vs_baseline": None, "dtype": prec, "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak" if (clamped or args.rays) else wl.scaling, "vs_baseline": None, "dtype": prec,
+            "data": "synthetic",
             "config": {"workload": wl.label, "rays_per_gpu": n, "rays_total": rays_total,
                        "segments_per_ray": segs_step / n, "leaf_surfaces": S_LEAVES, "input_batches_rotated": n_inputs,
                        "parallelism": f"ray-shard x{world}, scene replicated"},
@@ -493,6 +534,11 @@ def main():
         if heavy:
             line["roofline"]["note"] = ("this workload is VALU/latency-bound (S >= 24, SURVEY.md §8d): the HBM fraction is "
                                         "reported for comparison, not as its roof")
+        if clamped:  # the config names a total that does not fit this few GPUs: every rank traces its HBM's worth instead
+            line["clamped"] = True
+            line["total_requested"] = wl.total_rays
+            line["scaling_note"] = (f"{wl.name} names {wl.total_rays} rays in total; {world} rank(s) x {MAX_PER_RANK[wl.name]} (the per-rank HBM "
+                                    "cap with the full history) is less, so the per-rank size is fixed and the total grows with N: weak scaling")
         if args.dry_run:
             line["dry_run"] = True
         if "sustained" in extra:
@@ -507,6 +553,14 @@ def main():
         elif gather_ms is not None:
             line["gather_ms"] = gather_ms
             line["value_incl_gather"] = segs_total_step * S_LEAVES * args.steps / (dt + gather_ms / 1e3)
+            if gather_split:
+                line["gather"] = {"sizes_ms": gather_split["sizes_ms"], "payload_ms": gather_split["payload_ms"],
+                                  "payload_bytes": int(sum(gather_split["shard_sizes"])) * 12 * (8 if prec == "f64" else 4),
+                                  "shard_sizes": gather_split["shard_sizes"]}
+        if ranks_info is not None:
+            line["ranks"] = ranks_info
+            line["comm"] = {"backend": "rccl" if use_nccl else "gloo",
+                            "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if use_nccl else None}
         if world == 1 and not args.dry_run and wl.name == "cfg2" and not args.no_configs and args.rays is None:
             # the other BASELINE configs, at the size one GPU sees in the configuration they are quoted on
             del batches, outs

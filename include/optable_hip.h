@@ -85,8 +85,13 @@ enum ot_roc_kind {
 
 enum ot_node_flags {
     OT_NODE_CHECK_AABB = 1, /* set for groups and for children of groups (component_group.py:98-107) */
-    OT_NODE_GRID = 2        /* group: aux -> 2-D grid over the children's AABBs (acceleration only: the
+    OT_NODE_GRID = 2,       /* group: aux -> 2-D grid over the children's AABBs (acceleration only: the
                                children found through it still pass their own AABB test)             */
+    OT_NODE_BOX_TRUSTED = 4 /* the node's aabb contains its geometry.  The reference caches boxes and never updates
+                               them (optical_component.py:62-67): a box that went stale is still THE pass / fail gate,
+                               but nothing may be skipped because of where it lies.  The kernels prune a node whose
+                               box starts behind the best hit only when this flag is set; callers that are not sure
+                               leave it clear (results are the same, a little slower).                  */
 };
 
 typedef struct ot_node {

@@ -361,6 +361,8 @@ static int validate_root_grid(const ot_scene_desc* s) {
     for (int i = 0; i < s->n_nodes; ++i)
         if (s->nodes[i].kind == OT_NODE_LEAF && s->nodes[i].max_interact_count >= 0)
             return fail(OT_ERR_INVALID, "a root grid cannot be combined with count-limited leaves");
+    for (int i = 0; i < s->n_nodes; ++i)
+        if (!(s->nodes[i].flags & OT_NODE_BOX_TRUSTED)) return fail(OT_ERR_INVALID, "a root grid needs OT_NODE_BOX_TRUSTED on every node (the walk stops early on the strength of the boxes)");
     return 0;
 }
 
@@ -450,6 +452,9 @@ static int validate_scene(const ot_scene_desc* s) {
                 const int ci = (int)items[k];
                 if (ci <= i || ci >= nd.end || s->nodes[ci].kind != OT_NODE_LEAF) return fail(OT_ERR_INVALID, "grid item is not a leaf child");
             }
+            if (!(nd.flags & OT_NODE_BOX_TRUSTED)) return fail(OT_ERR_INVALID, "a gridded group needs OT_NODE_BOX_TRUSTED on itself and its children");
+            for (int ci = i + 1; ci < nd.end; ++ci)
+                if (!(s->nodes[ci].flags & OT_NODE_BOX_TRUSTED)) return fail(OT_ERR_INVALID, "a gridded group needs OT_NODE_BOX_TRUSTED on itself and its children");
         }
     }
     return 0;

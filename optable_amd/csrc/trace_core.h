@@ -271,7 +271,10 @@ __device__ __forceinline__ bool slab_inv(T ox, T oy, T oz, const RayInv<T>& ri, 
 // t1 up to rounding (the margin is 16x the self-hit guard, relative: 1.6e-8 / 1.6e-4).  The reference has no such
 // test — it evaluates everything and keeps the minimum — so skipping what cannot become the minimum changes
 // nothing, EXCEPT for count-limited leaves, whose counters see every geometric hit (optical_component.py:359-362):
-// callers apply it only where no limited leaf is behind the box.
+// callers apply it only where no limited leaf is behind the box — and, for a LAB box, only when the box is trusted
+// (OT_NODE_BOX_TRUSTED): a component's cached box may have gone stale (the reference never updates it; it then still
+// gates hits, but the geometry can lie in front of it).  The local box of a curved leaf is derived from the surface at
+// upload and needs no such flag.
 template <class T> __device__ __forceinline__ bool beyond_best(T t1, T best_t) {
     return t1 > best_t + T(16) * Num<T>::eps_t() * (T(1) + best_t);  // false while best_t is +inf
 }
@@ -744,7 +747,7 @@ __device__ __forceinline__ void test_leaf(const Scene<T>& sc, const NodeRef<T>& 
         if (DEFER_AABB && (nd.flags & OT_NODE_CHECK_AABB)) {  // curved leaves: the slab test is the cheap one
             T u1, u2;
             if (!slab_inv(r.ox, r.oy, r.oz, *ri, nr.geo + 3, u1, u2)) return;
-            if (beyond_best(u1, prune_t)) return;
+            if ((nd.flags & OT_NODE_BOX_TRUSTED) && beyond_best(u1, prune_t)) return;
         }
         T ox, oy, oz, dx, dy, dz;
         to_local(nd, rx, ry, rz, ox, oy, oz);
@@ -817,7 +820,7 @@ __device__ __forceinline__ void grid_children(const Scene<T>& sc, const DNode<T>
             const NodeRef<T> ch = node_ref<T, F>(sc, ci);
             T u1, u2;
             if (!slab_inv(r.ox, r.oy, r.oz, ri, ch.geo + 3, u1, u2)) continue;  // the child's own AABB test, unchanged
-            if (beyond_best(u1, best.t)) continue;  // (gridded groups hold no count-limited child)
+            if (beyond_best(u1, best.t)) continue;  // (gridded groups hold no count-limited child, and only trusted boxes: scene.py)
             if (ncand == 0) cand0 = ci;
             else if (ncand == 1) cand1 = ci;
             else if (ncand == 2) cand2 = ci;
@@ -844,7 +847,7 @@ __device__ __forceinline__ void walk_subtree(const Scene<T>& sc, int first, cons
         T t1 = T(0), t2 = T(0);
         if (nd.flags & OT_NODE_CHECK_AABB) {
             if (!slab_inv(r.ox, r.oy, r.oz, ri, nr.geo + 3, t1, t2)) { j = nd.end; continue; }
-            if (!(F & F_LIMIT) && beyond_best(t1, best.t)) { j = nd.end; continue; }
+            if (!(F & F_LIMIT) && (nd.flags & OT_NODE_BOX_TRUSTED) && beyond_best(t1, best.t)) { j = nd.end; continue; }
         }
         if (nd.kind == OT_NODE_GROUP) {
             if constexpr (F & F_GRID) {
@@ -1231,7 +1234,7 @@ __device__ __forceinline__ Hit<T> nearest_hit(const Scene<T>& sc, const RayState
             if (nd.kind == OT_NODE_GROUP && (nd.flags & OT_NODE_CHECK_AABB)) {
                 if (i >= skip_until) {
                     inside = slab_inv(r.ox, r.oy, r.oz, ri, nr.geo + 3, t1, t2);
-                    if (!(F & F_LIMIT) && beyond_best(t1, best.t)) inside = false;  // nothing in this group can be nearer
+                    if (!(F & F_LIMIT) && (nd.flags & OT_NODE_BOX_TRUSTED) && beyond_best(t1, best.t)) inside = false;  // nothing in this group can be nearer
                     if (!inside) skip_until = nd.end;
                 }
             }

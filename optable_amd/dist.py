@@ -44,23 +44,51 @@ def final_state(segs):
     return torch.stack([segs.field(f)[last] for f in FINAL_FIELDS])
 
 
-def gather_final_state(local, dst=0, group=None):
-    """One gather of every rank's [12, n_local] block to `dst`; returns [12, n_total] there,
-    None elsewhere.  Shard sizes may differ by one ray; blocks are padded to the largest."""
+def gather_final_state(local, dst=0, group=None, timings=None):
+    """The one collective of a job: every rank's [12, n_local] block to `dst`; returns [12, n_total] there, None
+    elsewhere.  The root allocates the result ONCE and every field row of every shard is received straight into its
+    place (row f of rank r's shard is the contiguous slice out[f, off_r : off_r + n_r]): no padding to the widest shard
+    and no `world` staging blocks on the root.  Two steps, timed apart into `timings` (a dict) when given:
+      sizes    all-gather of the shard sizes (one int64 per rank)
+      payload  12 sends per rank, 12 (world - 1) receives on the root, issued as one batch (RCCL: one group)
+    Shard sizes may differ (contiguous shards differ by at most one ray, id-class shards by one class)."""
+    import time
+
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    if dist.get_backend(group) == "gloo":  # CPU rehearsal of the collective (tests, 1-GPU boxes)
+    on_gpu = dist.get_backend(group) != "gloo"
+    if not on_gpu:  # CPU rehearsal of the collective (tests, 1-GPU boxes)
         local = local.cpu()
+    local = local.contiguous()
+
+    def now():
+        if on_gpu:
+            torch.cuda.synchronize(local.device)
+        return time.perf_counter()
+
+    t0 = now()
     n_local = torch.tensor([local.shape[1]], dtype=torch.int64, device=local.device)
     sizes = [torch.zeros_like(n_local) for _ in range(world)]
     dist.all_gather(sizes, n_local, group=group)
     sizes = [int(s.item()) for s in sizes]
-    width = max(sizes)
-    if local.shape[1] < width:
-        local = torch.cat([local, local.new_zeros(local.shape[0], width - local.shape[1])], dim=1)
-    local = local.contiguous()
-    bucket = [torch.empty_like(local) for _ in range(world)] if rank == dst else None
-    dist.gather(local, bucket, dst=dst, group=group)
-    if rank != dst:
-        return None
-    return torch.cat([b[:, :s] for b, s in zip(bucket, sizes)], dim=1)
+    t1 = now()
+    offs = [0]
+    for sz in sizes:
+        offs.append(offs[-1] + sz)
+    rows = local.shape[0]
+    out, ops = None, []
+    if rank == dst:
+        out = torch.empty((rows, offs[-1]), dtype=local.dtype, device=local.device)
+        out[:, offs[dst]:offs[dst + 1]] = local
+        for r in range(world):
+            if r != dst and sizes[r] > 0:
+                ops.extend(dist.P2POp(dist.irecv, out[f, offs[r]:offs[r + 1]], r, group) for f in range(rows))
+    elif sizes[rank] > 0:
+        ops.extend(dist.P2POp(dist.isend, local[f], dst, group) for f in range(rows))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    t2 = now()
+    if timings is not None:
+        timings.update(sizes_ms=(t1 - t0) * 1e3, payload_ms=(t2 - t1) * 1e3, shard_sizes=sizes)
+    return out

@@ -67,6 +67,8 @@ class _Builder:
         self.nodes, self.materials, self.aux = [], [], []
         self.mat_index = {}
         self.leaves, self.limited = [], []
+        self.leaf_pose = []   # per leaf: (transform_matrix, origin, local box) for the fresh lab boxes (_trust_boxes)
+        self.groups = []      # node indices of the groups, in node order
         self.max_children = 0
         self.always_branches = False
 
@@ -108,7 +110,7 @@ class _Builder:
         for child in grp.components:
             self.add(child, in_group=True)
         node.end = len(self.nodes)
-        self._maybe_grid(node, slot)
+        self.groups.append(slot)
         return slot
 
     GRID_MIN_CHILDREN = 24
@@ -136,6 +138,8 @@ class _Builder:
         kids = list(range(slot + 1, node.end))
         if not self.accelerate or len(kids) < self.GRID_MIN_CHILDREN:
             return
+        if not (node.flags & abi.NODE_BOX_TRUSTED) or not all(self.nodes[k].flags & abi.NODE_BOX_TRUSTED for k in kids):
+            return  # a cached box that no longer holds its geometry (moved after a trace): plain AABB tests, no shortcuts
         if any(self.nodes[k].kind != abi.NODE_LEAF or self.nodes[k].max_interact_count >= 0 for k in kids):
             return
         gbox = np.array(node.aabb[:], dtype=float).reshape(3, 2)
@@ -231,6 +235,8 @@ class _Builder:
             self.limited.append(comp)
         node.leaf_id = len(self.leaves)
         self.leaves.append(comp)
+        self.leaf_pose.append((np.asarray(comp.transform_matrix, dtype=float), np.asarray(comp.origin, dtype=float),
+                               np.asarray(surf.get_bbox_local(), dtype=float)))
         self.nodes.append(node)
         self.max_children = max(self.max_children, _fanout(kind, node.reflectivity, node.transmission))
         if kind in (MIRROR, REFRACT) and node.reflectivity > 0 and node.transmission > 0:
@@ -264,6 +270,60 @@ def _lattice_raster(boxes, gbox):
     if np.any(dims > LATTICE_MAX_CELLS):
         return None
     return [float(org[0]), float(org[1])], [float(med[0]), float(med[1])], [int(dims[0]), int(dims[1])]
+
+
+_CORNERS = np.array([[i, 2 + j, 4 + k] for k in (0, 1) for j in (0, 1) for i in (0, 1)])  # picks of (xmin,xmax,ymin,ymax,zmin,zmax)
+
+
+def _trust_boxes(b):
+    """Which cached boxes still hold their geometry.  A component caches its lab AABB on first use and never updates it
+    (optical_component.py:62-67, component_group.py:29-38): after a move the box is stale, and the reference keeps using
+    it as a pure pass / fail gate — so do the kernels.  But every SHORTCUT built on a box (skipping a node whose box
+    starts behind the best hit, listing a component in grid cells by its box, stopping a grid walk early) assumes that
+    hits lie inside the box.  A node gets NODE_BOX_TRUSTED when its cached box contains the box computed afresh from
+    the current pose (leaves: the 8 corners of the local box; groups: all leaves below); the device prunes by trusted
+    boxes only, and grids are built only over trusted nodes.  Returns the fresh leaf boxes [n_leaves, 6] (the
+    top-level grid bins top-level leaves, which have no AABB gate at all, by these) and whether every box is trusted."""
+    if not b.leaves:
+        return np.zeros((0, 6)), True
+    M = np.stack([p[0] for p in b.leaf_pose])
+    org = np.stack([p[1] for p in b.leaf_pose])
+    lb = np.stack([p[2] for p in b.leaf_pose])
+    lab = np.einsum("nij,ncj->nci", M, lb[:, _CORNERS]) + org[:, None, :]          # [n, 8, 3]
+    fresh = np.stack([lab[:, :, 0].min(1), lab[:, :, 0].max(1), lab[:, :, 1].min(1), lab[:, :, 1].max(1),
+                      lab[:, :, 2].min(1), lab[:, :, 2].max(1)], axis=1)
+    leaf_nodes = [i for i, nd in enumerate(b.nodes) if nd.kind == abi.NODE_LEAF]
+    tol = 1e-9 * (1.0 + np.abs(fresh).max(axis=1))
+    everything = True
+    node_fresh = {}
+    for i in leaf_nodes:
+        nd = b.nodes[i]
+        f = fresh[nd.leaf_id]
+        node_fresh[i] = f
+        if not (nd.flags & abi.NODE_CHECK_AABB) and not any(nd.aabb[:]):
+            nd.flags |= abi.NODE_BOX_TRUSTED  # no cached box in play: the fresh one is filled in by compile_scene
+            continue
+        c = np.array(nd.aabb[:])
+        t = tol[nd.leaf_id]
+        ok = bool(np.all(c[0::2] <= f[0::2] + t) and np.all(c[1::2] >= f[1::2] - t))
+        if ok:
+            nd.flags |= abi.NODE_BOX_TRUSTED
+        everything &= ok
+    for g in reversed(b.groups):  # inner groups first: a group's fresh box is the union of what lies below it
+        nd = b.nodes[g]
+        below = [node_fresh[i] for i in range(g + 1, nd.end) if b.nodes[i].kind == abi.NODE_LEAF]
+        if not below:
+            nd.flags |= abi.NODE_BOX_TRUSTED
+            continue
+        f = np.array(below)
+        f = np.array([f[:, 0].min(), f[:, 1].max(), f[:, 2].min(), f[:, 3].max(), f[:, 4].min(), f[:, 5].max()])
+        c = np.array(nd.aabb[:])
+        t = 1e-9 * (1.0 + np.abs(f).max())
+        ok = bool(np.all(c[0::2] <= f[0::2] + t) and np.all(c[1::2] >= f[1::2] - t))
+        if ok:
+            nd.flags |= abi.NODE_BOX_TRUSTED
+        everything &= ok
+    return fresh, everything
 
 
 def _fanout(kind, refl, trans):
@@ -381,9 +441,12 @@ def compile_scene(components, unit=1e-2, accelerate=True) -> CompiledScene:
     for comp in components:
         tops.append(len(b.nodes))
         b.add(comp, in_group=False)
-    for i in tops:  # top-level leaves carry no AABB test in the reference; the grid still needs their boxes
+    fresh, all_trusted = _trust_boxes(b)
+    for i in tops:  # top-level leaves carry no AABB test in the reference; the grid still needs their boxes: the CURRENT ones
         nd = b.nodes[i]
         if nd.kind == abi.NODE_LEAF and not any(nd.aabb[:]):
-            nd.aabb[:] = [float(x) for x in b.leaves[nd.leaf_id].bbox]
-    root = _root_grid(b, tops) if accelerate else -1
+            nd.aabb[:] = [float(x) for x in fresh[nd.leaf_id]]
+    for g in b.groups:
+        b._maybe_grid(b.nodes[g], g)
+    root = _root_grid(b, tops) if accelerate and all_trusted else -1
     return CompiledScene(b.nodes, b.materials, b.aux, b.leaves, b.limited, b.max_children, unit, root, b.always_branches)

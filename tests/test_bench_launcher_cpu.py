@@ -47,3 +47,29 @@ def test_mismatched_world_size_fails_loudly():
     proc, lines = run_bench("--gpus", "2", "--dry-run", env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert proc.returncode != 0 and not lines
     assert "--gpus 2 but WORLD_SIZE=1" in proc.stderr
+
+
+def test_eight_ranks_report_per_rank_diagnostics():
+    """The line of a multi-rank run names every rank's own step time and work, the two halves of the gather and the
+    communication backend: when the scaling curve is finally measured a straggler can be attributed."""
+    proc, lines = run_bench("--gpus", "8", "--backend", "gloo", "--rays", "20001", "--dry-run", "--steps", "2", "--warmup", "0")
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    line = lines[0]
+    assert line["n_gpus"] == 8 and line["config"]["rays_total"] == 8 * 20001
+    ranks = line["ranks"]
+    assert len(ranks["ms_per_step"]["by_rank"]) == 8 and len(ranks["segments_per_step_by_rank"]) == 8
+    assert ranks["ms_per_step"]["min"] <= ranks["ms_per_step"]["median"] <= ranks["ms_per_step"]["max"]
+    assert line["ms_per_step"] == ranks["ms_per_step"]["max"] or abs(line["ms_per_step"] - ranks["ms_per_step"]["max"]) < 1e-9
+    g = line["gather"]
+    assert g["sizes_ms"] > 0 and g["payload_ms"] > 0 and len(g["shard_sizes"]) == 8
+    assert line["gathered_shape"] == [12, sum(g["shard_sizes"])] and "gather_error" not in line
+    assert line["comm"]["backend"] == "gloo"
+
+
+def test_a_clamped_total_is_labelled_weak():
+    # cfg 5 names 1e8 rays; two ranks take 2.5e7 each (the per-rank HBM cap): the total grows with N
+    proc, lines = run_bench("--gpus", "2", "--workload", "cfg5", "--dry-run", "--steps", "1", "--warmup", "0")
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    line = lines[0]
+    assert line["clamped"] is True and line["total_requested"] == 100_000_000 and line["scaling"] == "weak"
+    assert line["config"]["rays_per_gpu"] == 25_000_000

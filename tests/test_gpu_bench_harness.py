@@ -27,8 +27,8 @@ def test_bench_line_contract(workload, rays):
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in line, key
     assert line["n_gpus"] == 1 and line["steps"] == 3 and line["warmup"] == 1 and line["vs_baseline"] is None
-    # cfg 2 repeats its size on every GPU; cfg 5 names a total that is sharded over the GPUs
-    assert line["scaling"] == ("weak" if workload == "cfg2" else "strong")
+    # --rays fixes the per-GPU size: weak scaling whatever the workload (cfg 5 without it shards its 1e8-ray total)
+    assert line["scaling"] == "weak"
     assert line["higher_is_better"] is True and line["data"] == "synthetic"
     assert line["config"]["rays_per_gpu"] == rays and "model" not in line["config"]
     roof = line["roofline"]
@@ -62,14 +62,32 @@ def test_two_ranks_on_one_card_gloo_rehearsal():
     assert line["config"]["segments_per_ray"] == 5.0
 
 
+def test_six_ranks_on_one_card_gloo_rehearsal():
+    """The multi-rank line with as many ranks as may share the one card of this box (6; the eight-rank line is rehearsed
+    without a GPU in tests/test_bench_launcher_cpu.py): rank -> device modulo the card count, per-rank diagnostics, the
+    gather received straight into one [12, n_total] block on the root."""
+    line = _run("--gpus", "6", "--backend", "gloo", "--workload", "cfg5", "--rays", "20000", "--no-cpu-baseline")
+    assert line["n_gpus"] == 6 and line["config"]["rays_total"] == 120000 and line["scaling"] == "weak"
+    assert line["gathered_shape"] == [12, 120000] and "gather_error" not in line
+    assert len(line["ranks"]["ms_per_step"]["by_rank"]) == 6 and min(line["ranks"]["segments_per_step_by_rank"]) > 20000
+    assert line["gather"]["payload_ms"] > 0 and line["gather"]["shard_sizes"] == [20000] * 6
+    assert line["comm"]["backend"] == "gloo"
+
+
 def test_one_rank_rccl_rehearsal():
     """The RCCL calls of the multi-GPU path (init with device_id, barrier, all_reduce MAX / SUM, the end-of-job gather) with
     the one rank a 1-GPU box allows: `torchrun --nproc-per-node 1 bench.py --gpus 1 --force-dist` uses backend nccl."""
+    import socket
+
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    with socket.socket() as sock:  # a free port, as bench.py's own launcher picks one
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
-                          "--master-port", "29731", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "3", "--warmup", "1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "3", "--warmup", "1",
                           "--rays", "20000", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
     assert line["n_gpus"] == 1 and line["gathered_shape"] == [12, 20000] and line["gather_ms"] > 0 and "gather_error" not in line
+    assert line["comm"]["backend"] == "rccl" and line["comm"]["rccl_version"]

@@ -68,15 +68,16 @@ def _table(components):
     return t
 
 
-# q tolerance: 1e-9 except through aspheres.  ASphere.roc is a 3-point finite difference with
-# h = 1e-4*radius (surfaces.py:355-369): rounding noise in F is amplified by 1/h^2 ~ 1.6e7, so a
-# 1-ulp change of the INPUT moves the reference algorithm's own q by up to ~1e-4 relative after 50
-# segments (tests/test_oracle_golden.py::test_asphere_q_is_ill_conditioned shows it on the oracle).
+# q tolerance: 1e-9 until a ray's q has passed an aspheric interface.  ASphere.roc is a 3-point finite difference
+# with h = 1e-4*radius (surfaces.py:355-369): rounding noise in F is amplified by 1/h^2 ~ 1.6e7, so a 1-ulp change of
+# the INPUT moves the reference algorithm's own q by up to ~1e-4 relative after 50 segments
+# (tests/test_oracle_golden.py::test_asphere_q_is_ill_conditioned).  Behind an asphere the bound is therefore 50 x the
+# spread of the oracle's q under +-2 ulp of its input, per segment (oracle.q_tolerance) — not a flat number.
 # Positions, directions, lengths and path lengths stay at 1e-9 everywhere.
 CASES = {
-    "cfg2": (lambda oa: scenes.cfg2_components(oa), lambda n: scenes.cfg2_rays(n, 0), 20000, 5, 1e-9),
-    "cfg3": (lambda oa: scenes.cfg3_components(oa), lambda n: scenes.cfg3_rays(n, 2), 20000, 20, 1e-9),
-    "cfg5": (lambda oa: scenes.cfg5_components(oa), lambda n: scenes.cfg5_rays(n, 3), 3000, 50, 2e-3),
+    "cfg2": (lambda oa: scenes.cfg2_components(oa), lambda n: scenes.cfg2_rays(n, 0), 20000, 5),
+    "cfg3": (lambda oa: scenes.cfg3_components(oa), lambda n: scenes.cfg3_rays(n, 2), 20000, 20),
+    "cfg5": (lambda oa: scenes.cfg5_components(oa), lambda n: scenes.cfg5_rays(n, 3), 3000, 50),
 }
 
 
@@ -85,19 +86,24 @@ def test_batch_trace_matches_oracle(case, oracle):
     """Scalable API (RayBatch -> SegmentBatch), fused kernel, against the oracle on the same inputs."""
     import optable_amd as oa
 
-    comps, gen, n, K, q_rtol = CASES[case]
+    comps, gen, n, K = CASES[case]
     table = _table(comps(oa))
     o, d = gen(n)
     batch = _batch(o, d)
     segs = table.trace_batch(batch, max_segments=K)
     got = segs.to_host(reference_order=True)
-    ref = oracle.trace(table.compile(), batch.to_host(), max_trace_num=K)
+    scene, host = table.compile(), batch.to_host()
+    ref = oracle.trace(scene, host, max_trace_num=K)
     assert len(got["ray"]) == len(ref["ray"])
     np.testing.assert_array_equal(got["ray"], ref["ray"])
     np.testing.assert_array_equal(got["surface"], ref["surface"])
     for f in abi.SEG_FIELDS:
-        rtol = q_rtol if f in ("q_re", "q_im") else 1e-9
-        np.testing.assert_allclose(got[f], ref[f], rtol=rtol, atol=1e-9 if rtol == 1e-9 else 1e-3, err_msg=f)
+        if f not in ("q_re", "q_im"):
+            np.testing.assert_allclose(got[f], ref[f], rtol=1e-9, atol=1e-9, err_msg=f)
+    qtol, clean = oracle.q_tolerance(scene, host, ref, K)
+    qerr = np.hypot(got["q_re"] - ref["q_re"], got["q_im"] - ref["q_im"])
+    assert np.all(qerr <= qtol), float((qerr / qtol).max())
+    assert case == "cfg5" or clean.all()  # only cfg 5 has aspheres: everywhere else the bound IS 1e-9
     capped = (got["count"] >= K) if "count" in got else segs.capped.cpu().numpy()
     np.testing.assert_array_equal(capped, ref["capped"].astype(bool))
 
@@ -297,7 +303,7 @@ def test_blocked_kernel_equals_lane_per_ray_kernel(case):
     import optable_amd as oa
     from optable_amd.engine import get_engine
 
-    comps, gen, n, K, _ = CASES[case]
+    comps, gen, n, K = CASES[case]
     n = min(n, 5000) + 37  # ragged last chunk
     table = _table(comps(oa))
     o, d = gen(n)
@@ -327,7 +333,7 @@ def test_heavy_kernel_edge_sizes_dead_rays_and_finite_lengths(case, prec):
     from optable_amd.batch import RayBatch
     from optable_amd.engine import get_engine
 
-    comps, gen, _, K, _ = CASES[case]
+    comps, gen, _, K = CASES[case]
     table = _table(comps(oa))
     eng = get_engine()
     q = 1j * np.pi * scenes.W0**2 / scenes.WL
@@ -367,7 +373,7 @@ def test_pair_queue_walk_equals_per_lane_walk(prec):
     from optable_amd.batch import RayBatch
     from optable_amd.engine import get_engine
 
-    comps, gen, _, K, _ = CASES["cfg3"]
+    comps, gen, _, K = CASES["cfg3"]
     table = _table(comps(oa))
     eng = get_engine()
     q = 1j * np.pi * scenes.W0**2 / scenes.WL
@@ -411,7 +417,7 @@ def test_acceleration_grids_do_not_change_results(case):
     import torch
     import optable_amd as oa
 
-    comps, gen, n, K, _ = CASES[case]
+    comps, gen, n, K = CASES[case]
     n = min(n, 6000)
     o, d = gen(n)
     batch = _batch(o, d)
@@ -435,7 +441,7 @@ def test_fp32_heavy_scenes_track_fp64(case, min_same):
     import optable_amd as oa
     from optable_amd.batch import RayBatch
 
-    comps, gen, n, K, _ = CASES[case]
+    comps, gen, n, K = CASES[case]
     n = min(n, 8000)
     table = _table(comps(oa))
     o, d = gen(n)
@@ -464,7 +470,7 @@ def test_segment_chain_is_continuous(case, prec, tol):
     import optable_amd as oa
     from optable_amd.batch import RayBatch
 
-    comps, gen, n, K, _ = CASES[case]
+    comps, gen, n, K = CASES[case]
     n = min(n, 6000)
     table = _table(comps(oa))
     o, d = gen(n)
@@ -552,7 +558,7 @@ def test_sorted_spatially_is_a_pure_reordering():
     import torch
     import optable_amd as oa
 
-    comps, gen, n, K, _ = CASES["cfg3"]
+    comps, gen, n, K = CASES["cfg3"]
     n = 5000
     table = _table(comps(oa))
     o, d = gen(n)
@@ -997,3 +1003,42 @@ def test_monitor_export_rays_npz(tmp_path, capsys):
     np.testing.assert_array_equal(data["yList"], mon.zList)
     np.testing.assert_array_equal(data["tXList"], mon.tYList)
     np.testing.assert_array_equal(data["IList"], mon.IList)
+
+
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_stale_cached_boxes_gate_but_never_prune(kernel, oracle):
+    """A component moved AFTER a first trace keeps its cached bounding boxes (optical_component.py:62-67,
+    component_group.py:29-38: never invalidated).  The reference goes on using the stale box as a pass / fail gate, and
+    the true geometry can then lie in front of it: a MirrorPair pulled towards the source is hit BEFORE the lens that
+    stands between the pair's new place and its old box.  The kernels must not skip the pair because its box starts
+    behind the lens (nearer-hit pruning assumed every hit lies inside its box)."""
+    import optable_amd as oa
+    from optable_amd.engine import get_engine
+
+    lens = oa.Lens([7, 0, 0], focal_length=6, radius=1.5)
+    pair = oa.MirrorPair([10, 0, 0], 4, 4)
+    table = _table([lens, pair])
+    o, d = scenes.cfg2_rays(4000, 0)
+    d = np.stack([np.ones(len(d)), 0.3 * d[:, 1], 0.3 * d[:, 2]], 1)
+    batch = _batch(o, d)
+    eng = get_engine()
+    eng.set_option(abi.OPT_KERNEL, kernel)
+    try:
+        first = table.trace_batch(batch, max_segments=6).to_host(reference_order=True)  # caches every box
+        ref0 = oracle.trace(table.compile(), batch.to_host(), max_trace_num=6)
+        np.testing.assert_array_equal(first["surface"], ref0["surface"])
+        pair._Translate([-5.0, 0.0, 0.0])  # the group and its mirrors move; their cached boxes stay at x ~ 10
+        scene = table.compile()
+        nodes = scene.node_table()
+        assert not all(nodes["flags"] & abi.NODE_BOX_TRUSTED)
+        got = table.trace_batch(batch, max_segments=6).to_host(reference_order=True)
+        ref = oracle.trace(scene, batch.to_host(), max_trace_num=6)
+    finally:
+        eng.set_option(abi.OPT_KERNEL, 0)
+    assert len(got["ray"]) == len(ref["ray"])
+    np.testing.assert_array_equal(got["surface"], ref["surface"])
+    for f in abi.SEG_FIELDS:
+        np.testing.assert_allclose(got[f], ref[f], rtol=1e-9, atol=1e-9, err_msg=f)
+    # the scenario is real: most first segments now end on the moved pair (x ~ 5), in front of the lens at x = 7
+    first_seg = np.r_[True, np.diff(ref["ray"]) != 0]
+    assert (ref["length"][first_seg] < 6.5).mean() > 0.5

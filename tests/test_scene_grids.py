@@ -99,10 +99,11 @@ def test_root_grid_lists_every_component_in_the_cells_it_overlaps():
                     assert t in items[start[c1 * g0 + c0]:start[c1 * g0 + c0 + 1]]
 
 
-def test_root_grid_keeps_a_group_whose_cached_box_went_stale():
-    """A group moved after its bbox was cached (optical_component.py:62-67: never invalidated) no longer
-    contains its children's boxes; its own AABB test then prunes hits and cannot be skipped, so the grid must
-    list the group, not its leaves."""
+def test_no_shortcuts_over_a_box_that_went_stale():
+    """A group moved after its bbox was cached (optical_component.py:62-67: never invalidated) no longer contains its
+    children.  The stale box is still the reference's pass / fail gate, but a hit can now lie in FRONT of it, so nothing
+    may be skipped on its strength: the node loses NODE_BOX_TRUSTED (the kernels prune by trusted boxes only) and the
+    scene gets no top-level grid, whose early stop assumes that hits lie inside the boxes it was binned by."""
     comps = scenes.cfg3_components(oa)
     slab = next(c for c in comps if type(c).__name__ == "GlassSlab")
     from optable_amd.geometry import _NO_BOX
@@ -113,15 +114,22 @@ def test_root_grid_keeps_a_group_whose_cached_box_went_stale():
         child._bbox = _NO_BOX
     scene = oa.compile_scene(comps)
     nodes = scene.node_table()
-    aux = np.ctypeslib.as_array(scene.aux)[: scene.n_aux]
-    g = aux[scene.root_grid:]
-    cells = int(g[2]) * int(g[3])
-    start = g[11:11 + cells + 1].astype(int)
-    items = set(g[11 + cells + 1: 11 + cells + 1 + start[-1]].astype(int).tolist())
-    groups = [i for i in items if nodes["kind"][i] == 0]
-    assert len(groups) == 1
-    gi = groups[0]
-    assert not any(gi < i < nodes["end"][gi] for i in items)   # its leaves are reached through it only
+    assert scene.root_grid < 0
+    untrusted = [i for i in range(scene.n_nodes) if not nodes["flags"][i] & abi.NODE_BOX_TRUSTED]
+    assert len(untrusted) == 1 and nodes["kind"][untrusted[0]] == abi.NODE_GROUP
+    # a leaf moved without its own box being recomputed is untrusted as well
+    comps = scenes.cfg3_components(oa)
+    mirror = next(c for c in comps if type(c).__name__ == "Mirror")
+    slab = next(c for c in comps if type(c).__name__ == "GlassSlab")
+    _ = slab.bbox
+    slab._Translate([0.3, 0.0, 0.0])
+    scene = oa.compile_scene(comps)
+    nodes = scene.node_table()
+    assert scene.root_grid < 0
+    assert sum(1 for i in range(scene.n_nodes) if not nodes["flags"][i] & abi.NODE_BOX_TRUSTED) == 3  # the slab and its two faces
+    # an untouched scene trusts every box
+    nodes = oa.compile_scene(scenes.cfg3_components(oa)).node_table()
+    assert all(nodes["flags"] & abi.NODE_BOX_TRUSTED)
 
 
 def test_no_grids_when_a_leaf_is_count_limited():
