@@ -242,7 +242,7 @@ int ot_trace_f32(ot_ctx* ctx, const ot_rays* rays, int64_t n_rays, int32_t max_s
  *   - order: the records of one ray lie at increasing slot numbers in segment order, so a STABLE sort by `ray` yields the
  *     reference's order (input ray major, then segment order) — the contract of ot_trace_generation_*'s flat list.  The
  *     order of rays among each other is not deterministic.  seg_count[i] is written as by ot_trace_*.
- *   - capacity (a multiple of 64; base 16-byte aligned): if *n_slots > capacity the records that did not fit are lost
+ *   - capacity (a multiple of 64, below 2^30 slots in single and 2^29 in double precision; base 16-byte aligned): if *n_slots > capacity the records that did not fit are lost
  *     (nothing is written outside the block); *n_slots is still exact, so the caller can retry with enough room.
  *     sum(seg_count) + chunk * (number of waves launched) always suffices; max_segments * n_rays + that slack never fails.
  * Works for every scene ot_trace_* accepts, always on the rolling-list kernel. */

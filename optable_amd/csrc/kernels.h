@@ -100,18 +100,24 @@ template <class T> struct SegPlanes {
     uint8_t* base;
     int64_t cap;
 };
+// Every plane is addressed as (wave-uniform plane base) + (one 32-bit lane offset): the store takes its base from a
+// scalar register pair and the lane offset from ONE vector register computed once per record, instead of a 64-bit vector
+// add per field (the host keeps capacity below 2^30 slots so that the byte offset fits 32 bits).
 template <class T, bool NT = false>
 __device__ __forceinline__ void store_segment(const SegPlanes<T>& out, int64_t slot, const RayState<T>& r, T len, int32_t tree,
                                               int32_t surface) {
-    T* p = reinterpret_cast<T*>(out.base) + slot;
+    const uint32_t s = (uint32_t)slot;
+    uint8_t* b = out.base;
+    asm volatile("" : "+s"(b));  // the fourteen plane bases are formed HERE, two scalar adds each, not kept in 28 registers across the pass loop
+    T* p = reinterpret_cast<T*>(b);
     const int64_t cap = out.cap;
-    st<NT>(p, r.ox); p += cap; st<NT>(p, r.oy); p += cap; st<NT>(p, r.oz); p += cap;
-    st<NT>(p, r.dx); p += cap; st<NT>(p, r.dy); p += cap; st<NT>(p, r.dz); p += cap;
-    st<NT>(p, len); p += cap; st<NT>(p, r.I); p += cap;
-    st<NT>(p, r.qr); p += cap; st<NT>(p, r.qi); p += cap;
-    st<NT>(p, r.n); p += cap; st<NT>(p, r.pl);
-    int32_t* q = reinterpret_cast<int32_t*>(reinterpret_cast<T*>(out.base) + 12 * cap) + slot;
-    st<NT>(q, tree); st<NT>(q + cap, surface);
+    st<NT>(p + s, r.ox); p += cap; st<NT>(p + s, r.oy); p += cap; st<NT>(p + s, r.oz); p += cap;
+    st<NT>(p + s, r.dx); p += cap; st<NT>(p + s, r.dy); p += cap; st<NT>(p + s, r.dz); p += cap;
+    st<NT>(p + s, len); p += cap; st<NT>(p + s, r.I); p += cap;
+    st<NT>(p + s, r.qr); p += cap; st<NT>(p + s, r.qi); p += cap;
+    st<NT>(p + s, r.n); p += cap; st<NT>(p + s, r.pl); p += cap;
+    int32_t* q = reinterpret_cast<int32_t*>(p);
+    st<NT>(q + s, tree); st<NT>(q + cap + s, surface);
 }
 template <class T> __device__ __forceinline__ int32_t* ray_plane(const SegPlanes<T>& out) { return reinterpret_cast<int32_t*>(reinterpret_cast<T*>(out.base) + 12 * out.cap); }
 
@@ -314,7 +320,7 @@ __global__ __launch_bounds__((rolling_threads<T, F, REC_LDS>()), (rolling_minw<T
     // as it is).  They are read from the kernel-argument segment where they are used instead; `in` itself is never touched.
     // (The segment is laid out like a struct of the parameters in order, each at its natural alignment: LeadArgs below;
     // tools/kernel_resources.sh --args prints the offsets the code object records.)
-    struct LeadArgs { SceneBlob blob; T unit; RaysT<T> in; };
+    struct LeadArgs { SceneBlob blob; T unit; RaysT<T> in; int64_t n; int32_t K; OUT out; };
     typedef const __attribute__((address_space(4))) RaysT<T>* RaysArgPtr;
     const RaysArgPtr in_arg = (RaysArgPtr)((uintptr_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(LeadArgs, in));
     (void)in;
@@ -524,7 +530,20 @@ __global__ __launch_bounds__((rolling_threads<T, F, REC_LDS>()), (rolling_minw<T
                 else { chunk_pos += need; chunk_left -= need; }
                 room = slot < ac.capacity;  // an output that is too small loses records, never writes outside (the cursor tells)
             }
-            if (entry && room) store_segment<T, NT>(out, slot, r, hit ? h.t : r.len, (int32_t)i, hit ? leaf_id_of<T, F>(sc, h.node) : (active ? -1 : -2));
+            if constexpr (APPEND) {
+                if (entry && room) store_segment<T, NT>(out, slot, r, hit ? h.t : r.len, (int32_t)i, hit ? leaf_id_of<T, F>(sc, h.node) : (active ? -1 : -2));
+            } else {  // the fourteen [k][ray] array pointers: from the kernel-argument segment, like the caller's ray pointers
+                typedef const __attribute__((address_space(4))) uint64_t* ArgWords;
+                ArgWords src = (ArgWords)((uintptr_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(LeadArgs, out));
+                asm volatile("" : "+s"(src));
+                static_assert(sizeof(SegsT<T>) == 14 * sizeof(uint64_t), "SegsT is fourteen pointers");
+                uint64_t words[14];
+#pragma unroll
+                for (int w = 0; w < 14; ++w) words[w] = src[w];
+                SegsT<T> out_now;
+                __builtin_memcpy(&out_now, words, sizeof(out_now));
+                if (entry) store_segment<T, NT>(out_now, slot, r, hit ? h.t : r.len, (int32_t)i, hit ? leaf_id_of<T, F>(sc, h.node) : (active ? -1 : -2));
+            }
             bool survive = false;
             RayState<T> child = {};
             if (entry) {

@@ -815,6 +815,7 @@ static int trace_append(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, co
     if (rc) return rc;
     if (!out || !out->base || out->capacity < 0 || !n_slots) return fail(OT_ERR_INVALID, "bad segment block / n_slots");
     if ((uintptr_t)out->base % 16 || out->capacity % 64) return fail(OT_ERR_INVALID, "segment block: base must be 16-byte aligned, capacity a multiple of 64");
+    if (out->capacity >= ((int64_t)1 << 30) / (int64_t)(sizeof(T) / 4)) return fail(OT_ERR_INVALID, "segment block: capacity must stay below 2^30 slots (2^29 in double precision) per launch");
     HIP_TRY(hipSetDevice(c->device));
     if (n == 0) {
         HIP_TRY(hipMemsetAsync(n_slots, 0, sizeof(int64_t), c->stream));

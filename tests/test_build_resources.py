@@ -1,0 +1,65 @@
+"""CPU: the code objects of the last build (optable_amd/csrc/build/*.o, cross-compiled for gfx950) — no kernel uses
+scratch memory or spills a vector register, the library stays small, and the kernel-argument layout that
+k_trace_rolling reads its ray pointers from (kernels.h: LeadArgs) is what the code object records."""
+import glob
+import os
+import re
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin"
+BUILD = os.path.join(ROOT, "optable_amd", "csrc", "build")
+
+
+@pytest.fixture(scope="module")
+def kernels():
+    if not glob.glob(os.path.join(BUILD, "*.o")):
+        import __graft_entry__ as g
+
+        g.build()
+    objs = sorted(glob.glob(os.path.join(BUILD, "*.o")))
+    assert objs, "no objects: run `make -C optable_amd/csrc`"
+    out = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for o in objs:
+            fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "dev.co")
+            subprocess.check_call([f"{LLVM}/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", o, fat])
+            subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--type=o", f"--input={fat}", "--unbundle",
+                                   "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"])
+            notes = subprocess.check_output([f"{LLVM}/llvm-readelf", "--notes", co], text=True)
+            # one block per kernel: "- .agpr_count ... .args: ... .name: ..." in the amdhsa.kernels list
+            for block in notes.split("\n  - .agpr_count")[1:]:
+                def field(name):
+                    m = re.search(rf"\.{name}:\s+(\S+)", block)
+                    return m.group(1) if m else None
+                args = [(int(a), int(b)) for a, b in re.findall(r"\.offset:\s+(\d+)\s+\.size:\s+(\d+)", block)]
+                out.append({"name": field("name"), "scratch": int(field("private_segment_fixed_size")), "vgpr": int(field("vgpr_count")),
+                            "vgpr_spill": int(field("vgpr_spill_count")), "sgpr_spill": int(field("sgpr_spill_count")), "args": args})
+    return out
+
+
+def test_no_kernel_uses_scratch_or_spills_vector_registers(kernels):
+    bad = [(k["name"], k["scratch"], k["vgpr_spill"]) for k in kernels if k["scratch"] or k["vgpr_spill"]]
+    assert not bad, bad
+
+
+def test_library_stays_small(kernels):
+    # round 2 shipped 461 kernels (338 of them a scan library's tuning variants) and took two minutes to build
+    assert 40 <= len(kernels) < 150, len(kernels)
+    names = [k["name"] for k in kernels]
+    assert not any("rocprim" in n or "hipcub" in n for n in names)
+    assert sum("k_trace_rolling" in n for n in names) <= 48
+
+
+def test_rolling_kernel_reads_its_ray_pointers_where_the_code_object_puts_them(kernels):
+    """kernels.h reads the caller's 15 ray pointers from the kernel-argument segment at offsetof(LeadArgs, in) = 56
+    (SceneBlob 48 bytes, unit padded to 8): argument 2 of every k_trace_rolling instantiation must sit exactly there."""
+    rolling = [k for k in kernels if "k_trace_rolling" in k["name"]]
+    assert rolling
+    for k in rolling:
+        assert k["args"][0] == (0, 48) and k["args"][2] == (56, 120), (k["name"], k["args"][:3])
+        # ... and the output descriptor (14 array pointers, or the plane block) right behind n and K
+        assert k["args"][5][0] == 192 and k["args"][5][1] in (112, 16), (k["name"], k["args"][5])
