@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define OT_ABI_VERSION 7  /* 3: ot_trace_generation_f32; 4: ot_bench_stream_f32; 5: OT_OPT_LIST_CAP, ray flags bits 8..31, ot_debug_generation_mismatches; 6: ot_debug_last_launch, OT_OPT_FLAT_QUEUE, OT_OPT_LDS_RECORDS; 7: ot_trace_append_*, ot_segment_block, OT_OPT_APPEND_CHUNK, OT_OPT_INSTANCING */
+#define OT_ABI_VERSION 8  /* 8: OT_SHAPE_ASPHERE_CHEB, OT_MAT_CHEB, OT_NODE_BOX_TRUSTED; 3: ot_trace_generation_f32; 4: ot_bench_stream_f32; 5: OT_OPT_LIST_CAP, ray flags bits 8..31, ot_debug_generation_mismatches; 6: ot_debug_last_launch, OT_OPT_FLAT_QUEUE, OT_OPT_LDS_RECORDS; 7: ot_trace_append_*, ot_segment_block, OT_OPT_APPEND_CHUNK, OT_OPT_INSTANCING */
 
 /* ---- status codes ------------------------------------------------------------------- */
 enum ot_status {
@@ -65,7 +65,11 @@ enum ot_shape_kind {
     OT_SHAPE_ASPHERE_EXACT = 6, /* component_group.py:1061-1064 p[0]=aperture radius p[1]=EFL p[2]=n */
     OT_SHAPE_CYLINDER = 7,   /* surfaces.py:212-281   p[0]=R p[1]=height/2 p[2]=theta0 p[3]=theta1  */
     OT_SHAPE_POINT = 8,      /* surfaces.py:68-86     never hit                                     */
-    OT_SHAPE_CSG = 9         /* Plane.union/subtract  surfaces.py:100-136: aux -> postfix program   */
+    OT_SHAPE_CSG = 9,        /* Plane.union/subtract  surfaces.py:100-136: aux -> postfix program   */
+    OT_SHAPE_ASPHERE_CHEB = 10 /* ASphere with an arbitrary sag F(r) (component_group.py:1014-1055), given as a verified
+                                Chebyshev series: p[0]=aperture radius, aux -> [N, lo, hi, c[N], c'[N], c''[N]]: F, dF/dr and
+                                d2F/dr2 as series in t = (2r - lo - hi) / (hi - lo); [lo, hi] covers -2h .. radius*sqrt2 + 2h,
+                                h = 1e-4 radius (the reference's finite-difference step, surfaces.py:355-369)            */
 };
 
 /* interaction kinds (what interact_local does) */
@@ -117,11 +121,17 @@ typedef struct ot_node {
     int32_t leaf_id;     /* index among leaves (what ot_segments.surface reports)         */
 } ot_node;
 
-enum ot_material_kind { OT_MAT_CONST = 0, OT_MAT_SELLMEIER = 1 };
+enum ot_material_kind {
+    OT_MAT_CONST = 0,
+    OT_MAT_SELLMEIER = 1,
+    OT_MAT_CHEB = 2      /* n(wavelength in metres) as a verified Chebyshev series of a user function (material.py:4-21):
+                            ot_material.n holds the aux offset of [N, lo, hi, c[N]]; wavelengths outside [lo, hi] are clamped
+                            to the interval (callers check their rays against it: optable_amd/engine.py)                   */
+};
 
 /* material.py:48-85 (RefractiveIndex), :106-120 (Sellmeier, wavelength in metres -> microns) */
 typedef struct ot_material {
-    double n;        /* OT_MAT_CONST                        */
+    double n;        /* OT_MAT_CONST; OT_MAT_CHEB: aux offset  */
     double B[3];     /* OT_MAT_SELLMEIER                    */
     double C[3];     /* microns^2                           */
     int32_t kind;

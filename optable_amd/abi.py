@@ -7,7 +7,7 @@ __graft_entry__ as g; g.build()"` or `make -C optable_amd/csrc`).
 import ctypes as C
 import os
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "liboptable_hip.so")
 
@@ -69,7 +69,7 @@ class OtMonitor(C.Structure):
 # flags / enums (== header)
 NODE_GROUP, NODE_LEAF = 0, 1
 NODE_CHECK_AABB, NODE_GRID, NODE_BOX_TRUSTED = 1, 2, 4
-MAT_CONST, MAT_SELLMEIER = 0, 1
+MAT_CONST, MAT_SELLMEIER, MAT_CHEB = 0, 1, 2
 RAY_HAS_Q, RAY_DEAD = 1, 2
 OPT_NT_STORES, OPT_MIN_WAVES, OPT_BLOCKS_PER_CU, OPT_KERNEL, OPT_LDS_LIMIT_KB, OPT_LIST_CAP, OPT_PAIR_STORES, OPT_MIX_GENERATIONS, OPT_FLAT_QUEUE, OPT_LDS_RECORDS = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 OPT_APPEND_CHUNK, OPT_INSTANCING = 11, 12

@@ -47,8 +47,8 @@ def _asphere(surf):
         elif {"EFL", "n"} <= set(cells):
             spec = (shapes.ASPHERE_EXACT, (float(cells["EFL"]), float(cells["n"])))
             mine = shapes.sag_exact(*spec[1])
-        else:
-            raise AdapterError("ASphere with an unrecognised f_asphere closure has no device form")
+        else:  # any other function of r: a verified Chebyshev series, or a refusal that says why (shapes.py)
+            return shapes.lower_asphere_callable(float(surf.radius), f)
         probe = np.linspace(0.0, float(surf.radius), 7)
         if not np.allclose([f(r) for r in probe], [mine(r) for r in probe], rtol=1e-13, atol=1e-15):
             raise AdapterError("ASphere closure does not match the recognised sag formula")
@@ -163,9 +163,9 @@ def lower_material(mat):
         pad = 3 - len(mat.Bs)
         return _Spec(("sellmeier", list(mat.Bs) + [0.0] * pad, list(mat.Cs) + [-1.0] * pad), getattr(mat, "name", "?"))
     if hasattr(mat, "n_func"):
-        vals = [float(mat.n_func(w)) for w in (0.0, 4e-7, 7.8e-7, 1.55e-6)]
-        if max(vals) == min(vals):
-            return _Spec(("const", vals[0]), getattr(mat, "name", "?"))
+        from .materials import callable_spec
+
+        return _Spec(callable_spec(mat.n_func, getattr(mat, "wavelength_range", None)), getattr(mat, "name", "?"))
     return _Spec(None, getattr(mat, "name", "?"))  # the scene compiler reports it
 
 

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256, MINW) void k_trace_fused(SceneBlob blob, T uni
             const int32_t fl = in.flags[i];
             r = load_ray(in, i, fl);
             if ((uint32_t)r.last >= (uint32_t)sc.n_nodes) r.last = -1;  // bits 8.. of a caller's flags that name no node of this scene
-            if constexpr (F & F_REFRACT) mc = make_matcache(sc, r.wl);
+            if constexpr (F & F_REFRACT) mc = make_matcache<T, F>(sc, r.wl);
             cls = in.id[i];
             if (fl & OT_RAY_DEAD) {  // optical_component.py:349: a dead ray hits nothing and is returned as is
                 store_segment<T, NT>(out, i, r, r.len, (int32_t)i, -2);
@@ -550,7 +550,7 @@ __global__ __launch_bounds__((rolling_threads<T, F, REC_LDS>()), (rolling_minw<T
                 int32_t used = k + 1;
                 if (hit) {
                     MatCache<T> mc = {T(1)};
-                    if constexpr (F & F_REFRACT) mc = make_matcache(sc, r.wl);
+                    if constexpr (F & F_REFRACT) mc = make_matcache<T, F>(sc, r.wl);
                     const int nk = interact<T, F, 1>(sc, r, h, &child, mc);
                     if (nk == 1) survive = k + 1 < K;
                     else if (nk > 1) used = -(k + 1);  // the tree branches here: the caller re-traces it generation by generation
@@ -763,7 +763,7 @@ __global__ __launch_bounds__(256) void k_gen_pass(SceneBlob blob, T unit, RaysT<
     const Hit<T> h = nearest_hit<T, F, GATE_TABLE>(sc, r, active && !dead, gate);
     int32_t nk = 0;
     RayState<T> ch[2];  // indexed by constants only
-    if (active && !dead && h.node >= 0) nk = interact<T, F, 2>(sc, r, h, ch, make_matcache(sc, r.wl));
+    if (active && !dead && h.node >= 0) nk = interact<T, F, 2>(sc, r, h, ch, make_matcache<T, F>(sc, r.wl));
     if (!EMIT) {
         if (i < n) code[i] = (uint8_t)((active ? 1 : 0) | (nk << 1));
         // wave totals: processed rays and children

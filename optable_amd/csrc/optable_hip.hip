@@ -330,12 +330,15 @@ static uint32_t scene_features(const ot_scene_desc* s) {
         if (nd.shape != OT_SHAPE_CIRCLE && nd.shape != OT_SHAPE_RECT && nd.shape != OT_SHAPE_POLYGON2D &&
             nd.shape != OT_SHAPE_CSG)
             f |= F_CURVED;
+        if (nd.shape == OT_SHAPE_ASPHERE_CHEB) f |= F_MISC;
         if (nd.shape == OT_SHAPE_POLYGON3D) f |= F_POLY | F_MISC;
         if (nd.shape == OT_SHAPE_CYLINDER) f |= F_MISC;
         if (nd.interaction == OT_INT_REFRACT) f |= F_REFRACT;
         if (nd.interaction == OT_INT_LENS) f |= F_LENS;
         if (nd.max_interact_count >= 0) f |= F_LIMIT;
     }
+    for (int i = 0; i < s->n_materials; ++i)
+        if (s->materials[i].kind == OT_MAT_CHEB) f |= F_MISC;  // series materials: evaluated by the all-features kernels only
     return f;
 }
 
@@ -375,6 +378,15 @@ static int64_t polygon_record_len(const ot_scene_desc* s, int64_t off) {
     return off + len <= s->n_aux ? len : -1;
 }
 
+// Chebyshev series record: [N, lo, hi | blocks x N coefficients] (trace_core.h cheb_eval); returns its length or -1
+static int64_t series_record_len(const ot_scene_desc* s, int64_t off, int blocks) {
+    if (off < 0 || off + 3 > s->n_aux) return -1;
+    const double n = s->aux[off];
+    if (!(n >= 1 && n <= 512) || n != (double)(int)n || !(s->aux[off + 2] > s->aux[off + 1])) return -1;
+    const int64_t len = 3 + blocks * (int64_t)n;
+    return off + len <= s->n_aux ? len : -1;
+}
+
 // CSG record: [ntok | ntok x (kind, len, body[len])], postfix over a 32-deep bit stack (trace_core.h csg_inside)
 static int validate_csg(const ot_scene_desc* s, int64_t off) {
     if (off < 0 || off + 1 > s->n_aux) return fail(OT_ERR_INVALID, "CSG program out of range");
@@ -411,15 +423,20 @@ static int validate_scene(const ot_scene_desc* s) {
     if (s->n_aux && !s->aux) return fail(OT_ERR_INVALID, "aux is NULL");
     if (s->max_children < 0 || s->max_children > 2) return fail(OT_ERR_INVALID, "max_children must be 0, 1 or 2");
     if (!(s->unit > 0)) return fail(OT_ERR_INVALID, "unit must be positive");
-    for (int i = 0; i < s->n_materials; ++i)
-        if (s->materials[i].kind != OT_MAT_CONST && s->materials[i].kind != OT_MAT_SELLMEIER)
+    for (int i = 0; i < s->n_materials; ++i) {
+        const ot_material& m = s->materials[i];
+        if (m.kind != OT_MAT_CONST && m.kind != OT_MAT_SELLMEIER && m.kind != OT_MAT_CHEB)
             return fail(OT_ERR_UNSUPPORTED, "unknown material kind");
+        if (m.kind == OT_MAT_CHEB && series_record_len(s, (int64_t)m.n, 1) < 0) return fail(OT_ERR_INVALID, "material series record out of range");
+    }
     for (int i = 0; i < s->n_nodes; ++i) {
         const ot_node& nd = s->nodes[i];
         if (nd.end <= i || nd.end > s->n_nodes) return fail(OT_ERR_INVALID, "node.end out of range at " + std::to_string(i));
         if (nd.kind == OT_NODE_LEAF) {
             if (nd.end != i + 1) return fail(OT_ERR_INVALID, "leaf.end must be index+1");
-            if (nd.shape < 0 || nd.shape > OT_SHAPE_CSG) return fail(OT_ERR_UNSUPPORTED, "unknown shape kind");
+            if (nd.shape < 0 || nd.shape > OT_SHAPE_ASPHERE_CHEB) return fail(OT_ERR_UNSUPPORTED, "unknown shape kind");
+            if (nd.shape == OT_SHAPE_ASPHERE_CHEB && series_record_len(s, nd.aux, 3) < 0)
+                return fail(OT_ERR_INVALID, "asphere series record out of range at node " + std::to_string(i));
             if (nd.interaction < 0 || nd.interaction > OT_INT_BLOCK) return fail(OT_ERR_UNSUPPORTED, "unknown interaction kind");
             if (nd.interaction == OT_INT_REFRACT &&
                 (nd.mat1 < 0 || nd.mat1 >= s->n_materials || nd.mat2 < 0 || nd.mat2 >= s->n_materials))
@@ -544,7 +561,7 @@ int ot_scene_upload(ot_ctx* c, const ot_scene_desc* s) {
     c->root_pack = packable_cells(s) > 0 ? s->n_aux : -1;
     c->cache_mat = -1;
     for (int i = 0; i < s->n_materials; ++i)
-        if (s->materials[i].kind == OT_MAT_SELLMEIER) { c->cache_mat = i; break; }
+        if (s->materials[i].kind != OT_MAT_CONST) { c->cache_mat = i; break; }  // the first dispersive material: evaluated once per ray
     if (c->root_grid >= 0) {
         c->features |= F_ROOT | F_AABB;
         const double* g = s->aux + s->root_grid;

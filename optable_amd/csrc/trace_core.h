@@ -281,8 +281,30 @@ template <class T> __device__ __forceinline__ bool beyond_best(T t1, T best_t) {
 
 // ---------------------------------------------------------------------------------------------
 // material.py:54-72, 106-120
-template <class T> __device__ __forceinline__ T material_index(const DMat<T>& m, T wavelength_m) {
+// A user function as a verified Chebyshev series (optable_amd/cheb.py): record [N, lo, hi, c[N], ...further blocks of N],
+// evaluated by Clenshaw's recurrence in t = (2x - lo - hi) / (hi - lo).  block 0: the function, 1 / 2: its derivatives.
+template <class T> __device__ __forceinline__ T cheb_eval(const T* rec, T x, int block = 0) {
+    const int n = (int)rec[0];
+    const T lo = rec[1], hi = rec[2];
+    const T t2 = T(2) * qd(T(2) * x - (lo + hi), hi - lo);
+    const T* c = rec + 3 + block * n;
+    T b1 = T(0), b2 = T(0);
+    for (int k = n - 1; k >= 1; --k) {
+        const T b0 = c[k] + t2 * b1 - b2;
+        b2 = b1;
+        b1 = b0;
+    }
+    return c[0] + T(0.5) * t2 * b1 - b2;
+}
+
+template <class T, uint32_t F> __device__ __forceinline__ T material_index(const Scene<T>& sc, const DMat<T>& m, T wavelength_m) {
     if (m.kind == OT_MAT_CONST) return m.n;
+    if constexpr ((F & F_MISC) != 0) {
+        if (m.kind == OT_MAT_CHEB) {  // Material(n = callable), material.py:4-21: the series, on its interval
+            const T* rec = sc.aux + (int)m.n;
+            return cheb_eval(rec, min_t(max_t(wavelength_m, rec[1]), rec[2]));
+        }
+    }
     // 1 + sum_i B_i L^2/(L^2 - C_i) over a common denominator: one division instead of three
     const T um = qd(wavelength_m, T(1e-6)), um2 = um * um;
     const T p0 = um2 - m.C[0], p1 = um2 - m.C[1], p2 = um2 - m.C[2];
@@ -297,14 +319,14 @@ template <class T> __device__ __forceinline__ T material_index(const DMat<T>& m,
 template <class T> struct MatCache {
     T v;
 };
-template <class T> __device__ __forceinline__ MatCache<T> make_matcache(const Scene<T>& sc, T wl) {
+template <class T, uint32_t F> __device__ __forceinline__ MatCache<T> make_matcache(const Scene<T>& sc, T wl) {
     MatCache<T> m = {T(1)};
-    if (sc.cache_mat >= 0) m.v = material_index(sc.mats[sc.cache_mat], wl * sc.unit);
+    if (sc.cache_mat >= 0) m.v = material_index<T, F>(sc, sc.mats[sc.cache_mat], wl * sc.unit);
     return m;
 }
-template <class T> __device__ __forceinline__ T cached_index(const Scene<T>& sc, const MatCache<T>& m, int idx, T wl) {
+template <class T, uint32_t F> __device__ __forceinline__ T cached_index(const Scene<T>& sc, const MatCache<T>& m, int idx, T wl) {
     if (idx == sc.cache_mat) return m.v;
-    return material_index(sc.mats[idx], wl * sc.unit);
+    return material_index<T, F>(sc, sc.mats[idx], wl * sc.unit);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -391,6 +413,20 @@ template <class T> __device__ __forceinline__ T sag_d2(const DNode<T>& nd, T r) 
     return (sag(nd, r + h) - T(2) * sag(nd, r) + sag(nd, r - h)) / (h * h);
 }
 
+// Slope and curvature of a sag given as a series (OT_SHAPE_ASPHERE_CHEB).  fp64: the reference's central differences of
+// F with h = 1e-4 * radius, term by term (surfaces.py:355-369) — F being the series; fp32: the series of F' and F'', for
+// the reason given at sag_d1.
+template <class T> __device__ __forceinline__ T cheb_d1(const T* rec, T radius, T r) {
+    if (sizeof(T) == 4) return cheb_eval(rec, r, 1);
+    const T h = T(1e-4) * radius;
+    return (cheb_eval(rec, r + h) - cheb_eval(rec, r - h)) / (T(2) * h);
+}
+template <class T> __device__ __forceinline__ T cheb_d2(const T* rec, T radius, T r) {
+    if (sizeof(T) == 4) return cheb_eval(rec, r, 2);
+    const T h = T(1e-4) * radius;
+    return (cheb_eval(rec, r + h) - T(2) * cheb_eval(rec, r) + cheb_eval(rec, r - h)) / (h * h);
+}
+
 // polygon aux record: [nverts, n(3), v0(3), u(3), v(3), (x,y)*nverts]   (surfaces.py:534-558)
 template <class T> __device__ __forceinline__ bool poly_inside(const T* rec, T Px, T Py, T Pz) {
     const T tol = T(1e-9);
@@ -463,6 +499,7 @@ __device__ __forceinline__ bool curved_boundary(const Scene<T>& sc, const DNode<
             const T th = atan2(Py, Px);
             return nd.p[2] <= th && th <= nd.p[3] && -nd.p[1] <= Pz && Pz <= nd.p[1];
         }
+        if (nd.shape == OT_SHAPE_ASPHERE_CHEB) return sqrt_t(Py * Py + Pz * Pz) <= nd.p[0] + T(1e-12);  // surfaces.py:375-378
     }
     switch (nd.shape) {
         case OT_SHAPE_SPHERE:
@@ -490,6 +527,12 @@ __device__ __forceinline__ T surf_g(const Scene<T>& sc, const DNode<T>& nd, T ox
             const T* rec = sc.aux + nd.aux;
             if (dg) *dg = rec[1] * dx + rec[2] * dy + rec[3] * dz;
             return rec[1] * (Px - rec[4]) + rec[2] * (Py - rec[5]) + rec[3] * (Pz - rec[6]);
+        }
+        if (nd.shape == OT_SHAPE_ASPHERE_CHEB) {  // x + F(r), F the series of the user's sag (surfaces.py:371-373)
+            const T* rec = sc.aux + nd.aux;
+            const T r = sqrt_t(Py * Py + Pz * Pz);
+            if (dg) *dg = dx + (r > Num<T>::tiny() ? qd(cheb_eval(rec, r, 1) * (Py * dy + Pz * dz), r) : T(0));
+            return Px + cheb_eval(rec, r);
         }
     }
     switch (nd.shape) {
@@ -1321,11 +1364,14 @@ __device__ __forceinline__ void surf_normal(const Scene<T>& sc, const DNode<T>& 
                     nx = rec[1]; ny = rec[2]; nz = rec[3];
                 }
                 return;
+            case OT_SHAPE_ASPHERE_CHEB:
             case OT_SHAPE_ASPHERE_PARAM:
             case OT_SHAPE_ASPHERE_EXACT: {  // surfaces.py:380-388
                 const T r = sqrt_t(Py * Py + Pz * Pz);
                 if (r < T(1e-12)) return;
-                const T s = sag_d1(nd, r);
+                T s;
+                if constexpr ((F & F_MISC) != 0) s = nd.shape == OT_SHAPE_ASPHERE_CHEB ? cheb_d1(sc.aux + nd.aux, nd.p[0], r) : sag_d1(nd, r);
+                else s = sag_d1(nd, r);
                 const T ay = s * qd(Py, r), az = s * qd(Pz, r);
                 const T inv = rsqrt_t(T(1) + ay * ay + az * az);
                 nx = inv; ny = ay * inv; nz = az * inv;
@@ -1387,14 +1433,19 @@ __device__ __forceinline__ int interact(const Scene<T>& sc, const RayState<T>& r
         return nk;
     }
     if constexpr (F & F_REFRACT) {  // optical_component.py:617-717
-        const T n1 = cached_index(sc, mc, nd.mat1, r.wl), n2 = cached_index(sc, mc, nd.mat2, r.wl);
+        const T n1 = cached_index<T, F>(sc, mc, nd.mat1, r.wl), n2 = cached_index<T, F>(sc, mc, nd.mat2, r.wl);
         T ROC = Num<T>::inf();
         if (nd.roc_kind == OT_ROC_CONST) ROC = nd.roc;
         if constexpr (F & F_CURVED) {
             if (nd.roc_kind == OT_ROC_ASPHERE) {  // surfaces.py:362-373
-                const T rr = sqrt_t(h.py * h.py + h.pz * h.pz), s = sag_d1(nd, rr);
+                const T rr = sqrt_t(h.py * h.py + h.pz * h.pz);
+                T s, c;
+                bool series = false;
+                if constexpr ((F & F_MISC) != 0) series = nd.shape == OT_SHAPE_ASPHERE_CHEB;
+                if (series) { s = cheb_d1(sc.aux + nd.aux, nd.p[0], rr); c = cheb_d2(sc.aux + nd.aux, nd.p[0], rr); }
+                else { s = sag_d1(nd, rr); c = sag_d2(nd, rr); }
                 const T w = T(1) + s * s;
-                ROC = qd(w * sqrt_t(w), sag_d2(nd, rr));
+                ROC = qd(w * sqrt_t(w), c);
             }
         }
         T nin = n1, nout = n2;

@@ -48,6 +48,18 @@ class Engine:
         abi.check(self.lib.ot_scene_upload(self._ctx, C.byref(desc)), self.lib)
         self.scene = scene
 
+    def _check_wavelengths(self, rays):
+        """Scenes with a dispersion SERIES (Material(n = callable), fitted over a wavelength interval: materials.py) say
+        nothing outside that interval; the reference would call the function there.  Refuse rather than extrapolate."""
+        rng = getattr(self.scene, "wavelength_range", None)
+        if rng is None or rays.n == 0:
+            return
+        wl = rays.wavelength.double() * self.scene.unit
+        lo, hi = float(wl.min().item()), float(wl.max().item())
+        if lo < rng[0] * (1 - 1e-12) or hi > rng[1] * (1 + 1e-12):
+            raise ValueError(f"ray wavelengths {lo:.4g} .. {hi:.4g} m leave the interval {rng[0]:.4g} .. {rng[1]:.4g} m on which the "
+                             "scene's dispersion functions have their device form (Material(..., wavelength_range=(lo, hi)) widens it)")
+
     # -- non-branching trace ---------------------------------------------------------------
     def trace(self, rays: RayBatch, max_segments, out: SegmentBatch = None, counts=None, layout="slots", capacity=None):
         """All segments of every ray in one launch; returns the SegmentBatch.
@@ -58,6 +70,7 @@ class Engine:
         if self.scene is None:
             raise RuntimeError("upload a scene first")
         n, K = rays.n, int(max_segments)
+        self._check_wavelengths(rays)
         if layout == "append":
             return self._trace_append(rays, K, out, counts, capacity)
         if layout != "slots":
@@ -126,12 +139,14 @@ class Engine:
         if self.scene is None:
             raise RuntimeError("upload a scene first")
         prec = rays.precision
+        self._check_wavelengths(rays)
         gen_fn = self.lib.ot_trace_generation_f64 if prec == "f64" else self.lib.ot_trace_generation_f32
         dev, n = rays.device, rays.n
         if n == 0:
             out = SegmentBatch(0, prec, dev)
             out.n_valid, out.counts_table = 0, counts
             out.capped = torch.zeros(0, dtype=torch.bool, device=dev)
+            out.timed_out = False
             return out
         fan = max(self.scene.max_children, 1)
         if out_capacity is None:

@@ -10,11 +10,39 @@ from typing import Callable, List, Union
 import numpy as np
 
 
-class Material:
-    """`n(wavelength in metres)` (material.py:4-21)."""
+WAVELENGTH_RANGE = (0.2e-6, 2.5e-6)  # metres: where a dispersion callable is fitted unless the Material names its own range
 
-    def __init__(self, name: str, n: Union[Callable, float]):
+
+def callable_spec(n_func, wavelength_range=None):
+    """Device form of n(wavelength in metres) given as a Python function (material.py:4-21): constant if it is one,
+    else a verified Chebyshev series over `wavelength_range` (cheb.py) — ('cheb', lo, hi, coefficients) — or None
+    with the reason in `callable_spec.why` when no series reproduces it.  Rays whose wavelength (in metres) lies
+    outside the range are refused at trace time (engine.py): the series says nothing there."""
+    from . import cheb
+
+    lo, hi = wavelength_range or WAVELENGTH_RANGE
+    try:
+        vals = [float(n_func(w)) for w in (lo, 0.5 * (lo + hi), hi, 0.37 * lo + 0.63 * hi)]
+        if max(vals) == min(vals):
+            return ("const", vals[0])
+        coef, _ = cheb.fit(n_func, lo, hi, what="Material n(wavelength)")
+    except (cheb.FitError, TypeError, ValueError, ZeroDivisionError) as exc:
+        callable_spec.why = str(exc)
+        return None
+    return ("cheb", float(lo), float(hi), [float(c) for c in coef])
+
+
+callable_spec.why = ""
+
+
+class Material:
+    """`n(wavelength in metres)` (material.py:4-21).  `wavelength_range` (metres) is where a callable n is valid and
+    gets its device form; the reference has no such argument (it calls the function wherever a ray asks)."""
+
+    def __init__(self, name: str, n: Union[Callable, float], wavelength_range=None):
         self.name = name
+        self.wavelength_range = wavelength_range
+        self._spec = False  # device form of a callable: computed once, on first use
         if isinstance(n, (int, float)):
             self._const = float(n)
             self.n_func = lambda wavelength_m, _c=n: _c
@@ -26,10 +54,13 @@ class Material:
         return self.n_func(wavelength_m)
 
     def device_spec(self):
-        """('const', n) | ('sellmeier', Bs, Cs) | None when not representable on the device."""
+        """('const', n) | ('sellmeier', Bs, Cs) | ('cheb', lo, hi, coefficients) | None when not representable on the
+        device (a callable that no Chebyshev series reproduces: the scene compiler raises)."""
         if self._const is not None:
             return ("const", self._const)
-        return None
+        if self._spec is False:
+            self._spec = callable_spec(self.n_func, self.wavelength_range)
+        return self._spec
 
 
 class ConstMaterial(Material):
@@ -88,7 +119,7 @@ class SellmeierMaterial(Material):
 
     def device_spec(self):
         if len(self.Bs) > 3 or len(self.Bs) != len(self.Cs):
-            return None
+            return Material.device_spec(self)  # more terms than the closed form holds: a series of the same function
         # missing terms: B = 0 over a denominator that cannot vanish (lam^2 - C with C = -1 is > 0 for every wavelength;
         # the device forms one common denominator of the three terms, so a padded C = 1 would give 0/0 at exactly 1 um)
         pad = 3 - len(self.Bs)

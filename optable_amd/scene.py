@@ -27,7 +27,9 @@ class SceneError(NotImplementedError):
 class CompiledScene:
     """Owner of the ctypes tables handed to `ot_scene_upload`."""
 
-    def __init__(self, nodes, materials, aux, leaves, limited, max_children, unit, root_grid=-1, always_branches=False):
+    def __init__(self, nodes, materials, aux, leaves, limited, max_children, unit, root_grid=-1, always_branches=False,
+                 wavelength_range=None):
+        self.wavelength_range = wavelength_range  # metres; None when no material is a fitted series
         self.root_grid = root_grid
         self.always_branches = always_branches
         self.nodes = (abi.OtNode * max(len(nodes), 1))(*nodes)
@@ -67,6 +69,7 @@ class _Builder:
         self.nodes, self.materials, self.aux = [], [], []
         self.mat_index = {}
         self.leaves, self.limited = [], []
+        self.wavelength_range = None  # metres: where every fitted dispersion series of the scene is valid
         self.leaf_pose = []   # per leaf: (transform_matrix, origin, local box) for the fresh lab boxes (_trust_boxes)
         self.groups = []      # node indices of the groups, in node order
         self.max_children = 0
@@ -78,13 +81,22 @@ class _Builder:
             mat = Material("Constant", float(mat))
         spec = mat.device_spec()
         if spec is None:
-            raise SceneError(f"Material {mat.name!r} is defined by a Python callable and has no device form "
-                             "(use a constant or a SellmeierMaterial)")
-        key = (spec[0],) + tuple(np.ravel(spec[1:]).tolist())
+            from .materials import callable_spec
+
+            raise SceneError(f"Material {mat.name!r} is defined by a Python callable that has no device form: "
+                             f"{callable_spec.why or 'not a function of the wavelength the compiler can sample'}")
+        key = (spec[0],) + tuple(np.ravel(np.concatenate([np.ravel(x) for x in spec[1:]])).tolist())
         if key not in self.mat_index:
             rec = abi.OtMaterial()
             if spec[0] == "const":
                 rec.kind, rec.n = abi.MAT_CONST, spec[1]
+            elif spec[0] == "cheb":  # n holds the aux offset of the series record [N, lo, hi, c...]
+                from . import cheb
+
+                rec.kind, rec.n = abi.MAT_CHEB, float(len(self.aux))
+                self.aux.extend(cheb.record(spec[3], spec[1], spec[2]))
+                lo, hi = self.wavelength_range or (spec[1], spec[2])
+                self.wavelength_range = (max(lo, spec[1]), min(hi, spec[2]))
             else:
                 rec.kind, rec.n = abi.MAT_SELLMEIER, 0.0
                 rec.B[:], rec.C[:] = spec[1], spec[2]
@@ -449,4 +461,5 @@ def compile_scene(components, unit=1e-2, accelerate=True) -> CompiledScene:
     for g in b.groups:
         b._maybe_grid(b.nodes[g], g)
     root = _root_grid(b, tops) if accelerate and all_trusted else -1
-    return CompiledScene(b.nodes, b.materials, b.aux, b.leaves, b.limited, b.max_children, unit, root, b.always_branches)
+    return CompiledScene(b.nodes, b.materials, b.aux, b.leaves, b.limited, b.max_children, unit, root, b.always_branches,
+                         b.wavelength_range)

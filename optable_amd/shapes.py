@@ -14,7 +14,7 @@ from .geometry import Base, unit_vector
 from .slab import solve_ray_bboxes_intersections
 
 # shape kinds == ot_shape_kind
-CIRCLE, RECT, POLYGON2D, POLYGON3D, SPHERE, ASPHERE_PARAM, ASPHERE_EXACT, CYLINDER, POINT, CSG = range(10)
+CIRCLE, RECT, POLYGON2D, POLYGON3D, SPHERE, ASPHERE_PARAM, ASPHERE_EXACT, CYLINDER, POINT, CSG, ASPHERE_CHEB = range(11)
 # CSG postfix opcodes (aux program): operand kinds reuse CIRCLE/RECT/POLYGON2D
 CSG_OR, CSG_ANDNOT = 100, 101
 
@@ -286,11 +286,32 @@ class ASphere(Surface):
     def lower(self):
         spec = getattr(self.f_asphere, "device_spec", None)
         if spec is None:
-            raise NotImplementedError(
-                "ASphere with an arbitrary Python f_asphere has no device form; use "
-                "ASphericParametricLens / ASphericExactSphericalLens or optable_amd.sag_parametric / sag_exact")
+            return lower_asphere_callable(self.radius, self.f_asphere)
         kind, coeffs = spec
         return Lowered(kind, [self.radius] + list(coeffs), planar=False)
+
+
+def lower_asphere_callable(radius, f_asphere):
+    """Device form of an ASphere whose sag is an arbitrary Python function F(r) (component_group.py:1014-1055): a
+    verified Chebyshev series of F on every radius the kernels can ask for — the root scan looks at points of the
+    local box (r up to radius * sqrt 2), the reference's finite differences step h = 1e-4 * radius to either side,
+    also across the axis (surfaces.py:355-369) — with the series of F' and F'' beside it (Newton slope of the root
+    polish; normals and curvature in single precision, where a finite difference with that h loses five digits).
+    A function that no series reproduces to 5e-14 of its range is refused (cheb.FitError names the reason)."""
+    from . import cheb
+
+    h = 1e-4 * radius
+    lo, hi = -2.0 * h, radius * (np.sqrt(2.0) * 1.001) + 2.0 * h
+    try:
+        f_asphere(lo)
+        func = f_asphere
+    except Exception:  # noqa: BLE001 - a sag that only takes r >= 0: the reference's stencil reaches across the axis as F(|r|) would
+        func = lambda r: f_asphere(abs(r))  # noqa: E731
+    try:
+        coef, _ = cheb.fit(func, lo, hi, what="ASphere f_asphere(r)")
+    except cheb.FitError as exc:
+        raise NotImplementedError(str(exc)) from exc
+    return Lowered(ASPHERE_CHEB, [radius], aux=cheb.record(coef, lo, hi, derivatives=2), planar=False)
 
 
 def sag_parametric(R, kappa, a4=0.0, a6=0.0, a8=0.0):

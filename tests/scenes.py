@@ -243,7 +243,28 @@ def g21_ties(ns):
     return dict(components=[back, near_a, near_b, pair], monitors=[], rays=rays, limit={"max_trace_num": 6})
 
 
+def g24_callables(ns):
+    """User functions in the scene (component_group.py:1014-1055 ASphericLens(f_asphere_1 / _2 = callable),
+    material.py:4-21 Material(name, n = callable)): a lens with two sags that are none of the recognised closed
+    forms, made of a glass whose dispersion is a Python function, a tilted slab of a second such glass, a mirror
+    that sends the light back through both; three wavelengths."""
+    sag_front = lambda r: 0.5 * (np.cosh(0.3 * r) - 1.0) + 1e-3 * r**4          # noqa: E731
+    sag_back = lambda r: -0.02 * r**2 / (1.0 + 0.1 * r**2)                        # noqa: E731
+    flint = ns.Material("cauchy flint", n=lambda wl_m: 1.6 + 8e-15 / wl_m**2)
+    crown = ns.Material("two-term crown", n=lambda wl_m: np.sqrt(2.2 + 6e-15 / wl_m**2 - 1e9 * wl_m**2))
+    lens = ns.ASphericLens([6, 0, 0], CT=0.7, f_asphere_1=sag_front, f_asphere_2=sag_back, diameter=2.6, n=flint)
+    slab = ns.GlassSlab([12, 0.1, 0], width=3, height=3, thickness=0.6, n1=ns.Vacuum(), n2=crown).RotZ(0.3)
+    mirror = ns.Mirror([16, 0, 0], radius=2.0).RotZ(np.pi + 0.04)
+    rays = []
+    for wl in (450e-7, 633e-7, 850e-7):
+        for y in (-0.9, -0.45, 0.0, 0.3, 0.75):
+            for z in (-0.4, 0.2):
+                rays.append(ns.Ray([0, y, z], [1, 0.01 * y, -0.02 * z], wavelength=wl, w0=W0))
+    return dict(components=[lens, slab, mirror], monitors=[], rays=rays, limit={"max_trace_num": 24})
+
+
 SCENES = {
+    "g24_callables": g24_callables,
     "g01_gaussian_beam": g01_gaussian_beam, "g02_cfg2": g02_cfg2, "g03_chromatic": g03_chromatic,
     "g04_glass_slab": g04_glass_slab, "g05_cavity": g05_cavity, "g06_mirror_pair": g06_mirror_pair,
     "g07_spherical_lenses": g07_spherical_lenses, "g08_asphere": g08_asphere, "g09_cfg5": g09_cfg5,

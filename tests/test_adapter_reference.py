@@ -124,3 +124,14 @@ def test_reference_ray_objects_round_trip_through_pack_and_scatter(ref):
     clones = _clone_rays(per_ray[0])
     clones[0].origin[0] = 99.0
     assert per_ray[0][0].origin[0] == 0.0                                        # the returned list is independent
+
+
+def test_reference_objects_with_user_functions_get_the_same_series(ref):
+    """ASphericLens(f_asphere = callable) and Material(n = callable) built with the REFERENCE's classes lower to the same
+    Chebyshev records as this package's own (optable_amd/cheb.py through adapter.py)."""
+    a = oa.compile_scene(scenes.g24_callables(ref)["components"])
+    b = oa.compile_scene(scenes.g24_callables(oa)["components"])
+    assert a.n_aux == b.n_aux > 100
+    np.testing.assert_array_equal(np.ctypeslib.as_array(a.aux)[: a.n_aux], np.ctypeslib.as_array(b.aux)[: b.n_aux])
+    assert [m.kind for m in a.materials[: a.n_materials]] == [m.kind for m in b.materials[: b.n_materials]]
+    assert list(a.node_table()["shape"]) == list(b.node_table()["shape"]) and 10 in a.node_table()["shape"]
