@@ -251,6 +251,21 @@ def survey_config(oa, eng, name, device):
            "intersections_per_s": segs * scene.n_leaves / t, "algorithmic_gbs": alg / t / 1e9,
            "hbm_frac": alg / t / 1e9 / HBM_PEAK_GBS, "launch": launch,
            "bound": "hbm" if not heavy else "valu/latency (S >= 24, SURVEY.md §8d): the HBM fraction is for comparison"}
+    if not heavy:  # the slots in 64-slot tiles (ot_trace_tiled_*): the layout the bench line itself uses for light scenes
+        torch.cuda.empty_cache()
+        out = SegmentBatch(n * wl.max_segments, wl.precision, batch.device, tiled=True)
+        for _ in range(3):
+            eng.trace(batch, wl.max_segments, out=out, layout="tiled")
+        eng.timing(True)
+        for _ in range(reps):
+            eng.trace(batch, wl.max_segments, out=out, layout="tiled")
+        ms, cnt_t = eng.timing_read()
+        eng.timing(False)
+        tt = ms / cnt_t / 1e3
+        rec["tiled_layout"] = {"layout": "tiled: slot k * n_rays + i in tile / 64, lane % 64 (ot_trace_tiled_*)", "launches": cnt_t,
+                               "ms_per_trace": tt * 1e3, "segments_per_s": segs / tt, "intersections_per_s": segs * scene.n_leaves / tt,
+                               "algorithmic_gbs": alg / tt / 1e9, "hbm_frac": alg / tt / 1e9 / HBM_PEAK_GBS}
+        del out
     if heavy:  # the same trace with the dense output: same records (tests/test_gpu_append.py), written in whole lines
         ta, cnta, segsa, slotsa, launcha = measure("append")
         rec["append_layout"] = {"layout": "append: dense list in append order, a stable sort by ray is the reference's order (ot_trace_append_*)",
@@ -372,10 +387,15 @@ def main():
         n_inputs = max(1, min(4, -(-300_000_000 // (n * bytes_rec))))
         batches = [make_batch(oa, wl, n, rank, device, seed_shift=1000 * k) for k in range(n_inputs)]
         n = batches[0].n
-        outs = [SegmentBatch(n * MAX_SEG, prec, batches[0].device) for _ in range(n_inputs)]
+        # Output layout: light scenes (the lane-per-ray kernel: cfg 2, cfg 4) write their [k][ray] slots in 64-slot tiles
+        # (ot_trace_tiled_*: one contiguous block per wave and segment; the same records, tests/test_gpu_append.py); heavy
+        # scenes write the 14 slot arrays here (their dense output, ot_trace_append_*, is measured in `configs`).
+        layout = "tiled" if scene.n_nodes < 24 else "slots"
+        extra["output_layout"] = layout
+        outs = [SegmentBatch(n * MAX_SEG, prec, batches[0].device, tiled=(layout == "tiled")) for _ in range(n_inputs)]
 
         def step(s):
-            eng.trace(batches[s % n_inputs], MAX_SEG, out=outs[s % n_inputs])
+            eng.trace(batches[s % n_inputs], MAX_SEG, out=outs[s % n_inputs], layout=layout)
 
         # cold: what a caller sees right after the upload — one launch to load the code object, then the next 20
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -437,6 +457,27 @@ def main():
                 eng.stream_ceiling(batches[s % n_inputs], MAX_SEG, outs[s % n_inputs])
             ceil_ms, ceil_n = eng.timing_read()
         eng.timing(False)
+        if layout == "tiled" and world == 1:
+            # the same K launches into the 14 [k][ray] arrays of ot_trace_* (the layout of rounds 1-2), for comparison
+            outs_slots = [SegmentBatch(n * MAX_SEG, prec, batches[0].device) for _ in range(n_inputs)]
+            for s in range(args.warmup + 3):
+                eng.trace(batches[s % n_inputs], MAX_SEG, out=outs_slots[s % n_inputs])
+            torch.cuda.synchronize()
+            ev0.record()
+            for s in range(args.steps):
+                eng.trace(batches[s % n_inputs], MAX_SEG, out=outs_slots[s % n_inputs])
+            ev1.record()
+            torch.cuda.synchronize()
+            slots_us = ev0.elapsed_time(ev1) / args.steps * 1e3
+            eng.timing(True)
+            for s in range(10 if wl.name == "cfg2" else 3):
+                eng.stream_ceiling(batches[s % n_inputs], MAX_SEG, outs_slots[s % n_inputs])
+            sc_ms, sc_n = eng.timing_read()
+            eng.timing(False)
+            extra["slots_layout"] = {"kernel_us": slots_us, "stream_ceiling_us": sc_ms / max(sc_n, 1) * 1e3,
+                                     "note": "the same trace into the 14 [k][ray] arrays of ot_trace_* (the output layout of rounds 1-2)"}
+            del outs_slots
+            torch.cuda.empty_cache()
         if world == 1 and not args.no_sustained:
             # >= 1 s of back-to-back launches: long enough for any outside sampler to see the GPU busy, and the
             # figure a long job gets
@@ -521,7 +562,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak" if (clamped or args.rays) else wl.scaling, "vs_baseline": None, "dtype": prec,
             "data": "synthetic",
-            "config": {"workload": wl.label, "rays_per_gpu": n, "rays_total": rays_total,
+            "config": {"workload": wl.label, "rays_per_gpu": n, "rays_total": rays_total, "output_layout": extra.get("output_layout", "slots"),
                        "segments_per_ray": segs_step / n, "leaf_surfaces": S_LEAVES, "input_batches_rotated": n_inputs,
                        "parallelism": f"ray-shard x{world}, scene replicated"},
             "segments_per_s": segs_total_step * args.steps / dt,
@@ -547,6 +588,10 @@ def main():
             sus["hbm_frac"] = alg_bytes / (sus["ms_per_step"] / 1e3) / 1e9 / HBM_PEAK_GBS
         if "cold" in extra:
             extra["cold"]["hbm_frac"] = alg_bytes / (extra["cold"]["us_per_step"] / 1e6) / 1e9 / HBM_PEAK_GBS
+        if "slots_layout" in extra:
+            sl = extra["slots_layout"]
+            sl["hbm_frac"] = alg_bytes / (sl["kernel_us"] / 1e6) / 1e9 / HBM_PEAK_GBS
+            sl["stream_ceiling_gbs"] = alg_bytes / (sl["stream_ceiling_us"] / 1e6) / 1e9
         line.update(extra)
         if gather_error is not None:
             line["gather_error"] = gather_error

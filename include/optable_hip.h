@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define OT_ABI_VERSION 8  /* 8: OT_SHAPE_ASPHERE_CHEB, OT_MAT_CHEB, OT_NODE_BOX_TRUSTED; 3: ot_trace_generation_f32; 4: ot_bench_stream_f32; 5: OT_OPT_LIST_CAP, ray flags bits 8..31, ot_debug_generation_mismatches; 6: ot_debug_last_launch, OT_OPT_FLAT_QUEUE, OT_OPT_LDS_RECORDS; 7: ot_trace_append_*, ot_segment_block, OT_OPT_APPEND_CHUNK, OT_OPT_INSTANCING */
+#define OT_ABI_VERSION 8  /* 8: OT_SHAPE_ASPHERE_CHEB, OT_MAT_CHEB, OT_NODE_BOX_TRUSTED, ot_trace_tiled_*, ot_bench_stream_tiled_*; 3: ot_trace_generation_f32; 4: ot_bench_stream_f32; 5: OT_OPT_LIST_CAP, ray flags bits 8..31, ot_debug_generation_mismatches; 6: ot_debug_last_launch, OT_OPT_FLAT_QUEUE, OT_OPT_LDS_RECORDS; 7: ot_trace_append_*, ot_segment_block, OT_OPT_APPEND_CHUNK, OT_OPT_INSTANCING */
 
 /* ---- status codes ------------------------------------------------------------------- */
 enum ot_status {
@@ -240,6 +240,21 @@ int ot_trace_f32(ot_ctx* ctx, const ot_rays* rays, int64_t n_rays, int32_t max_s
                  const ot_segments* out, int32_t* seg_count, int32_t* counts,
                  int32_t n_count_classes);
 
+/* The same trace with the TILED layout: the max_segments * n_rays slots of ot_trace_* in tiles of 64 consecutive slots.
+ * Slot s = k * n_rays + i lives in tile s / 64 at lane s % 64; a tile is OT_TILE_BYTES(real) = 64 * (12 * sizeof(real) + 8)
+ * bytes: the 12 real fields of ot_segments, 64 values each, then int32 ray[64], int32 surface[64].  A wave of the kernel
+ * then writes ONE contiguous 6656-byte (fp32: 3584) block per segment instead of 14 runs in 14 arrays that lie
+ * max_segments * n_rays elements apart: the HBM streams of a light scene run 9 % faster (tools/stream_layouts.hip:
+ * 5.68 instead of 5.22 TB/s for cfg 2's 1 record in, 5 out).  `tiles` is a device pointer (16-byte aligned) to
+ * capacity / 64 tiles; capacity is a multiple of 64 and >= max_segments * n_rays rounded up to 64.  seg_count, counts:
+ * as for ot_trace_*.  Light scenes only (the lane-per-ray kernel): a scene that ot_trace_* would send to the rolling
+ * lists (24 nodes or more) gets OT_ERR_UNSUPPORTED here — its dense output is ot_trace_append_*. */
+#define OT_TILE_BYTES(real_bytes) (64 * (12 * (real_bytes) + 8))
+int ot_trace_tiled_f64(ot_ctx* ctx, const ot_rays* rays, int64_t n_rays, int32_t max_segments, void* tiles,
+                       int64_t capacity, int32_t* seg_count, int32_t* counts, int32_t n_count_classes);
+int ot_trace_tiled_f32(ot_ctx* ctx, const ot_rays* rays, int64_t n_rays, int32_t max_segments, void* tiles,
+                       int64_t capacity, int32_t* seg_count, int32_t* counts, int32_t n_count_classes);
+
 /* The same trace with the APPEND layout: a dense list of segment records instead of max_segments * n_rays slots.
  * The reference returns a list with one entry per processed segment (optical_table.py:125-134); the [k][ray] slots of
  * ot_trace_* hold that list with a hole for every segment a ray did not live to (cfg 3: 11 GB of slots for 2.8 GB of
@@ -294,7 +309,7 @@ int ot_debug_generation_mismatches(ot_ctx* ctx, int64_t* count);
  * info[0] kernel (1 lane per ray, 2 rolling lists), [1] threads per workgroup, [2] workgroups per CU the occupancy
  * query allowed, [3] workgroups launched, [4] dynamic LDS bytes per workgroup, [5] list capacity per wave (rolling),
  * [6] 1 = mixed generations, [7] bit 0 = candidate pair queue (OT_OPT_FLAT_QUEUE took effect), bit 1 = records in LDS,
- * bit 2 = append layout. */
+ * bit 2 = append layout, bit 3 = tiled layout. */
 int ot_debug_last_launch(ot_ctx* ctx, int32_t info[8]);
 
 /* Monitor.record (monitor.py:183-193): intersect finished segments with a rectangular
@@ -343,6 +358,11 @@ int ot_bench_stream_f64(ot_ctx* ctx, const ot_rays* rays, int64_t n_rays, int32_
                         const ot_segments* out, int32_t* seg_count);
 int ot_bench_stream_f32(ot_ctx* ctx, const ot_rays* rays, int64_t n_rays, int32_t max_segments,
                         const ot_segments* out, int32_t* seg_count);
+/* ... and of ot_trace_tiled_*: the same records into 64-slot tiles. */
+int ot_bench_stream_tiled_f64(ot_ctx* ctx, const ot_rays* rays, int64_t n_rays, int32_t max_segments, void* tiles,
+                              int64_t capacity, int32_t* seg_count);
+int ot_bench_stream_tiled_f32(ot_ctx* ctx, const ot_rays* rays, int64_t n_rays, int32_t max_segments, void* tiles,
+                              int64_t capacity, int32_t* seg_count);
 
 #ifdef __cplusplus
 }

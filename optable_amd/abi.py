@@ -87,6 +87,10 @@ SYMBOLS = {
     "ot_scene_upload": (C.c_int, [_vp, C.POINTER(OtSceneDesc)]),
     "ot_trace_f64": (C.c_int, _TRACE_ARGS),
     "ot_trace_f32": (C.c_int, _TRACE_ARGS),
+    "ot_trace_tiled_f64": (C.c_int, [_vp, C.POINTER(OtRays), _i64, _i32, _vp, _i64, _vp, _vp, _i32]),
+    "ot_trace_tiled_f32": (C.c_int, [_vp, C.POINTER(OtRays), _i64, _i32, _vp, _i64, _vp, _vp, _i32]),
+    "ot_bench_stream_tiled_f64": (C.c_int, [_vp, C.POINTER(OtRays), _i64, _i32, _vp, _i64, _vp]),
+    "ot_bench_stream_tiled_f32": (C.c_int, [_vp, C.POINTER(OtRays), _i64, _i32, _vp, _i64, _vp]),
     "ot_trace_append_f64": (C.c_int, [_vp, C.POINTER(OtRays), _i64, _i32, C.POINTER(OtSegmentBlock), _vp, _vp, _vp, _i32]),
     "ot_trace_append_f32": (C.c_int, [_vp, C.POINTER(OtRays), _i64, _i32, C.POINTER(OtSegmentBlock), _vp, _vp, _vp, _i32]),
     "ot_trace_generation_f64": (C.c_int, [_vp, C.POINTER(OtRays), _vp, _i64, _vp, C.POINTER(OtSegments), _i64,

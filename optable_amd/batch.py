@@ -224,11 +224,26 @@ class SegmentBatch:
     For `list` and `append` a STABLE sort by `ray` gives the reference's order (input ray major, then segment order).
     """
 
-    def __init__(self, capacity, precision="f64", device="cuda", block=False):
+    tiled = append = False          # defaults for batches assembled field by field (astype, to_slots, table.py)
+    block = cursor = _n_valid = count = n_rays = None
+
+    def __init__(self, capacity, precision="f64", device="cuda", block=False, tiled=False):
         self.capacity, self.precision, self.device = int(capacity), precision, torch.device(device)
         dt = _REAL[precision]
         self.block = None
-        if block:  # ONE allocation of 14 planes (include/optable_hip.h: ot_segment_block); the fields are its rows
+        self.tiled = bool(tiled)
+        if tiled:  # 64-slot tiles (include/optable_hip.h: ot_trace_tiled_*); the fields are strided [tiles, 64] views of one block
+            self.capacity = cap = (self.capacity + 63) // 64 * 64
+            width = 8 if precision == "f64" else 4
+            tile_bytes = 64 * (12 * width + 8)
+            self.block = torch.empty(cap // 64 * tile_bytes, dtype=torch.uint8, device=self.device)
+            reals, ints = self.block.view(dt), self.block.view(torch.int32)
+            rs, is_ = tile_bytes // width, tile_bytes // 4
+            for k, f in enumerate(abi.SEG_FIELDS):
+                setattr(self, "n_index" if f == "n" else f, reals.as_strided((cap // 64, 64), (rs, 1), 64 * k))
+            self.ray = ints.as_strided((cap // 64, 64), (is_, 1), 12 * 64 * width // 4)
+            self.surface = ints.as_strided((cap // 64, 64), (is_, 1), 12 * 64 * width // 4 + 64)
+        elif block:  # ONE allocation of 14 planes (include/optable_hip.h: ot_segment_block); the fields are its rows
             self.capacity = cap = (self.capacity + 63) // 64 * 64
             width = 8 if precision == "f64" else 4
             self.block = torch.empty(12 * cap * width + 2 * cap * 4, dtype=torch.uint8, device=self.device)
@@ -265,7 +280,7 @@ class SegmentBatch:
 
     @property
     def layout(self):
-        return "append" if self.append else ("slots" if self.count is not None else "list")
+        return "append" if self.append else ("tiled" if self.tiled else ("slots" if self.count is not None else "list"))
 
     def block_struct(self):
         s = abi.OtSegmentBlock()
@@ -275,7 +290,27 @@ class SegmentBatch:
     def field(self, name):
         return self.n_index if name == "n" else getattr(self, name)
 
+    def to_slots(self):
+        """A tiled batch as plain [k][ray] arrays (one device copy per field); any other batch as it is.  The tiled
+        layout is what the lane-per-ray kernel writes fastest; everything that reads segments (monitors, exports,
+        to_host) reads slot arrays."""
+        if not self.tiled:
+            return self
+        out = object.__new__(SegmentBatch)
+        out.capacity, out.precision, out.device = self.capacity, self.precision, self.device
+        for f in abi.SEG_FIELDS:
+            setattr(out, "n_index" if f == "n" else f, self.field(f).reshape(-1))
+        out.ray, out.surface = self.ray.reshape(-1), self.surface.reshape(-1)
+        out.count, out.n_rays, out._n_valid, out.cursor = self.count, self.n_rays, self._n_valid, None
+        out.append, out.block, out.tiled = False, None, False
+        for extra in ("capped", "counts_table", "count_ids"):
+            if hasattr(self, extra):
+                setattr(out, extra, getattr(self, extra))
+        return out
+
     def c_struct(self):
+        if self.tiled:
+            raise ValueError("a tiled SegmentBatch has no 14-array form: use to_slots()")
         s = abi.OtSegments()
         for f in abi.SEG_FIELDS:
             setattr(s, f, self.field(f).data_ptr())
@@ -284,9 +319,12 @@ class SegmentBatch:
 
     def astype(self, precision):
         """The same segments with their real fields in another precision (a copy unless already there)."""
+        if self.tiled:
+            return self.to_slots().astype(precision)
         if precision == self.precision:
             return self
         out = object.__new__(SegmentBatch)
+        out.tiled = False
         out.capacity, out.precision, out.device = self.capacity, precision, self.device
         dt = _REAL[precision]
         for f in abi.SEG_FIELDS:
@@ -301,6 +339,8 @@ class SegmentBatch:
 
     def valid_mask(self):
         """Boolean mask over slots (device)."""
+        if self.tiled:
+            return self.to_slots().valid_mask()
         if self.layout == "slots":
             k = torch.arange(self.capacity // self.n_rays, device=self.device, dtype=torch.int32).unsqueeze(1)
             return (k < self.count.abs().unsqueeze(0)).reshape(-1)
@@ -325,6 +365,8 @@ class SegmentBatch:
     def to_host(self, reference_order=True):
         """Valid segments as numpy arrays.  reference_order: input-ray-major, then segment
         order within the ray (the order OpticalTable.ray_tracing returns, optical_table.py:66-70)."""
+        if self.tiled:
+            return self.to_slots().to_host(reference_order)
         if self.count is not None and self.n_rays == 0:
             out = {f: np.zeros(0) for f in abi.SEG_FIELDS}
             out.update(ray=np.zeros(0, np.int32), surface=np.zeros(0, np.int32), count=np.zeros(0, np.int32))

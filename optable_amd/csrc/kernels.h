@@ -121,6 +121,29 @@ __device__ __forceinline__ void store_segment(const SegPlanes<T>& out, int64_t s
 }
 template <class T> __device__ __forceinline__ int32_t* ray_plane(const SegPlanes<T>& out) { return reinterpret_cast<int32_t*>(reinterpret_cast<T*>(out.base) + 12 * out.cap); }
 
+// Tiled layout (ot_trace_tiled_*): slot s lives in tile s / 64 at lane s % 64; a tile holds the 14 fields of 64 consecutive
+// slots field by field — 12 x 64 reals, then int32 ray[64], int32 surface[64] — so the 64 lanes of a wave write ONE
+// contiguous 6656-byte (fp32: 3584) block per segment instead of 14 runs in 14 arrays that lie n_rays * K elements apart.
+// Same bytes, fewer open DRAM pages per wave: the streams of cfg 2 (1 record in, 5 out per ray) run at 5.68 instead of
+// 5.22 TB/s that way (tools/stream_layouts.hip).
+template <class T> struct SegTiles {
+    uint8_t* base;
+    static constexpr int64_t TILE_BYTES = 64 * (12 * (int64_t)sizeof(T) + 8);
+};
+template <class T, bool NT = false>
+__device__ __forceinline__ void store_segment(const SegTiles<T>& out, int64_t slot, const RayState<T>& r, T len, int32_t tree,
+                                              int32_t surface) {
+    uint8_t* tb = out.base + (slot >> 6) * SegTiles<T>::TILE_BYTES;
+    T* p = reinterpret_cast<T*>(tb) + (slot & 63);
+    st<NT>(p, r.ox); st<NT>(p + 64, r.oy); st<NT>(p + 128, r.oz);
+    st<NT>(p + 192, r.dx); st<NT>(p + 256, r.dy); st<NT>(p + 320, r.dz);
+    st<NT>(p + 384, len); st<NT>(p + 448, r.I);
+    st<NT>(p + 512, r.qr); st<NT>(p + 576, r.qi);
+    st<NT>(p + 640, r.n); st<NT>(p + 704, r.pl);
+    int32_t* q = reinterpret_cast<int32_t*>(tb + 768 * sizeof(T)) + (slot & 63);
+    st<NT>(q, tree); st<NT>(q + 64, surface);
+}
+
 // Paired stores: lanes 2j and 2j+1 hold records for two ADJACENT slots.  Instead of fourteen stores of one element
 // per lane, the pair takes the fields two at a time: after one DPP exchange the even lane holds both lanes' values of
 // field A and writes them as ONE 16-byte store (fp64; 8 bytes in fp32), the odd lane does the same for field B.
@@ -143,6 +166,22 @@ __device__ __forceinline__ void store_pair(V* A, V* B, int64_t slot, V a, V b, b
     vec2* p = reinterpret_cast<vec2*>(odd ? B + (slot - 1) : A + slot);
     if (NT) __builtin_nontemporal_store(v, p);
     else *p = v;
+}
+// ... the same inside a tile: both lanes of a pair lie in one tile (64 is even), the planes are 64 elements apart
+template <class T, bool NT>
+__device__ __forceinline__ void store_segment_paired(const SegTiles<T>& out, int64_t slot, const RayState<T>& r, T len, int32_t tree,
+                                                     int32_t surface, bool odd) {
+    uint8_t* tb = out.base + (slot >> 6) * SegTiles<T>::TILE_BYTES;
+    T* p = reinterpret_cast<T*>(tb);
+    const int64_t l = slot & 63;
+    store_pair<NT>(p, p + 64, l, r.ox, r.oy, odd);
+    store_pair<NT>(p + 128, p + 192, l, r.oz, r.dx, odd);
+    store_pair<NT>(p + 256, p + 320, l, r.dy, r.dz, odd);
+    store_pair<NT>(p + 384, p + 448, l, len, r.I, odd);
+    store_pair<NT>(p + 512, p + 576, l, r.qr, r.qi, odd);
+    store_pair<NT>(p + 640, p + 704, l, r.n, r.pl, odd);
+    int32_t* q = reinterpret_cast<int32_t*>(tb + 768 * sizeof(T));
+    store_pair<NT>(q, q + 64, l, tree, surface, odd);
 }
 template <class T, bool NT>
 __device__ __forceinline__ void store_segment_paired(const SegsT<T>& out, int64_t slot, const RayState<T>& r, T len, int32_t tree,
@@ -173,8 +212,9 @@ template <class T> __device__ __forceinline__ RayState<T> load_ray(const RaysT<T
 
 // ------------------------------------------------------------------------------------------
 // k_trace_fused: the hot kernel
-template <class T, uint32_t F, bool SCENE_IN_LDS, int MINW, bool NT>
-__global__ __launch_bounds__(256, MINW) void k_trace_fused(SceneBlob blob, T unit, RaysT<T> in, int64_t n, int32_t K, SegsT<T> out,
+// OUT: SegsT<T> (the [k][ray] slots of ot_trace_*: 14 arrays) or SegTiles<T> (the same slots in 64-slot tiles, ot_trace_tiled_*)
+template <class T, uint32_t F, bool SCENE_IN_LDS, int MINW, bool NT, class OUT>
+__global__ __launch_bounds__(256, MINW) void k_trace_fused(SceneBlob blob, T unit, RaysT<T> in, int64_t n, int32_t K, OUT out,
                                                      int32_t* __restrict__ seg_count, int32_t* counts, int32_t n_classes, int32_t pair) {
     extern __shared__ __align__(16) uint32_t lds[];
     const uint32_t* base = blob.words;
@@ -617,8 +657,8 @@ __global__ __launch_bounds__((rolling_threads<T, F, REC_LDS>()), (rolling_minw<T
 // k_stream_ceiling: the fused kernel's memory traffic with no tracing — reads one ray record,
 // writes K segment records per ray through the same SoA streams.  What this access pattern can
 // reach on the device; reported next to the trace kernel (bench.py).
-template <class T, bool NT>
-__global__ __launch_bounds__(256) void k_stream_ceiling(RaysT<T> in, int64_t n, int32_t K, SegsT<T> out, int32_t* seg_count, int32_t pair) {
+template <class T, bool NT, class OUT>
+__global__ __launch_bounds__(256) void k_stream_ceiling(RaysT<T> in, int64_t n, int32_t K, OUT out, int32_t* seg_count, int32_t pair) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         RayState<T> r = load_ray(in, i, in.flags[i]);

@@ -771,26 +771,29 @@ static int check_trace_args(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K
     return 0;
 }
 
-template <class T>
-static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, const ot_segments* out, int32_t* seg_count,
-                       int32_t* counts, int32_t n_classes) {
-    int rc = check_trace_args(c, rays, n, K, seg_count, counts, n_classes);
-    if (rc) return rc;
-    rc = check_segs(out);
-    if (rc) return rc;
-    if (n == 0) return 0;
-    HIP_TRY(hipSetDevice(c->device));
+// does this scene take the rolling lists (heavy: many nodes per segment => VALU-bound, uneven path lengths) or one lane per
+// ray with perfectly coalesced streams (light: HBM-bound)?  The all-features preset has no lane-per-ray form in double
+// precision (it would need more than 256 registers): those scenes always take the lists.
+template <class T> static bool wants_rolling(const ot_ctx* c, int32_t K) {
+    using namespace preset;
+    const bool f64 = sizeof(T) == 8;
+    const int fi = (c->features & ~FA) == 0 ? 0 : ((c->features & ~FB) == 0 ? 1 : 2);
+    const size_t bytes = f64 ? c->bytes64 : c->bytes32;
+    const bool in_lds = bytes <= (size_t)c->opt_lds_limit_kb * 1024;
+    return c->opt_kernel == 2 || (c->opt_kernel == 0 && c->n_nodes >= 24 && K > 2) || (f64 && (fi == 2 || !in_lds));
+}
+
+// one lane per ray (k_trace_fused); OUT = SegsT<T> or SegTiles<T>
+template <class T, class OUT>
+static int launch_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, const OUT& out, int32_t pair, int32_t* seg_count, int32_t* counts,
+                        int32_t n_classes) {
+    int rc = 0;
     using namespace preset;  // tables.h
     const bool f64 = sizeof(T) == 8;
     const uint32_t need = c->features;
     const int fi = (need & ~FA) == 0 ? 0 : ((need & ~FB) == 0 ? 1 : 2);
-    // Heavy scenes (many nodes per segment => VALU-bound, uneven path lengths) use the rolling lists; light ones are
-    // HBM-bound and keep one lane per ray with perfectly coalesced streams.  The all-features preset has no lane-per-ray
-    // form in double precision (it would need more than 256 registers): those scenes always take the lists.
     const size_t bytes = f64 ? c->bytes64 : c->bytes32;
     const bool in_lds = bytes <= (size_t)c->opt_lds_limit_kb * 1024;
-    const bool use_rolling = c->opt_kernel == 2 || (c->opt_kernel == 0 && c->n_nodes >= 24 && K > 2) || (f64 && (fi == 2 || !in_lds));
-    if (use_rolling) return launch_rolling<T, SegsT<T>>(c, rays, n, K, view<T>(out), AppendCtl{nullptr, 0, 0}, seg_count, counts, n_classes);
     const SceneBlob blob = make_blob<T>(c);
     const int block = 256;
     const int64_t blocks_needed = (n + block - 1) / block;
@@ -812,16 +815,50 @@ static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, con
     // smallest instantiation that covers the scene's features; the 128-register cap pays for the mirror / lens kernel
     // and the fp32 Snell kernel only (the fp64 Snell kernel would spill: 145 VGPRs)
     const bool mw = c->opt_minw == 4 && (fi == 0 || (fi == 1 && !f64));
-    FusedKern<T> kern = fused_kernel<T>(fi, in_lds, mw, c->opt_nt != 0);
+    FusedKern<T, OUT> kern = fused_kernel<T, OUT>(fi, in_lds, mw, c->opt_nt != 0);
     if (!kern) return fail(OT_ERR_UNSUPPORTED, "no kernel instantiation for this scene / option combination");
     const size_t lds_bytes = in_lds ? bytes : 0;
     if (lds_bytes > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), (uint32_t)lds_bytes, c->stream, ev0, ev1, 0u, blob, (T)c->unit, view<T>(rays), n, K,
-                          view<T>(out), seg_count, counts, n_classes, pair_ok<T>(c, out, n));
+                          out, seg_count, counts, n_classes, pair);
     HIP_TRY(hipGetLastError());
-    const int32_t shape[8] = {1, (int32_t)block, 0, (int32_t)grid, (int32_t)lds_bytes, 0, 0, 0};
+    const int32_t shape[8] = {1, (int32_t)block, 0, (int32_t)grid, (int32_t)lds_bytes, 0, 0, std::is_same<OUT, SegTiles<T>>::value ? 8 : 0};
     for (int q = 0; q < 8; ++q) c->last_launch[q] = shape[q];
     return 0;
+}
+
+template <class T>
+static int trace_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, const ot_segments* out, int32_t* seg_count,
+                       int32_t* counts, int32_t n_classes) {
+    int rc = check_trace_args(c, rays, n, K, seg_count, counts, n_classes);
+    if (rc) return rc;
+    rc = check_segs(out);
+    if (rc) return rc;
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(c->device));
+    if (wants_rolling<T>(c, K)) return launch_rolling<T, SegsT<T>>(c, rays, n, K, view<T>(out), AppendCtl{nullptr, 0, 0}, seg_count, counts, n_classes);
+    return launch_fused<T, SegsT<T>>(c, rays, n, K, view<T>(out), pair_ok<T>(c, out, n), seg_count, counts, n_classes);
+}
+
+// Tiled layout: the lane-per-ray kernel only (light scenes; heavy ones have the append layout)
+template <class T> static int check_tiles(const void* tiles, int64_t capacity, int64_t n, int32_t K) {
+    if (!tiles || (uintptr_t)tiles % 16) return fail(OT_ERR_INVALID, "tiles must be a 16-byte aligned device pointer");
+    if (capacity % 64 || capacity < ((n * K + 63) / 64) * 64) return fail(OT_ERR_CAPACITY, "tiled layout: capacity must be a multiple of 64 and hold max_segments * n_rays slots");
+    return 0;
+}
+template <class T>
+static int trace_tiled(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, void* tiles, int64_t capacity, int32_t* seg_count, int32_t* counts,
+                       int32_t n_classes) {
+    int rc = check_trace_args(c, rays, n, K, seg_count, counts, n_classes);
+    if (rc) return rc;
+    rc = check_tiles<T>(tiles, capacity, n, K);
+    if (rc) return rc;
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(c->device));
+    if (wants_rolling<T>(c, K))
+        return fail(OT_ERR_UNSUPPORTED, "the tiled layout belongs to the lane-per-ray kernel (light scenes); heavy scenes write [k][ray] slots (ot_trace_*) or the append layout (ot_trace_append_*)");
+    const int32_t pair = (c->opt_pair && !(n & 1) && sizeof(T) == 8) ? 1 : 0;  // lane pairs write 16 bytes: even slot on the even lane
+    return launch_fused<T, SegTiles<T>>(c, rays, n, K, SegTiles<T>{(uint8_t*)tiles}, pair, seg_count, counts, n_classes);
 }
 
 // Append layout: always the rolling lists (a light scene takes the planar preset FC).
@@ -855,6 +892,14 @@ int ot_trace_f64(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, const ot_
 int ot_trace_f32(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, const ot_segments* out, int32_t* seg_count,
                  int32_t* counts, int32_t n_classes) {
     return trace_fused<float>(c, rays, n, K, out, seg_count, counts, n_classes);
+}
+int ot_trace_tiled_f64(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, void* tiles, int64_t capacity, int32_t* seg_count, int32_t* counts,
+                       int32_t n_classes) {
+    return trace_tiled<double>(c, rays, n, K, tiles, capacity, seg_count, counts, n_classes);
+}
+int ot_trace_tiled_f32(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, void* tiles, int64_t capacity, int32_t* seg_count, int32_t* counts,
+                       int32_t n_classes) {
+    return trace_tiled<float>(c, rays, n, K, tiles, capacity, seg_count, counts, n_classes);
 }
 int ot_trace_append_f64(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, const ot_segment_block* out, int64_t* n_slots,
                         int32_t* seg_count, int32_t* counts, int32_t n_classes) {
@@ -1056,12 +1101,10 @@ int ot_set_option(ot_ctx* c, int32_t option, int32_t value) {
 
 }  // extern "C"
 
-template <class T>
-static int bench_stream(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, const ot_segments* out, int32_t* seg_count) {
+template <class T, class OUT>
+static int bench_stream(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, const OUT& out, int32_t pair, int32_t* seg_count) {
     if (!c) return fail(OT_ERR_INVALID, "ctx is NULL");
     int rc = check_rays(rays, "rays");
-    if (rc) return rc;
-    rc = check_segs(out);
     if (rc) return rc;
     if (n < 1 || K < 1 || !seg_count || n >= (int64_t)1 << 31) return fail(OT_ERR_INVALID, "bad n / K / seg_count");
     HIP_TRY(hipSetDevice(c->device));
@@ -1071,9 +1114,9 @@ static int bench_stream(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, co
     rc = timing_begin(c);
     if (rc) return rc;
     if (c->opt_nt)
-        hipLaunchKernelGGL((k_stream_ceiling<T, true>), dim3(grid), dim3(block), 0, c->stream, view<T>(rays), n, K, view<T>(out), seg_count, pair_ok<T>(c, out, n));
+        hipLaunchKernelGGL((k_stream_ceiling<T, true, OUT>), dim3(grid), dim3(block), 0, c->stream, view<T>(rays), n, K, out, seg_count, pair);
     else
-        hipLaunchKernelGGL((k_stream_ceiling<T, false>), dim3(grid), dim3(block), 0, c->stream, view<T>(rays), n, K, view<T>(out), seg_count, pair_ok<T>(c, out, n));
+        hipLaunchKernelGGL((k_stream_ceiling<T, false, OUT>), dim3(grid), dim3(block), 0, c->stream, view<T>(rays), n, K, out, seg_count, pair);
     HIP_TRY(hipGetLastError());
     return timing_end(c);
 }
@@ -1081,10 +1124,20 @@ static int bench_stream(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, co
 extern "C" {
 
 int ot_bench_stream_f64(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, const ot_segments* out, int32_t* seg_count) {
-    return bench_stream<double>(c, rays, n, K, out, seg_count);
+    const int rc = check_segs(out);
+    return rc ? rc : bench_stream<double, SegsT<double>>(c, rays, n, K, view<double>(out), pair_ok<double>(c, out, n), seg_count);
 }
 int ot_bench_stream_f32(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, const ot_segments* out, int32_t* seg_count) {
-    return bench_stream<float>(c, rays, n, K, out, seg_count);
+    const int rc = check_segs(out);
+    return rc ? rc : bench_stream<float, SegsT<float>>(c, rays, n, K, view<float>(out), pair_ok<float>(c, out, n), seg_count);
+}
+int ot_bench_stream_tiled_f64(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, void* tiles, int64_t capacity, int32_t* seg_count) {
+    const int rc = check_tiles<double>(tiles, capacity, n, K);
+    return rc ? rc : bench_stream<double, SegTiles<double>>(c, rays, n, K, SegTiles<double>{(uint8_t*)tiles}, (c && c->opt_pair && !(n & 1)) ? 1 : 0, seg_count);
+}
+int ot_bench_stream_tiled_f32(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, void* tiles, int64_t capacity, int32_t* seg_count) {
+    const int rc = check_tiles<float>(tiles, capacity, n, K);
+    return rc ? rc : bench_stream<float, SegTiles<float>>(c, rays, n, K, SegTiles<float>{(uint8_t*)tiles}, 0, seg_count);
 }
 
 #ifdef OT_STAMP

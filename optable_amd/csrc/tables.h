@@ -17,8 +17,8 @@ constexpr uint32_t FRP = FR | F_POLY;                          // ... with polyg
 constexpr uint32_t FD = F_AABB | F_REFRACT | F_CURVED | F_GRID;  // spherical / aspheric optics in gridded groups (cfg 5)
 }  // namespace preset
 
-template <class T>
-using FusedKern = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, SegsT<T>, int32_t*, int32_t*, int32_t, int32_t);
+template <class T, class OUT>
+using FusedKern = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, OUT, int32_t*, int32_t*, int32_t, int32_t);
 template <class T, class OUT>
 using RollingKern = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, OUT, AppendCtl, int32_t*, int32_t*, int32_t, WaveScratch<T>, int32_t,
                              int32_t, unsigned long long*, int32_t, int32_t);
@@ -30,7 +30,7 @@ template <class T>
 using ProbeKern = void (*)(SceneBlob, T, RaysT<T>, const int32_t*, int64_t, const int32_t*, int32_t*, int32_t, int32_t*);
 
 // k_trace_fused: fi = 0 FA, 1 FB, 2 F_ALL; image in LDS; 128-register cap (4 waves per SIMD); non-temporal segment stores
-template <class T> FusedKern<T> fused_kernel(int fi, bool lds, bool minw4, bool nt);
+template <class T, class OUT> FusedKern<T, OUT> fused_kernel(int fi, bool lds, bool minw4, bool nt);
 // k_trace_rolling: fr = 0 FR, 1 FC, 2 FD, 3 F_ALL, 4 FRP; flat = the pair-queue walk (FR / FRP only); image in LDS or read
 // from L2 (all-features preset only); records of the live rays in LDS (fp32: pair queue and FD) or in the global scratch.
 // OUT = SegsT<T> ([k][ray] slots) or SegPlanes<T> (append layout).  Non-temporal segment stores are part of the choice:
@@ -42,7 +42,8 @@ template <class T> GenKern<T> gen_kernel(bool small, bool lds, bool emit);
 template <class T> ProbeKern<T> probe_kernel(bool lds);
 
 #define OT_DECLARE_TABLES(T)                                                       \
-    template <> FusedKern<T> fused_kernel<T>(int, bool, bool, bool);               \
+    template <> FusedKern<T, SegsT<T>> fused_kernel<T, SegsT<T>>(int, bool, bool, bool);         \
+    template <> FusedKern<T, SegTiles<T>> fused_kernel<T, SegTiles<T>>(int, bool, bool, bool);   \
     template <> RollingKern<T, SegsT<T>> rolling_kernel<T, SegsT<T>>(int, bool, bool, bool);          \
     template <> RollingKern<T, SegPlanes<T>> rolling_kernel<T, SegPlanes<T>>(int, bool, bool, bool);  \
     template <> int rolling_max_threads<T>(int, bool, bool);                       \

@@ -33,6 +33,9 @@ def final_state(segs):
     if segs.count is None:
         raise ValueError("final_state needs a non-branching trace (slots or append layout); a ray tree has no single last segment")
     n = segs.n_rays
+    if getattr(segs, "tiled", False):  # slot s at [s // 64, s % 64] of the strided field views
+        last = (segs.count.long().abs() - 1).clamp_(min=0) * n + torch.arange(n, device=segs.device)
+        return torch.stack([segs.field(f)[last >> 6, last & 63] for f in FINAL_FIELDS])
     if segs.append:  # the records of a ray lie at increasing slots: its last segment is its highest slot
         m = segs.n_valid
         ray = segs.ray[:m].long()

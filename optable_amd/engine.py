@@ -73,6 +73,8 @@ class Engine:
         self._check_wavelengths(rays)
         if layout == "append":
             return self._trace_append(rays, K, out, counts, capacity)
+        if layout == "tiled":
+            return self._trace_tiled(rays, K, out, counts)
         if layout != "slots":
             raise ValueError(f"unknown layout {layout!r}")
         if out is None:
@@ -92,6 +94,29 @@ class Engine:
         fn = self.lib.ot_trace_f64 if rays.precision == "f64" else self.lib.ot_trace_f32
         rs, ss = rays.c_struct(), out.c_struct()
         abi.check(fn(self._ctx, C.byref(rs), n, K, C.byref(ss), out.count.data_ptr(),
+                     None if counts is None else counts.data_ptr(), n_classes), self.lib)
+        out.counts_table = counts
+        return out
+
+    def _trace_tiled(self, rays, K, out, counts):
+        """[k][ray] slots in 64-slot tiles (ot_trace_tiled_*): light scenes, the layout the HBM streams like best."""
+        n = rays.n
+        if out is None:
+            out = SegmentBatch(n * K, rays.precision, rays.device, tiled=True)
+        elif not out.tiled or out.capacity < n * K or out.precision != rays.precision:
+            raise ValueError("tiled layout needs a SegmentBatch(tiled=True) of the rays' precision with max_segments * n slots")
+        if out.count is None or out.count.numel() != n:
+            out.count = torch.empty(n, dtype=torch.int32, device=rays.device)
+        out.n_rays, out.counts_table = n, counts
+        if n == 0:
+            return out
+        n_slots_table = len(self.scene.limited)
+        if n_slots_table and counts is None:
+            counts = torch.zeros((n_slots_table, n), dtype=torch.int32, device=rays.device)
+        n_classes = 0 if counts is None else counts.shape[1]
+        fn = self.lib.ot_trace_tiled_f64 if rays.precision == "f64" else self.lib.ot_trace_tiled_f32
+        rs = rays.c_struct()
+        abi.check(fn(self._ctx, C.byref(rs), n, K, out.block.data_ptr(), out.capacity, out.count.data_ptr(),
                      None if counts is None else counts.data_ptr(), n_classes), self.lib)
         out.counts_table = counts
         return out
@@ -238,6 +263,7 @@ class Engine:
 
     def _monitor_record(self, monitor_struct, segs, n_segments):
         dev = segs.device
+        segs = segs.to_slots()  # (a tiled history: one copy into slot arrays)
         if segs.precision != "f64":  # the monitor pass is fp64: widen an fp32 history once
             segs = segs.astype("f64")
         if segs.layout == "slots":
@@ -273,9 +299,14 @@ class Engine:
         abi.check(self.lib.ot_set_option(self._ctx, option, value), self.lib)
 
     def stream_ceiling(self, rays: RayBatch, max_segments, out: SegmentBatch):
-        """Same bytes as `trace` with no tracing (roofline companion)."""
+        """Same bytes as `trace` with no tracing (roofline companion), in the layout of `out` (slots or tiled)."""
         if out.count is None or out.count.numel() != rays.n:
             out.count = torch.empty(rays.n, dtype=torch.int32, device=rays.device)
+        if out.tiled:
+            fn = self.lib.ot_bench_stream_tiled_f64 if rays.precision == "f64" else self.lib.ot_bench_stream_tiled_f32
+            rs = rays.c_struct()
+            abi.check(fn(self._ctx, C.byref(rs), rays.n, int(max_segments), out.block.data_ptr(), out.capacity, out.count.data_ptr()), self.lib)
+            return
         rs, ss = rays.c_struct(), out.c_struct()
         fn = self.lib.ot_bench_stream_f64 if rays.precision == "f64" else self.lib.ot_bench_stream_f32
         abi.check(fn(self._ctx, C.byref(rs), rays.n, int(max_segments), C.byref(ss),
@@ -285,7 +316,7 @@ class Engine:
         """Shape of the last trace launch (include/optable_hip.h: ot_debug_last_launch) as a dict."""
         info = (C.c_int32 * 8)()
         abi.check(self.lib.ot_debug_last_launch(self._ctx, C.byref(info)), self.lib)
-        keys = ("kernel", "threads", "workgroups_per_cu", "workgroups", "lds_bytes", "list_cap", "mixed", "pair_queue")
+        keys = ("kernel", "threads", "workgroups_per_cu", "workgroups", "lds_bytes", "list_cap", "mixed", "pair_queue")  # pair_queue: bit flags, see the header
         return dict(zip(keys, (int(v) for v in info)))
 
     def generation_mismatches(self):

@@ -162,3 +162,41 @@ def test_instancing_shrinks_the_cfg5_image_and_moves_the_records_to_lds():
     info = get_engine().last_launch()
     assert info["kernel"] == 2 and info["pair_queue"] & 2, info  # rolling lists, records of the live rays in LDS
     assert info["threads"] * info["workgroups_per_cu"] >= 12 * 64, info
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+@pytest.mark.parametrize("n", [20000, 20001, 777])
+def test_tiled_layout_equals_slots(precision, n):
+    """ot_trace_tiled_*: the [k][ray] slots in 64-slot tiles — the same records bit for bit (even and odd n: lane pairs
+    write 16 bytes only when the slot parity allows), monitors and final states read them like slot arrays."""
+    import optable_amd as oa
+    from optable_amd import dist
+    from optable_amd import workloads as W
+
+    for comps, gen, K in ((scenes.cfg2_components, lambda m: scenes.cfg2_rays(m, 0) + (scenes.WL,), 5),
+                          (lambda ns: W.cfg4_components(ns), lambda m: W.cfg4_rays(max(m // 8, 1), 4, n_wavelengths=8), 3)):
+        table = _table(comps(oa))
+        o, d, wl = gen(n)
+        from optable_amd.batch import RayBatch
+
+        batch = RayBatch.from_arrays(o, d, wavelength=wl, q=1j * np.pi * scenes.W0**2 / wl, precision=precision)
+        slots = table.trace_batch(batch, max_segments=K)
+        tiled = table.trace_batch(batch, max_segments=K, layout="tiled")
+        assert tiled.layout == "tiled" and tiled.capacity % 64 == 0
+        a, b = slots.to_host(reference_order=True), tiled.to_host(reference_order=True)
+        for f in abi.SEG_FIELDS + ("ray", "surface", "count"):
+            np.testing.assert_array_equal(a[f], b[f], err_msg=f)
+        np.testing.assert_array_equal(dist.final_state(tiled).cpu().numpy(), dist.final_state(slots).cpu().numpy())
+    mon = oa.Monitor(origin=[1.0, 0, 0], width=8, height=8)
+    h0, h1 = table.record_batch(mon, slots), table.record_batch(mon, tiled)
+    assert len(h0) == len(h1)
+    np.testing.assert_array_equal(h0.yList().cpu().numpy(), h1.yList().cpu().numpy())
+
+
+def test_tiled_layout_is_for_light_scenes():
+    import optable_amd as oa
+
+    table = _table(scenes.cfg3_components(oa))
+    batch = _batch(*scenes.cfg3_rays(5000, 2))
+    with pytest.raises(RuntimeError, match="tiled layout belongs"):
+        table.trace_batch(batch, max_segments=20, layout="tiled")

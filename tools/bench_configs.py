@@ -83,17 +83,22 @@ def _run(name, comps, o, d, wl, K, prec, reps=5):
                 del probe
                 torch.cuda.empty_cache()
                 out = SegmentBatch(cap, prec, batch.device, block=True)
+            elif layout == "tiled":
+                if scene.n_nodes >= 24:
+                    continue
+                out = SegmentBatch(n * K, prec, batch.device, tiled=True)
             else:
                 out = SegmentBatch(n * K, prec, batch.device)
-            eng.trace(batch, K, out=out, layout=layout)
+            for _ in range(200 if n * K < 2e7 else 1):  # light launches: clocks up first
+                eng.trace(batch, K, out=out, layout=layout)
             eng.timing(True)
-            for _ in range(reps):
+            for _ in range(reps * (20 if n * K < 2e7 else 1)):
                 eng.trace(batch, K, out=out, layout=layout)
             ms, cnt = eng.timing_read()
             eng.timing(False)
             segs = int(out.count.abs().sum().item())
             t = ms / cnt / 1e3
-            mode = "fused" if layout == "slots" else "append"
+            mode = {"slots": "fused", "append": "append", "tiled": "tiled"}[layout]
             if os.environ.get("SHAPE"):
                 print("   launch:", eng.last_launch(), flush=True)
             if layout != LAYOUTS[-1]:
@@ -101,15 +106,16 @@ def _run(name, comps, o, d, wl, K, prec, reps=5):
                 print(f"{name:28s} {prec} {mode:11s} n={n:9d} S={S:3d} K={K:2d} segs/ray={segs / n:5.2f} time={t * 1e3:9.3f} ms "
                       f"{segs / t:10.3e} seg/s {segs * S / t:10.3e} isect/s  {gbs:7.1f} GB/s ({gbs / 80:4.1f}% of 8 TB/s)", flush=True)
         if os.environ.get("CEILING"):  # the same streams with no tracing (fixed K records per ray)
+            for _ in range(20):
+                eng.stream_ceiling(batch, K, out)
             eng.timing(True)
             for _ in range(reps):
                 eng.stream_ceiling(batch, K, out)
             cms, ccnt = eng.timing_read()
             eng.timing(False)
             cb = n * b + n * K * b
-            print(f"   stream ceiling for n={n} K={K}: {cms / ccnt:.3f} ms = {cb / (cms / ccnt / 1e3) / 1e9:.0f} GB/s "
+            print(f"   stream ceiling ({out.layout}) for n={n} K={K}: {cms / ccnt:.3f} ms = {cb / (cms / ccnt / 1e3) / 1e9:.0f} GB/s "
                   f"(trace moves {(n * b + segs * b) / 1e9:.2f} GB in {t * 1e3:.3f} ms)", flush=True)
-            eng.trace(batch, K, out=out)
     else:
         eng.timing(True)
         torch.cuda.synchronize()
