@@ -222,7 +222,7 @@ def survey_config(oa, eng, name, device):
         torch.cuda.empty_cache()
         if layout == "append":
             probe = eng.trace(batch, wl.max_segments, layout="append")
-            cap = probe.n_valid + 4096
+            cap = eng.append_capacity(int(probe.count.abs().sum().item()))  # records + one chunk per wave (where the holes can be)
             del probe
             torch.cuda.empty_cache()
             out = SegmentBatch(cap, wl.precision, batch.device, block=True)
@@ -453,6 +453,9 @@ def main():
         eng.timing_reset()
         ceil_ms, ceil_n = 0.0, 0
         if scene.n_nodes < 24:  # the HBM-bound workloads: the same streams with no tracing (every ray fills its K slots)
+            for s in range(3):  # (untimed: the first launch of a kernel loads its code object)
+                eng.stream_ceiling(batches[s % n_inputs], MAX_SEG, outs[s % n_inputs])
+            eng.timing_reset()
             for s in range(10 if wl.name == "cfg2" else 3):
                 eng.stream_ceiling(batches[s % n_inputs], MAX_SEG, outs[s % n_inputs])
             ceil_ms, ceil_n = eng.timing_read()
@@ -469,6 +472,8 @@ def main():
             ev1.record()
             torch.cuda.synchronize()
             slots_us = ev0.elapsed_time(ev1) / args.steps * 1e3
+            for s in range(3):
+                eng.stream_ceiling(batches[s % n_inputs], MAX_SEG, outs_slots[s % n_inputs])
             eng.timing(True)
             for s in range(10 if wl.name == "cfg2" else 3):
                 eng.stream_ceiling(batches[s % n_inputs], MAX_SEG, outs_slots[s % n_inputs])

@@ -121,6 +121,14 @@ class Engine:
         out.counts_table = counts
         return out
 
+    def append_capacity(self, n_records):
+        """Slots an append-layout block needs for `n_records` segment records on this device: every wave of the launch
+        may leave the tail of its last chunk (512 slots) unused.  Call after a trace of the same scene (the launch shape
+        is taken from it); `sum(|count|)` of that trace is the record count."""
+        info = self.last_launch()
+        waves = max(info["workgroups"] * info["threads"] // 64, 1) if info["kernel"] == 2 else 256 * 16
+        return (int(n_records) + 512 * waves + 63) // 64 * 64
+
     APPEND_SLACK = 1 << 23  # slots beyond the records: chunk (512) x waves of the launch (at most 256 CUs x 16 x 2)
 
     def _trace_append(self, rays, K, out, counts, capacity):

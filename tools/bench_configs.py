@@ -79,7 +79,7 @@ def _run(name, comps, o, d, wl, K, prec, reps=5):
             torch.cuda.empty_cache()
             if layout == "append":  # sized by the records of a first trace, like a caller who knows the job
                 probe = eng.trace(batch, K, layout="append")
-                cap = probe.n_valid + 4096
+                cap = eng.append_capacity(int(probe.count.abs().sum().item()))
                 del probe
                 torch.cuda.empty_cache()
                 out = SegmentBatch(cap, prec, batch.device, block=True)
