@@ -674,7 +674,16 @@ __device__ __forceinline__ bool hit_leaf(const Scene<T>& sc, const DNode<T>& nd,
             // shows a sign change, brentq converges to that root and the |t| < EPS filter throws it away
             // (optical_component.py:221-227).  The samples are taken as always — a second crossing further along still
             // shows in its own interval — but polishing the root at the start point only to discard it is skipped.
-            if (own && tl <= T(0) && tr >= T(0)) continue;
+            // ... provided the crossing in that bracket IS the start point's: with the start point rounded to the far side of
+            // the surface (fp32: up to 1e-5 off) its root falls before the first sample, and the crossing seen here is a
+            // genuine second hit (a short chord); then g at the bracket's start already has the sign the ray is heading
+            // for, i.e. g(tl) and dg/dt at the start point have the same sign.  Grazing starts are polished like any
+            // other bracket and left to the |t| < EPS filter, as the reference does.
+            if (own && tl <= T(0) && tr >= T(0)) {
+                T dg0;
+                (void)surf_g<T, F>(sc, nd, ox, oy, oz, dx, dy, dz, T(0), &dg0);
+                if (abs_t(dg0) > T(0.05) && sample(tl) * dg0 < T(0)) continue;
+            }
             const T t = polish_root<T, F>(sc, nd, ox, oy, oz, dx, dy, dz, tl, tr, sample(tl), sample(tr));
             if (t >= T(0) && abs_t(t) >= EPS && t <= len) {
                 const T X = ox + t * dx, Y = oy + t * dy, Z = oz + t * dz;

@@ -259,7 +259,11 @@ class Engine:
             None if counts is None else counts.data_ptr(), n_classes), self.lib)
         written, n_next = state.tolist()
         out.n_valid, out.counts_table = int(written), counts
-        return out, nxt.slice(0, int(n_next)), nxt_tree[: int(n_next)]
+        kids = nxt.slice(0, int(n_next))
+        # bits 8.. of the flags name the node a child starts on IN THIS SCENE (include/optable_hip.h); the batch is handed to
+        # the caller, who may trace it through any scene: drop them (the start-plane rule then falls back to the |t| guard)
+        kids.flags.bitwise_and_(0xff)
+        return out, kids, nxt_tree[: int(n_next)]
 
     # -- monitors -------------------------------------------------------------------------------
     def monitor_record(self, monitor_struct, segs: SegmentBatch, n_segments=None):

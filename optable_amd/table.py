@@ -99,7 +99,11 @@ class OpticalTable:
         if len(rays) and cap > 0 and max_time > 0:  # the reference's loop does not start on an exhausted limit
             traced, capped = self._trace_objects(list(rays), cap, max_time)
             if capped:
-                print(f"Ray tracing time exceeds the maximum tracing time after {cap} traces. "
+                # the reference prints the number of traces its loop got through (optical_table.py:138-143): `cap` when
+                # the count limit cut a tree, what was done by then when the clock did (the clock here runs over the
+                # whole call and is read after every generation of the batch, not per input ray)
+                done = min(cap, self._last_trace_num) if getattr(self, "_last_trace_num", None) else cap
+                print(f"Ray tracing time exceeds the maximum tracing time after {done} traces. "
                       f"({capped} ray tree(s) truncated)")
             self.rays.extend(traced)
         elif len(rays):  # an exhausted limit: the reference's loop does not start, nothing is archived, the message is printed
@@ -389,6 +393,9 @@ class OpticalTable:
                 segs = eng.trace_tree(batch, cap, counts=counts, max_trace_time=max_time)
                 host_segs = segs.to_host(reference_order=True)
                 capped = int(segs.capped.sum().item())
+                if capped:  # traces done by the largest truncated tree (what the cap message reports)
+                    per_tree = np.bincount(host_segs["ray"], minlength=len(sub))
+                    self._last_trace_num = int(per_tree[segs.capped.cpu().numpy()].max())
             total_capped += capped
             _scatter_segments(host_segs, sub, pick, per_ray)
         if scene.limited:

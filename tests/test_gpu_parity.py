@@ -1042,3 +1042,45 @@ def test_stale_cached_boxes_gate_but_never_prune(kernel, oracle):
     # the scenario is real: most first segments now end on the moved pair (x ~ 5), in front of the lens at x = 7
     first_seg = np.r_[True, np.diff(ref["ray"]) != 0]
     assert (ref["length"][first_seg] < 6.5).mean() > 0.5
+
+
+@pytest.mark.parametrize("shape", ["sphere", "paraboloid"])
+def test_repeated_hits_on_one_curved_surface(shape, oracle):
+    """A ray that leaves a curved surface can meet THE SAME surface again (whispering-gallery reflections along a concave
+    spherical cap; two reflections inside a deep paraboloid).  The root at the start point is thrown away, the next
+    one is a hit — in double precision against the oracle, and in single precision too, where the start point can lie
+    1e-5 off the surface (the start-point bracket must not swallow a genuine second crossing)."""
+    import optable_amd as oa
+    from optable_amd.batch import RayBatch
+
+    n = 2000
+    rng = np.random.default_rng(21)
+    if shape == "sphere":
+        comp = oa.SphereRefractive([0, 0, 0], radius=5.0, height=2.0, n1=1.0, n2=1.0, reflectivity=1.0, transmission=0.0)
+        th = np.deg2rad(rng.uniform(-45, -30, n))
+        rad = rng.uniform(4.6, 4.95, n)
+        delta = rng.uniform(0.08, 0.3, n)            # angle between the ray and the tangent: chords of 0.8 .. 3
+        o = np.stack([rad * np.cos(th), rad * np.sin(th), rng.uniform(-0.2, 0.2, n)], 1)
+        d = np.stack([-np.sin(th - delta), np.cos(th - delta), np.zeros(n)], 1)
+        K, min_repeats = 12, 3
+    else:
+        comp = oa.BaseRefraciveSurface(origin=[0, 0, 0], n1=1.0, n2=1.0, surface=oa.ASphere(3.0, oa.sag_parametric(1.0, -1.0)),
+                                       reflectivity=1.0, transmission=0.0)
+        yz = rng.uniform(-2.2, 2.2, (n, 2))
+        o = np.stack([np.full(n, -6.0), yz[:, 0], yz[:, 1]], 1)       # inside the bowl x = -r^2 / 2, travelling towards its bottom
+        d = np.tile([1.0, 0.0, 0.0], (n, 1))
+        K, min_repeats = 6, 2
+    table = _table([comp])
+    out = {}
+    for prec in ("f64", "f32"):
+        b = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=1j * np.pi * scenes.W0**2 / scenes.WL, precision=prec)
+        out[prec] = table.trace_batch(b, max_segments=K)
+    got = out["f64"].to_host(reference_order=True)
+    host = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=1j * np.pi * scenes.W0**2 / scenes.WL, device="cpu").to_host()
+    ref = oracle.trace(table.compile(), host, max_trace_num=K)
+    np.testing.assert_array_equal(got["surface"], ref["surface"])
+    for f in ("ox", "oy", "oz", "dx", "dy", "dz", "length"):
+        np.testing.assert_allclose(got[f], ref[f], rtol=1e-9, atol=1e-9, err_msg=f)
+    c64, c32 = out["f64"].count.cpu().numpy(), out["f32"].count.cpu().numpy()
+    assert np.median(c64) > min_repeats            # the rays really do come back to the surface they left
+    assert (c64 == c32).mean() >= 0.99, (c64 == c32).mean()

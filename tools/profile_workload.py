@@ -18,7 +18,7 @@ from optable_amd.batch import RayBatch, SegmentBatch
 from optable_amd.engine import get_engine
 
 name = sys.argv[1]
-reps = int(sys.argv[2]) if len(sys.argv) > 2 else (20 if name == "cfg3" else 5)  # cfg3: enough launches that the clock ramp of the first ones does not carry the average
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else {"cfg2": 400, "cfg3": 20}.get(name, 5)  # cfg3: enough launches that the clock ramp of the first ones does not carry the average
 SIZES = {"cfg2": 1_000_000, "cfg3": 10_000_000, "cfg4": 160_000_000, "cfg5": 12_500_000, "cfg4b": 12_800_000, "monitor": 1_000_000}
 n = int(os.environ.get("RAYS", SIZES[name]))
 eng = get_engine()
@@ -28,6 +28,19 @@ for _env, _opt in (("FLAT", _abi.OPT_FLAT_QUEUE), ("RECLDS", _abi.OPT_LDS_RECORD
         eng.set_option(_opt, int(os.environ[_env]))
 Q = lambda lam: 1j * np.pi * W.W0**2 / lam
 
+# output layout of the non-branching traces: what the bench measures for this workload unless LAYOUT says otherwise
+LAYOUT = os.environ.get("LAYOUT") or {"cfg2": "tiled", "cfg4": "tiled", "cfg3": "append", "cfg5": "append"}.get(name, "slots")
+
+
+def output_for(batch, K, precision, records=None):
+    if LAYOUT == "append":
+        if records is None:
+            records = int(eng.trace(batch, K, layout="append").count.abs().sum().item())
+            torch.cuda.empty_cache()
+        return SegmentBatch(eng.append_capacity(records), precision, batch.device, block=True)
+    return SegmentBatch(batch.n * K, precision, batch.device, tiled=(LAYOUT == "tiled"))
+
+
 if name in ("cfg2", "cfg3", "cfg5"):
     wl = W.baseline_workloads(oa)[name]
     table = oa.OpticalTable()
@@ -35,11 +48,11 @@ if name in ("cfg2", "cfg3", "cfg5"):
     eng.upload(table.compile())
     o, d, lam = wl.rays(n, 0)
     batch = RayBatch.from_arrays(o, d, wavelength=lam, q=Q(lam), precision=wl.precision)
-    out = SegmentBatch(n * wl.max_segments, wl.precision, batch.device)
+    out = output_for(batch, wl.max_segments, wl.precision)
     for _ in range(reps + 2):
-        eng.trace(batch, wl.max_segments, out=out)
+        eng.trace(batch, wl.max_segments, out=out, layout=LAYOUT)
     torch.cuda.synchronize()
-    print(f"{name}: {n} rays, {int(out.count.abs().sum())} segments per trace, {reps + 2} traces")
+    print(f"{name}: {n} rays, {int(out.count.abs().sum())} segments per trace, {reps + 2} traces, layout {LAYOUT}, launch {eng.last_launch()}")
 elif name in ("cfg4", "cfg4b"):
     table = oa.OpticalTable()
     table.add_components(W.cfg4_components(oa, reflectivity=0.2 if name == "cfg4b" else 0))
@@ -50,11 +63,11 @@ elif name in ("cfg4", "cfg4b"):
     base = RayBatch.from_arrays(o, d, wavelength=W.WL, q=Q(W.WL), precision="f64")
     batch = base.multiplexed_in_wavelength(np.linspace(400e-7, 1100e-7, W.CFG4_WAVELENGTHS))
     if name == "cfg4":
-        out = SegmentBatch(batch.n * 3, "f64", batch.device)
+        out = output_for(batch, 3, "f64")
         for _ in range(reps):
-            eng.trace(batch, 3, out=out)
+            eng.trace(batch, 3, out=out, layout=LAYOUT)
         torch.cuda.synchronize()
-        print(f"cfg4: {batch.n} ray-wavelength pairs, {int(out.count.abs().sum())} segments per trace, {reps} traces")
+        print(f"cfg4: {batch.n} ray-wavelength pairs, {int(out.count.abs().sum())} segments per trace, {reps} traces, layout {LAYOUT}")
     else:
         for _ in range(max(reps // 2, 2)):
             t0 = time.perf_counter()
