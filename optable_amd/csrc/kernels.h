@@ -757,7 +757,8 @@ __global__ __launch_bounds__(256) void k_gen_pass(SceneBlob blob, T unit, RaysT<
                                                   int32_t* __restrict__ budget, const int64_t* cursor, SegsT<T> out,
                                                   int64_t out_capacity, RaysOutT<T> next, int32_t* next_tree, int64_t next_capacity,
                                                   uint8_t* code, unsigned long long* wave_total, const unsigned long long* wave_prefix,
-                                                  int32_t* counts, int32_t n_classes, const int32_t* rank, unsigned long long* mismatch) {
+                                                  int32_t* counts, int32_t n_classes, const int32_t* rank, unsigned long long* mismatch,
+                                                  int32_t* hit_node, T* hit_t) {
     extern __shared__ __align__(16) uint32_t lds[];
     const uint32_t* base = blob.words;
     if (SCENE_IN_LDS) {
@@ -800,7 +801,17 @@ __global__ __launch_bounds__(256) void k_gen_pass(SceneBlob blob, T unit, RaysT<
     }
     const bool dead = active && (fl & OT_RAY_DEAD);
     const GateCtx gate = {counts, n_classes, cls, rank, nullptr, n, i};
-    const Hit<T> h = nearest_hit<T, F, GATE_TABLE>(sc, r, active && !dead, gate);
+    // Heavy scenes (hit_node != NULL): the count pass leaves its decision per ray — hit node and distance, 12 bytes in
+    // double precision — and the emit pass rebuilds the hit from them instead of searching the scene a second time: the
+    // search is what a generation of such a scene costs, and the two passes cannot disagree.  Light scenes trace twice:
+    // for them the search is a few planes and the passes run at memory speed either way.
+    Hit<T> h;
+    if (EMIT && hit_node) {
+        h = rebuild_hit<T, F>(sc, r, (active && !dead) ? hit_node[i] : -1, (active && !dead) ? hit_t[i] : Num<T>::inf());
+    } else {
+        h = nearest_hit<T, F, GATE_TABLE>(sc, r, active && !dead, gate);
+        if (!EMIT && hit_node && i < n) { hit_node[i] = h.node; hit_t[i] = h.t; }
+    }
     int32_t nk = 0;
     RayState<T> ch[2];  // indexed by constants only
     if (active && !dead && h.node >= 0) nk = interact<T, F, 2>(sc, r, h, ch, make_matcache<T, F>(sc, r.wl));

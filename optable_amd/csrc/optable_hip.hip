@@ -57,6 +57,7 @@ struct ot_ctx {
     int32_t n_phys = 0, n_runs = 0, runs_word64 = 0, runs_word32 = 0;  // instanced runs folded by fill_blob (trace_core.h NodeRef)
     int32_t opt_append_chunk = 512;  // append layout: slots per claim
     int32_t opt_instancing = 1;      // fold lattice children into instanced runs at upload
+    int32_t opt_gen_reuse = -1;      // generation kernels: emit pass rebuilds the count pass's hit instead of searching again (-1 auto)
     double unit = 1e-2;
     uint32_t features = 0;
     int32_t root_max_items = 0;  // most items in one cell of the top-level grid
@@ -938,7 +939,10 @@ static int trace_generation(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
     const size_t sz_tot = align_up(sizeof(int64_t) * 4);
     const int64_t n_waves = (n + 63) / 64;
     const size_t sz_code = align_up((size_t)n), sz_wave = align_up(sizeof(unsigned long long) * n_waves);
-    const size_t total = sz_tot + sz_code + 2 * sz_wave + (ns > 0 ? 3 * sz_slot : 0);
+    // heavy scenes keep the count pass's decision per ray for the emit pass (kernels.h k_gen_pass); OT_OPT_GEN_REUSE: -1 auto
+    const bool reuse = c->opt_gen_reuse < 0 ? c->n_nodes >= 12 : c->opt_gen_reuse != 0;
+    const size_t sz_hn = reuse ? align_up(sizeof(int32_t) * n) : 0, sz_ht = reuse ? align_up(sizeof(T) * n) : 0;
+    const size_t total = sz_tot + sz_code + 2 * sz_wave + (ns > 0 ? 3 * sz_slot : 0) + sz_hn + sz_ht;
     if (c->gen.ensure(total)) return fail(OT_ERR_HIP, "hipMalloc of generation scratch failed");
     uint8_t* p = (uint8_t*)c->gen.p;
     int64_t* totals = (int64_t*)p;
@@ -947,9 +951,15 @@ static int trace_generation(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
     uint8_t* code = p; p += sz_code;
     unsigned long long* wave_total = (unsigned long long*)p; p += sz_wave;
     unsigned long long* wave_prefix = (unsigned long long*)p; p += sz_wave;
-    int32_t* probe = (int32_t*)p; p += sz_slot;
-    int32_t* probe_ex = (int32_t*)p; p += sz_slot;
-    int32_t* rank = (int32_t*)p;
+    int32_t *probe = nullptr, *probe_ex = nullptr, *rank = nullptr;
+    if (ns > 0) {
+        probe = (int32_t*)p; p += sz_slot;
+        probe_ex = (int32_t*)p; p += sz_slot;
+        rank = (int32_t*)p; p += sz_slot;
+    }
+    int32_t* hit_node = reuse ? (int32_t*)p : nullptr;
+    p += sz_hn;
+    T* hit_t = reuse ? (T*)p : nullptr;
     const size_t tmp = ns > 0 ? scan_tmp_bytes<int32_t>(n) : 0, tmp_w = scan_tmp_bytes<unsigned long long>(n_waves);
     if (c->scan_tmp.ensure((tmp > tmp_w ? tmp : tmp_w) + 256)) return fail(OT_ERR_HIP, "hipMalloc of scan scratch failed");
     const int block = 256;
@@ -985,13 +995,13 @@ static int trace_generation(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
     // count -> scan of the wave totals -> emit (kernels.h: k_gen_pass)
     hipLaunchKernelGGL(k_count, dim3(g1), dim3(block), lds_bytes, c->stream, blob, (T)c->unit, view<T>(rays), tree, n, budget,
                        (const int64_t*)seg_cursor, view<T>(out), out_capacity, view_out<T>(next), next_tree, next_capacity, code, wave_total,
-                       (const unsigned long long*)wave_prefix, counts, n_classes, (const int32_t*)rank, mismatch);
+                       (const unsigned long long*)wave_prefix, counts, n_classes, (const int32_t*)rank, mismatch, hit_node, hit_t);
     exclusive_scan<unsigned long long, unsigned long long>(c->scan_tmp.p, wave_total, wave_prefix, n_waves, c->stream);
     hipLaunchKernelGGL(k_gen_totals, dim3(1), dim3(64), 0, c->stream, (const unsigned long long*)wave_total,
                        (const unsigned long long*)wave_prefix, n_waves, totals, seg_cursor, n_next);
     hipLaunchKernelGGL(k_emit, dim3(g1), dim3(block), lds_bytes, c->stream, blob, (T)c->unit, view<T>(rays), tree, n, budget,
                        (const int64_t*)(totals + 2), view<T>(out), out_capacity, view_out<T>(next), next_tree, next_capacity, code, wave_total,
-                       (const unsigned long long*)wave_prefix, counts, n_classes, (const int32_t*)rank, mismatch);
+                       (const unsigned long long*)wave_prefix, counts, n_classes, (const int32_t*)rank, mismatch, hit_node, hit_t);
     if (ns > 0)
         hipLaunchKernelGGL(k_gen_counts, dim3(g1), dim3(block), 0, c->stream, tree, rays->id, n, ns, rank, probe, c->slot_max, counts,
                            n_classes);
@@ -1091,6 +1101,9 @@ int ot_set_option(ot_ctx* c, int32_t option, int32_t value) {
         case OT_OPT_APPEND_CHUNK:
             if (value < 64 || value > (1 << 20) || value % 64) return fail(OT_ERR_INVALID, "OT_OPT_APPEND_CHUNK takes a multiple of 64, 64..1048576");
             c->opt_append_chunk = value; return 0;
+        case OT_OPT_GEN_REUSE:
+            if (value < -1 || value > 1) return fail(OT_ERR_INVALID, "OT_OPT_GEN_REUSE takes -1 (auto), 0 or 1");
+            c->opt_gen_reuse = value; return 0;
         case OT_OPT_INSTANCING: c->opt_instancing = value != 0; return 0;  // takes effect at the next ot_scene_upload
         case OT_OPT_BLOCKS_PER_CU:
             if (value < 0 || value > 65536) return fail(OT_ERR_INVALID, "OT_OPT_BLOCKS_PER_CU out of range");

@@ -1345,6 +1345,32 @@ __device__ __forceinline__ Hit<T> nearest_hit(const Scene<T>& sc, const RayState
     return best;
 }
 
+// The hit record of a decision taken earlier (k_gen_pass: the count pass stores node and t, the emit pass rebuilds the
+// local hit point from them instead of searching again): the very expressions test_leaf / hit_leaf form the point with,
+// so the interaction sees the same bits.
+template <class T, uint32_t F> __device__ __forceinline__ Hit<T> rebuild_hit(const Scene<T>& sc, const RayState<T>& r, int32_t node, T t) {
+    Hit<T> h;
+    h.node = node; h.t = t; h.px = h.py = h.pz = T(0);
+    if (node < 0) return h;
+    const NodeRef<T> nr = node_ref<T, F>(sc, node);
+    const DNode<T>& nd = *nr.nd;
+    const T rx = r.ox - nr.geo[0], ry = r.oy - nr.geo[1], rz = r.oz - nr.geo[2];
+    const int sh = nd.shape;
+    const bool planar = sh == OT_SHAPE_CIRCLE || sh == OT_SHAPE_RECT || sh == OT_SHAPE_POLYGON2D || sh == OT_SHAPE_CSG;
+    if (!(F & F_CURVED) || planar) {
+        const T lox = dot3_t(nd.M[0], rx, nd.M[3], ry, nd.M[6], rz), ldx = dot3_t(nd.M[0], r.dx, nd.M[3], r.dy, nd.M[6], r.dz);
+        const T loy = dot3_t(nd.M[1], rx, nd.M[4], ry, nd.M[7], rz), loz = dot3_t(nd.M[2], rx, nd.M[5], ry, nd.M[8], rz);
+        const T ldy = dot3_t(nd.M[1], r.dx, nd.M[4], r.dy, nd.M[7], r.dz), ldz = dot3_t(nd.M[2], r.dx, nd.M[5], r.dy, nd.M[8], r.dz);
+        h.px = fma_t(t, ldx, lox); h.py = fma_t(t, ldy, loy); h.pz = fma_t(t, ldz, loz);
+    } else {
+        T ox, oy, oz, dx, dy, dz;
+        to_local(nd, rx, ry, rz, ox, oy, oz);
+        to_local(nd, r.dx, r.dy, r.dz, dx, dy, dz);
+        h.px = ox + t * dx; h.py = oy + t * dy; h.pz = oz + t * dz;
+    }
+    return h;
+}
+
 // a / b for complex numbers with one real division
 template <class T> __device__ __forceinline__ void cdiv(T ar, T ai, T br, T bi, T& cr, T& ci) {
     const T inv = rcp_t(br * br + bi * bi);

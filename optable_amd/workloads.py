@@ -28,7 +28,9 @@ def cfg2_components(ns):
     return [ns.Lens([5, 0, 0], focal_length=5, radius=1.0), ns.MirrorPair([10, 0, 0], 4, 4)]
 
 
-def cfg3_components(ns):
+def cfg3_components(ns, slab_reflectivity=0):
+    """`slab_reflectivity=0.1` is a heavy BRANCHING variant (every slab face splits the ray: trees of up to 20 segments
+    through 56 leaves, generation kernels) used to measure that path; the BASELINE config has 0."""
     rng = np.random.default_rng(1)
     comps = []
     for ix in range(8):
@@ -42,7 +44,7 @@ def cfg3_components(ns):
                 f = rng.uniform(4, 12)
                 comps.append(ns.Lens(origin, focal_length=f, radius=1).RotZ(0.2 * a))
             elif kind == "GlassSlab":
-                comps.append(ns.GlassSlab(origin, width=2, height=2, thickness=0.5, n1=1, n2=1.5).RotZ(0.3 * a))
+                comps.append(ns.GlassSlab(origin, width=2, height=2, thickness=0.5, n1=1, n2=1.5, reflectivity=slab_reflectivity).RotZ(0.3 * a))
             else:
                 comps.append(ns.Prism(origin, width=1.5, height=2, n1=1, n2=1.5).RotZ(a))
     return comps

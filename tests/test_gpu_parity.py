@@ -1084,3 +1084,30 @@ def test_repeated_hits_on_one_curved_surface(shape, oracle):
     c64, c32 = out["f64"].count.cpu().numpy(), out["f32"].count.cpu().numpy()
     assert np.median(c64) > min_repeats            # the rays really do come back to the surface they left
     assert (c64 == c32).mean() >= 0.99, (c64 == c32).mean()
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_generation_emit_pass_reuses_the_count_pass_decision(prec):
+    """Heavy branching scenes: the emit pass rebuilds the hit the count pass found (node + distance kept per ray) instead
+    of searching the scene again (OT_OPT_GEN_REUSE).  Same trees, bit for bit, as with two searches; no mismatches."""
+    import optable_amd as oa
+    from optable_amd import workloads as W
+    from optable_amd.batch import RayBatch
+    from optable_amd.engine import get_engine
+
+    n, cap = 20000, 20
+    table = _table(W.cfg3_components(oa, slab_reflectivity=0.1))
+    o, d = scenes.cfg3_rays(n, 2)
+    batch = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=1j * np.pi * scenes.W0**2 / scenes.WL, precision=prec)
+    eng = get_engine()
+    got = {}
+    for reuse in (0, 1):
+        eng.set_option(abi.OPT_GEN_REUSE, reuse)
+        try:
+            got[reuse] = table.trace_batch(batch, max_segments=cap).to_host(reference_order=True)
+        finally:
+            eng.set_option(abi.OPT_GEN_REUSE, -1)
+    assert len(got[0]["ray"]) > 3 * n  # the trees do branch
+    for f in abi.SEG_FIELDS + ("ray", "surface"):
+        np.testing.assert_array_equal(got[0][f], got[1][f], err_msg=f)
+    assert eng.generation_mismatches() == 0

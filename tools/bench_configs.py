@@ -140,7 +140,7 @@ n3 = int(os.environ.get("N3", 2_000_000))
 n4 = int(os.environ.get("N4", 100_000))
 n5 = int(os.environ.get("N5", 200_000))
 only = set(filter(None, os.environ.get("ONLY", "").split(",")))   # e.g. ONLY=cfg3,cfg5
-want = lambda c: (not only and c != "cfg4b") or c in only
+want = lambda c: (not only and c not in ("cfg4b", "cfg3b")) or c in only
 for prec in filter(None, os.environ.get("PREC", "f64,f32").split(",")):
     if want("cfg2"):
         o, d = scenes.cfg2_rays(n2, 0)
@@ -166,6 +166,12 @@ for prec in filter(None, os.environ.get("PREC", "f64,f32").split(",")):
         wl = np.repeat(np.linspace(400e-7, 1100e-7, nwl), nb)
         slab = [oa.GlassSlab([0, 0, 0], width=2, height=2, thickness=0.5, n1=oa.Vacuum(), n2=oa.Glass_NBK7(), reflectivity=0.2)]
         run("cfg4b NBK7 slab R=0.2 trees", slab, np.tile(ob, (nwl, 1)), np.tile(db, (nwl, 1)), wl, 12, prec)
+    if want("cfg3b") and prec == "f32":   # heavy branching: cfg 3 with 10 % reflecting slab faces, trees capped at 20 segments
+        o, d = scenes.cfg3_rays(int(os.environ.get("N3B", 2_000_000)), 2)
+        for reuse in (0, 1):
+            eng.set_option(abi.OPT_GEN_REUSE, reuse)
+            run(f"cfg3b slabs R=0.1 reuse={reuse}", scenes.cfg3_components(oa, slab_reflectivity=0.1), o, d, scenes.WL, 20, prec)
+        eng.set_option(abi.OPT_GEN_REUSE, -1)
     if want("cfg5"):
         o, d = scenes.cfg5_rays(n5, 3)
         run("cfg5 asphere+MMA16x16", scenes.cfg5_components(oa), o, d, scenes.WL, 50, prec)
