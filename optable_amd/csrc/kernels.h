@@ -324,6 +324,13 @@ template <class T> struct WaveScratch {
     int64_t wave_bytes;  // bytes per wave: CAP * record bytes, rounded up
 };
 template <uint32_t F> constexpr int rec_int_words() { return (F & F_LIMIT) ? 2 : 1; }
+// one kernel argument, loaded from the kernel-argument segment HERE (the asm keeps the load from being hoisted and kept live)
+template <class V> __device__ __forceinline__ V karg(size_t offset) {
+    typedef const __attribute__((address_space(4))) V* ArgPtr;
+    ArgPtr p = (ArgPtr)((uintptr_t)__builtin_amdgcn_kernarg_segment_ptr() + offset);
+    asm volatile("" : "+s"(p));
+    return *p;
+}
 
 // Largest workgroup an instantiation may be launched with, and the workgroups per CU the compiler has to leave registers
 // for.  The waves never synchronise after staging, so the workgroup size only decides how many waves share one image:
@@ -360,7 +367,16 @@ __global__ __launch_bounds__((rolling_threads<T, F, REC_LDS>()), (rolling_minw<T
     // as it is).  They are read from the kernel-argument segment where they are used instead; `in` itself is never touched.
     // (The segment is laid out like a struct of the parameters in order, each at its natural alignment: LeadArgs below;
     // tools/kernel_resources.sh --args prints the offsets the code object records.)
-    struct LeadArgs { SceneBlob blob; T unit; RaysT<T> in; int64_t n; int32_t K; OUT out; };
+    struct LeadArgs {  // the kernel's parameter list, in order: the layout of the kernel-argument segment
+        SceneBlob blob; T unit; RaysT<T> in; int64_t n; int32_t K; OUT out; AppendCtl ac; int32_t* seg_count; int32_t* counts;
+        int32_t n_classes; WaveScratch<T> ws; int32_t CAP; int32_t capl; unsigned long long* queue; int32_t mix; int32_t flat_cap;
+    };
+    // ... and so are the arguments a pass needs once or less: the ticket queue, the append cursor and its
+    // bounds, seg_count.  A scalar that is live across the nearest-hit search is spilled into a vector lane before it
+    // and read back after it (one VALU instruction each way, per pass); one that is loaded from the argument segment
+    // when it is needed costs a scalar load.
+#define OT_KARG(field) karg<decltype(LeadArgs::field)>(offsetof(LeadArgs, field))
+    (void)ac; (void)seg_count; (void)queue;
     typedef const __attribute__((address_space(4))) RaysT<T>* RaysArgPtr;
     const RaysArgPtr in_arg = (RaysArgPtr)((uintptr_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(LeadArgs, in));
     (void)in;
@@ -418,7 +434,7 @@ __global__ __launch_bounds__((rolling_threads<T, F, REC_LDS>()), (rolling_minw<T
 #endif
     auto draw_ticket = [&]() -> unsigned long long {
         unsigned long long first = 0;
-        if (lane == 0) first = atomicAdd(queue, 64ull);
+        if (lane == 0) first = atomicAdd(OT_KARG(queue), 64ull);
         return ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(first >> 32)) << 32) |
                (uint32_t)__builtin_amdgcn_readfirstlane((int)(first & 0xffffffffull));
     };
@@ -429,19 +445,21 @@ __global__ __launch_bounds__((rolling_threads<T, F, REC_LDS>()), (rolling_minw<T
         if (mix) {
             if (!exhausted && alive + 64 <= CAP) {
                 const unsigned long long first = draw_ticket();
-                if (first >= (unsigned long long)n) {
+                const unsigned long long n_now = (unsigned long long)n;
+                if (first >= n_now) {
                     exhausted = true;
                 } else {
                     fresh = true;
                     fresh_first = first;
-                    fresh_cnt = (int)((unsigned long long)n - first < 64ull ? (unsigned long long)n - first : 64ull);
+                    fresh_cnt = (int)(n_now - first < 64ull ? n_now - first : 64ull);
                 }
             }
         } else if (round_left == 0 && alive == 0) {
             while (!exhausted && alive + 64 <= CAP) {
                 const unsigned long long first = draw_ticket();
-                if (first >= (unsigned long long)n) { exhausted = true; break; }
-                const int cnt = (int)((unsigned long long)n - first < 64ull ? (unsigned long long)n - first : 64ull);
+                const unsigned long long n_now = (unsigned long long)n;
+                if (first >= n_now) { exhausted = true; break; }
+                const int cnt = (int)(n_now - first < 64ull ? n_now - first : 64ull);
                 if (lane < cnt) ring32[tail + lane] = (uint32_t)first + (uint32_t)lane;  // segment index 0
                 tail += cnt;
                 alive += cnt;
@@ -554,21 +572,21 @@ __global__ __launch_bounds__((rolling_threads<T, F, REC_LDS>()), (rolling_minw<T
             OT_STAMP_AT(1);
             // the segment record: every entry of the pass writes exactly one
             const bool hit = active && h.node >= 0;
-            int64_t slot = (int64_t)k * n + (int64_t)i;
+            int64_t slot = APPEND ? 0 : (int64_t)k * n + (int64_t)i;
             bool room = true;
             if constexpr (APPEND) {
                 const unsigned long long writers = __ballot(entry);
                 const int need = __popcll(writers), rank = __popcll(writers & ((1ull << lane) - 1ull));
                 int64_t fresh_pos = 0;
                 if (need > chunk_left) {  // wave-uniform: claim the next chunk; the pass may straddle the two
-                    const unsigned long long c0 = lane == 0 ? atomicAdd(ac.cursor, (unsigned long long)ac.chunk) : 0ull;
+                    const unsigned long long c0 = lane == 0 ? atomicAdd(OT_KARG(ac.cursor), (unsigned long long)OT_KARG(ac.chunk)) : 0ull;
                     fresh_pos = (int64_t)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(c0 >> 32)) << 32) |
                                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(c0 & 0xffffffffull)));
                 }
                 slot = rank < chunk_left ? chunk_pos + rank : fresh_pos + (rank - chunk_left);
-                if (need > chunk_left) { chunk_pos = fresh_pos + (need - chunk_left); chunk_left = ac.chunk - (need - chunk_left); }
+                if (need > chunk_left) { chunk_pos = fresh_pos + (need - chunk_left); chunk_left = OT_KARG(ac.chunk) - (need - chunk_left); }
                 else { chunk_pos += need; chunk_left -= need; }
-                room = slot < ac.capacity;  // an output that is too small loses records, never writes outside (the cursor tells)
+                room = slot < OT_KARG(ac.capacity);  // an output that is too small loses records, never writes outside (the cursor tells)
             }
             if constexpr (APPEND) {
                 if (entry && room) store_segment<T, NT>(out, slot, r, hit ? h.t : r.len, (int32_t)i, hit ? leaf_id_of<T, F>(sc, h.node) : (active ? -1 : -2));
@@ -595,7 +613,7 @@ __global__ __launch_bounds__((rolling_threads<T, F, REC_LDS>()), (rolling_minw<T
                     if (nk == 1) survive = k + 1 < K;
                     else if (nk > 1) used = -(k + 1);  // the tree branches here: the caller re-traces it generation by generation
                 }
-                if (!survive) seg_count[i] = used;
+                if (!survive) OT_KARG(seg_count)[i] = used;
             }
             const unsigned long long mk = __ballot(survive);
             if (survive) {
@@ -647,7 +665,7 @@ __global__ __launch_bounds__((rolling_threads<T, F, REC_LDS>()), (rolling_minw<T
     if constexpr (APPEND) {  // the unused tail of this wave's last chunk: holes
         int32_t* rp = ray_plane(out);
         for (int64_t s = chunk_pos + lane; s < chunk_pos + chunk_left; s += 64)
-            if (s < ac.capacity) rp[s] = -1;
+            if (s < OT_KARG(ac.capacity)) rp[s] = -1;
     }
 #ifdef OT_STAMP
     if (lane == 0) for (int q = 0; q < 12; ++q) atomicAdd(&queue[8 + q], st_acc[q]);

@@ -63,3 +63,23 @@ def test_rolling_kernel_reads_its_ray_pointers_where_the_code_object_puts_them(k
         assert k["args"][0] == (0, 48) and k["args"][2] == (56, 120), (k["name"], k["args"][:3])
         # ... and the output descriptor (14 array pointers, or the plane block) right behind n and K
         assert k["args"][5][0] == 192 and k["args"][5][1] in (112, 16), (k["name"], k["args"][5])
+
+
+def test_rolling_kernel_argument_segment_is_laid_out_like_the_struct_the_kernel_indexes(kernels):
+    """k_trace_rolling loads the arguments it needs once per pass or less (queue, n, the append cursor and bounds,
+    seg_count) from the argument segment at offsetof(LeadArgs, field).  LeadArgs lists the 16 parameters in order, so
+    the code object must place every explicit argument where a C struct of members of those sizes places it: members
+    of 8 bytes and more (pointers, int64, structs of pointers) on 8, the 4-byte ones on 4, nothing packed or padded
+    otherwise."""
+    rolling = [k for k in kernels if "k_trace_rolling" in k["name"]]
+    for k in rolling:
+        explicit = k["args"][:16]
+        assert len(explicit) == 16, (k["name"], len(k["args"]))
+        at = 0
+        for idx, (offset, size) in enumerate(explicit):
+            align = 8 if size >= 8 else 4
+            at = (at + align - 1) // align * align
+            assert offset == at, (k["name"], idx, offset, at)
+            at += size
+        sizes = [s for _, s in explicit]
+        assert sizes[6] == 24 and sizes[7] == 8 and sizes[13] == 8, (k["name"], sizes)  # AppendCtl, seg_count, queue
