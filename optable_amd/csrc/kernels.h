@@ -396,15 +396,15 @@ __global__ __launch_bounds__((rolling_threads<T, F, REC_LDS>()), (rolling_minw<T
     uint32_t* ring32 = reinterpret_cast<uint32_t*>(ring64);
     uint8_t* lds_next = reinterpret_cast<uint8_t*>(lds_tail) + n_waves * ring_bytes;
     // F_FLAT: per-wave key table and pair queue of flat_grid_hit, behind the lists of all waves
-    FlatLds<T> flat = {nullptr, nullptr, nullptr, nullptr, 0};
+    FlatLds<T> flat = {nullptr, nullptr, nullptr, 0};
     if constexpr ((F & F_FLAT) != 0) {
         const int per_wave = (FlatLds<T>::fixed_bytes + flat_cap * 2 + 15) & ~15;
         uint8_t* fb = lds_next + wave * per_wave;
         flat.key = reinterpret_cast<unsigned long long*>(fb);
-        flat.point = reinterpret_cast<T*>(fb + 64 * 8);
-        if constexpr (sizeof(T) == 8) flat.node = reinterpret_cast<int32_t*>(fb + 64 * (8 + 24));
+        if constexpr (sizeof(T) == 8) flat.node = reinterpret_cast<int32_t*>(fb + 64 * 8);
         flat.queue = reinterpret_cast<uint16_t*>(fb + FlatLds<T>::fixed_bytes);
         flat.queue_cap = flat_cap;
+        for (int q = lane; q < flat_cap; q += 64) flat.queue[q] = 0;  // markers only; every round leaves it zeroed again
         lds_next += n_waves * per_wave;
     }
     __syncthreads();  // the only workgroup barrier: the scene image is staged

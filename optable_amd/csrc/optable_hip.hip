@@ -154,13 +154,13 @@ static int timing_end(ot_ctx* c) {
 
 // host -> device node conversion
 // Cells of the top-level grid in one word each (first item | count << 11) behind the caller's aux array, for the pair-queue
-// walk (trace_core.h flat_grid_hit): possible when the item list has at most 1024 entries and no cell more than 42.
+// walk (trace_core.h flat_grid_hit): possible when the item list has at most 1023 entries and no cell more than 42.
 // Returns the number of cells to append, 0 when the grid is absent or too large for the packing.
 static int64_t packable_cells(const ot_scene_desc* s) {
     if (s->root_grid < 0) return 0;
     const double* g = s->aux + s->root_grid;
     const int64_t cells = (int64_t)g[2] * (int64_t)g[3];
-    if ((int64_t)g[11 + cells] > 1024) return 0;
+    if ((int64_t)g[11 + cells] > 1023) return 0;  // a queue marker is (lane << 10 | index into the item list) + 1, in 16 bits
     for (int64_t k = 0; k < cells; ++k)
         if (g[11 + k + 1] - g[11 + k] > 42) return 0;
     return cells;

@@ -981,7 +981,8 @@ __device__ __forceinline__ void root_grid_hit(const Scene<T>& sc, const RayState
 // tests per pass where a ray needs 4.0 — the cell loop is ~85 % of the kernel's VALU instructions at 21 % active
 // lanes.  Here the walk and the tests are separated:
 //   walk   every lane steps through up to FLAT_CELLS cells WITHOUT testing and notes the item ranges of those cells;
-//          one wave-wide scan of the counts gives every lane its place in a queue of (lane, leaf) pairs in LDS;
+//          one wave-wide scan of the counts gives every lane its place in a queue of (lane, leaf) pairs in LDS (kept as
+//          one marker per item range, see "queue" below);
 //   test   the wave takes the pairs 64 at a time: lane q tests pair q (the ray's origin, direction, length and
 //          start leaf come from the owner lane's registers by ds_bpermute), so every lane has a real
 //          candidate; a hit goes into the ray's slot of a key table with ONE 64-bit LDS atomic minimum on
@@ -989,8 +990,8 @@ __device__ __forceinline__ void root_grid_hit(const Scene<T>& sc, const RayState
 //          rule of optical_table.py:119-123 / component_group.py:118-120;
 //   round  a lane is done when its best hit lies inside the part of the ray the walk has covered, or when the walk left
 //          the grid; the others walk on (second and later rounds have few lanes, but also few pairs).
-// The lane that holds a ray's minimum after a slot leaves the hit point next to the key (computed from the ray's own
-// values: the same bits as a test in the ray's own lane).
+// A slot ends with its atomic and reads nothing back; the owner of a ray forms the winner's hit point after the last round
+// from its own registers and the winner's t (rebuild_hit: the expressions of the test, the same bits).
 // Planar leaves only (preset FR); results are bit-identical to root_grid_hit in both precisions
 // (test_pair_queue_walk_equals_per_lane_walk, test_random_planar_scene_pair_queue_variants_agree).  In double precision
 // t does not fit a 64-bit key next to the index: the key is t alone and the node index lives in a second table (see
@@ -1002,11 +1003,10 @@ static constexpr int FLAT_CELLS = OT_FLAT_CELLS;
 template <class T> struct FlatLds {
     unsigned long long* key;   // [64]  fp32: t bits << 32 | node; fp64: t bits
     int32_t* node;             // [64]  fp64 only: lowest node index among the candidates at the key's t
-    T* point;                  // [64][4 (fp32) / 3 (fp64)] hit point of the winning candidate
     uint16_t* queue;           // [queue_cap]
     int32_t queue_cap;
     // bytes per wave, without the queue (kernels.h and the host size the LDS with this)
-    static constexpr int fixed_bytes = sizeof(T) == 4 ? 64 * 24 : 64 * (8 + 4 + 24);
+    static constexpr int fixed_bytes = sizeof(T) == 4 ? 64 * 8 : 64 * (8 + 4);
 };
 // exclusive add-scan over the 64 lanes in six DPP adds (row_shr 1 / 2 / 4 / 8 inside the rows of 16, then row_bcast 15 /
 // 31 across the rows) — no LDS crossbar round trips; the wave total comes back in a scalar register.  Called with all 64
@@ -1041,6 +1041,7 @@ __device__ __forceinline__ int wave_incl_max_i32(int v) {
 #define OT_FLAT_AT(k) do {} while (0)
 #define OT_FLAT_COUNT(k) do {} while (0)
 #endif
+template <class T, uint32_t F> __device__ __forceinline__ Hit<T> rebuild_hit(const Scene<T>& sc, const RayState<T>& r, int32_t node, T t);
 template <class T, uint32_t F, int GATE>
 __device__ __forceinline__ Hit<T> flat_grid_hit(const Scene<T>& sc, const RayState<T>& r, bool active, const GateCtx& gate,
                                                 const FlatLds<T>& L, int lane OT_FLAT_STAMP_PARAMS) {
@@ -1075,7 +1076,7 @@ __device__ __forceinline__ Hit<T> flat_grid_hit(const Scene<T>& sc, const RaySta
     const T* items = g + 11 + (g0 * g1 + 1);
     const T* cellpack = sc.aux + sc.root_pack;  // (the host launches this walk only when the packed cells exist)
     const T slack = T(4) * margin;
-    const int max_items = L.queue_cap / (64 * FLAT_CELLS);  // the host sizes the queue for 64 lanes x FLAT_CELLS x the fullest cell
+    // (the host sizes the queue for 64 lanes x FLAT_CELLS x the fullest cell: the pairs of a round always fit)
     bool first_round = true;
     while (true) {  // rounds (wave-uniform)
         const unsigned long long wmask = __ballot(walking);
@@ -1084,7 +1085,7 @@ __device__ __forceinline__ Hit<T> flat_grid_hit(const Scene<T>& sc, const RaySta
         // walking it takes twice as many — their pairs fit the same queue, the slots of such a round are half empty
         // anyway, and a round less is a scan, two fences and a partly filled slot less.
         const int ncell = 2 * __popcll(wmask) <= 64 ? 2 * FLAT_CELLS : FLAT_CELLS;
-        int kb[2 * FLAT_CELLS], ke[2 * FLAT_CELLS], cnt = 0, cm = 0;
+        int kb[2 * FLAT_CELLS], ke[2 * FLAT_CELLS], cnt = 0;
         T covered = T(0);
         bool left = !walking;
 #pragma unroll
@@ -1095,43 +1096,51 @@ __device__ __forceinline__ Hit<T> flat_grid_hit(const Scene<T>& sc, const RaySta
                 kb[w] = pk & 2047;
                 ke[w] = kb[w] + (pk >> 11);
                 cnt += pk >> 11;
-                cm = max(cm, pk >> 11);
                 covered = min_t(tmax0, tmax1);
                 if (tmax0 < tmax1) { c0 += s0; tmax0 += dt0; if (c0 < 0 || c0 >= g0) left = true; }
                 else { c1 += s1; tmax1 += dt1; if (c1 < 0 || c1 >= g1) left = true; }
             }
         }
         // The leaf a ray starts on lies in the first cell of its walk and can never be hit (test_leaf: idx == r.last): it is
-        // taken out here, before it costs a pair — one candidate in six on cfg 3.
-        // (loops over the items of a cell run to the fullest cell of the grid or, in grids with crowded cells, to the
-        // fullest cell any lane walked this round — wave-uniform either way, so the writes below are predicated stores in
-        // straight-line code)
-        int cmax = max_items;
-        if (max_items > 4) cmax = min(__builtin_amdgcn_readlane(wave_incl_max_i32(cm), 63), max_items);  // (scene-uniform branch)
-        unsigned long long skip0 = 0ull;
+        // taken out here, before it costs a pair — one candidate in six on cfg 3.  (The search runs to the fullest first
+        // cell of the wave, four independent reads at a time; a leaf is listed once per cell.)
+        int skip_at = -1;
         if (first_round) {
             const int c = ke[0] - kb[0];
-            for (int j = 0; j < cmax; ++j)
-                if (j < c && (int)items[kb[0] + j] == r.last) skip0 |= 1ull << j;
-            cnt -= __popcll(skip0);
+            const int c0max = __builtin_amdgcn_readlane(wave_incl_max_i32(c), 63);
+            for (int j0 = 0; j0 < c0max; j0 += 4) {
+                int it[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) it[u] = j0 + u < c ? (int)items[kb[0] + j0 + u] : -2;
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (it[u] == r.last) skip_at = j0 + u;
+            }
+            if (skip_at >= 0) cnt -= 1;
             first_round = false;
         }
         OT_FLAT_AT(5);
         OT_FLAT_COUNT(10);
-        // ---- queue: one scan of the counts, every lane writes its pairs (lane << 10 | index into the grid's item list);
-        // the item itself is looked up by the lane that tests the pair.
+        // ---- queue: one scan of the counts gives every lane the place of its pairs in the round's queue.  A lane does not
+        // write its pairs one by one (a loop to the fullest cell with a predicated store per item was a sixth of the
+        // kernel): it writes ONE 16-bit marker per item range — (lane << 10 | first index into the grid's item list) + 1 at
+        // the queue position where the range begins; everything else in the queue is zero.  The lane that tests pair q finds
+        // the last marker at or before q with a max-scan over the slot (see below) and takes the item (q - marker
+        // position) places after the marker's.  At most five ranges per lane: the cells of the round, the first one split
+        // around the start leaf.
         int total;
         int off = wave_excl_scan_i32(cnt, total);
+        auto mark = [&](int at, int first) { L.queue[at] = (uint16_t)(((lane << 10) | first) + 1); };
 #pragma unroll
         for (int w = 0; w < 2 * FLAT_CELLS; ++w) {
             if (w >= ncell) break;  // wave-uniform
             const int c = ke[w] - kb[w];
-            if (w == 0) {
-                for (int j = 0; j < cmax; ++j)
-                    if (j < c && !((skip0 >> j) & 1ull)) L.queue[off++] = (uint16_t)((lane << 10) | (kb[w] + j));
+            if (w == 0 && skip_at >= 0) {
+                if (skip_at > 0) mark(off, kb[0]);
+                if (skip_at < c - 1) mark(off + skip_at, kb[0] + skip_at + 1);
+                off += c - 1;
             } else {
-                for (int j = 0; j < cmax; ++j)
-                    if (j < c) L.queue[off + j] = (uint16_t)((lane << 10) | (kb[w] + j));
+                if (c > 0) mark(off, kb[w]);
                 off += c;
             }
         }
@@ -1144,25 +1153,15 @@ __device__ __forceinline__ Hit<T> flat_grid_hit(const Scene<T>& sc, const RaySta
         // before).  Everything is evaluated, the verdict is one conjunction.  The arithmetic is test_leaf's, expression by
         // expression with the roundings written down (dot3_t, fma_t): bit-identical results
         // (test_pair_queue_walk_equals_per_lane_walk).
-        struct Cand { int src, item; bool ok; T t, Px, Py, Pz; };
-        auto eval = [&](int q) -> Cand {
+        struct Cand { int src, item; bool ok; T t; };
+        auto eval = [&](int q, int src, int item) -> Cand {
             Cand cd;
-            const int pair = q < total ? (int)L.queue[q] : 0;
-            const int src = pair >> 10, item = (int)items[pair & 1023];
             // the ray of the pair, straight from its owner's registers (ds_bpermute: a crossbar read, no bank conflicts)
             const T sx = __shfl(r.ox, src, 64), sy = __shfl(r.oy, src, 64), sz = __shfl(r.oz, src, 64);
             const T sdx = __shfl(r.dx, src, 64), sdy = __shfl(r.dy, src, 64), sdz = __shfl(r.dz, src, 64);
             const T slen = __shfl(r.len, src, 64);
             const int slast = __shfl(r.last, src, 64);
             const DNode<T>& nd = sc.nodes[item];
-            const unsigned long long cur = L.key[src];  // the ray's best so far (read between slots: it only prunes)
-            T best_t = Num<T>::inf();
-            int best_node = -1;
-            if constexpr (F32) {
-                if (cur != ~0ull) { best_t = __uint_as_float((unsigned)(cur >> 32)); best_node = (int)(cur & 0xffffffffull); }
-            } else {
-                if (cur != ~0ull) { best_t = __longlong_as_double((long long)cur); best_node = L.node[src]; }
-            }
             const T rx = sx - nd.org[0], ry = sy - nd.org[1], rz = sz - nd.org[2];
             const T lox = dot3_t(nd.M[0], rx, nd.M[3], ry, nd.M[6], rz);
             const T ldx = dot3_t(nd.M[0], sdx, nd.M[3], sdy, nd.M[6], sdz);
@@ -1176,30 +1175,26 @@ __device__ __forceinline__ Hit<T> flat_grid_hit(const Scene<T>& sc, const RaySta
                                                 : (sh == OT_SHAPE_RECT && abs_t(Py) <= nd.p[0] && abs_t(Pz) <= nd.p[1]);
             bool ok = q < total && item != slast && ldx != T(0) && s != T(0) && ((s > T(0)) == (ldx > T(0)));
             ok = ok && !(abs_t(t) < Num<T>::eps_t() || t < T(0) || t > slen);
-            ok = ok && (t < best_t || (t == best_t && item < best_node));
+            // (no look at the ray's best so far: it could only save the atomic, and costs an LDS read, the decoding and two
+            // comparisons in every slot — cfg 3: 2.80 against 2.89 ms without it)
             if constexpr (F & F_POLY) {  // polygon / boolean apertures: only for the few pairs that got this far
                 if (ok && sh != OT_SHAPE_CIRCLE && sh != OT_SHAPE_RECT) inside = planar_boundary<T, F>(sc, nd, Px, Py, Pz);
             }
             ok = ok && inside;
-            if (ok && (nd.flags & OT_NODE_CHECK_AABB)) {  // the leaf's own AABB test (component_group.py:104-107), for would-be hits
-                const RayInv<T> rinv = make_inv(sdx, sdy, sdz);
-                T u1, u2;
-                ok = slab_inv(sx, sy, sz, rinv, nd.aabb, u1, u2);
-            }
-            cd.src = src; cd.item = item; cd.ok = ok; cd.t = t; cd.Px = Px; cd.Py = Py; cd.Pz = Pz;
+            // (the leaf's own AABB test, component_group.py:104-107, can only turn a would-be hit down.  Here it would run
+            // in every slot for the one lane in six that holds a would-be hit — ~50 instructions at a sixth of the lanes, a
+            // fifth of the kernel's VALU work on cfg 3.  The owner of the ray applies it to the WINNER after the last round
+            // instead; see below for the ray whose winner fails it.)
+            cd.src = src; cd.item = item; cd.ok = ok; cd.t = t;
             return cd;
         };
         auto commit = [&](const Cand& cd) {
             if (cd.ok) {  // the candidate beat what this lane saw: let the table decide
                 if constexpr (F32) {
                     const unsigned long long mine = ((unsigned long long)__float_as_uint(cd.t) << 32) | (unsigned long long)(unsigned)cd.item;
-                    atomicMin(&L.key[cd.src], mine);
-                    // whoever holds the minimum after the atomics of this slot leaves its hit point next to the key (the same
-                    // pair can sit in the queue twice when a leaf is listed in two cells: same key, same point)
-                    if (L.key[cd.src] == mine) {
-                        T* pt = L.point + 4 * cd.src;
-                        pt[0] = cd.Px; pt[1] = cd.Py; pt[2] = cd.Pz;
-                    }
+                    // nothing is read back: the slot ends with the atomic, and the next slot's reads are already on their way.
+                    // The owner of the ray forms the hit point of the winner itself after the last round (rebuild_hit)
+                    __hip_atomic_fetch_min(&L.key[cd.src], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 } else {
                     // double precision: t does not fit a 64-bit key next to the index.  The key is t alone; a lane that
                     // LOWERS the minimum clears the node table's entry, then every lane whose t equals the minimum takes part
@@ -1208,18 +1203,21 @@ __device__ __forceinline__ Hit<T> flat_grid_hit(const Scene<T>& sc, const RaySta
                     const unsigned long long old = atomicMin(&L.key[cd.src], mine);
                     if (mine < old) L.node[cd.src] = 0x7fffffff;
                     if (L.key[cd.src] == mine) atomicMin(&L.node[cd.src], cd.item);
-                    if (L.key[cd.src] == mine && L.node[cd.src] == cd.item) {
-                        T* pt = L.point + 3 * cd.src;
-                        pt[0] = cd.Px; pt[1] = cd.Py; pt[2] = cd.Pz;
-                    }
                 }
             }
         };
-        // (Two slots evaluated before either commits, so that their LDS round trips overlap inside the wave, and the next
-        // slot's queue entry fetched ahead: measured, no gain — 3.90 vs 3.88 ms, 3.76 vs 3.71 ms.)
+        // (two slots evaluated before either commits, so that the LDS round trips of one overlap the arithmetic of the
+        // other: measured twice, no gain — the slot is bound by instruction issue, not by latency)
+        int carry = -1;  // the last marker before this slot
         for (int q0 = 0; q0 < total; q0 += 64) {
             OT_FLAT_COUNT(9);
-            commit(eval(q0 + lane));
+            const int q = q0 + lane;
+            const int v = q < total ? (int)L.queue[q] : 0;
+            if (v) L.queue[q] = 0;  // (the queue is all zeros again when the round is over)
+            const int m = max(wave_incl_max_i32(v ? (q << 16) | v : -1), carry);  // position << 16 | marker: later ranges are larger
+            carry = __builtin_amdgcn_readlane(m, 63);
+            const int first = ((m & 0xffff) - 1) & 1023, src = ((m & 0xffff) - 1) >> 10;
+            commit(eval(q, src, q < total ? (int)items[first + (q - (m >> 16))] : 0));
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         OT_FLAT_AT(7);
@@ -1232,10 +1230,25 @@ __device__ __forceinline__ Hit<T> flat_grid_hit(const Scene<T>& sc, const RaySta
         if (walking) walking = !left && !(best.t + slack < covered);
         OT_FLAT_AT(8);
     }
-    // the hit point of the winner was computed by the lane that tested it, from this ray's own values: same bits as a
-    // test in the ray's own lane
-    if (active && best.node >= 0) { const T* pt = L.point + (F32 ? 4 : 3) * lane; best.px = pt[0]; best.py = pt[1]; best.pz = pt[2]; }
-    else { best.t = Num<T>::inf(); best.node = -1; }
+    if (!(active && best.node >= 0)) { best.t = Num<T>::inf(); best.node = -1; }
+    // The winner's own AABB test, by the owner of the ray.  The winner is the nearest candidate that passes every test BUT
+    // this one: if it passes this one too it is the nearest that passes all of them.  If it does not (the top-level grid
+    // is only built over boxes that hold their surfaces, so this is a hit within rounding of its box's face), the nearest
+    // valid candidate is unknown and the ray takes the per-lane walk, which applies every test to every candidate.
+    bool redo = false;
+    if (best.node >= 0) {
+        const DNode<T>& nd = sc.nodes[best.node];
+        T u1, u2;
+        if (nd.flags & OT_NODE_CHECK_AABB) redo = !slab_inv(r.ox, r.oy, r.oz, ri, nd.aabb, u1, u2);
+    }
+    if (__any(redo)) {
+        if (redo) {
+            best.t = Num<T>::inf(); best.node = -1; best.px = best.py = best.pz = T(0);
+            root_grid_hit<T, F, GATE>(sc, r, ri, best, gate);
+        }
+    }
+    // the hit point of the winner, from the ray's own values and the winner's t: the expressions of the test, the same bits
+    if (best.node >= 0 && !redo) return rebuild_hit<T, F>(sc, r, best.node, best.t);
     return best;
 }
 

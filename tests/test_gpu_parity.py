@@ -410,6 +410,60 @@ def test_pair_queue_walk_equals_per_lane_walk(prec):
         eng.set_option(abi.OPT_LDS_RECORDS, -1)
 
 
+@pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_pair_queue_winner_that_fails_its_own_box_takes_the_per_lane_walk(prec, oracle):
+    """In the pair queue a leaf's own AABB test (component_group.py:104-107) is applied to the WINNER of a ray, not to
+    every candidate (trace_core.h flat_grid_hit); a ray whose winner fails it repeats the search lane by lane with every
+    test on every candidate.  With honest boxes that happens only within rounding of a box face, so the boxes here are
+    cut: every second gated leaf keeps z <= 0.1 of a face that reaches z = 1, and the rays that meet the face above
+    that must pass THROUGH it, as the reference's gate has it — a quarter of all rays take the fallback.  Same bits as
+    the per-lane kernel; in double precision also the oracle's answer for the same (cut) scene."""
+    import torch
+    import optable_amd as oa
+    from optable_amd.batch import RayBatch
+    from optable_amd.engine import get_engine
+
+    comps, gen, _, K = CASES["cfg3"]
+    table = _table(comps(oa))
+    honest = table.compile()
+    scene = table.compile()
+    nodes = scene.node_table()
+    gated = [i for i in range(len(nodes)) if nodes["kind"][i] == abi.NODE_LEAF and nodes["flags"][i] & abi.NODE_CHECK_AABB]
+    assert len(gated) >= 30
+    for i in gated[::2]:
+        nodes["aabb"][i][5] = 0.1
+    n = 20_011
+    o, d = gen(n)
+    q = 1j * np.pi * scenes.W0**2 / scenes.WL
+    batch = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=q, precision=prec)
+    eng = get_engine()
+    try:
+        eng.set_option(abi.OPT_KERNEL, 2)
+        eng.set_option(abi.OPT_FLAT_QUEUE, 0)
+        a = table.trace_batch(batch, max_segments=K, scene=scene)
+        eng.set_option(abi.OPT_FLAT_QUEUE, 1)
+        b = table.trace_batch(batch, max_segments=K, scene=scene)
+        assert eng.last_launch()["pair_queue"] & 1
+        whole = table.trace_batch(batch, max_segments=K, scene=honest)
+    finally:
+        eng.set_option(abi.OPT_KERNEL, 0)
+        eng.set_option(abi.OPT_FLAT_QUEUE, 1)
+    assert torch.equal(a.count, b.count)
+    valid = a.valid_mask()
+    for f in abi.SEG_FIELDS + ("ray", "surface"):
+        assert torch.equal(a.field(f)[valid], b.field(f)[valid]), f
+    # the cut boxes matter: many rays now pass through a face they used to end on
+    changed = (b.count != whole.count).float().mean().item()
+    assert changed > 0.1, changed
+    if prec == "f64":
+        got = b.to_host(reference_order=True)
+        ref = oracle.trace(scene, batch.to_host(), max_trace_num=K)
+        np.testing.assert_array_equal(got["ray"], ref["ray"])
+        np.testing.assert_array_equal(got["surface"], ref["surface"])
+        for f in ("ox", "oy", "oz", "length"):
+            np.testing.assert_allclose(got[f], ref[f], rtol=1e-9, atol=1e-9, err_msg=f)
+
+
 @pytest.mark.parametrize("case", ["cfg3", "cfg5"])
 def test_acceleration_grids_do_not_change_results(case):
     """Group grids and the top-level grid only choose WHICH nodes get tested; every bit of the output
