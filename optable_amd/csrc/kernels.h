@@ -409,6 +409,8 @@ __global__ __launch_bounds__((rolling_threads<T, F, REC_LDS>()), (rolling_minw<T
     }
     __syncthreads();  // the only workgroup barrier: the scene image is staged
     const Scene<T> sc = bind_scene<T>(base, blob, unit);
+    FlatGrid<T> flat_grid = {};
+    if constexpr ((F & F_FLAT) != 0) flat_grid = flat_grid_header<T>(sc);
     // ONE base pointer per wave; field f of ring position p is element p + f * CAP (twelve reals, then the integer words
     // behind them).  Separate base pointers per field cost scalar registers that the kernel does not have.
     const int64_t gw = (int64_t)blockIdx.x * n_waves + wave;
@@ -560,7 +562,7 @@ __global__ __launch_bounds__((rolling_threads<T, F, REC_LDS>()), (rolling_minw<T
             const bool active = entry && !(fl & OT_RAY_DEAD);  // optical_component.py:349: a dead ray is returned as it came
             const GateCtx gate = {counts, n_classes, cls, nullptr, nullptr, 0, 0};
             Hit<T> h;
-            if constexpr ((F & F_FLAT) != 0) h = flat_grid_hit<T, F, GATE_PLAIN>(sc, r, active, gate, flat, lane OT_FLAT_STAMP_ARGS);
+            if constexpr ((F & F_FLAT) != 0) h = flat_grid_hit<T, F, GATE_PLAIN>(sc, flat_grid, r, active, gate, flat, lane OT_FLAT_STAMP_ARGS);
             else {
 #ifdef OT_STAMP
                 h = nearest_hit<T, F, GATE_PLAIN>(sc, r, active, gate, st_acc, &st_last);

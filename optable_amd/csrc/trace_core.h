@@ -136,6 +136,11 @@ template <class T> struct NodeRef {
     const T* geo;      // org[0..2], aabb[3..8]
     int32_t inst;      // member number inside its run, 0 for ordinary nodes
 };
+// Record i of a table, for a PER-LANE index: the byte offset by a 24-bit multiply (v_mul_u32_u24, full rate).  Plain pointer
+// arithmetic on a 212-byte record compiles to v_mul_lo_u32, which issues at a quarter of that; indices are far below 2^24.
+template <class R> __device__ __forceinline__ const R* record_at(const R* table, int i) {
+    return reinterpret_cast<const R*>(reinterpret_cast<const char*>(table) + __umul24((unsigned)i, (unsigned)sizeof(R)));
+}
 template <class T, uint32_t F> __device__ __forceinline__ NodeRef<T> node_ref(const Scene<T>& sc, int v) {
     NodeRef<T> r;
     r.inst = 0;
@@ -164,9 +169,9 @@ template <class T, uint32_t F> __device__ __forceinline__ NodeRef<T> node_ref(co
                 }
             }
         }
-        r.nd = sc.nodes + (v - shift);
+        r.nd = record_at(sc.nodes, v - shift);
     } else {
-        r.nd = sc.nodes + v;
+        r.nd = record_at(sc.nodes, v);
     }
     r.geo = r.nd->org;  // org[3] and aabb[6] are adjacent in the record
     return r;
@@ -326,7 +331,7 @@ template <class T, uint32_t F> __device__ __forceinline__ MatCache<T> make_matca
 }
 template <class T, uint32_t F> __device__ __forceinline__ T cached_index(const Scene<T>& sc, const MatCache<T>& m, int idx, T wl) {
     if (idx == sc.cache_mat) return m.v;
-    return material_index<T, F>(sc, sc.mats[idx], wl * sc.unit);
+    return material_index<T, F>(sc, *record_at(sc.mats, idx), wl * sc.unit);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -952,7 +957,7 @@ __device__ __forceinline__ void root_grid_hit(const Scene<T>& sc, const RayState
     const T* items = start + (g0 * g1 + 1);
     const T slack = T(4) * margin;
     for (int guard = 0; guard < g0 + g1 + 2; ++guard) {
-        const int cidx = c1 * g0 + c0;
+        const int cidx = __mul24(c1, g0) + c0;
         const int kb = (int)start[cidx], ke = (int)start[cidx + 1];
         for (int k = kb; k < ke; ++k) {
             const int item = (int)items[k];
@@ -1022,14 +1027,17 @@ __device__ __forceinline__ int wave_excl_scan_i32(int v, int& total) {
     total = __builtin_amdgcn_readlane(incl, 63);
     return incl - v;
 }
-// inclusive max-scan over the 64 lanes, same DPP steps (identity -1: lanes without a source keep their own value)
+// inclusive max-scan over the 64 lanes, same DPP steps.  (Lanes without a source read INT_MIN, the identity of a signed
+// maximum: with the identity as the fill value the compiler folds the cross-lane move into the v_max_i32 itself — one
+// instruction per step instead of four.)
 __device__ __forceinline__ int wave_incl_max_i32(int v) {
-    v = max(v, __builtin_amdgcn_update_dpp(-1, v, 0x111, 0xf, 0xf, false));
-    v = max(v, __builtin_amdgcn_update_dpp(-1, v, 0x112, 0xf, 0xf, false));
-    v = max(v, __builtin_amdgcn_update_dpp(-1, v, 0x114, 0xf, 0xf, false));
-    v = max(v, __builtin_amdgcn_update_dpp(-1, v, 0x118, 0xf, 0xf, false));
-    v = max(v, __builtin_amdgcn_update_dpp(-1, v, 0x142, 0xa, 0xf, false));
-    v = max(v, __builtin_amdgcn_update_dpp(-1, v, 0x143, 0xc, 0xf, false));
+    constexpr int LOWEST = (int)0x80000000;
+    v = max(v, __builtin_amdgcn_update_dpp(LOWEST, v, 0x111, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(LOWEST, v, 0x112, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(LOWEST, v, 0x114, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(LOWEST, v, 0x118, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(LOWEST, v, 0x142, 0xa, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(LOWEST, v, 0x143, 0xc, 0xf, false));
     return v;
 }
 #ifdef OT_STAMP  // diagnostic build: phases of a call into st_acc[5..] (walk, queue, test, verdict; [9] slots, [10] rounds)
@@ -1041,9 +1049,30 @@ __device__ __forceinline__ int wave_incl_max_i32(int v) {
 #define OT_FLAT_AT(k) do {} while (0)
 #define OT_FLAT_COUNT(k) do {} while (0)
 #endif
+// The header of the top-level grid, decoded ONCE per wave before the pass loop (kernels.h): the table sits in LDS, which
+// the pass loop writes to, so the compiler cannot keep these values across passes on its own — every call used to read and
+// convert them again, ~35 instructions per pass for numbers that never change.  (Vector registers: the pair-queue kernels
+// run at 3 waves per SIMD for their LDS, a third of the register file is unused.)
+template <class T> struct FlatGrid {
+    int a0, a1, g0, g1;
+    T org0, org1, inv0, inv1, size0, size1, hi0, hi1, slack;
+    const T* items;
+    const T* cellpack;  // cells as (first item | count << 11)
+};
+template <class T> __device__ __forceinline__ FlatGrid<T> flat_grid_header(const Scene<T>& sc) {
+    FlatGrid<T> G;
+    const T* g = sc.aux + sc.root;
+    G.a0 = (int)g[0]; G.a1 = (int)g[1]; G.g0 = (int)g[2]; G.g1 = (int)g[3];
+    G.org0 = g[4]; G.org1 = g[5]; G.inv0 = g[6]; G.inv1 = g[7]; G.size0 = g[9]; G.size1 = g[10];
+    G.hi0 = G.org0 + G.size0 * T(G.g0); G.hi1 = G.org1 + G.size1 * T(G.g1);
+    G.slack = T(4) * g[8];
+    G.items = g + 11 + (G.g0 * G.g1 + 1);
+    G.cellpack = sc.aux + sc.root_pack;  // (the host launches this walk only when the packed cells exist)
+    return G;
+}
 template <class T, uint32_t F> __device__ __forceinline__ Hit<T> rebuild_hit(const Scene<T>& sc, const RayState<T>& r, int32_t node, T t);
 template <class T, uint32_t F, int GATE>
-__device__ __forceinline__ Hit<T> flat_grid_hit(const Scene<T>& sc, const RayState<T>& r, bool active, const GateCtx& gate,
+__device__ __forceinline__ Hit<T> flat_grid_hit(const Scene<T>& sc, const FlatGrid<T>& G, const RayState<T>& r, bool active, const GateCtx& gate,
                                                 const FlatLds<T>& L, int lane OT_FLAT_STAMP_PARAMS) {
     constexpr bool F32 = sizeof(T) == 4;
     Hit<T> best;
@@ -1051,17 +1080,16 @@ __device__ __forceinline__ Hit<T> flat_grid_hit(const Scene<T>& sc, const RaySta
     const RayInv<T> ri = make_inv(r.dx, r.dy, r.dz);
     L.key[lane] = ~0ull;
     if constexpr (!F32) L.node[lane] = 0x7fffffff;
-    // grid header and DDA start (root_grid_hit's, per lane)
-    const T* g = sc.aux + sc.root;
-    const int a0 = (int)g[0], a1 = (int)g[1], g0 = (int)g[2], g1 = (int)g[3];
-    const T org0 = g[4], org1 = g[5], inv0 = g[6], inv1 = g[7], margin = g[8], size0 = g[9], size1 = g[10];
+    // DDA start (root_grid_hit's, per lane)
+    const int a0 = G.a0, a1 = G.a1, g0 = G.g0, g1 = G.g1;
+    const T org0 = G.org0, org1 = G.org1, inv0 = G.inv0, inv1 = G.inv1, size0 = G.size0, size1 = G.size1;
     const T o0 = pick(a0, r.ox, r.oy, r.oz), o1 = pick(a1, r.ox, r.oy, r.oz);
     const T d0 = pick(a0, r.dx, r.dy, r.dz), d1 = pick(a1, r.dx, r.dy, r.dz);
     const T i0 = pick(a0, ri.inv[0], ri.inv[1], ri.inv[2]), i1 = pick(a1, ri.inv[0], ri.inv[1], ri.inv[2]);
     const bool par0 = abs_t(d0) <= T(1e-12), par1 = abs_t(d1) <= T(1e-12);
     bool walking = active;
     T tin = T(0), tout = Num<T>::inf();
-    const T hi0 = org0 + size0 * T(g0), hi1 = org1 + size1 * T(g1);
+    const T hi0 = G.hi0, hi1 = G.hi1;
     if (par0) { if (o0 < org0 || o0 > hi0) walking = false; }
     else { const T a = (org0 - o0) * i0, b = (hi0 - o0) * i0; tin = max_t(tin, min_t(a, b)); tout = min_t(tout, max_t(a, b)); }
     if (par1) { if (o1 < org1 || o1 > hi1) walking = false; }
@@ -1073,9 +1101,9 @@ __device__ __forceinline__ Hit<T> flat_grid_hit(const Scene<T>& sc, const RaySta
     T tmax0 = par0 ? Num<T>::inf() : (org0 + size0 * T(c0 + (s0 > 0 ? 1 : 0)) - o0) * i0;
     T tmax1 = par1 ? Num<T>::inf() : (org1 + size1 * T(c1 + (s1 > 0 ? 1 : 0)) - o1) * i1;
     const T dt0 = par0 ? Num<T>::inf() : size0 * abs_t(i0), dt1 = par1 ? Num<T>::inf() : size1 * abs_t(i1);
-    const T* items = g + 11 + (g0 * g1 + 1);
-    const T* cellpack = sc.aux + sc.root_pack;  // (the host launches this walk only when the packed cells exist)
-    const T slack = T(4) * margin;
+    const T* items = G.items;
+    const T* cellpack = G.cellpack;
+    const T slack = G.slack;
     // (the host sizes the queue for 64 lanes x FLAT_CELLS x the fullest cell: the pairs of a round always fit)
     bool first_round = true;
     while (true) {  // rounds (wave-uniform)
@@ -1092,7 +1120,7 @@ __device__ __forceinline__ Hit<T> flat_grid_hit(const Scene<T>& sc, const RaySta
         for (int w = 0; w < 2 * FLAT_CELLS; ++w) {
             kb[w] = ke[w] = 0;
             if (w < ncell && !left) {  // (w < ncell: wave-uniform)
-                const int pk = (int)cellpack[c1 * g0 + c0];  // first item | count << 11: one LDS word per cell instead of two
+                const int pk = (int)cellpack[__mul24(c1, g0) + c0];  // first item | count << 11: one LDS word per cell instead of two
                 kb[w] = pk & 2047;
                 ke[w] = kb[w] + (pk >> 11);
                 cnt += pk >> 11;
@@ -1161,7 +1189,8 @@ __device__ __forceinline__ Hit<T> flat_grid_hit(const Scene<T>& sc, const RaySta
             const T sdx = __shfl(r.dx, src, 64), sdy = __shfl(r.dy, src, 64), sdz = __shfl(r.dz, src, 64);
             const T slen = __shfl(r.len, src, 64);
             const int slast = __shfl(r.last, src, 64);
-            const DNode<T>& nd = sc.nodes[item];
+            const DNode<T>& nd = *record_at(sc.nodes, item);
+            OT_FLAT_AT(11);
             const T rx = sx - nd.org[0], ry = sy - nd.org[1], rz = sz - nd.org[2];
             const T lox = dot3_t(nd.M[0], rx, nd.M[3], ry, nd.M[6], rz);
             const T ldx = dot3_t(nd.M[0], sdx, nd.M[3], sdy, nd.M[6], sdz);
@@ -1218,6 +1247,7 @@ __device__ __forceinline__ Hit<T> flat_grid_hit(const Scene<T>& sc, const RaySta
             carry = __builtin_amdgcn_readlane(m, 63);
             const int first = ((m & 0xffff) - 1) & 1023, src = ((m & 0xffff) - 1) >> 10;
             commit(eval(q, src, q < total ? (int)items[first + (q - (m >> 16))] : 0));
+            OT_FLAT_AT(7);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         OT_FLAT_AT(7);
@@ -1237,7 +1267,7 @@ __device__ __forceinline__ Hit<T> flat_grid_hit(const Scene<T>& sc, const RaySta
     // valid candidate is unknown and the ray takes the per-lane walk, which applies every test to every candidate.
     bool redo = false;
     if (best.node >= 0) {
-        const DNode<T>& nd = sc.nodes[best.node];
+        const DNode<T>& nd = *record_at(sc.nodes, best.node);
         T u1, u2;
         if (nd.flags & OT_NODE_CHECK_AABB) redo = !slab_inv(r.ox, r.oy, r.oz, ri, nd.aabb, u1, u2);
     }

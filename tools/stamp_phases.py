@@ -54,5 +54,7 @@ if not rounds and walk + queue + test + verdict:  # the linear pass (nearest_hit
 if rounds:  # the pair-queue walk (flat_grid_hit): its phases are part of none of the above ("nearest hit" holds only the setup)
     tot2 = tot + walk + queue + test + verdict
     print(f"   pair queue: {rounds / passes:.2f} rounds and {slots / passes:.2f} slots of 64 pairs per pass")
-    for label, v in (("walk", walk), ("scan + queue", queue), ("pair tests", test), ("verdict", verdict)):
+    fetch = int(acc[11])  # inside a slot: marker, scan, item, the ray by ds_bpermute and the node record, waited for
+    tot2 += fetch
+    for label, v in (("walk", walk), ("scan + queue", queue), ("pair tests: operands (waited)", fetch), ("pair tests: arithmetic + atomic", test), ("verdict", verdict)):
         print(f"   {label:36s} {v / passes:9.0f} cycles per pass  {100 * v / tot2:5.1f} % of {tot2 / passes:.0f}")
