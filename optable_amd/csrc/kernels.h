@@ -430,16 +430,22 @@ __global__ __launch_bounds__((rolling_threads<T, F, REC_LDS>()), (rolling_minw<T
 #define OT_STAMP_AT(k) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long _t = __builtin_amdgcn_s_memtime(); st_acc[k] += _t - st_last; st_last = _t; } while (0)
     unsigned long long st_last = __builtin_amdgcn_s_memtime();
 #define OT_FLAT_STAMP_ARGS , st_acc, st_last
+#elif defined(OT_MARK)  // static census (tools/isa_census.py): the stamp sites as comments in the assembly
+#define OT_STAMP_AT(k) asm volatile("; OT_MARK pass " #k)
+#define OT_FLAT_STAMP_ARGS
 #else
 #define OT_STAMP_AT(k) do {} while (0)
 #define OT_FLAT_STAMP_ARGS
 #endif
+    // (Tickets drawn one ahead, the atomic's round trip under a pass instead of in front of one: measured, cfg 3 2.63
+    // against 2.59 ms, cfg 5 14.4 against 14.0 — the result register and the wait it drags into the pass cost more.)
     auto draw_ticket = [&]() -> unsigned long long {
         unsigned long long first = 0;
         if (lane == 0) first = atomicAdd(OT_KARG(queue), 64ull);
         return ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(first >> 32)) << 32) |
                (uint32_t)__builtin_amdgcn_readfirstlane((int)(first & 0xffffffffull));
     };
+
     for (;;) {
         bool fresh = false;
         unsigned long long fresh_first = 0;

@@ -138,8 +138,12 @@ template <class T> struct NodeRef {
 };
 // Record i of a table, for a PER-LANE index: the byte offset by a 24-bit multiply (v_mul_u32_u24, full rate).  Plain pointer
 // arithmetic on a 212-byte record compiles to v_mul_lo_u32, which issues at a quarter of that; indices are far below 2^24.
-template <class R> __device__ __forceinline__ const R* record_at(const R* table, int i) {
-    return reinterpret_cast<const R*>(reinterpret_cast<const char*>(table) + __umul24((unsigned)i, (unsigned)sizeof(R)));
+// Only where the index differs from lane to lane (the pair-queue kernels, LANES = true): in the linear pass every lane
+// holds the same node index, the compiler multiplies in the scalar unit, and the intrinsic would drag that into vector
+// registers (cfg 5: 14.4 against 14.1 ms).
+template <bool LANES, class R> __device__ __forceinline__ const R* record_at(const R* table, int i) {
+    if constexpr (LANES) return reinterpret_cast<const R*>(reinterpret_cast<const char*>(table) + __umul24((unsigned)i, (unsigned)sizeof(R)));
+    else return table + i;
 }
 template <class T, uint32_t F> __device__ __forceinline__ NodeRef<T> node_ref(const Scene<T>& sc, int v) {
     NodeRef<T> r;
@@ -169,9 +173,9 @@ template <class T, uint32_t F> __device__ __forceinline__ NodeRef<T> node_ref(co
                 }
             }
         }
-        r.nd = record_at(sc.nodes, v - shift);
+        r.nd = sc.nodes + (v - shift);
     } else {
-        r.nd = record_at(sc.nodes, v);
+        r.nd = record_at<(F & F_FLAT) != 0>(sc.nodes, v);
     }
     r.geo = r.nd->org;  // org[3] and aabb[6] are adjacent in the record
     return r;
@@ -331,7 +335,7 @@ template <class T, uint32_t F> __device__ __forceinline__ MatCache<T> make_matca
 }
 template <class T, uint32_t F> __device__ __forceinline__ T cached_index(const Scene<T>& sc, const MatCache<T>& m, int idx, T wl) {
     if (idx == sc.cache_mat) return m.v;
-    return material_index<T, F>(sc, *record_at(sc.mats, idx), wl * sc.unit);
+    return material_index<T, F>(sc, *record_at<(F & F_FLAT) != 0>(sc.mats, idx), wl * sc.unit);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1044,6 +1048,10 @@ __device__ __forceinline__ int wave_incl_max_i32(int v) {
 #define OT_FLAT_STAMP_PARAMS , unsigned long long* st_acc, unsigned long long& st_last
 #define OT_FLAT_AT(k) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long _t = __builtin_amdgcn_s_memtime(); st_acc[k] += _t - st_last; st_last = _t; } while (0)
 #define OT_FLAT_COUNT(k) do { st_acc[k] += 1; } while (0)
+#elif defined(OT_MARK)
+#define OT_FLAT_STAMP_PARAMS
+#define OT_FLAT_AT(k) asm volatile("; OT_MARK flat " #k)
+#define OT_FLAT_COUNT(k) do {} while (0)
 #else
 #define OT_FLAT_STAMP_PARAMS
 #define OT_FLAT_AT(k) do {} while (0)
@@ -1189,7 +1197,7 @@ __device__ __forceinline__ Hit<T> flat_grid_hit(const Scene<T>& sc, const FlatGr
             const T sdx = __shfl(r.dx, src, 64), sdy = __shfl(r.dy, src, 64), sdz = __shfl(r.dz, src, 64);
             const T slen = __shfl(r.len, src, 64);
             const int slast = __shfl(r.last, src, 64);
-            const DNode<T>& nd = *record_at(sc.nodes, item);
+            const DNode<T>& nd = *record_at<true>(sc.nodes, item);
             OT_FLAT_AT(11);
             const T rx = sx - nd.org[0], ry = sy - nd.org[1], rz = sz - nd.org[2];
             const T lox = dot3_t(nd.M[0], rx, nd.M[3], ry, nd.M[6], rz);
@@ -1199,11 +1207,16 @@ __device__ __forceinline__ Hit<T> flat_grid_hit(const Scene<T>& sc, const FlatGr
             const T loy = dot3_t(nd.M[1], rx, nd.M[4], ry, nd.M[7], rz), loz = dot3_t(nd.M[2], rx, nd.M[5], ry, nd.M[8], rz);
             const T ldy = dot3_t(nd.M[1], sdx, nd.M[4], sdy, nd.M[7], sdz), ldz = dot3_t(nd.M[2], sdx, nd.M[5], sdy, nd.M[8], sdz);
             const T Px = fma_t(t, ldx, lox), Py = fma_t(t, ldy, loy), Pz = fma_t(t, ldz, loz);
+            // (operands read up front and the verdict formed with & and |, not && and ||: with the short-circuit forms the
+            // compiler reads r2 / p[] inside branches on the shape and leaves the slot through a dozen exec-mask
+            // branches — ~40 scalar instructions per slot for two LDS words saved)
             const int sh = nd.shape;
-            bool inside = sh == OT_SHAPE_CIRCLE ? (dot3_t(Px, Px, Py, Py, Pz, Pz) <= nd.r2)
-                                                : (sh == OT_SHAPE_RECT && abs_t(Py) <= nd.p[0] && abs_t(Pz) <= nd.p[1]);
-            bool ok = q < total && item != slast && ldx != T(0) && s != T(0) && ((s > T(0)) == (ldx > T(0)));
-            ok = ok && !(abs_t(t) < Num<T>::eps_t() || t < T(0) || t > slen);
+            const T r2 = nd.r2, p0 = nd.p[0], p1 = nd.p[1];
+            const bool in_circle = dot3_t(Px, Px, Py, Py, Pz, Pz) <= r2;
+            const bool in_rect = (abs_t(Py) <= p0) & (abs_t(Pz) <= p1);
+            bool inside = sh == OT_SHAPE_CIRCLE ? in_circle : ((sh == OT_SHAPE_RECT) & in_rect);
+            bool ok = (q < total) & (item != slast) & (ldx != T(0)) & (s != T(0)) & ((s > T(0)) == (ldx > T(0)));
+            ok = ok & !((abs_t(t) < Num<T>::eps_t()) | (t < T(0)) | (t > slen));
             // (no look at the ray's best so far: it could only save the atomic, and costs an LDS read, the decoding and two
             // comparisons in every slot — cfg 3: 2.80 against 2.89 ms without it)
             if constexpr (F & F_POLY) {  // polygon / boolean apertures: only for the few pairs that got this far
@@ -1267,7 +1280,7 @@ __device__ __forceinline__ Hit<T> flat_grid_hit(const Scene<T>& sc, const FlatGr
     // valid candidate is unknown and the ray takes the per-lane walk, which applies every test to every candidate.
     bool redo = false;
     if (best.node >= 0) {
-        const DNode<T>& nd = *record_at(sc.nodes, best.node);
+        const DNode<T>& nd = *record_at<true>(sc.nodes, best.node);
         T u1, u2;
         if (nd.flags & OT_NODE_CHECK_AABB) redo = !slab_inv(r.ox, r.oy, r.oz, ri, nd.aabb, u1, u2);
     }
@@ -1289,6 +1302,9 @@ __device__ __forceinline__ Hit<T> flat_grid_hit(const Scene<T>& sc, const FlatGr
                  // groups (cell lookup + children), [8] deferred curved leaves
 #define OT_NH_STAMP_PARAMS , unsigned long long* st_acc = nullptr, unsigned long long* st_last = nullptr
 #define OT_NH_AT(k) do { if (st_acc) { __builtin_amdgcn_s_waitcnt(0); const unsigned long long _t = __builtin_amdgcn_s_memtime(); st_acc[k] += _t - *st_last; *st_last = _t; } } while (0)
+#elif defined(OT_MARK)
+#define OT_NH_STAMP_PARAMS
+#define OT_NH_AT(k) asm volatile("; OT_MARK nh " #k)
 #else
 #define OT_NH_STAMP_PARAMS
 #define OT_NH_AT(k) do {} while (0)
