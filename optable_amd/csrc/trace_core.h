@@ -1494,8 +1494,15 @@ __device__ __forceinline__ int interact(const Scene<T>& sc, const RayState<T>& r
     to_lab(nd, h.px, h.py, h.pz, Ox, Oy, Oz);
     Ox += nr.geo[0]; Oy += nr.geo[1]; Oz += nr.geo[2];
     int nk = 0;
+    // One outgoing ray at most (the non-branching kernels): the branches below only choose the outgoing direction in the
+    // leaf frame and what rides along; normalising, turning it into the lab frame and filling the record happen ONCE behind
+    // them.  With `emit` expanded inside every branch a pass whose rays meet a lens, a mirror and a glass face ran that
+    // tail three times at partial lanes.  Same expressions in the same order either way: the same bits.
+    T out_x = T(0), out_y = T(0), out_z = T(0), out_I = T(0), out_qr = T(0), out_qi = T(0), out_n = T(0), out_pl = T(0);
     auto emit = [&](T lx, T ly, T lz, T I, T qr, T qi, T n, T pl) {
-        if (nk < MAXK) {
+        if constexpr (MAXK == 1) {
+            if (nk == 0) { out_x = lx; out_y = ly; out_z = lz; out_I = I; out_qr = qr; out_qi = qi; out_n = n; out_pl = pl; }
+        } else if (nk < MAXK) {
             RayState<T> k;
             const T inv = rsqrt_t(lx * lx + ly * ly + lz * lz);
             to_lab(nd, lx * inv, ly * inv, lz * inv, k.dx, k.dy, k.dz);
@@ -1504,10 +1511,24 @@ __device__ __forceinline__ int interact(const Scene<T>& sc, const RayState<T>& r
             k.I = I; k.qr = qr; k.qi = qi; k.n = n; k.pl = pl;
             // constant indices only: kids[nk] with a run-time nk would put both children into private scratch
             // (240 B per lane in the fp64 generation kernel of round 1)
-            if (MAXK == 1 || nk == 0) kids[0] = k;
+            if (nk == 0) kids[0] = k;
             else kids[MAXK > 1 ? 1 : 0] = k;
         }
         ++nk;
+    };
+    auto finish = [&]() -> int {
+        if constexpr (MAXK == 1) {
+            if (nk > 0) {
+                RayState<T> k;
+                const T inv = rsqrt_t(out_x * out_x + out_y * out_y + out_z * out_z);
+                to_lab(nd, out_x * inv, out_y * inv, out_z * inv, k.dx, k.dy, k.dz);
+                k.ox = Ox; k.oy = Oy; k.oz = Oz;
+                k.wl = r.wl; k.has_q = r.has_q; k.len = Num<T>::inf(); k.last = h.node;
+                k.I = out_I; k.qr = out_qr; k.qi = out_qi; k.n = out_n; k.pl = out_pl;
+                kids[0] = k;
+            }
+        }
+        return nk;
     };
     if constexpr (F & F_LENS) {
         if (nd.inter == OT_INT_LENS) {  // optical_component.py:930-948
@@ -1515,7 +1536,7 @@ __device__ __forceinline__ int interact(const Scene<T>& sc, const RayState<T>& r
             const T jf = nd.inv_focal;
             if (r.has_q) cdiv(q1r, q1i, T(1) - q1r * jf, -q1i * jf, qr, qi);
             emit(dx - h.px * jf, dy - h.py * jf, dz - h.pz * jf, r.I * nd.trans, qr, qi, r.n, r.pl);  // pathlength, n unchanged
-            return nk;
+            return finish();
         }
     }
     T nx, ny, nz;
@@ -1524,7 +1545,7 @@ __device__ __forceinline__ int interact(const Scene<T>& sc, const RayState<T>& r
     if (!(F & F_REFRACT) || nd.inter == OT_INT_MIRROR) {  // optical_component.py:536-570
         if (nd.refl > T(0)) emit(dx - T(2) * dn * nx, dy - T(2) * dn * ny, dz - T(2) * dn * nz, r.I * nd.refl, q1r, q1i, r.n, pl_hit);
         if (nd.trans > T(0)) emit(dx, dy, dz, r.I * nd.trans, q1r, q1i, r.n, pl_hit);
-        return nk;
+        return finish();
     }
     if constexpr (F & F_REFRACT) {  // optical_component.py:617-717
         const T n1 = cached_index<T, F>(sc, mc, nd.mat1, r.wl), n2 = cached_index<T, F>(sc, mc, nd.mat2, r.wl);
@@ -1570,7 +1591,7 @@ __device__ __forceinline__ int interact(const Scene<T>& sc, const RayState<T>& r
         if (nd.refl > T(0))
             emit(dx - T(2) * ci * nx, dy - T(2) * ci * ny, dz - T(2) * ci * nz, r.I * nd.refl, qrr, qri, r.n, pl_hit);
     }
-    return nk;
+    return finish();
 }
 
 }  // namespace ot
