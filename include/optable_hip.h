@@ -349,8 +349,10 @@ enum ot_option {
                                   of a generation-pure list of OT_OPT_LIST_CAP entries spills to global scratch): -1 auto, 0 never, 1 whenever it fits */
     OT_OPT_APPEND_CHUNK = 11,  /* ot_trace_append_*: slots a wave claims per atomic (multiple of 64, default 512) */
     OT_OPT_INSTANCING = 12,    /* fold identical lattice children (MMA / MLA / DMD) into one record + per-member pose at upload (0/1) */
-    OT_OPT_GEN_REUSE = 13      /* ot_trace_generation_*: the emit pass rebuilds the hit the count pass found (node + distance kept per
+    OT_OPT_GEN_REUSE = 13,     /* ot_trace_generation_*: the emit pass rebuilds the hit the count pass found (node + distance kept per
                                   ray) instead of searching the scene again: -1 auto (scenes of 12 nodes or more), 0 never, 1 always */
+    OT_OPT_BLOCK_POOL = 14     /* heavy scenes with curved surfaces, fp32: the live rays of a workgroup in one pool of 64-ray blocks in
+                                  LDS, shared by its sixteen waves (k_trace_pool), instead of a list per wave: -1 auto, 0 never, 1 whenever it fits */
 };
 int ot_set_option(ot_ctx* ctx, int32_t option, int32_t value);
 

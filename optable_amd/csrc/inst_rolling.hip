@@ -41,6 +41,12 @@ template <> RollingKern<T, OUT> rolling_kernel<T, OUT>(int fr, bool flat, bool l
             return lds ? k_trace_rolling<T, F_ALL, true, true, false, OUT> : k_trace_rolling<T, F_ALL, false, true, false, OUT>;
     }
 }
+template <> RollingKern<T, OUT> pool_kernel<T, OUT>(int fr) {
+    if constexpr (sizeof(T) == 4) {
+        if (fr == 2) return k_trace_pool<T, FD, true, OUT>;
+    }
+    return nullptr;
+}
 #if !OT_APPEND
 template <> int rolling_max_threads<T>(int fr, bool flat, bool rec_lds) {
     if (flat) return rec_lds ? rolling_threads<T, FR | F_FLAT, true>() : rolling_threads<T, FR | F_FLAT, false>();

@@ -680,6 +680,326 @@ __global__ __launch_bounds__((rolling_threads<T, F, REC_LDS>()), (rolling_minw<T
 #endif
 }
 
+// k_trace_pool — generation-pure tracing with the live rays of a WORKGROUP in one pool of blocks (single precision, the
+// curved-surface preset: cfg 5).
+// k_trace_rolling's generation-pure lists are private to a wave: 256 rays that die at different times, worked off in
+// rounds, every round ending in a partial pass — 53 lanes per pass on cfg 5 — and only the first 128 positions of a list
+// have their records in LDS.  Here the sixteen waves of the workgroup share ONE pool of NB blocks in LDS; a block holds up
+// to 64 rays that are all on the same segment index (its generation), their records with them:
+//     block = [ray index][ox oy oz dx dy dz qr qi I n pl wl][meta], 14 x 64 words
+// and a state word (count | generation << 8 | LOCKED).  A wave that needs work looks at all state words at once (one lane
+// per block), takes the block of the LOWEST generation with the fewest rays (A), and a second block of the same generation
+// (B) to fill its lanes from: all of A's rays and as many from the END of B as make 64.  Both are locked with a
+// compare-and-swap; B is released, shortened, as soon as the pass has read its records; the survivors go back into A — one
+// generation on — and A is released.  Young generations first: a cohort that was filled later catches up with the older
+// ones and merges with them, so partners are rarely missing.  Free blocks are refilled from the ticket queue several at a
+// time (one atomic for the lot), which is what makes cohorts.
+// No wave ever waits for another one while it has anything to do: a wave that finds nothing to trace and nothing to
+// fill sleeps a few hundred cycles and looks again (somebody holds the blocks that are left), and leaves when the queue
+// is exhausted and every block is free.
+// Ordering between waves needs no waiting: the LDS executes the instructions of one wave in the order they were issued, so
+// a state word written after a block's records is seen after them, and records read before a state word is written have
+// been read when it lands; the fences below are wave-scope (they only keep the compiler from reordering).  A
+// workgroup-scope release would also wait for the pass's fourteen global segment stores — 1.8x the pass time.
+// Passes are generation-pure by construction, so the nearest-hit search runs as in k_trace_rolling; nothing about a ray's
+// arithmetic depends on which wave or pass carries it: results are bit-identical (tests/test_gpu_pool.py).
+static constexpr int POOL_BLOCK_WORDS = 14 * 64;
+static constexpr uint32_t POOL_LOCKED = 0x80000000u;
+__device__ __forceinline__ int wave_all_min_i32(int v) {  // DPP steps of wave_incl_max_i32, minimum; the result of lane 63 to all
+    constexpr int HIGHEST = 0x7fffffff;
+    v = min(v, __builtin_amdgcn_update_dpp(HIGHEST, v, 0x111, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(HIGHEST, v, 0x112, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(HIGHEST, v, 0x114, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(HIGHEST, v, 0x118, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(HIGHEST, v, 0x142, 0xa, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(HIGHEST, v, 0x143, 0xc, 0xf, false));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+template <class T, uint32_t F, bool NT, class OUT>
+__global__ __launch_bounds__(1024, 1) void k_trace_pool(
+    SceneBlob blob, T unit, RaysT<T> in, int64_t n, int32_t K, OUT out, AppendCtl ac, int32_t* __restrict__ seg_count, int32_t* counts,
+    int32_t n_classes, WaveScratch<T> ws, int32_t NB, int32_t capl_arg, unsigned long long* queue, int32_t mix, int32_t flat_cap) {
+    static_assert(sizeof(T) == 4, "a double-precision record is 100 bytes: too few blocks would fit");
+    static_assert((F & (F_LIMIT | F_FLAT)) == 0, "no count classes, no pair queue");
+    constexpr bool APPEND = std::is_same<OUT, SegPlanes<T>>::value;
+    struct LeadArgs {  // the parameter list: the layout of the kernel-argument segment (see k_trace_rolling)
+        SceneBlob blob; T unit; RaysT<T> in; int64_t n; int32_t K; OUT out; AppendCtl ac; int32_t* seg_count; int32_t* counts;
+        int32_t n_classes; WaveScratch<T> ws; int32_t CAP; int32_t capl; unsigned long long* queue; int32_t mix; int32_t flat_cap;
+    };
+    (void)ac; (void)seg_count; (void)queue; (void)in; (void)ws; (void)capl_arg; (void)mix; (void)flat_cap;
+    typedef const __attribute__((address_space(4))) RaysT<T>* RaysArgPtr;
+    const RaysArgPtr in_arg = (RaysArgPtr)((uintptr_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(LeadArgs, in));
+    extern __shared__ __align__(16) uint32_t lds[];
+    for (int w = threadIdx.x; w < blob.n_words; w += blockDim.x) lds[w] = blob.words[w];
+    uint32_t* const state = lds + ((blob.n_words + 3) & ~3);   // [64] block states, then [4] control words
+    uint32_t* const ctl = state + 64;                          // [0] the ticket queue is exhausted; [1], [2], [4..11]: append layout, see claim()
+    uint32_t* const pool = ctl + 16;                           // NB blocks of POOL_BLOCK_WORDS
+    if (threadIdx.x < 80) state[threadIdx.x] = 0;
+    const int lane = threadIdx.x & 63;
+    __syncthreads();  // the only workgroup barrier: image staged, pool empty
+    const Scene<T> sc = bind_scene<T>(lds, blob, unit);
+    // Append layout: slots are claimed per WORKGROUP.  A ray changes waves from pass to pass; if every wave filled chunks
+    // of its own (as in k_trace_rolling), the records of one ray would not lie at increasing addresses, and "a stable
+    // sort by ray is the reference's order" (include/optable_hip.h) would not hold.  So the workgroup fills ONE chunk
+    // of wg_chunk slots at a time: ctl[1] = (epoch << 20 | next free offset), bumped by every pass with one LDS atomic;
+    // the pass whose claim crosses the end of the chunk marks what is left of it as holes, claims the next chunk from the
+    // device-wide cursor, enters its base in ctl[4 + 2 * (epoch & 3)] and opens the new epoch; passes that claimed beyond
+    // the end wait for that (a few microseconds, for a wave that itself waits for nobody).  Claims within a workgroup are
+    // in time order and chunks are claimed in address order: segment k + 1 of a ray, whose pass begins after the pass of
+    // segment k has released its block, lies behind segment k.
+    const uint32_t wg_chunk = APPEND ? (uint32_t)min(16 * OT_KARG(ac.chunk), 1 << 19) : 0u;
+    if (APPEND && threadIdx.x == 0) ctl[1] = wg_chunk;  // epoch 0 is already full: the first claim opens the first chunk
+    auto chunk_base = [&](uint32_t epoch) -> int64_t {
+        const uint32_t lo = __hip_atomic_load(&ctl[4 + 2 * (epoch & 3u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint32_t hi = __hip_atomic_load(&ctl[5 + 2 * (epoch & 3u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return (int64_t)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)hi) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)lo));
+    };
+    auto claim = [&](int take) -> int64_t {  // first of `take` consecutive slots (wave-uniform)
+      if constexpr (APPEND) {
+        for (int tries = 0; tries < (1 << 16); ++tries) {
+            uint32_t old = 0;
+            if (lane == 0) old = atomicAdd(&ctl[1], (uint32_t)take);
+            old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+            const uint32_t epoch = old >> 20, off = old & 0xfffffu;
+            if (off + (uint32_t)take <= wg_chunk) return chunk_base(epoch) + (int64_t)off;
+            if (off <= wg_chunk) {  // this claim crosses the end of the chunk
+                if (off < wg_chunk) {
+                    const int64_t hole = chunk_base(epoch) + (int64_t)off + lane;  // fewer than `take` <= 64 slots are left
+                    if (off + (uint32_t)lane < wg_chunk && hole < OT_KARG(ac.capacity)) ray_plane(out)[hole] = -1;
+                }
+                unsigned long long nb = 0;
+                if (lane == 0) nb = atomicAdd(OT_KARG(ac.cursor), (unsigned long long)wg_chunk);
+                const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(nb & 0xffffffffull)), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(nb >> 32));
+                if (lane == 0) {
+                    __hip_atomic_store(&ctl[4 + 2 * ((epoch + 1u) & 3u)], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_store(&ctl[5 + 2 * ((epoch + 1u) & 3u)], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (lane == 0) __hip_atomic_store(&ctl[1], ((epoch + 1u) << 20) | (uint32_t)take, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                return (int64_t)(((unsigned long long)hi << 32) | lo);
+            }
+            for (int w = 0; w < (1 << 16); ++w) {  // claimed beyond the end: the wave that crossed it is opening the next chunk
+                if ((__hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 20) != epoch) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        return OT_KARG(ac.capacity);  // (unreachable; a claim that never succeeds drops its records instead of writing anywhere)
+      } else {
+        return 0;
+      }
+    };
+    int idle = 0;
+#ifdef OT_STAMP  // diagnostic build: [0] passes [1] rays in them [2] sleeps [3] lost locks [4] fills [5] blocks filled [6] passes with a second block
+    unsigned long long pc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [7] cycles between passes, [8] cycles in passes
+    unsigned long long pt = __builtin_amdgcn_s_memtime();
+#define OT_POOL_COUNT(k, v) pc[k] += (v)
+#define OT_POOL_TIME(k) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); pc[k] += _t - pt; pt = _t; } while (0)
+#else
+#define OT_POOL_COUNT(k, v) do {} while (0)
+#define OT_POOL_TIME(k) do {} while (0)
+#endif
+    for (;;) {
+        // ---- choose: every lane looks at one block
+        const uint32_t st = lane < NB ? __hip_atomic_load(&state[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : POOL_LOCKED;
+        const int cnt_l = (int)(st & 127u), gen_l = (int)((st >> 8) & 0xfffffu);
+        const bool elig = !(st & POOL_LOCKED) && cnt_l > 0;
+        const int key = elig ? ((gen_l << 7) | cnt_l) : 0x7fffffff;
+        const int kmin = wave_all_min_i32(key);
+        if (kmin == 0x7fffffff) {  // nothing to trace right now
+            const unsigned long long freeb = __ballot(lane < NB && st == 0u);
+            const bool exhausted = __hip_atomic_load(&ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u;
+            if (freeb != 0ull && !exhausted) {
+                // ---- fill: lock the free blocks, ONE ticket atomic for all of them, 64 consecutive rays each
+                bool got = false;
+                if ((freeb >> lane) & 1ull) got = atomicCAS(&state[lane], 0u, POOL_LOCKED) == 0u;
+                const unsigned long long gm = __ballot(got);
+                const int m = __popcll(gm);
+                if (m > 0) {
+                    unsigned long long first = 0;
+                    if (lane == 0) first = atomicAdd(OT_KARG(queue), 64ull * (unsigned long long)m);
+                    first = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(first >> 32)) << 32) |
+                            (uint32_t)__builtin_amdgcn_readfirstlane((int)(first & 0xffffffffull));
+                    const unsigned long long n_now = (unsigned long long)n;
+                    unsigned long long left = gm;
+                    int j = 0;
+                    while (left) {  // wave-uniform: the blocks this wave locked, in index order
+                        const int b = __builtin_ctzll(left);
+                        left &= left - 1ull;
+                        const unsigned long long start = first + 64ull * (unsigned long long)j;
+                        const int c = start >= n_now ? 0 : (int)(n_now - start < 64ull ? n_now - start : 64ull);
+                        if (lane < c) pool[b * POOL_BLOCK_WORDS + lane] = (uint32_t)start + (uint32_t)lane;
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        if (lane == 0) __hip_atomic_store(&state[b], (uint32_t)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // generation 0, unlocked (0 rays: free)
+                        ++j;
+                    }
+                    if (first + 64ull * (unsigned long long)m >= n_now && lane == 0)
+                        __hip_atomic_store(&ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    idle = 0;
+                    OT_POOL_COUNT(4, 1);
+                    OT_POOL_COUNT(5, m);
+                }
+                continue;
+            }
+            if (exhausted && !__any(lane < NB && st != 0u)) break;  // nothing left anywhere
+            // blocks exist but other waves hold them (or are filling them): look again shortly
+            __builtin_amdgcn_s_sleep(4);
+            OT_POOL_COUNT(2, 1);
+            if (++idle > (1 << 22)) break;  // (a wave never holds a block longer than one pass: this cannot trigger; it bounds a bug)
+            continue;
+        }
+        idle = 0;
+        const int gen = kmin >> 7, cntA = kmin & 127;
+        const int A = __builtin_ctzll(__ballot(key == kmin));
+        int B = -1, cntB = 0, takeB = 0;
+        if (cntA < 64) {
+            const int key2 = (elig && gen_l == gen && lane != A) ? cnt_l : 0x7fffffff;
+            const int k2 = wave_all_min_i32(key2);
+            if (k2 != 0x7fffffff) {
+                B = __builtin_ctzll(__ballot(key2 == k2));
+                cntB = k2;
+                takeB = min(64 - cntA, cntB);
+            }
+        }
+        // lock A (and B): the states must still be what this wave saw
+        bool mine = true;
+        if (lane == A || lane == B) mine = atomicCAS(&state[lane], st, st | POOL_LOCKED) == st;
+        const unsigned long long failed = __ballot(!mine);
+        if (failed != 0ull) {  // somebody was faster: give back what was locked and choose again
+            if ((lane == A || lane == B) && mine) __hip_atomic_store(&state[lane], st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            OT_POOL_COUNT(3, 1);
+            continue;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // ---- one pass: all of A, the last takeB rays of B
+        {
+            const int take = cntA + takeB;
+            OT_POOL_TIME(7);
+            OT_POOL_COUNT(0, 1);
+            OT_POOL_COUNT(1, take);
+            OT_POOL_COUNT(6, B >= 0 ? 1 : 0);
+            const bool entry = lane < take;
+            const bool from_b = lane >= cntA;
+            const uint32_t* src = pool + (from_b ? B * POOL_BLOCK_WORDS + (cntB - takeB) + (lane - cntA) : A * POOL_BLOCK_WORDS + lane);
+            const int32_t k = gen;
+            int32_t i = 0;
+            RayState<T> r = {};
+            int32_t fl = 0;
+            if (entry) {
+                i = (int32_t)src[0];
+                if (k == 0) {  // first segment: the caller's arrays
+                    RaysArgPtr ip = in_arg;
+                    asm volatile("" : "+s"(ip));
+                    RaysT<T> in_now;
+                    {
+                        static_assert(sizeof(RaysT<T>) == 15 * sizeof(uint64_t), "RaysT is fifteen pointers");
+                        const __attribute__((address_space(4))) uint64_t* w = (const __attribute__((address_space(4))) uint64_t*)ip;
+                        uint64_t words[15];
+#pragma unroll
+                        for (int q = 0; q < 15; ++q) words[q] = w[q];
+                        __builtin_memcpy(&in_now, words, sizeof(in_now));
+                    }
+                    fl = in_now.flags[i];
+                    r.ox = ld_once(in_now.ox + i); r.oy = ld_once(in_now.oy + i); r.oz = ld_once(in_now.oz + i);
+                    r.dx = ld_once(in_now.dx + i); r.dy = ld_once(in_now.dy + i); r.dz = ld_once(in_now.dz + i);
+                    r.len = in_now.len ? in_now.len[i] : Num<T>::inf();
+                    r.has_q = (fl & OT_RAY_HAS_Q) != 0;
+                    r.last = (int32_t)((uint32_t)fl >> 8) - 1;
+                    if ((uint32_t)r.last >= (uint32_t)sc.n_nodes) r.last = -1;
+                    fl &= 0xff;
+                    r.wl = ld_once(in_now.wl + i); r.qr = ld_once(in_now.qr + i); r.qi = ld_once(in_now.qi + i);
+                    r.I = ld_once(in_now.I + i); r.n = ld_once(in_now.n + i); r.pl = ld_once(in_now.pl + i);
+                } else {
+                    const T* rec = reinterpret_cast<const T*>(src);
+                    r.ox = rec[64]; r.oy = rec[2 * 64]; r.oz = rec[3 * 64];
+                    r.dx = rec[4 * 64]; r.dy = rec[5 * 64]; r.dz = rec[6 * 64];
+                    r.qr = rec[7 * 64]; r.qi = rec[8 * 64]; r.I = rec[9 * 64];
+                    r.n = rec[10 * 64]; r.pl = rec[11 * 64]; r.wl = rec[12 * 64];
+                    const int32_t meta = (int32_t)src[13 * 64];
+                    r.last = (meta >> 8) - 1;
+                    r.has_q = meta & OT_RAY_HAS_Q;
+                    r.len = Num<T>::inf();
+                }
+            }
+            // B's rays are in registers: give it back, shorter (its remaining rays sit where they sat)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (B >= 0 && lane == 0) {
+                const int rest = cntB - takeB;
+                __hip_atomic_store(&state[B], rest > 0 ? (uint32_t)((gen << 8) | rest) : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            const bool active = entry && !(fl & OT_RAY_DEAD);
+            const GateCtx gate = {counts, n_classes, 0, nullptr, nullptr, 0, 0};
+            const Hit<T> h = nearest_hit<T, F, GATE_PLAIN>(sc, r, active, gate);
+            const bool hit = active && h.node >= 0;
+            int64_t slot = APPEND ? 0 : (int64_t)k * n + (int64_t)i;
+            bool room = true;
+            if constexpr (APPEND) {
+                slot = claim(take) + lane;  // the entries of a pass are its first `take` lanes
+                room = slot < OT_KARG(ac.capacity);
+                if (entry && room) store_segment<T, NT>(out, slot, r, hit ? h.t : r.len, (int32_t)i, hit ? leaf_id_of<T, F>(sc, h.node) : (active ? -1 : -2));
+            } else {
+                typedef const __attribute__((address_space(4))) uint64_t* ArgWords;
+                ArgWords w = (ArgWords)((uintptr_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(LeadArgs, out));
+                asm volatile("" : "+s"(w));
+                static_assert(sizeof(SegsT<T>) == 14 * sizeof(uint64_t), "SegsT is fourteen pointers");
+                uint64_t words[14];
+#pragma unroll
+                for (int q = 0; q < 14; ++q) words[q] = w[q];
+                SegsT<T> out_now;
+                __builtin_memcpy(&out_now, words, sizeof(out_now));
+                if (entry) store_segment<T, NT>(out_now, slot, r, hit ? h.t : r.len, (int32_t)i, hit ? leaf_id_of<T, F>(sc, h.node) : (active ? -1 : -2));
+            }
+            bool survive = false;
+            RayState<T> child = {};
+            if (entry) {
+                int32_t used = k + 1;
+                if (hit) {
+                    MatCache<T> mc = {T(1)};
+                    if constexpr (F & F_REFRACT) mc = make_matcache<T, F>(sc, r.wl);
+                    const int nk = interact<T, F, 1>(sc, r, h, &child, mc);
+                    if (nk == 1) survive = k + 1 < K;
+                    else if (nk > 1) used = -(k + 1);  // the tree branches here: the caller re-traces it generation by generation
+                }
+                if (!survive) OT_KARG(seg_count)[i] = used;
+            }
+            const unsigned long long mk = __ballot(survive);
+            if (survive) {  // into A, from its first position on (every ray of A is in this pass's registers)
+                uint32_t* dst = pool + A * POOL_BLOCK_WORDS + __popcll(mk & ((1ull << lane) - 1ull));
+                T* rec = reinterpret_cast<T*>(dst);
+                dst[0] = (uint32_t)i;
+                rec[64] = child.ox; rec[2 * 64] = child.oy; rec[3 * 64] = child.oz;
+                rec[4 * 64] = child.dx; rec[5 * 64] = child.dy; rec[6 * 64] = child.dz;
+                rec[7 * 64] = child.qr; rec[8 * 64] = child.qi; rec[9 * 64] = child.I;
+                rec[10 * 64] = child.n; rec[11 * 64] = child.pl; rec[12 * 64] = r.wl;
+                dst[13 * 64] = (uint32_t)((r.has_q ? OT_RAY_HAS_Q : 0) | ((child.last + 1) << 8));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (lane == 0) {
+                const int left = __popcll(mk);
+                __hip_atomic_store(&state[A], left > 0 ? (uint32_t)(((gen + 1) << 8) | left) : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            OT_POOL_TIME(8);
+        }
+    }
+    if constexpr (APPEND) {  // the last wave to leave marks the unused tail of the workgroup's last chunk: holes
+        uint32_t gone = 0;
+        if (lane == 0) gone = atomicAdd(&ctl[2], 1u);
+        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)gone) + 1u == (blockDim.x >> 6)) {
+            const uint32_t last = __hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t epoch = (uint32_t)__builtin_amdgcn_readfirstlane((int)last) >> 20, off = (uint32_t)__builtin_amdgcn_readfirstlane((int)last) & 0xfffffu;
+            if (off < wg_chunk) {
+                const int64_t b = chunk_base(epoch);
+                int32_t* rp = ray_plane(out);
+                for (int64_t s = b + off + lane; s < b + wg_chunk; s += 64)
+                    if (s < OT_KARG(ac.capacity)) rp[s] = -1;
+            }
+        }
+    }
+#ifdef OT_STAMP
+    OT_POOL_TIME(7);
+    if (lane == 0) for (int q = 0; q < 10; ++q) atomicAdd(&queue[8 + q], pc[q]);
+#endif
+}
+
 // k_stream_ceiling: the fused kernel's memory traffic with no tracing — reads one ray record,
 // writes K segment records per ray through the same SoA streams.  What this access pattern can
 // reach on the device; reported next to the trace kernel (bench.py).

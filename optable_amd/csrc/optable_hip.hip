@@ -82,6 +82,7 @@ struct ot_ctx {
     struct RollingPlan { uint64_t epoch = 0; int wpb = 4, per_cu = 1; int32_t cap = 128, capl = 0; bool lds = false, rec_lds = false; size_t lds_bytes = 0; };
     RollingPlan plan[2][2];  // [precision][output layout]
     uint64_t plan_epoch = 1;
+    int32_t opt_pool = -1;       // curved-surface scenes, fp32: workgroup-wide block pool (-1 auto, 0 never, 1 whenever it fits)
     int32_t opt_rec_lds = -1;    // pair-queue scenes: records of the live rays in LDS (-1 auto, 0 never, 1 whenever it fits)
     int32_t opt_list_cap = 128;  // k_trace_rolling: live rays per wave (cfg 3: 128 beats 256 and 512)
     int32_t opt_flat = 1;  // fp32 planar top-level-grid scenes: wave-wide pair queue (flat_grid_hit)
@@ -676,6 +677,42 @@ static int launch_rolling(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, 
     // pass over the global part waits for its loads behind the segment stores of the pass before (one in-order counter):
     // cfg 5 fp32, append layout, 16 waves per CU: 14.9 ms at 128, 13.5 at 256, 16+ at 384 and beyond.
     const int32_t cap0 = mix ? c->opt_list_cap : (c->opt_list_cap_pure > 0 ? c->opt_list_cap_pure : 256);
+    // Generation-pure scenes of the curved-surface preset, single precision, append layout: the workgroup-wide block pool
+    // (k_trace_pool) when at least 24 blocks of 64 records fit next to the image (cfg 5: 15 KB image, 41 blocks; 12.1 ms
+    // against 13.8 with the per-wave lists).  Not for the [k][ray] slots unless asked for (OT_OPT_BLOCK_POOL = 1): blocks
+    // that merge mix rays of many tickets, a pass then stores 64 scattered elements per plane instead of runs (20 ms
+    // against 14.4).
+    if (!mix && !f64 && img_fits && (c->opt_pool > 0 || (c->opt_pool < 0 && append)) && c->opt_rec_lds != 0) {
+        const auto kp = pool_kernel<T, OUT>(fr);
+        const size_t fixed = img + (64 + 16) * sizeof(uint32_t);
+        const int64_t nb_fit = fixed < 158 * 1024 ? (int64_t)((158 * 1024 - fixed) / (POOL_BLOCK_WORDS * 4)) : 0;
+        const int32_t NB = (int32_t)(nb_fit > 64 ? 64 : nb_fit);
+        if (kp && NB >= (c->opt_pool > 0 ? 16 : 24)) {
+            const size_t lds_p = fixed + (size_t)NB * POOL_BLOCK_WORDS * 4;
+            HIP_TRY(hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p));
+            const int64_t want = (n + 1023) / 1024;
+            const int gridp = (int)(want < c->n_cus ? want : c->n_cus);
+            if (c->blocked.ensure(256)) return fail(OT_ERR_HIP, "hipMalloc of the ticket counter failed");
+            c->blocked_queue_off = 0;
+            unsigned long long* queue = (unsigned long long*)c->blocked.p;
+#ifdef OT_STAMP
+            HIP_TRY(hipMemsetAsync(queue, 0, 24 * sizeof(unsigned long long), c->stream));
+#else
+            HIP_TRY(hipMemsetAsync(queue, 0, sizeof(unsigned long long), c->stream));
+#endif
+            if (append) HIP_TRY(hipMemsetAsync(ac.cursor, 0, sizeof(unsigned long long), c->stream));
+            hipEvent_t ev0, ev1;
+            int rc = timing_pair(c, &ev0, &ev1);
+            if (rc) return rc;
+            WaveScratch<T> ws = {nullptr, 0};
+            hipExtLaunchKernelGGL(kp, dim3(gridp), dim3(1024), (uint32_t)lds_p, c->stream, ev0, ev1, 0u, blob, (T)c->unit, view<T>(rays), n, K, out,
+                                  ac, seg_count, counts, n_classes, ws, NB, 0, queue, 0, 0);
+            HIP_TRY(hipGetLastError());
+            const int32_t shape[8] = {2, 1024, 1, gridp, (int32_t)lds_p, NB * 64, 0, 2 | 8 | (append ? 4 : 0)};  // bit 3: block pool
+            for (int q = 0; q < 8; ++q) c->last_launch[q] = shape[q];
+            return 0;
+        }
+    }
     ot_ctx::RollingPlan& plan = c->plan[f64 ? 1 : 0][append ? 1 : 0];
     if (plan.epoch != c->plan_epoch) {
         struct Try { int waves = 0, wpb = 0, per_cu = 0; int32_t cap = 0, capl = 0; size_t lds = 0; };
@@ -1104,6 +1141,9 @@ int ot_set_option(ot_ctx* c, int32_t option, int32_t value) {
         case OT_OPT_GEN_REUSE:
             if (value < -1 || value > 1) return fail(OT_ERR_INVALID, "OT_OPT_GEN_REUSE takes -1 (auto), 0 or 1");
             c->opt_gen_reuse = value; return 0;
+        case OT_OPT_BLOCK_POOL:
+            if (value < -1 || value > 1) return fail(OT_ERR_INVALID, "OT_OPT_BLOCK_POOL takes -1 (auto), 0 or 1");
+            c->opt_pool = value; return 0;
         case OT_OPT_INSTANCING: c->opt_instancing = value != 0; return 0;  // takes effect at the next ot_scene_upload
         case OT_OPT_BLOCKS_PER_CU:
             if (value < 0 || value > 65536) return fail(OT_ERR_INVALID, "OT_OPT_BLOCKS_PER_CU out of range");

@@ -37,6 +37,8 @@ template <class T, class OUT> FusedKern<T, OUT> fused_kernel(int fi, bool lds, b
 // the sparse [k][ray] slots of mixed lists want plain stores (partial lines merge in L2), everything else streams.
 template <class T, class OUT> RollingKern<T, OUT> rolling_kernel(int fr, bool flat, bool lds, bool rec_lds);
 template <class T> int rolling_max_threads(int fr, bool flat, bool rec_lds);
+// k_trace_pool (same arguments; CAP carries the number of blocks): the curved-surface preset FD in single precision, else nullptr
+template <class T, class OUT> RollingKern<T, OUT> pool_kernel(int fr);
 // k_gen_pass / k_gen_probe: small = the planar preset FB instead of F_ALL
 template <class T> GenKern<T> gen_kernel(bool small, bool lds, bool emit);
 template <class T> ProbeKern<T> probe_kernel(bool lds);
@@ -47,6 +49,8 @@ template <class T> ProbeKern<T> probe_kernel(bool lds);
     template <> RollingKern<T, SegsT<T>> rolling_kernel<T, SegsT<T>>(int, bool, bool, bool);          \
     template <> RollingKern<T, SegPlanes<T>> rolling_kernel<T, SegPlanes<T>>(int, bool, bool, bool);  \
     template <> int rolling_max_threads<T>(int, bool, bool);                       \
+    template <> RollingKern<T, SegsT<T>> pool_kernel<T, SegsT<T>>(int);            \
+    template <> RollingKern<T, SegPlanes<T>> pool_kernel<T, SegPlanes<T>>(int);    \
     template <> GenKern<T> gen_kernel<T>(bool, bool, bool);                        \
     template <> ProbeKern<T> probe_kernel<T>(bool);
 OT_DECLARE_TABLES(double)

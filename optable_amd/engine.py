@@ -126,6 +126,10 @@ class Engine:
         may leave the tail of its last chunk (512 slots) unused.  Call after a trace of the same scene (the launch shape
         is taken from it); `sum(|count|)` of that trace is the record count."""
         info = self.last_launch()
+        if info["kernel"] == 2 and info["pair_queue"] & 8:
+            # block pool: a workgroup fills one chunk of 16 x 512 slots at a time, loses at most 63 slots where a pass
+            # crosses into the next chunk and leaves the tail of its last chunk unused
+            return (int(n_records) + int(n_records) // 128 + (16 * 512 + 64) * max(info["workgroups"], 1) + 63) // 64 * 64
         waves = max(info["workgroups"] * info["threads"] // 64, 1) if info["kernel"] == 2 else 256 * 16
         return (int(n_records) + 512 * waves + 63) // 64 * 64
 
@@ -134,7 +138,9 @@ class Engine:
     def _trace_append(self, rays, K, out, counts, capacity):
         n = rays.n
         if capacity is None:
-            capacity = n * K + min(self.APPEND_SLACK, 512 * ((n + 63) // 64 + 1))
+            # holes: the tail of every wave's last chunk of 512 slots (one wave per ticket of 64 rays at most); with the
+            # block pool (curved scenes, fp32) 63 slots per chunk of 8192 and the last chunk of every workgroup
+            capacity = n * K + n * K // 128 + min(self.APPEND_SLACK, max(512 * ((n + 63) // 64 + 1), (16 * 512 + 64) * ((n + 1023) // 1024)))
         if out is None:
             out = SegmentBatch(capacity, rays.precision, rays.device, block=True)
         elif out.block is None or out.precision != rays.precision:

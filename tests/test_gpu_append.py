@@ -62,7 +62,7 @@ def test_append_layout_equals_slots(case, precision):
     assert (ray >= 0).sum() == len(a["ray"]) == int(np.abs(a["count"]).sum())
     info = eng.last_launch()
     waves = info["workgroups"] * info["threads"] // 64
-    assert (ray < 0).sum() < 512 * waves
+    assert (ray < 0).sum() < 512 * waves + len(ray) // 128 + 64  # (block pool: up to 63 more where a pass crosses into the workgroup's next chunk)
     # a stable sort by ray is the reference's order: within a ray the records lie at increasing slots in segment order
     keep = ray >= 0
     order = np.argsort(ray[keep], kind="stable")
