@@ -734,10 +734,19 @@ __global__ __launch_bounds__(1024, 1) void k_trace_pool(
     uint32_t* const state = lds + ((blob.n_words + 3) & ~3);   // [64] block states, then [4] control words
     uint32_t* const ctl = state + 64;                          // [0] the ticket queue is exhausted; [1], [2], [4..11]: append layout, see claim()
     uint32_t* const pool = ctl + 16;                           // NB blocks of POOL_BLOCK_WORDS
-    if (threadIdx.x < 80) state[threadIdx.x] = 0;
+    if (threadIdx.x < 80) state[threadIdx.x] = threadIdx.x == 65 && APPEND ? (uint32_t)min(16 * OT_KARG(ac.chunk), 1 << 19) : 0u;  // (ctl[1]: see claim())
     const int lane = threadIdx.x & 63;
     __syncthreads();  // the only workgroup barrier: image staged, pool empty
     const Scene<T> sc = bind_scene<T>(lds, blob, unit);
+#ifdef OT_STAMP  // diagnostic build: [0] passes [1] rays in them [2] sleeps [3] lost locks [4] fills [5] blocks filled [6] passes with a second block [9] sleeps inside claim()
+    unsigned long long pc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [7] cycles between passes, [8] cycles in passes
+    unsigned long long pt = __builtin_amdgcn_s_memtime();
+#define OT_POOL_COUNT(k, v) pc[k] += (v)
+#define OT_POOL_TIME(k) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); pc[k] += _t - pt; pt = _t; } while (0)
+#else
+#define OT_POOL_COUNT(k, v) do {} while (0)
+#define OT_POOL_TIME(k) do {} while (0)
+#endif
     // Append layout: slots are claimed per WORKGROUP.  A ray changes waves from pass to pass; if every wave filled chunks
     // of its own (as in k_trace_rolling), the records of one ray would not lie at increasing addresses, and "a stable
     // sort by ray is the reference's order" (include/optable_hip.h) would not hold.  So the workgroup fills ONE chunk
@@ -748,7 +757,7 @@ __global__ __launch_bounds__(1024, 1) void k_trace_pool(
     // in time order and chunks are claimed in address order: segment k + 1 of a ray, whose pass begins after the pass of
     // segment k has released its block, lies behind segment k.
     const uint32_t wg_chunk = APPEND ? (uint32_t)min(16 * OT_KARG(ac.chunk), 1 << 19) : 0u;
-    if (APPEND && threadIdx.x == 0) ctl[1] = wg_chunk;  // epoch 0 is already full: the first claim opens the first chunk
+    // (ctl[1] starts as epoch 0, offset wg_chunk — a full chunk: the first claim opens the first real one)
     auto chunk_base = [&](uint32_t epoch) -> int64_t {
         const uint32_t lo = __hip_atomic_load(&ctl[4 + 2 * (epoch & 3u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const uint32_t hi = __hip_atomic_load(&ctl[5 + 2 * (epoch & 3u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -779,8 +788,10 @@ __global__ __launch_bounds__(1024, 1) void k_trace_pool(
                 return (int64_t)(((unsigned long long)hi << 32) | lo);
             }
             for (int w = 0; w < (1 << 16); ++w) {  // claimed beyond the end: the wave that crossed it is opening the next chunk
-                if ((__hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 20) != epoch) break;
+                const uint32_t now = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if ((now >> 20) != epoch) break;
                 __builtin_amdgcn_s_sleep(1);
+                OT_POOL_COUNT(9, 1);
             }
         }
         return OT_KARG(ac.capacity);  // (unreachable; a claim that never succeeds drops its records instead of writing anywhere)
@@ -789,21 +800,15 @@ __global__ __launch_bounds__(1024, 1) void k_trace_pool(
       }
     };
     int idle = 0;
-#ifdef OT_STAMP  // diagnostic build: [0] passes [1] rays in them [2] sleeps [3] lost locks [4] fills [5] blocks filled [6] passes with a second block
-    unsigned long long pc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [7] cycles between passes, [8] cycles in passes
-    unsigned long long pt = __builtin_amdgcn_s_memtime();
-#define OT_POOL_COUNT(k, v) pc[k] += (v)
-#define OT_POOL_TIME(k) do { const unsigned long long _t = __builtin_amdgcn_s_memtime(); pc[k] += _t - pt; pt = _t; } while (0)
-#else
-#define OT_POOL_COUNT(k, v) do {} while (0)
-#define OT_POOL_TIME(k) do {} while (0)
-#endif
     for (;;) {
         // ---- choose: every lane looks at one block
         const uint32_t st = lane < NB ? __hip_atomic_load(&state[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : POOL_LOCKED;
         const int cnt_l = (int)(st & 127u), gen_l = (int)((st >> 8) & 0xfffffu);
         const bool elig = !(st & POOL_LOCKED) && cnt_l > 0;
-        const int key = elig ? ((gen_l << 7) | cnt_l) : 0x7fffffff;
+        // lowest generation first; among its blocks the first one from a starting point of this wave's own (sixteen waves
+        // that all went for "the smallest block" would fight over the same one and fifteen would choose again)
+        const int rot = (lane - 4 * (int)(threadIdx.x >> 6)) & 63;
+        const int key = elig ? ((gen_l << 6) | rot) : 0x7fffffff;
         const int kmin = wave_all_min_i32(key);
         if (kmin == 0x7fffffff) {  // nothing to trace right now
             const unsigned long long freeb = __ballot(lane < NB && st == 0u);
@@ -848,15 +853,15 @@ __global__ __launch_bounds__(1024, 1) void k_trace_pool(
             continue;
         }
         idle = 0;
-        const int gen = kmin >> 7, cntA = kmin & 127;
-        const int A = __builtin_ctzll(__ballot(key == kmin));
+        const int gen = kmin >> 6;
+        const int A = ((kmin & 63) + 4 * (int)(threadIdx.x >> 6)) & 63;
+        const int cntA = __builtin_amdgcn_readlane(cnt_l, A);
         int B = -1, cntB = 0, takeB = 0;
-        if (cntA < 64) {
-            const int key2 = (elig && gen_l == gen && lane != A) ? cnt_l : 0x7fffffff;
-            const int k2 = wave_all_min_i32(key2);
+        if (cntA < 64) {  // a second block of the same generation to fill the lanes from
+            const int k2 = wave_all_min_i32((elig && gen_l == gen && lane != A) ? rot : 0x7fffffff);
             if (k2 != 0x7fffffff) {
-                B = __builtin_ctzll(__ballot(key2 == k2));
-                cntB = k2;
+                B = (k2 + 4 * (int)(threadIdx.x >> 6)) & 63;
+                cntB = __builtin_amdgcn_readlane(cnt_l, B);
                 takeB = min(64 - cntA, cntB);
             }
         }

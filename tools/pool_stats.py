@@ -24,11 +24,11 @@ table.add_components(wl.components())
 eng.upload(table.compile())
 o, d, lam = wl.rays(n, 0)
 batch = RayBatch.from_arrays(o, d, wavelength=lam, q=1j * np.pi * W.W0**2 / lam, precision="f32")
-out = SegmentBatch(n * wl.max_segments, "f32", batch.device)
+out = None
 for _ in range(2):
-    eng.trace(batch, wl.max_segments, out=out)
+    out = eng.trace(batch, wl.max_segments, out=out, layout="append")
 eng.timing(True)
-eng.trace(batch, wl.max_segments, out=out)
+out = eng.trace(batch, wl.max_segments, out=out, layout="append")
 ms, cnt = eng.timing_read()
 eng.timing(False)
 print(eng.last_launch())
@@ -37,6 +37,8 @@ eng.lib.ot_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
 abi.check(eng.lib.ot_debug_stamps(eng._ctx, acc), eng.lib)
 passes, rays, sleeps, lost, fills, filled, with_b, t_between, t_pass = [int(x) for x in acc][:9]
 segs = int(out.count.abs().sum().item())
+claim_waits = int(acc[9])
+print(f"claim waits {claim_waits}")
 print(f"n={n}: {ms / cnt:.3f} ms (diagnostic build); {segs} segments in {passes} passes = {rays / max(passes, 1):.1f} rays per pass "
       f"({with_b / max(passes, 1):.2f} with a second block); {sleeps / max(passes, 1):.2f} sleeps and {lost / max(passes, 1):.2f} lost locks per pass; "
       f"{fills} fills of {filled / max(fills, 1):.1f} blocks; {t_pass / max(passes, 1):.0f} cycles per pass, {t_between / max(passes, 1):.0f} between passes (s_memtime, 100 MHz ticks)")
