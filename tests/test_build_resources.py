@@ -57,7 +57,7 @@ def test_library_stays_small(kernels):
 def test_rolling_kernel_reads_its_ray_pointers_where_the_code_object_puts_them(kernels):
     """kernels.h reads the caller's 15 ray pointers from the kernel-argument segment at offsetof(LeadArgs, in) = 56
     (SceneBlob 48 bytes, unit padded to 8): argument 2 of every k_trace_rolling instantiation must sit exactly there."""
-    rolling = [k for k in kernels if "k_trace_rolling" in k["name"]]
+    rolling = [k for k in kernels if "k_trace_rolling" in k["name"] or "k_trace_pool" in k["name"]]
     assert rolling
     for k in rolling:
         assert k["args"][0] == (0, 48) and k["args"][2] == (56, 120), (k["name"], k["args"][:3])
@@ -71,7 +71,8 @@ def test_rolling_kernel_argument_segment_is_laid_out_like_the_struct_the_kernel_
     the code object must place every explicit argument where a C struct of members of those sizes places it: members
     of 8 bytes and more (pointers, int64, structs of pointers) on 8, the 4-byte ones on 4, nothing packed or padded
     otherwise."""
-    rolling = [k for k in kernels if "k_trace_rolling" in k["name"]]
+    rolling = [k for k in kernels if "k_trace_rolling" in k["name"] or "k_trace_pool" in k["name"]]
+    assert any("k_trace_pool" in k["name"] for k in rolling)
     for k in rolling:
         explicit = k["args"][:16]
         assert len(explicit) == 16, (k["name"], len(k["args"]))
