@@ -335,7 +335,8 @@ template <class V> __device__ __forceinline__ V karg(size_t offset) {
 // Largest workgroup an instantiation may be launched with, and the workgroups per CU the compiler has to leave registers
 // for.  The waves never synchronise after staging, so the workgroup size only decides how many waves share one image:
 //   pair queue, records in LDS: LDS decides the occupancy — one 768-thread workgroup per CU (170 registers allowed, ~100 used);
-//   pair queue, records in global memory: five 256-thread workgroups = 5 waves per SIMD (96 registers: it uses 95), fp64 three;
+//   pair queue, records in global memory: four 256-thread workgroups = 4 waves per SIMD (128 registers; it needs ~110 since the
+//     grid header is kept in registers across passes), fp64 three;
 //   curved-surface preset (cfg 5) in fp32: one 1024-thread workgroup = 4 waves per SIMD on one image (128 registers);
 //   all features in fp64: 256 threads (255 registers); everything else 512 = 2 waves per SIMD.
 template <class T, uint32_t F, bool REC_LDS> constexpr int rolling_threads() {
@@ -344,7 +345,7 @@ template <class T, uint32_t F, bool REC_LDS> constexpr int rolling_threads() {
     if (sizeof(T) == 4 && F == (F_AABB | F_REFRACT | F_CURVED | F_GRID)) return 1024;
     return 512;
 }
-template <class T, uint32_t F, bool REC_LDS> constexpr int rolling_minw() { return ((F & F_FLAT) != 0 && !REC_LDS) ? (sizeof(T) == 4 ? 5 : 3) : 1; }
+template <class T, uint32_t F, bool REC_LDS> constexpr int rolling_minw() { return ((F & F_FLAT) != 0 && !REC_LDS) ? (sizeof(T) == 4 ? 4 : 3) : 1; }
 
 template <class T, uint32_t F, bool SCENE_IN_LDS, bool NT, bool REC_LDS, class OUT>
 __global__ __launch_bounds__((rolling_threads<T, F, REC_LDS>()), (rolling_minw<T, F, REC_LDS>())) void k_trace_rolling(
