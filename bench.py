@@ -268,7 +268,9 @@ def survey_config(oa, eng, name, device):
         del out
     if heavy:  # the same trace with the dense output: same records (tests/test_gpu_append.py), written in whole lines
         ta, cnta, segsa, slotsa, launcha = measure("append")
+        pooled = bool(launcha.get("pair_queue", 0) & 8)  # curved-surface scenes, fp32: the workgroup-wide block pool
         rec["append_layout"] = {"layout": "append: dense list in append order, a stable sort by ray is the reference's order (ot_trace_append_*)",
+                                "kernel": ("k_trace_pool" if pooled else "k_trace_rolling") + ("<double>" if wl.precision == "f64" else "<float>"),
                                 "output_slots": slotsa, "holes": slotsa - segsa, "launches": cnta, "ms_per_trace": ta * 1e3,
                                 "segments_per_s": segsa / ta, "intersections_per_s": segsa * scene.n_leaves / ta,
                                 "algorithmic_gbs": alg / ta / 1e9, "hbm_frac": alg / ta / 1e9 / HBM_PEAK_GBS, "launch": launcha}
@@ -557,7 +559,12 @@ def main():
         achieved = alg_bytes / avg_kernel_s / 1e9
         traffic = traffic_source = None
         tpath = os.path.join(ROOT, "profiles", "traffic_cfg2_f64.json")
-        if wl.name == "cfg2" and os.path.exists(tpath):  # PMC-measured HBM bytes exist for the bench workload only
+        r03 = committed_counters("cfg2") if wl.name == "cfg2" else None
+        if r03 and "hbm_bytes" in r03.get("derived", {}):  # this round's PMC passes of the bench workload, in the layout the bench runs
+            traffic = r03["derived"]["hbm_bytes"]
+            traffic_source = (f"{r03['source']}: rocprofv3 --pmc passes of this workload (FETCH_SIZE x 2 + WRITE_SIZE per launch of "
+                              f"{r03['kernel']}), committed — not re-measured by this run")
+        elif wl.name == "cfg2" and os.path.exists(tpath):
             traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
             traffic_source = ("profiles/traffic_cfg2_f64.json: rocprofv3 --pmc passes of this workload (FETCH_SIZE x 2 + "
                               "WRITE_SIZE, calibrated on k_stream_ceiling), committed — not re-measured by this run")
