@@ -34,6 +34,24 @@ def compare(table, batch, K, n, tag):
         err = np.abs(x[fin] - y[fin]) / np.maximum(1.0, np.abs(y[fin]))
         worst = max(worst, float(err.max()) if err.size else 0.0)
     flag = "" if (frac <= 0.002 and worst < 1e-7) else "   <<<<<<"
+    # the same scene in single precision through the heavy-scene kernels: the append layout (pair queue with markers, block
+    # pool, workgroup chunks — whatever the scene selects) must hold the very records of the [k][ray] slots
+    if scene.max_children <= 1 and not scene.limited:
+        from optable_amd.engine import get_engine
+        eng = get_engine()
+        b32 = batch.astype("f32")
+        eng.upload(scene)
+        try:
+            eng.set_option(abi.OPT_KERNEL, 2)
+            eng.set_option(abi.OPT_BLOCK_POOL, 0)
+            s32 = eng.trace(b32, K).to_host(reference_order=True)
+            eng.set_option(abi.OPT_BLOCK_POOL, -1)
+            a32 = eng.trace(b32, K, layout="append").to_host(reference_order=True)
+        finally:
+            eng.set_option(abi.OPT_KERNEL, 0)
+            eng.set_option(abi.OPT_BLOCK_POOL, -1)
+        if not all(np.array_equal(s32[f], a32[f]) for f in abi.SEG_FIELDS + ("ray", "surface")):
+            flag += "   <<<<<< fp32 append != slots"
     if flag: bad += 1
     print(f"{tag}: paths differ {frac*100:.3f}%  worst rel err {worst:.2e}{flag}", flush=True)
 N_SEEDS = int(os.environ.get('SEEDS', 0))  # SEEDS=n: n seeds per family instead of the default 40 / 30 / 20
