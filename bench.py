@@ -268,7 +268,7 @@ def survey_config(oa, eng, name, device):
         del out
     if heavy:  # the same trace with the dense output: same records (tests/test_gpu_append.py), written in whole lines
         ta, cnta, segsa, slotsa, launcha = measure("append")
-        pooled = bool(launcha.get("pair_queue", 0) & 8)  # curved-surface scenes, fp32: the workgroup-wide block pool
+        pooled = bool(launcha.get("pair_queue", 0) & 16)  # curved-surface scenes, fp32: the workgroup-wide block pool
         rec["append_layout"] = {"layout": "append: dense list in append order, a stable sort by ray is the reference's order (ot_trace_append_*)",
                                 "kernel": ("k_trace_pool" if pooled else "k_trace_rolling") + ("<double>" if wl.precision == "f64" else "<float>"),
                                 "output_slots": slotsa, "holes": slotsa - segsa, "launches": cnta, "ms_per_trace": ta * 1e3,

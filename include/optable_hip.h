@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define OT_ABI_VERSION 8  /* 8: OT_SHAPE_ASPHERE_CHEB, OT_MAT_CHEB, OT_NODE_BOX_TRUSTED, ot_trace_tiled_*, ot_bench_stream_tiled_*; 3: ot_trace_generation_f32; 4: ot_bench_stream_f32; 5: OT_OPT_LIST_CAP, ray flags bits 8..31, ot_debug_generation_mismatches; 6: ot_debug_last_launch, OT_OPT_FLAT_QUEUE, OT_OPT_LDS_RECORDS; 7: ot_trace_append_*, ot_segment_block, OT_OPT_APPEND_CHUNK, OT_OPT_INSTANCING */
+#define OT_ABI_VERSION 9  /* 9: OT_OPT_BLOCK_POOL, ot_trace_append_* holes per workgroup chunk; 8: OT_SHAPE_ASPHERE_CHEB, OT_MAT_CHEB, OT_NODE_BOX_TRUSTED, ot_trace_tiled_*, ot_bench_stream_tiled_*; 3: ot_trace_generation_f32; 4: ot_bench_stream_f32; 5: OT_OPT_LIST_CAP, ray flags bits 8..31, ot_debug_generation_mismatches; 6: ot_debug_last_launch, OT_OPT_FLAT_QUEUE, OT_OPT_LDS_RECORDS; 7: ot_trace_append_*, ot_segment_block, OT_OPT_APPEND_CHUNK, OT_OPT_INSTANCING */
 
 /* ---- status codes ------------------------------------------------------------------- */
 enum ot_status {
@@ -262,15 +262,19 @@ int ot_trace_tiled_f32(ot_ctx* ctx, const ot_rays* rays, int64_t n_rays, int32_t
  * ONE allocation of 14 planes of `capacity` slots each — the 12 real fields in the order of ot_segments, then int32
  * ray[capacity], int32 surface[capacity] — filled in append order: every wave of the kernel claims chunks of slots from
  * a device-wide cursor and writes 64 consecutive records per pass.
- *   - *n_slots (device int64) receives the number of slots claimed.  Slots [0, *n_slots) hold records, except that the
- *     unused tail of each wave's last chunk is marked ray = -1 (at most OT_OPT_APPEND_CHUNK - 1 slots per wave).
+ *   - *n_slots (device int64) receives the number of slots claimed.  Slots [0, *n_slots) hold records, except for HOLES,
+ *     marked ray = -1: the unused tail of each wave's last chunk (at most OT_OPT_APPEND_CHUNK - 1 slots per wave); with
+ *     the block pool (OT_OPT_BLOCK_POOL: curved scenes in single precision) chunks of 16 * OT_OPT_APPEND_CHUNK slots belong
+ *     to a workgroup: up to 63 holes at the end of every chunk and the tail of each workgroup's last one.
  *   - order: the records of one ray lie at increasing slot numbers in segment order, so a STABLE sort by `ray` yields the
  *     reference's order (input ray major, then segment order) — the contract of ot_trace_generation_*'s flat list.  The
  *     order of rays among each other is not deterministic.  seg_count[i] is written as by ot_trace_*.
  *   - capacity (a multiple of 64, below 2^30 slots in single and 2^29 in double precision; base 16-byte aligned): if *n_slots > capacity the records that did not fit are lost
  *     (nothing is written outside the block); *n_slots is still exact, so the caller can retry with enough room.
- *     sum(seg_count) + chunk * (number of waves launched) always suffices; max_segments * n_rays + that slack never fails.
- * Works for every scene ot_trace_* accepts, always on the rolling-list kernel. */
+ *     sum(seg_count) + chunk * (number of waves launched) always suffices (block pool: sum(seg_count) * (1 + 1/128) +
+ *     (16 * chunk + 64) * (number of workgroups launched)); ot_debug_last_launch names the launch shape, and
+ *     max_segments * n_rays plus that slack never fails.
+ * Works for every scene ot_trace_* accepts, always on the heavy-scene kernels (rolling lists or block pool). */
 typedef struct ot_segment_block {
     void* base;        /* device pointer: 12 planes of `real`[capacity], then int32 ray[capacity], int32 surface[capacity] */
     int64_t capacity;  /* slots per plane */
@@ -309,7 +313,7 @@ int ot_debug_generation_mismatches(ot_ctx* ctx, int64_t* count);
  * info[0] kernel (1 lane per ray, 2 rolling lists), [1] threads per workgroup, [2] workgroups per CU the occupancy
  * query allowed, [3] workgroups launched, [4] dynamic LDS bytes per workgroup, [5] list capacity per wave (rolling),
  * [6] 1 = mixed generations, [7] bit 0 = candidate pair queue (OT_OPT_FLAT_QUEUE took effect), bit 1 = records in LDS,
- * bit 2 = append layout, bit 3 = tiled layout. */
+ * bit 2 = append layout, bit 3 = tiled layout, bit 4 = workgroup-wide block pool (OT_OPT_BLOCK_POOL; [5] = its slots). */
 int ot_debug_last_launch(ot_ctx* ctx, int32_t info[8]);
 
 /* Monitor.record (monitor.py:183-193): intersect finished segments with a rectangular

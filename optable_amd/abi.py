@@ -7,7 +7,7 @@ __graft_entry__ as g; g.build()"` or `make -C optable_amd/csrc`).
 import ctypes as C
 import os
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "liboptable_hip.so")
 

@@ -708,7 +708,7 @@ static int launch_rolling(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, 
             hipExtLaunchKernelGGL(kp, dim3(gridp), dim3(1024), (uint32_t)lds_p, c->stream, ev0, ev1, 0u, blob, (T)c->unit, view<T>(rays), n, K, out,
                                   ac, seg_count, counts, n_classes, ws, NB, 0, queue, 0, 0);
             HIP_TRY(hipGetLastError());
-            const int32_t shape[8] = {2, 1024, 1, gridp, (int32_t)lds_p, NB * 64, 0, 2 | 8 | (append ? 4 : 0)};  // bit 3: block pool
+            const int32_t shape[8] = {2, 1024, 1, gridp, (int32_t)lds_p, NB * 64, 0, 2 | 16 | (append ? 4 : 0)};  // bit 4: block pool
             for (int q = 0; q < 8; ++q) c->last_launch[q] = shape[q];
             return 0;
         }

@@ -126,7 +126,7 @@ class Engine:
         may leave the tail of its last chunk (512 slots) unused.  Call after a trace of the same scene (the launch shape
         is taken from it); `sum(|count|)` of that trace is the record count."""
         info = self.last_launch()
-        if info["kernel"] == 2 and info["pair_queue"] & 8:
+        if info["kernel"] == 2 and info["pair_queue"] & 16:
             # block pool: a workgroup fills one chunk of 16 x 512 slots at a time, loses at most 63 slots where a pass
             # crosses into the next chunk and leaves the tail of its last chunk unused
             return (int(n_records) + int(n_records) // 128 + (16 * 512 + 64) * max(info["workgroups"], 1) + 63) // 64 * 64

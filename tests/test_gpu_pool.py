@@ -32,13 +32,13 @@ def test_block_pool_equals_per_wave_lists(n, K):
     try:
         eng.set_option(abi.OPT_BLOCK_POOL, 0)
         lists = table.trace_batch(batch, max_segments=K)
-        assert not eng.last_launch()["pair_queue"] & 8
+        assert not eng.last_launch()["pair_queue"] & 16
         eng.set_option(abi.OPT_BLOCK_POOL, 1)  # (the slots take the pool only when asked to: scattered stores)
         pool = table.trace_batch(batch, max_segments=K)
         info = eng.last_launch()
-        assert info["kernel"] == 2 and info["pair_queue"] & 8 and info["pair_queue"] & 2, info
+        assert info["kernel"] == 2 and info["pair_queue"] & 16 and info["pair_queue"] & 2, info
         app = table.trace_batch(batch, max_segments=K, layout="append")
-        assert eng.last_launch()["pair_queue"] & 8 and eng.last_launch()["pair_queue"] & 4
+        assert eng.last_launch()["pair_queue"] & 16 and eng.last_launch()["pair_queue"] & 4
     finally:
         eng.set_option(abi.OPT_BLOCK_POOL, -1)
     assert torch.equal(lists.count, pool.count)
@@ -71,7 +71,7 @@ def test_block_pool_against_the_oracle(oracle):
     b64 = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=q, intensity=inten, device="cuda")
     b32 = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=q, intensity=inten, precision="f32", device="cuda")
     s32 = table.trace_batch(b32, max_segments=K, layout="append")
-    assert get_engine().last_launch()["pair_queue"] & 8
+    assert get_engine().last_launch()["pair_queue"] & 16
     ref = oracle.trace(table.compile(), b64.to_host(), max_trace_num=K)
     got = s32.to_host(reference_order=True)
     np.testing.assert_array_equal(got["ray"], ref["ray"])
@@ -131,7 +131,7 @@ def test_block_pool_on_random_curved_scenes(seed):
         eng.set_option(abi.OPT_BLOCK_POOL, -1)
         eng.set_option(abi.OPT_APPEND_CHUNK, 64)
         app = eng.trace(batch, K, layout="append")
-        pooled = bool(eng.last_launch()["pair_queue"] & 8)
+        pooled = bool(eng.last_launch()["pair_queue"] & 16)
     finally:
         eng.set_option(abi.OPT_KERNEL, 0)
         eng.set_option(abi.OPT_BLOCK_POOL, -1)
@@ -154,7 +154,7 @@ def test_block_pool_block_too_small_loses_records_not_memory():
     table, batch = _setup(30_000)
     K = 50
     full = table.trace_batch(batch, max_segments=K, layout="append")
-    assert get_engine().last_launch()["pair_queue"] & 8
+    assert get_engine().last_launch()["pair_queue"] & 16
     records = int(full.count.abs().sum().item())
     small = table.trace_batch(batch, max_segments=K, layout="append", capacity=(records // 3) // 64 * 64)
     with pytest.raises(RuntimeError, match="capacity >= "):
