@@ -271,6 +271,7 @@ int ot_trace_tiled_f32(ot_ctx* ctx, const ot_rays* rays, int64_t n_rays, int32_t
  *     order of rays among each other is not deterministic.  seg_count[i] is written as by ot_trace_*.
  *   - capacity (a multiple of 64, below 2^30 slots in single and 2^29 in double precision; base 16-byte aligned): if *n_slots > capacity the records that did not fit are lost
  *     (nothing is written outside the block); *n_slots is still exact, so the caller can retry with enough room.
+ *     (*n_slots >= 2^62: a wave of the block-pool kernel stopped at one of its internal bounds — a defect, never a capacity matter.)
  *     sum(seg_count) + chunk * (number of waves launched) always suffices (block pool: sum(seg_count) * (1 + 1/128) +
  *     (16 * chunk + 64) * (number of workgroups launched)); ot_debug_last_launch names the launch shape, and
  *     max_segments * n_rays plus that slack never fails.

@@ -268,6 +268,9 @@ class SegmentBatch:
     def n_valid(self):
         if self._n_valid is None and self.cursor is not None:
             claimed = int(self.cursor.item())  # synchronises with the trace
+            if claimed >= 1 << 62:
+                raise RuntimeError("append layout: the trace kernel stopped at an internal bound (rays may be untraced): a defect in "
+                                   "liboptable_hip.so, not a capacity problem — please report the scene")
             if claimed > self.capacity:
                 raise RuntimeError(f"append layout: the trace needed {claimed} slots, the block holds {self.capacity}; "
                                    f"records beyond it were dropped — trace again with capacity >= {claimed}")

@@ -759,6 +759,7 @@ __global__ __launch_bounds__(1024, 1) void k_trace_pool(
     // segment k has released its block, lies behind segment k.
     const uint32_t wg_chunk = APPEND ? (uint32_t)min(16 * OT_KARG(ac.chunk), 1 << 19) : 0u;
     // (ctl[1] starts as epoch 0, offset wg_chunk — a full chunk: the first claim opens the first real one)
+    bool broken = false;  // a bound that "cannot trigger" did: the launch is reported as failed (see the end of the kernel)
     auto chunk_base = [&](uint32_t epoch) -> int64_t {
         const uint32_t lo = __hip_atomic_load(&ctl[4 + 2 * (epoch & 3u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const uint32_t hi = __hip_atomic_load(&ctl[5 + 2 * (epoch & 3u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -795,6 +796,7 @@ __global__ __launch_bounds__(1024, 1) void k_trace_pool(
                 OT_POOL_COUNT(9, 1);
             }
         }
+        broken = true;
         return OT_KARG(ac.capacity);  // (unreachable; a claim that never succeeds drops its records instead of writing anywhere)
       } else {
         return 0;
@@ -850,7 +852,7 @@ __global__ __launch_bounds__(1024, 1) void k_trace_pool(
             // blocks exist but other waves hold them (or are filling them): look again shortly
             __builtin_amdgcn_s_sleep(4);
             OT_POOL_COUNT(2, 1);
-            if (++idle > (1 << 22)) break;  // (a wave never holds a block longer than one pass: this cannot trigger; it bounds a bug)
+            if (++idle > (1 << 22)) { broken = true; break; }  // (a wave never holds a block longer than one pass: this cannot trigger; it bounds a bug)
             continue;
         }
         idle = 0;
@@ -985,6 +987,11 @@ __global__ __launch_bounds__(1024, 1) void k_trace_pool(
             }
             OT_POOL_TIME(8);
         }
+    }
+    if constexpr (APPEND) {
+        // Should one of the bounds above ever stop a wave, rays may be left untraced: the slot count becomes impossible, and
+        // whoever reads it (ot_trace_append_*'s *n_slots; SegmentBatch.n_valid raises) sees that the launch failed
+        if (broken && lane == 0) atomicMax(OT_KARG(ac.cursor), 1ull << 62);
     }
     if constexpr (APPEND) {  // the last wave to leave marks the unused tail of the workgroup's last chunk: holes
         uint32_t gone = 0;
