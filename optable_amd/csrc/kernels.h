@@ -5,6 +5,8 @@
 //                        scene tables).  HBM-bound: SoA streams, 64 consecutive elements per wave instruction.
 //   k_trace_rolling<T>   the same trace for heavy scenes: persistent waves, each with its own list of live rays that
 //                        is compacted every segment and refilled from a device-wide queue.
+//   k_trace_pool<float>  heavy scenes whose rays all run through the same sequence of surfaces, append layout: the live
+//                        rays of a workgroup in one pool of 64-ray blocks in LDS, shared by its sixteen waves.
 //   k_stream_ceiling<T>  the fused kernel's streams with no tracing (roofline companion).
 //   k_gen_pass<T>        one breadth-first generation of branching ray trees (optical_table.py:115-134) in two
 //                        streaming passes: count (rank within the tree, trace) -> scan of wave totals -> emit (trace
