@@ -704,6 +704,9 @@ __global__ __launch_bounds__((rolling_threads<T, F, REC_LDS>()), (rolling_minw<T
 // a state word written after a block's records is seen after them, and records read before a state word is written have
 // been read when it lands; the fences below are wave-scope (they only keep the compiler from reordering).  A
 // workgroup-scope release would also wait for the pass's fourteen global segment stores — 1.8x the pass time.
+// Two policies matter more than anything else here (cfg 5, 12.3 ms as built): refilling EAGERLY, as soon as 16 / 8 / 4 blocks
+// are free instead of when a wave has nothing to trace, makes small cohorts whose generations never meet (13.7 / 15.1 /
+// 16.6 ms); the OLDEST generation first instead of the youngest lets every cohort run ahead on its own (21.7 ms).
 // Passes are generation-pure by construction, so the nearest-hit search runs as in k_trace_rolling; nothing about a ray's
 // arithmetic depends on which wave or pass carries it: results are bit-identical (tests/test_gpu_pool.py).
 static constexpr int POOL_BLOCK_WORDS = 14 * 64;
