@@ -349,7 +349,8 @@ enum ot_option {
     OT_OPT_LIST_CAP = 6,       /* heavy scenes: live rays per wave in the rolling list: a multiple of 64, 128..1024 (mixed lists use it only if it is a power of two) */
     OT_OPT_PAIR_STORES = 7,    /* lane-per-ray kernel: lane pairs write two fields per 16-byte store (0/1) */
     OT_OPT_MIX_GENERATIONS = 8,/* heavy scenes: -1 auto, 0 generation-pure lists even under a top-level grid */
-    OT_OPT_FLAT_QUEUE = 9,     /* planar scenes under a top-level grid: wave-wide candidate queue (0/1) */
+    OT_OPT_FLAT_QUEUE = 9,     /* planar scenes under a top-level grid: wave-wide candidate queue (0 / 1; a multiple of 64 in 192..8192:
+                                  on, with room for that many (ray, leaf) pairs per round instead of 512 — lanes that do not fit wait a round) */
     OT_OPT_LDS_RECORDS = 10,   /* heavy scenes, fp32: records of the live rays in LDS (the first 128 positions of every wave's list; the rest
                                   of a generation-pure list of OT_OPT_LIST_CAP entries spills to global scratch): -1 auto, 0 never, 1 whenever it fits */
     OT_OPT_APPEND_CHUNK = 11,  /* ot_trace_append_*: slots a wave claims per atomic (multiple of 64, default 512) */

@@ -336,13 +336,13 @@ template <class V> __device__ __forceinline__ V karg(size_t offset) {
 
 // Largest workgroup an instantiation may be launched with, and the workgroups per CU the compiler has to leave registers
 // for.  The waves never synchronise after staging, so the workgroup size only decides how many waves share one image:
-//   pair queue, records in LDS: LDS decides the occupancy — one 768-thread workgroup per CU (170 registers allowed, ~100 used);
+//   pair queue, records in LDS: LDS decides the occupancy — up to one 1024-thread workgroup per CU (128 registers, ~110 used);
 //   pair queue, records in global memory: four 256-thread workgroups = 4 waves per SIMD (128 registers; it needs ~110 since the
 //     grid header is kept in registers across passes), fp64 three;
 //   curved-surface preset (cfg 5) in fp32: one 1024-thread workgroup = 4 waves per SIMD on one image (128 registers);
 //   all features in fp64: 256 threads (255 registers); everything else 512 = 2 waves per SIMD.
 template <class T, uint32_t F, bool REC_LDS> constexpr int rolling_threads() {
-    if ((F & F_FLAT) != 0) return REC_LDS ? 768 : 256;
+    if ((F & F_FLAT) != 0) return REC_LDS ? 1024 : 256;
     if (sizeof(T) == 8 && F == F_ALL) return 256;
     if (sizeof(T) == 4 && F == (F_AABB | F_REFRACT | F_CURVED | F_GRID)) return 1024;
     return 512;
@@ -711,16 +711,6 @@ __global__ __launch_bounds__((rolling_threads<T, F, REC_LDS>()), (rolling_minw<T
 // arithmetic depends on which wave or pass carries it: results are bit-identical (tests/test_gpu_pool.py).
 static constexpr int POOL_BLOCK_WORDS = 14 * 64;
 static constexpr uint32_t POOL_LOCKED = 0x80000000u;
-__device__ __forceinline__ int wave_all_min_i32(int v) {  // DPP steps of wave_incl_max_i32, minimum; the result of lane 63 to all
-    constexpr int HIGHEST = 0x7fffffff;
-    v = min(v, __builtin_amdgcn_update_dpp(HIGHEST, v, 0x111, 0xf, 0xf, false));
-    v = min(v, __builtin_amdgcn_update_dpp(HIGHEST, v, 0x112, 0xf, 0xf, false));
-    v = min(v, __builtin_amdgcn_update_dpp(HIGHEST, v, 0x114, 0xf, 0xf, false));
-    v = min(v, __builtin_amdgcn_update_dpp(HIGHEST, v, 0x118, 0xf, 0xf, false));
-    v = min(v, __builtin_amdgcn_update_dpp(HIGHEST, v, 0x142, 0xa, 0xf, false));
-    v = min(v, __builtin_amdgcn_update_dpp(HIGHEST, v, 0x143, 0xc, 0xf, false));
-    return __builtin_amdgcn_readlane(v, 63);
-}
 template <class T, uint32_t F, bool NT, class OUT>
 __global__ __launch_bounds__(1024, 1) void k_trace_pool(
     SceneBlob blob, T unit, RaysT<T> in, int64_t n, int32_t K, OUT out, AppendCtl ac, int32_t* __restrict__ seg_count, int32_t* counts,

@@ -661,7 +661,11 @@ static int launch_rolling(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, 
     const bool img_fits = c->opt_lds_limit_kb != 0 && img <= 140 * 1024;  // else: read from L2, by the all-features preset
     const int fr = !img_fits ? 3 : ((c->root_grid >= 0 && (need & ~FR) == 0) ? 0 : ((c->root_grid >= 0 && (need & ~FRP) == 0) ? 4 : ((need & ~FC) == 0 ? 1 : ((need & ~FD) == 0 ? 2 : 3))));
     // planar scenes under a top-level grid of leaves: candidates through a wave-wide pair queue (flat_grid_hit)
-    const int32_t flat_cap = 64 * FLAT_CELLS * (c->root_max_items > 0 ? c->root_max_items : 1);
+    // pairs a round of the pair queue can hold: 512, not the worst case of 64 lanes x the fullest cells (cfg 3: 1152) — a round
+    // that would overflow defers lanes (flat_grid_hit), and the 1.3 KB per wave are what lets 16 waves per CU run instead of 12
+    const int32_t flat_full = 64 * FLAT_CELLS * (c->root_max_items > 0 ? c->root_max_items : 1);
+    const int32_t flat_room = c->opt_flat > 1 ? c->opt_flat : 512;  // (>= one lane's worst case: 2 * FLAT_CELLS * 42 items = 168)
+    const int32_t flat_cap = flat_full < flat_room ? flat_full : flat_room;
     const bool flat_ok = c->opt_flat && mix && (fr == 0 || fr == 4) && c->root_pack >= 0 && flat_cap <= 8192 && c->n_runs == 0;  // queue entry = lane << 10 | index into the grid's item list
     // Where the scene image and the records of the live rays live, and how many waves share an image.  The waves never
     // synchronise after staging, so the workgroup size is only packaging: take what keeps most waves resident per CU
@@ -1118,7 +1122,9 @@ int ot_set_option(ot_ctx* c, int32_t option, int32_t value) {
         case OT_OPT_NT_STORES: c->opt_nt = value != 0; return 0;
         case OT_OPT_PAIR_STORES: c->opt_pair = value != 0; return 0;
         case OT_OPT_MIX_GENERATIONS: c->opt_mix = value < 0 ? -1 : (value != 0); return 0;
-        case OT_OPT_FLAT_QUEUE: c->opt_flat = value != 0; return 0;
+        case OT_OPT_FLAT_QUEUE:
+            if (value < 0 || (value > 1 && (value < 192 || value > 8192 || value % 64))) return fail(OT_ERR_INVALID, "OT_OPT_FLAT_QUEUE takes 0, 1, or the pairs a round may hold: a multiple of 64, 192..8192");
+            c->opt_flat = value; ++c->plan_epoch; return 0;
         case OT_OPT_MIN_WAVES: 
             if (value != 0 && value != 4) return fail(OT_ERR_INVALID, "OT_OPT_MIN_WAVES takes 0 or 4");
             c->opt_minw = value; return 0;

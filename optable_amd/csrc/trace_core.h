@@ -1044,6 +1044,16 @@ __device__ __forceinline__ int wave_incl_max_i32(int v) {
     v = max(v, __builtin_amdgcn_update_dpp(LOWEST, v, 0x143, 0xc, 0xf, false));
     return v;
 }
+__device__ __forceinline__ int wave_all_min_i32(int v) {  // DPP steps of wave_incl_max_i32, minimum; the result of lane 63 to all
+    constexpr int HIGHEST = 0x7fffffff;
+    v = min(v, __builtin_amdgcn_update_dpp(HIGHEST, v, 0x111, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(HIGHEST, v, 0x112, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(HIGHEST, v, 0x114, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(HIGHEST, v, 0x118, 0xf, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(HIGHEST, v, 0x142, 0xa, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(HIGHEST, v, 0x143, 0xc, 0xf, false));
+    return __builtin_amdgcn_readlane(v, 63);
+}
 #ifdef OT_STAMP  // diagnostic build: phases of a call into st_acc[5..] (walk, queue, test, verdict; [9] slots, [10] rounds)
 #define OT_FLAT_STAMP_PARAMS , unsigned long long* st_acc, unsigned long long& st_last
 #define OT_FLAT_AT(k) do { __builtin_amdgcn_s_waitcnt(0); const unsigned long long _t = __builtin_amdgcn_s_memtime(); st_acc[k] += _t - st_last; st_last = _t; } while (0)
@@ -1124,6 +1134,8 @@ __device__ __forceinline__ Hit<T> flat_grid_hit(const Scene<T>& sc, const FlatGr
         int kb[2 * FLAT_CELLS], ke[2 * FLAT_CELLS], cnt = 0;
         T covered = T(0);
         bool left = !walking;
+        const int c0_was = c0, c1_was = c1;  // (a lane whose pairs do not fit the queue this round walks these cells again)
+        const T tmax0_was = tmax0, tmax1_was = tmax1;
 #pragma unroll
         for (int w = 0; w < 2 * FLAT_CELLS; ++w) {
             kb[w] = ke[w] = 0;
@@ -1166,7 +1178,17 @@ __device__ __forceinline__ Hit<T> flat_grid_hit(const Scene<T>& sc, const FlatGr
         // around the start leaf.
         int total;
         int off = wave_excl_scan_i32(cnt, total);
-        auto mark = [&](int at, int first) { L.queue[at] = (uint16_t)(((lane << 10) | first) + 1); };
+        // The queue holds 512 pairs or more, not the worst case of 64 lanes with the fullest cells (the host sizes it:
+        // LDS per wave decides how many waves run).  When a round's pairs do not fit (wave-uniform, rare: cfg 3 never),
+        // the lanes from the first one that does not fit onward sit the round out: they go back to where their walk stood
+        // and queue the same cells next round.  The pairs of one lane always fit (host), so every round gets somewhere.
+        bool deferred = false;
+        if (total > L.queue_cap) {
+            deferred = cnt > 0 && off + cnt > L.queue_cap;
+            total = wave_all_min_i32(deferred ? off : 0x7fffffff);  // offsets rise with the lane: everything before it fits
+            if (deferred) { c0 = c0_was; c1 = c1_was; tmax0 = tmax0_was; tmax1 = tmax1_was; left = false; covered = T(0); }
+        }
+        auto mark = [&](int at, int first) { if (!deferred) L.queue[at] = (uint16_t)(((lane << 10) | first) + 1); };
 #pragma unroll
         for (int w = 0; w < 2 * FLAT_CELLS; ++w) {
             if (w >= ncell) break;  // wave-uniform

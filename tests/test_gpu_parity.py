@@ -411,6 +411,42 @@ def test_pair_queue_walk_equals_per_lane_walk(prec):
 
 
 @pytest.mark.parametrize("prec", ["f64", "f32"])
+def test_pair_queue_round_that_does_not_fit_defers_lanes(prec):
+    """The pair queue of a wave holds 512 (ray, leaf) pairs per round, not the worst case of 64 lanes with the fullest
+    cells; lanes whose pairs do not fit sit the round out and queue the same cells again (trace_core.h flat_grid_hit).
+    cfg 3 never gets there at 512 — so the room is cut to 192 pairs, a third of its typical round: most rounds defer
+    lanes, and every record must still equal the per-lane walk's, bit for bit."""
+    import torch
+    import optable_amd as oa
+    from optable_amd.batch import RayBatch
+    from optable_amd.engine import get_engine
+
+    comps, gen, _, K = CASES["cfg3"]
+    table = _table(comps(oa))
+    eng = get_engine()
+    q = 1j * np.pi * scenes.W0**2 / scenes.WL
+    o, d = gen(50_003)
+    batch = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=q, precision=prec)
+    try:
+        eng.set_option(abi.OPT_KERNEL, 2)
+        eng.set_option(abi.OPT_FLAT_QUEUE, 0)
+        a = table.trace_batch(batch, max_segments=K)
+        eng.set_option(abi.OPT_FLAT_QUEUE, 192)
+        b = table.trace_batch(batch, max_segments=K)
+        assert eng.last_launch()["pair_queue"] & 1
+        eng.set_option(abi.OPT_FLAT_QUEUE, 1)
+        c = table.trace_batch(batch, max_segments=K)
+    finally:
+        eng.set_option(abi.OPT_KERNEL, 0)
+        eng.set_option(abi.OPT_FLAT_QUEUE, 1)
+    assert torch.equal(a.count, b.count) and torch.equal(a.count, c.count)
+    valid = a.valid_mask()
+    for f in abi.SEG_FIELDS + ("ray", "surface"):
+        assert torch.equal(a.field(f)[valid], b.field(f)[valid]), f
+        assert torch.equal(a.field(f)[valid], c.field(f)[valid]), f
+
+
+@pytest.mark.parametrize("prec", ["f64", "f32"])
 def test_pair_queue_winner_that_fails_its_own_box_takes_the_per_lane_walk(prec, oracle):
     """In the pair queue a leaf's own AABB test (component_group.py:104-107) is applied to the WINNER of a ray, not to
     every candidate (trace_core.h flat_grid_hit); a ray whose winner fails it repeats the search lane by lane with every
