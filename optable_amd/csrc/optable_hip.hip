@@ -686,7 +686,7 @@ static int launch_rolling(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, 
     // against 13.8 with the per-wave lists).  Not for the [k][ray] slots unless asked for (OT_OPT_BLOCK_POOL = 1): blocks
     // that merge mix rays of many tickets, a pass then stores 64 scattered elements per plane instead of runs (20 ms
     // against 14.4).
-    if (!mix && !f64 && img_fits && (c->opt_pool > 0 || (c->opt_pool < 0 && append)) && c->opt_rec_lds != 0) {
+    if (!mix && !f64 && img_fits && (c->opt_pool > 0 || (c->opt_pool < 0 && append)) && c->opt_rec_lds != 0 && K < (1 << 20)) {  // (a block's generation has 20 bits)
         const auto kp = pool_kernel<T, OUT>(fr);
         const size_t fixed = img + (64 + 16) * sizeof(uint32_t);
         const int64_t nb_fit = fixed < 158 * 1024 ? (int64_t)((158 * 1024 - fixed) / (POOL_BLOCK_WORDS * 4)) : 0;
