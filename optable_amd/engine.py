@@ -63,7 +63,9 @@ class Engine:
     # -- non-branching trace ---------------------------------------------------------------
     def trace(self, rays: RayBatch, max_segments, out: SegmentBatch = None, counts=None, layout="slots", capacity=None):
         """All segments of every ray in one launch; returns the SegmentBatch.
-        layout="slots": [k][ray] slots (ot_trace_*).  layout="append": a dense list in append order
+        layout="slots": [k][ray] slots (ot_trace_*).  layout="auto": "append" for heavy scenes (24 nodes or more: the
+        rolling-list / block-pool kernels), "tiled" for light ones — every reader of a SegmentBatch (to_host, monitors,
+        exports, final_state) takes all layouts.  layout="append": a dense list in append order
         (ot_trace_append_*, include/optable_hip.h) — `capacity` slots (default: max_segments * n_rays plus the
         chunk slack, which always suffices; pass what the job needs to save memory: if it turns out too small a
         RuntimeError names the size that fits)."""
@@ -71,6 +73,8 @@ class Engine:
             raise RuntimeError("upload a scene first")
         n, K = rays.n, int(max_segments)
         self._check_wavelengths(rays)
+        if layout == "auto":  # what this scene's kernels write fastest: dense list for heavy scenes, tiles for light ones
+            layout = "append" if self.scene.n_nodes >= 24 else "tiled"
         if layout == "append":
             return self._trace_append(rays, K, out, counts, capacity)
         if layout == "tiled":

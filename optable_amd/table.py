@@ -117,7 +117,8 @@ class OpticalTable:
         `scene`: a `table.compile()` result to reuse when the components have not changed since (flattening
         a few hundred components in Python costs milliseconds — 10 ms for cfg 5 — and the engine skips the
         upload when it already holds that very scene); default: compile now, poses are read at call time.
-        `layout`: "slots" ([segment][ray] slots), "tiled" (the same slots in 64-slot tiles: light scenes, 9 % faster
+        `layout`: "auto" (what the scene's kernels write fastest: "append" for heavy scenes, "tiled" for light ones),
+        "slots" ([segment][ray] slots, the default), "tiled" (the same slots in 64-slot tiles: light scenes, 9 % faster
         streams) or "append" (a dense list in append order, `capacity` slots: see Engine.trace) for the non-branching
         launch; ray trees always come back as a list in generation order."""
         eng = _engine()

@@ -203,3 +203,19 @@ def test_tiled_layout_is_for_light_scenes():
     batch = _batch(*scenes.cfg3_rays(5000, 2))
     with pytest.raises(RuntimeError, match="tiled layout belongs"):
         table.trace_batch(batch, max_segments=20, layout="tiled")
+
+
+@pytest.mark.parametrize("case", ["cfg2", "cfg3", "cfg5"])
+def test_auto_layout_holds_the_same_records(case):
+    """layout="auto": tiles for light scenes, the dense list for heavy ones — the records of the slots either way."""
+    import optable_amd as oa
+
+    comps, gen, n, K = CASES[case]
+    table = _table(comps(oa))
+    batch = _batch(*gen(n), precision="f32")
+    slots = table.trace_batch(batch, max_segments=K)
+    auto = table.trace_batch(batch, max_segments=K, layout="auto")
+    assert auto.layout == ("tiled" if case == "cfg2" else "append")
+    a, b = slots.to_host(reference_order=True), auto.to_host(reference_order=True)
+    for f in abi.SEG_FIELDS + ("ray", "surface"):
+        np.testing.assert_array_equal(a[f], b[f], err_msg=f)
