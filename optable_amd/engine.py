@@ -25,6 +25,7 @@ class Engine:
         stream = torch.cuda.current_stream(self.device).cuda_stream
         abi.check(self.lib.ot_ctx_create(device, C.c_void_p(stream), C.byref(self._ctx)), self.lib)
         self.scene = None
+        self.append_chunk = 512  # OT_OPT_APPEND_CHUNK as last set through set_option (the library's default)
         # An ot_ctx holds one scene and one set of scratch buffers: calls on it are serialised (include/
         # optable_hip.h).  The table-level entry points hold this lock across their upload + trace sequence so that
         # Python threads sharing the engine cannot interleave them (ctypes releases the GIL during a call).
@@ -133,9 +134,10 @@ class Engine:
         if info["kernel"] == 2 and info["pair_queue"] & 16:
             # block pool: a workgroup fills one chunk of 16 x 512 slots at a time, loses at most 63 slots where a pass
             # crosses into the next chunk and leaves the tail of its last chunk unused
-            return (int(n_records) + int(n_records) // 128 + (16 * 512 + 64) * max(info["workgroups"], 1) + 63) // 64 * 64
+            wg_chunk = min(16 * self.append_chunk, 1 << 19)
+            return (int(n_records) + 64 * (int(n_records) // (wg_chunk - 64) + 1) + (wg_chunk + 64) * max(info["workgroups"], 1) + 63) // 64 * 64
         waves = max(info["workgroups"] * info["threads"] // 64, 1) if info["kernel"] == 2 else 256 * 16
-        return (int(n_records) + 512 * waves + 63) // 64 * 64
+        return (int(n_records) + self.append_chunk * waves + 63) // 64 * 64
 
     APPEND_SLACK = 1 << 23  # slots beyond the records: chunk (512) x waves of the launch (at most 256 CUs x 16 x 2)
 
@@ -144,7 +146,9 @@ class Engine:
         if capacity is None:
             # holes: the tail of every wave's last chunk of 512 slots (one wave per ticket of 64 rays at most); with the
             # block pool (curved scenes, fp32) 63 slots per chunk of 8192 and the last chunk of every workgroup
-            capacity = n * K + n * K // 128 + min(self.APPEND_SLACK, max(512 * ((n + 63) // 64 + 1), (16 * 512 + 64) * ((n + 1023) // 1024)))
+            wg_chunk = min(16 * self.append_chunk, 1 << 19)
+            capacity = (n * K + 64 * (n * K // (wg_chunk - 64) + 1)
+                        + max(min(self.APPEND_SLACK, self.append_chunk * ((n + 63) // 64 + 1)), (wg_chunk + 64) * min((n + 1023) // 1024, 512)))
         if out is None:
             out = SegmentBatch(capacity, rays.precision, rays.device, block=True)
         elif out.block is None or out.precision != rays.precision:
@@ -319,6 +323,8 @@ class Engine:
 
     def set_option(self, option, value):
         abi.check(self.lib.ot_set_option(self._ctx, option, value), self.lib)
+        if option == abi.OPT_APPEND_CHUNK:
+            self.append_chunk = int(value)  # (the capacity estimates of the append layout count holes in chunks)
 
     def stream_ceiling(self, rays: RayBatch, max_segments, out: SegmentBatch):
         """Same bytes as `trace` with no tracing (roofline companion), in the layout of `out` (slots or tiled)."""
