@@ -10,5 +10,9 @@ template <uint32_t FM> static GenKern<T> pick(bool lds, bool emit) {
 }
 // beam splitters and partially reflecting slabs are planar scenes: they get the small instantiation (145 instead of 255
 // registers in fp64); count gates, curved shapes and polygons need the full one
-template <> GenKern<T> gen_kernel<T>(bool small, bool lds, bool emit) { return small ? pick<FB>(lds, emit) : pick<F_ALL>(lds, emit); }
+// ... and planar scenes big enough for grids (a top-level grid, gridded groups, subtrees) the planar preset with the grid
+// walks: the all-features kernel spends registers and branches on curved shapes, polygons and count gates they do not have
+template <> GenKern<T> gen_kernel<T>(int fg, bool lds, bool emit) {
+    return fg == 0 ? pick<FB>(lds, emit) : (fg == 1 ? pick<FC>(lds, emit) : pick<F_ALL>(lds, emit));
+}
 template <> ProbeKern<T> probe_kernel<T>(bool lds) { return lds ? k_gen_probe<T, F_ALL, true> : k_gen_probe<T, F_ALL, false>; }

@@ -1018,8 +1018,9 @@ static int trace_generation(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
     const bool in_lds = bytes <= (size_t)c->opt_lds_limit_kb * 1024;
     const size_t lds_bytes = in_lds ? bytes : 0;
     const bool small = (c->features & ~preset::FB) == 0;  // planar scenes without count gates: the small instantiation (tables.h)
+    const int fg = small ? 0 : ((c->features & ~preset::FC) == 0 ? 1 : 2);  // ... with grids: the planar preset that walks them
     const ProbeKern<T> k_probe = probe_kernel<T>(in_lds);
-    const GenKern<T> k_count = gen_kernel<T>(small, in_lds, false), k_emit = gen_kernel<T>(small, in_lds, true);
+    const GenKern<T> k_count = gen_kernel<T>(fg, in_lds, false), k_emit = gen_kernel<T>(fg, in_lds, true);
     if (lds_bytes > 48 * 1024) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         HIP_TRY(hipFuncSetAttribute((const void*)k_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
