@@ -13,6 +13,8 @@ template <uint32_t FM> static GenKern<T> pick(bool lds, bool emit) {
 // ... and planar scenes big enough for grids (a top-level grid, gridded groups, subtrees) the planar preset with the grid
 // walks: the all-features kernel spends registers and branches on curved shapes, polygons and count gates they do not have
 template <> GenKern<T> gen_kernel<T>(int fg, bool lds, bool emit) {
-    return fg == 0 ? pick<FB>(lds, emit) : (fg == 1 ? pick<FC>(lds, emit) : pick<F_ALL>(lds, emit));
+    if (fg == 0) return pick<FB>(lds, emit);
+    if (fg == 1 && lds) return emit ? k_gen_pass<T, FC, true, true> : k_gen_pass<T, FC, true, false>;  // (image in LDS only: what such scenes fit)
+    return pick<F_ALL>(lds, emit);
 }
 template <> ProbeKern<T> probe_kernel<T>(bool lds) { return lds ? k_gen_probe<T, F_ALL, true> : k_gen_probe<T, F_ALL, false>; }
