@@ -14,6 +14,21 @@ from .batch import RayBatch, SegmentBatch
 _engines = {}
 
 
+def append_slots(n_records, launch, chunk=512):
+    """Slots an append-layout block needs for `n_records` segment records written by a launch of shape `launch`
+    (`Engine.last_launch()`), holes included.  Per-wave lists: every wave may leave the tail of its last chunk unused.
+    Block pool (bit 4 of `pair_queue`): a workgroup fills one chunk of 16 x chunk slots at a time, loses at most 63 slots
+    where a pass crosses into the next chunk and leaves the tail of its last chunk unused.  A multiple of 64."""
+    n_records, chunk = int(n_records), int(chunk)
+    if launch["kernel"] == 2 and launch["pair_queue"] & 16:
+        wg_chunk = min(16 * chunk, 1 << 19)
+        slots = n_records + 64 * (n_records // (wg_chunk - 64) + 1) + (wg_chunk + 64) * max(launch["workgroups"], 1)
+    else:
+        waves = max(launch["workgroups"] * launch["threads"] // 64, 1) if launch["kernel"] == 2 else 256 * 16
+        slots = n_records + chunk * waves
+    return (slots + 63) // 64 * 64
+
+
 class Engine:
     def __init__(self, device=0):
         self.lib = abi.load()
@@ -130,14 +145,7 @@ class Engine:
         """Slots an append-layout block needs for `n_records` segment records on this device: every wave of the launch
         may leave the tail of its last chunk (512 slots) unused.  Call after a trace of the same scene (the launch shape
         is taken from it); `sum(|count|)` of that trace is the record count."""
-        info = self.last_launch()
-        if info["kernel"] == 2 and info["pair_queue"] & 16:
-            # block pool: a workgroup fills one chunk of 16 x 512 slots at a time, loses at most 63 slots where a pass
-            # crosses into the next chunk and leaves the tail of its last chunk unused
-            wg_chunk = min(16 * self.append_chunk, 1 << 19)
-            return (int(n_records) + 64 * (int(n_records) // (wg_chunk - 64) + 1) + (wg_chunk + 64) * max(info["workgroups"], 1) + 63) // 64 * 64
-        waves = max(info["workgroups"] * info["threads"] // 64, 1) if info["kernel"] == 2 else 256 * 16
-        return (int(n_records) + self.append_chunk * waves + 63) // 64 * 64
+        return append_slots(n_records, self.last_launch(), self.append_chunk)
 
     APPEND_SLACK = 1 << 23  # slots beyond the records: chunk (512) x waves of the launch (at most 256 CUs x 16 x 2)
 
