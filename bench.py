@@ -243,15 +243,9 @@ def survey_config(oa, eng, name, device):
         del out
         return ms / cnt / 1e3, cnt, segs, slots, launch
 
-    t, cnt, segs, slots, launch = measure("slots")
-    alg = n * b + segs * b
-    rec = {"workload": wl.label, "rays": n, "dtype": wl.precision, "kernel": kernel_name(scene, wl), "leaf_surfaces": scene.n_leaves,
-           "layout": "slots: segment k of ray i at k * n_rays + i (ot_trace_*)", "output_slots": slots,
-           "launches": cnt, "ms_per_trace": t * 1e3, "segments_per_ray": segs / n, "segments_per_s": segs / t,
-           "intersections_per_s": segs * scene.n_leaves / t, "algorithmic_gbs": alg / t / 1e9,
-           "hbm_frac": alg / t / 1e9 / HBM_PEAK_GBS, "launch": launch,
-           "bound": "hbm" if not heavy else "valu/latency (S >= 24, SURVEY.md §8d): the HBM fraction is for comparison"}
-    if not heavy:  # the slots in 64-slot tiles (ot_trace_tiled_*): the layout the bench line itself uses for light scenes
+    # Every config in the layout its kernels write fastest (what trace_batch(layout="auto") gives: tiles for light scenes,
+    # the dense append-order list for heavy ones) and, beside it, in the [k][ray] slot arrays of ot_trace_*.
+    def measure_tiled():
         torch.cuda.empty_cache()
         out = SegmentBatch(n * wl.max_segments, wl.precision, batch.device, tiled=True)
         for _ in range(3):
@@ -261,19 +255,34 @@ def survey_config(oa, eng, name, device):
             eng.trace(batch, wl.max_segments, out=out, layout="tiled")
         ms, cnt_t = eng.timing_read()
         eng.timing(False)
-        tt = ms / cnt_t / 1e3
-        rec["tiled_layout"] = {"layout": "tiled: slot k * n_rays + i in tile / 64, lane % 64 (ot_trace_tiled_*)", "launches": cnt_t,
-                               "ms_per_trace": tt * 1e3, "segments_per_s": segs / tt, "intersections_per_s": segs * scene.n_leaves / tt,
-                               "algorithmic_gbs": alg / tt / 1e9, "hbm_frac": alg / tt / 1e9 / HBM_PEAK_GBS}
+        segs_t = int(out.count.abs().sum().item())
+        launch_t = eng.last_launch()
         del out
-    if heavy:  # the same trace with the dense output: same records (tests/test_gpu_append.py), written in whole lines
-        ta, cnta, segsa, slotsa, launcha = measure("append")
-        pooled = bool(launcha.get("pair_queue", 0) & 16)  # curved-surface scenes, fp32: the workgroup-wide block pool
-        rec["append_layout"] = {"layout": "append: dense list in append order, a stable sort by ray is the reference's order (ot_trace_append_*)",
-                                "kernel": ("k_trace_pool" if pooled else "k_trace_rolling") + ("<double>" if wl.precision == "f64" else "<float>"),
-                                "output_slots": slotsa, "holes": slotsa - segsa, "launches": cnta, "ms_per_trace": ta * 1e3,
-                                "segments_per_s": segsa / ta, "intersections_per_s": segsa * scene.n_leaves / ta,
-                                "algorithmic_gbs": alg / ta / 1e9, "hbm_frac": alg / ta / 1e9 / HBM_PEAK_GBS, "launch": launcha}
+        return ms / cnt_t / 1e3, cnt_t, segs_t, n * wl.max_segments, launch_t
+
+    ts, cnts, segs, slots_s, launch_s = measure("slots")
+    alg = n * b + segs * b
+    if heavy:
+        t, cnt, segs_a, slots, launch = measure("append")
+        pooled = bool(launch.get("pair_queue", 0) & 16)  # curved-surface scenes, fp32: the workgroup-wide block pool
+        kern = ("k_trace_pool" if pooled else "k_trace_rolling") + ("<double>" if wl.precision == "f64" else "<float>")
+        layout = "append: dense list in append order, a stable sort by ray is the reference's order (ot_trace_append_*)"
+        assert segs_a == segs
+    else:
+        t, cnt, _, slots, launch = measure_tiled()
+        kern = kernel_name(scene, wl)
+        layout = "tiled: slot k * n_rays + i in tile / 64, lane % 64 (ot_trace_tiled_*)"
+    rec = {"workload": wl.label, "rays": n, "dtype": wl.precision, "kernel": kern, "leaf_surfaces": scene.n_leaves,
+           "layout": layout, "output_slots": slots, "launches": cnt, "ms_per_trace": t * 1e3, "segments_per_ray": segs / n,
+           "segments_per_s": segs / t, "intersections_per_s": segs * scene.n_leaves / t, "algorithmic_gbs": alg / t / 1e9,
+           "hbm_frac": alg / t / 1e9 / HBM_PEAK_GBS, "launch": launch,
+           "bound": "hbm" if not heavy else "valu (S >= 24, SURVEY.md §8d): the HBM fraction is for comparison"}
+    if heavy:
+        rec["holes"] = slots - segs
+    rec["slots_layout"] = {"layout": "slots: segment k of ray i at k * n_rays + i (ot_trace_*)", "kernel": kernel_name(scene, wl),
+                           "output_slots": slots_s, "launches": cnts, "ms_per_trace": ts * 1e3, "segments_per_s": segs / ts,
+                           "intersections_per_s": segs * scene.n_leaves / ts, "algorithmic_gbs": alg / ts / 1e9,
+                           "hbm_frac": alg / ts / 1e9 / HBM_PEAK_GBS, "launch": launch_s}
     counters = committed_counters(name)
     if counters:
         rec["sq_counters"] = counters
