@@ -121,6 +121,15 @@ def load():
         raise EngineUnavailable(
             f"{LIB_PATH} not found: the HIP engine is not built and optable_amd has no CPU fallback. "
             "Build it with `python -c \"import __graft_entry__ as g; g.build()\"`.")
+    # PyTorch brings a HIP runtime of its own; liboptable_hip.so links the system's.  Whichever initialises the device
+    # first decides whether the other can: torch after the library finds "No HIP GPUs" (seen with a test that called the
+    # C-ABI before its first tensor), the library after torch works.  So torch goes first — a no-op without a GPU.
+    try:
+        import torch
+
+        torch.cuda.is_available() and torch.cuda.init()
+    except Exception:  # noqa: BLE001 - no torch / no driver: the library's own checks report what is missing
+        pass
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as exc:
