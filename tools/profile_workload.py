@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One BASELINE workload, a handful of device traces and nothing else: the program rocprofv3 wraps for the
 profiles/ summaries (tools/profile_r02.sh).  Sizes are what one GPU sees in the quoted configuration.
-    python3 tools/profile_workload.py cfg3|cfg4|cfg5|cfg4b|monitor [reps]
+    python3 tools/profile_workload.py cfg3|cfg4|cfg5|cfg4b|cfg3b|monitor [reps]
 cfg4b = cfg 4 with reflectivity 0.2 (ray trees, generation kernels); monitor = Monitor.record over a cfg 2 history."""
 import os
 import sys
@@ -19,7 +19,7 @@ from optable_amd.engine import get_engine
 
 name = sys.argv[1]
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else {"cfg2": 400, "cfg3": 20}.get(name, 5)  # cfg3: enough launches that the clock ramp of the first ones does not carry the average
-SIZES = {"cfg2": 1_000_000, "cfg3": 10_000_000, "cfg4": 160_000_000, "cfg5": 12_500_000, "cfg4b": 12_800_000, "monitor": 1_000_000}
+SIZES = {"cfg2": 1_000_000, "cfg3": 10_000_000, "cfg4": 160_000_000, "cfg5": 12_500_000, "cfg4b": 12_800_000, "cfg3b": 2_000_000, "monitor": 1_000_000}
 n = int(os.environ.get("RAYS", SIZES[name]))
 eng = get_engine()
 from optable_amd import abi as _abi
@@ -74,6 +74,17 @@ elif name in ("cfg4", "cfg4b"):
             segs = eng.trace_tree(batch, 12, out_capacity=batch.n * 13)
             torch.cuda.synchronize()
             print(f"cfg4b: {batch.n} trees, {segs.n_valid} segments, {1e3 * (time.perf_counter() - t0):.1f} ms wall")
+elif name == "cfg3b":  # heavy branching: cfg 3 with 10 % reflecting slab faces, trees capped at 20 segments, fp32
+    table = oa.OpticalTable()
+    table.add_components(W.cfg3_components(oa, slab_reflectivity=0.1))
+    eng.upload(table.compile())
+    o, d = W.cfg3_rays(n, 2)
+    batch = RayBatch.from_arrays(o, d, wavelength=W.WL, q=Q(W.WL), precision="f32")
+    for _ in range(max(reps // 2, 2)):
+        t0 = time.perf_counter()
+        segs = eng.trace_tree(batch, 20, out_capacity=batch.n * 21)
+        torch.cuda.synchronize()
+        print(f"cfg3b: {batch.n} trees, {segs.n_valid} segments, {1e3 * (time.perf_counter() - t0):.1f} ms wall")
 else:  # Monitor.record over the [k][ray] history of a cfg 2 trace
     wl = W.baseline_workloads(oa)["cfg2"]
     table = oa.OpticalTable()
