@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define OT_ABI_VERSION 9  /* 9: OT_OPT_BLOCK_POOL, ot_trace_append_* holes per workgroup chunk; 8: OT_SHAPE_ASPHERE_CHEB, OT_MAT_CHEB, OT_NODE_BOX_TRUSTED, ot_trace_tiled_*, ot_bench_stream_tiled_*; 3: ot_trace_generation_f32; 4: ot_bench_stream_f32; 5: OT_OPT_LIST_CAP, ray flags bits 8..31, ot_debug_generation_mismatches; 6: ot_debug_last_launch, OT_OPT_FLAT_QUEUE, OT_OPT_LDS_RECORDS; 7: ot_trace_append_*, ot_segment_block, OT_OPT_APPEND_CHUNK, OT_OPT_INSTANCING */
+#define OT_ABI_VERSION 9  /* 9: OT_OPT_BLOCK_POOL, OT_OPT_GEN_DROP_DOOMED, ot_trace_append_* holes per workgroup chunk; 8: OT_SHAPE_ASPHERE_CHEB, OT_MAT_CHEB, OT_NODE_BOX_TRUSTED, ot_trace_tiled_*, ot_bench_stream_tiled_*; 3: ot_trace_generation_f32; 4: ot_bench_stream_f32; 5: OT_OPT_LIST_CAP, ray flags bits 8..31, ot_debug_generation_mismatches; 6: ot_debug_last_launch, OT_OPT_FLAT_QUEUE, OT_OPT_LDS_RECORDS; 7: ot_trace_append_*, ot_segment_block, OT_OPT_APPEND_CHUNK, OT_OPT_INSTANCING */
 
 /* ---- status codes ------------------------------------------------------------------- */
 enum ot_status {
@@ -293,7 +293,8 @@ int ot_trace_append_f32(ot_ctx* ctx, const ot_rays* rays, int64_t n_rays, int32_
  * (max_trace_num minus what it already used); rays beyond the budget are dropped as the
  * reference drops them (optical_table.py:138-144).  Output: one segment per processed ray
  * appended at *seg_cursor, and the next generation's rays (stable order: parent order, then
- * child order) in next/next_tree with *n_next.  All counters are device int64/int32 scalars. */
+ * child order) in next/next_tree with *n_next.  All counters are device int64/int32 scalars.  A tree that uses up its
+ * budget in this call emits no children (OT_OPT_GEN_DROP_DOOMED): the next call would drop them all. */
 int ot_trace_generation_f64(ot_ctx* ctx, const ot_rays* rays, const int32_t* rays_tree,
                             int64_t n_rays, int32_t* budget, const ot_segments* out,
                             int64_t out_capacity, int64_t* seg_cursor, const ot_rays* next,
@@ -357,8 +358,11 @@ enum ot_option {
     OT_OPT_INSTANCING = 12,    /* fold identical lattice children (MMA / MLA / DMD) into one record + per-member pose at upload (0/1) */
     OT_OPT_GEN_REUSE = 13,     /* ot_trace_generation_*: the emit pass rebuilds the hit the count pass found (node + distance kept per
                                   ray) instead of searching the scene again: -1 auto (scenes of 12 nodes or more), 0 never, 1 always */
-    OT_OPT_BLOCK_POOL = 14     /* heavy scenes with curved surfaces, fp32: the live rays of a workgroup in one pool of 64-ray blocks in
+    OT_OPT_BLOCK_POOL = 14,    /* heavy scenes with curved surfaces, fp32: the live rays of a workgroup in one pool of 64-ray blocks in
                                   LDS, shared by its sixteen waves (k_trace_pool), instead of a list per wave: -1 auto, 0 never, 1 whenever it fits */
+    OT_OPT_GEN_DROP_DOOMED = 15 /* ot_trace_generation_*: a tree whose budget ends with this generation gets no children in `next` (they
+                                  could never be processed: optical_table.py:138-144) — 1 (default) / 0: emit them, for a caller who
+                                  wants to go on with a larger budget */
 };
 int ot_set_option(ot_ctx* ctx, int32_t option, int32_t value);
 

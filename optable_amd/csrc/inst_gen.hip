@@ -14,7 +14,9 @@ template <uint32_t FM> static GenKern<T> pick(bool lds, bool emit) {
 // walks: the all-features kernel spends registers and branches on curved shapes, polygons and count gates they do not have
 template <> GenKern<T> gen_kernel<T>(int fg, bool lds, bool emit) {
     if (fg == 0) return pick<FB>(lds, emit);
-    if (fg == 1 && lds) return emit ? k_gen_pass<T, FC, true, true> : k_gen_pass<T, FC, true, false>;  // (image in LDS only: what such scenes fit)
+    if constexpr (sizeof(T) == 4) {  // (single precision, image in LDS: the combinations whose count / emit pair compiles without a stack slot)
+        if (fg == 1 && lds) return emit ? k_gen_pass<T, FC, true, true> : k_gen_pass<T, FC, true, false>;
+    }
     return pick<F_ALL>(lds, emit);
 }
 template <> ProbeKern<T> probe_kernel<T>(bool lds) { return lds ? k_gen_probe<T, F_ALL, true> : k_gen_probe<T, F_ALL, false>; }

@@ -1112,7 +1112,7 @@ __global__ __launch_bounds__(256) void k_gen_pass(SceneBlob blob, T unit, RaysT<
                                                   int64_t out_capacity, RaysOutT<T> next, int32_t* next_tree, int64_t next_capacity,
                                                   uint8_t* code, unsigned long long* wave_total, const unsigned long long* wave_prefix,
                                                   int32_t* counts, int32_t n_classes, const int32_t* rank, unsigned long long* mismatch,
-                                                  int32_t* hit_node, T* hit_t) {
+                                                  int32_t* hit_node, T* hit_t, int32_t drop_doomed) {
     extern __shared__ __align__(16) uint32_t lds[];
     const uint32_t* base = blob.words;
     if (SCENE_IN_LDS) {
@@ -1137,7 +1137,18 @@ __global__ __launch_bounds__(256) void k_gen_pass(SceneBlob blob, T unit, RaysT<
     int64_t head = (i - lane) + head_lane;
     if (i < n && head_lane == 0) head = tree_head(tree, i - lane);
     const int32_t c = (EMIT && i < n) ? (int32_t)code[i] : 0;  // EMIT: what the count pass decided
-    const bool active = EMIT ? (c & 1) != 0 : (i < n && (i - head) < (int64_t)budget[my_tree]);
+    const int64_t bud = (!EMIT && i < n) ? (int64_t)budget[my_tree] : 0;  // (only the count pass reads budgets)
+    const bool active = EMIT ? (c & 1) != 0 : (i < n && (i - head) < bud);
+    // A tree whose budget ends with this generation — it has a ray of rank budget - 1 here — will have every ray of the
+    // next generation dropped (optical_table.py:138-144): what its rays emit now can never be processed.  Such children
+    // are not emitted at all (OT_OPT_GEN_DROP_DOOMED): the last generation of a capped tree is its largest, and writing
+    // its children was a sixth of the bytes of a cfg 4 (R = 0.2) trace.  The count pass decides (it is the one that may
+    // read budgets), bit 3 of the code byte tells the emit pass.
+    bool doomed = (c & 8) != 0;
+    if (!EMIT && active && drop_doomed) {
+        const int64_t last_needed = head + bud - 1;
+        doomed = last_needed < n && tree[last_needed] == my_tree;
+    }
     if (EMIT && i < n && (i == n - 1 || tree[i + 1] != my_tree)) {
         // Last ray of its tree in this generation: the tree's budget shrinks by the rays processed (optical_table.py:
         // 138-144).  Only the count pass reads budgets, and it has finished: one writer per tree, no reader.
@@ -1169,8 +1180,9 @@ __global__ __launch_bounds__(256) void k_gen_pass(SceneBlob blob, T unit, RaysT<
     int32_t nk = 0;
     RayState<T> ch[2];  // indexed by constants only
     if (active && !dead && h.node >= 0) nk = interact<T, F, 2>(sc, r, h, ch, make_matcache<T, F>(sc, r.wl));
+    if (doomed) nk = 0;
     if (!EMIT) {
-        if (i < n) code[i] = (uint8_t)((active ? 1 : 0) | (nk << 1));
+        if (i < n) code[i] = (uint8_t)((active ? 1 : 0) | (nk << 1) | (doomed ? 8 : 0));
         // wave totals: processed rays and children
         const int n_act = __popcll(__ballot(active));
         int kids;
@@ -1180,7 +1192,7 @@ __global__ __launch_bounds__(256) void k_gen_pass(SceneBlob blob, T unit, RaysT<
     }
     // EMIT: slots from the scanned wave prefix and the counted codes
     const bool c_active = active;
-    const int32_t c_nk = c >> 1;
+    const int32_t c_nk = (c >> 1) & 3;
     const unsigned long long act_mask = __ballot(c_active);
     const int seg_rank = __popcll(act_mask & ((1ull << lane) - 1ull));
     int kids_total;

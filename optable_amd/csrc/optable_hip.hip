@@ -57,6 +57,7 @@ struct ot_ctx {
     int32_t n_phys = 0, n_runs = 0, runs_word64 = 0, runs_word32 = 0;  // instanced runs folded by fill_blob (trace_core.h NodeRef)
     int32_t opt_append_chunk = 512;  // append layout: slots per claim
     int32_t opt_instancing = 1;      // fold lattice children into instanced runs at upload
+    int32_t opt_gen_drop = 1;        // generation kernels: children of a tree whose budget ends with this generation are not emitted
     int32_t opt_gen_reuse = -1;      // generation kernels: emit pass rebuilds the count pass's hit instead of searching again (-1 auto)
     double unit = 1e-2;
     uint32_t features = 0;
@@ -1037,13 +1038,15 @@ static int trace_generation(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
     // count -> scan of the wave totals -> emit (kernels.h: k_gen_pass)
     hipLaunchKernelGGL(k_count, dim3(g1), dim3(block), lds_bytes, c->stream, blob, (T)c->unit, view<T>(rays), tree, n, budget,
                        (const int64_t*)seg_cursor, view<T>(out), out_capacity, view_out<T>(next), next_tree, next_capacity, code, wave_total,
-                       (const unsigned long long*)wave_prefix, counts, n_classes, (const int32_t*)rank, mismatch, hit_node, hit_t);
+                       (const unsigned long long*)wave_prefix, counts, n_classes, (const int32_t*)rank, mismatch, hit_node, hit_t,
+                       c->opt_gen_drop ? 1 : 0);
     exclusive_scan<unsigned long long, unsigned long long>(c->scan_tmp.p, wave_total, wave_prefix, n_waves, c->stream);
     hipLaunchKernelGGL(k_gen_totals, dim3(1), dim3(64), 0, c->stream, (const unsigned long long*)wave_total,
                        (const unsigned long long*)wave_prefix, n_waves, totals, seg_cursor, n_next);
     hipLaunchKernelGGL(k_emit, dim3(g1), dim3(block), lds_bytes, c->stream, blob, (T)c->unit, view<T>(rays), tree, n, budget,
                        (const int64_t*)(totals + 2), view<T>(out), out_capacity, view_out<T>(next), next_tree, next_capacity, code, wave_total,
-                       (const unsigned long long*)wave_prefix, counts, n_classes, (const int32_t*)rank, mismatch, hit_node, hit_t);
+                       (const unsigned long long*)wave_prefix, counts, n_classes, (const int32_t*)rank, mismatch, hit_node, hit_t,
+                       c->opt_gen_drop ? 1 : 0);
     if (ns > 0)
         hipLaunchKernelGGL(k_gen_counts, dim3(g1), dim3(block), 0, c->stream, tree, rays->id, n, ns, rank, probe, c->slot_max, counts,
                            n_classes);
@@ -1148,6 +1151,7 @@ int ot_set_option(ot_ctx* c, int32_t option, int32_t value) {
         case OT_OPT_GEN_REUSE:
             if (value < -1 || value > 1) return fail(OT_ERR_INVALID, "OT_OPT_GEN_REUSE takes -1 (auto), 0 or 1");
             c->opt_gen_reuse = value; return 0;
+        case OT_OPT_GEN_DROP_DOOMED: c->opt_gen_drop = value != 0; return 0;
         case OT_OPT_BLOCK_POOL:
             if (value < -1 || value > 1) return fail(OT_ERR_INVALID, "OT_OPT_BLOCK_POOL takes -1 (auto), 0 or 1");
             c->opt_pool = value; return 0;

@@ -25,7 +25,7 @@ using RollingKern = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, OUT, Appe
 template <class T>
 using GenKern = void (*)(SceneBlob, T, RaysT<T>, const int32_t*, int64_t, int32_t*, const int64_t*, SegsT<T>, int64_t, RaysOutT<T>, int32_t*,
                          int64_t, uint8_t*, unsigned long long*, const unsigned long long*, int32_t*, int32_t, const int32_t*,
-                         unsigned long long*, int32_t*, T*);
+                         unsigned long long*, int32_t*, T*, int32_t);
 template <class T>
 using ProbeKern = void (*)(SceneBlob, T, RaysT<T>, const int32_t*, int64_t, const int32_t*, int32_t*, int32_t, int32_t*);
 

@@ -265,7 +265,7 @@ class Engine:
         if n == 0:
             return out, RayBatch(0, prec, dev), torch.zeros(0, dtype=torch.int32, device=dev)
         fan = max(self.scene.max_children, 1)
-        budget = torch.ones(n, dtype=torch.int32, device=dev)
+        budget = torch.full((n,), 2, dtype=torch.int32, device=dev)  # (one ray per tree, room for one more: the children are wanted)
         state = torch.zeros(2, dtype=torch.int64, device=dev)
         tree = torch.arange(n, dtype=torch.int32, device=dev)
         nxt = RayBatch(n * fan, prec, dev, initialise=False)

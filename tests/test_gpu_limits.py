@@ -145,3 +145,45 @@ def test_two_pass_generations_agree_with_themselves():
         eng.upload(t2.compile())
         eng.trace_tree(b, 300)
     assert eng.generation_mismatches() == before
+
+
+@pytest.mark.parametrize("cap", [3, 7, 12, 40])
+def test_trees_capped_in_a_bushy_generation_drop_their_children(cap, oracle):
+    """A Mach-Zehnder-like lattice of beam splitters and mirrors: every splitter doubles the rays, so the generation in
+    which `max_trace_num` runs out is the tree's largest.  The kernels do not emit the children of that generation
+    (they could never be processed: optical_table.py:138-144; OT_OPT_GEN_DROP_DOOMED) — the segments must be exactly the
+    oracle's and exactly what the trace gives with the children emitted and dropped a generation later."""
+    from optable_amd import abi
+
+    comps = []
+    for k in range(5):
+        comps.append(oa.BeamSplitter([2.0 * (k + 1), 0, 0], width=6, height=2, eta=0.5).RotZ(np.pi / 4))
+        comps.append(oa.Mirror([2.0 * (k + 1), 3.0 + 0.1 * k, 0], radius=2).RotZ(-np.pi / 2))
+        comps.append(oa.BeamSplitter([2.0 * (k + 1) + 1.0, 1.5, 0], width=6, height=2, eta=0.3).RotZ(-np.pi / 4))
+    table = oa.OpticalTable()
+    table.add_components(comps)
+    scene = table.compile()
+    n = 3000
+    rng = np.random.default_rng(5)
+    o = np.stack([np.zeros(n), rng.uniform(-0.3, 0.3, n), rng.uniform(-0.2, 0.2, n)], 1)
+    d = np.stack([np.ones(n), rng.uniform(-0.02, 0.02, n), rng.uniform(-0.01, 0.01, n)], 1)
+    batch = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=1j * np.pi * scenes.W0**2 / scenes.WL)
+    eng = get_engine()
+    eng.upload(scene)
+    try:
+        eng.set_option(abi.OPT_GEN_DROP_DOOMED, 0)
+        kept = eng.trace_tree(batch, cap)
+        eng.set_option(abi.OPT_GEN_DROP_DOOMED, 1)
+        dropped = eng.trace_tree(batch, cap)
+    finally:
+        eng.set_option(abi.OPT_GEN_DROP_DOOMED, 1)
+    a, b = kept.to_host(reference_order=True), dropped.to_host(reference_order=True)
+    ref = oracle.trace(scene, batch.to_host(), max_trace_num=cap)
+    assert len(b["ray"]) == len(ref["ray"]) and np.bincount(b["ray"], minlength=n).max() == min(cap, np.bincount(ref["ray"]).max())
+    assert torch.equal(kept.capped, dropped.capped)
+    for f in abi.SEG_FIELDS + ("ray", "surface"):
+        np.testing.assert_array_equal(a[f], b[f], err_msg=f)
+    np.testing.assert_array_equal(b["ray"], ref["ray"])
+    np.testing.assert_array_equal(b["surface"], ref["surface"])
+    np.testing.assert_allclose(b["ox"], ref["ox"], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(b["intensity"], ref["intensity"], rtol=1e-9, atol=1e-12)
