@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define OT_ABI_VERSION 9  /* 9: OT_OPT_BLOCK_POOL, OT_OPT_GEN_DROP_DOOMED, ot_trace_append_* holes per workgroup chunk; 8: OT_SHAPE_ASPHERE_CHEB, OT_MAT_CHEB, OT_NODE_BOX_TRUSTED, ot_trace_tiled_*, ot_bench_stream_tiled_*; 3: ot_trace_generation_f32; 4: ot_bench_stream_f32; 5: OT_OPT_LIST_CAP, ray flags bits 8..31, ot_debug_generation_mismatches; 6: ot_debug_last_launch, OT_OPT_FLAT_QUEUE, OT_OPT_LDS_RECORDS; 7: ot_trace_append_*, ot_segment_block, OT_OPT_APPEND_CHUNK, OT_OPT_INSTANCING */
+#define OT_ABI_VERSION 9  /* 9: ot_trace_tree_*, OT_OPT_BLOCK_POOL, OT_OPT_GEN_DROP_DOOMED, ot_trace_append_* holes per workgroup chunk; 8: OT_SHAPE_ASPHERE_CHEB, OT_MAT_CHEB, OT_NODE_BOX_TRUSTED, ot_trace_tiled_*, ot_bench_stream_tiled_*; 3: ot_trace_generation_f32; 4: ot_bench_stream_f32; 5: OT_OPT_LIST_CAP, ray flags bits 8..31, ot_debug_generation_mismatches; 6: ot_debug_last_launch, OT_OPT_FLAT_QUEUE, OT_OPT_LDS_RECORDS; 7: ot_trace_append_*, ot_segment_block, OT_OPT_APPEND_CHUNK, OT_OPT_INSTANCING */
 
 /* ---- status codes ------------------------------------------------------------------- */
 enum ot_status {
@@ -305,6 +305,23 @@ int ot_trace_generation_f32(ot_ctx* ctx, const ot_rays* rays, const int32_t* ray
                             int64_t out_capacity, int64_t* seg_cursor, const ot_rays* next,
                             int32_t* next_tree, int64_t next_capacity, int64_t* n_next,
                             int32_t* counts, int32_t n_count_classes);
+
+/* The whole breadth-first trace of a batch of ray trees: the loop over ot_trace_generation_* (optical_table.py:115-147) run
+ * by the library — per generation one launch sequence and ONE 16-byte read-back.  `state` is device int64[2] = {segment
+ * cursor, rays of the pending generation}: zero it before the first call.  buf_a / buf_b (+ tree_a / tree_b) are two
+ * generation buffers of buf_capacity rays each.  result (host int64[5]): [0] segments written so far, [1] rays of the
+ * pending generation (0: finished), [2] where they are (0: the caller's `rays`, 1: buf_a, 2: buf_b), [3] generations run by
+ * this call, [4] why it stopped: 0 queue empty, 1 the segment arrays cannot take the pending generation, 2 the buffers
+ * cannot take its children (max_children x rays), 3 max_seconds (>= 0) ran out.  After 1 or 2 the caller provides more
+ * room and calls again with the pending generation as `rays` / `rays_tree` (and the same state and budget). */
+int ot_trace_tree_f64(ot_ctx* ctx, const ot_rays* rays, const int32_t* rays_tree, int64_t n_rays, int32_t* budget,
+                      const ot_segments* out, int64_t out_capacity, int64_t* state, const ot_rays* buf_a, int32_t* tree_a,
+                      const ot_rays* buf_b, int32_t* tree_b, int64_t buf_capacity, int32_t* counts, int32_t n_count_classes,
+                      double max_seconds, int64_t* result);
+int ot_trace_tree_f32(ot_ctx* ctx, const ot_rays* rays, const int32_t* rays_tree, int64_t n_rays, int32_t* budget,
+                      const ot_segments* out, int64_t out_capacity, int64_t* state, const ot_rays* buf_a, int32_t* tree_a,
+                      const ot_rays* buf_b, int32_t* tree_b, int64_t buf_capacity, int32_t* counts, int32_t n_count_classes,
+                      double max_seconds, int64_t* result);
 
 /* Diagnostic: how often the two passes of a generation (count, then emit: both run the same trace) disagreed about a
  * ray since the ctx was created.  Expected 0; a disagreement is contained (nothing is written outside the slots the

@@ -97,6 +97,10 @@ SYMBOLS = {
                                           _vp, C.POINTER(OtRays), _vp, _i64, _vp, _vp, _i32]),
     "ot_trace_generation_f32": (C.c_int, [_vp, C.POINTER(OtRays), _vp, _i64, _vp, C.POINTER(OtSegments), _i64,
                                           _vp, C.POINTER(OtRays), _vp, _i64, _vp, _vp, _i32]),
+    "ot_trace_tree_f64": (C.c_int, [_vp, C.POINTER(OtRays), _vp, _i64, _vp, C.POINTER(OtSegments), _i64, _vp, C.POINTER(OtRays), _vp,
+                                    C.POINTER(OtRays), _vp, _i64, _vp, _i32, C.c_double, _vp]),
+    "ot_trace_tree_f32": (C.c_int, [_vp, C.POINTER(OtRays), _vp, _i64, _vp, C.POINTER(OtSegments), _i64, _vp, C.POINTER(OtRays), _vp,
+                                    C.POINTER(OtRays), _vp, _i64, _vp, _i32, C.c_double, _vp]),
     "ot_monitor_record_f64": (C.c_int, [_vp, C.POINTER(OtMonitor), C.POINTER(OtSegments), _i64, _vp, _i64, _vp, _vp,
                                         _vp, _vp, _vp, _vp]),
     "ot_timing_enable": (C.c_int, [_vp, C.c_int]),

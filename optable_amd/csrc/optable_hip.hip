@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <chrono>
 #include <vector>
 
 #include "kernels.h"
@@ -95,6 +96,7 @@ struct ot_ctx {
     int32_t opt_nt = 1, opt_minw = 4, opt_blocks_per_cu = 0;  // defaults from tools/tune.py on MI355X
     Scratch gen, scan_tmp, mon;
     unsigned long long* gen_mismatch = nullptr;  // count / emit disagreements of k_gen_pass (expected: 0)
+    int64_t* pinned_state = nullptr;             // ot_trace_tree_*: page-locked landing place of the per-generation read-back
 };
 
 static int flush_events(ot_ctx* c) {
@@ -513,6 +515,7 @@ int ot_ctx_destroy(ot_ctx* c) {
     if (c->slot_max) (void)hipFree(c->slot_max);
     if (c->gen.p) (void)hipFree(c->gen.p);
     if (c->gen_mismatch) (void)hipFree(c->gen_mismatch);
+    if (c->pinned_state) (void)hipHostFree(c->pinned_state);
     if (c->scan_tmp.p) (void)hipFree(c->scan_tmp.p);
     if (c->mon.p) (void)hipFree(c->mon.p);
     if (c->blocked.p) (void)hipFree(c->blocked.p);
@@ -1054,7 +1057,64 @@ static int trace_generation(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
     return timing_end(c);
 }
 
+// The generation loop of a whole ray tree batch (optical_table.py:115-147) on the host side of the library: one
+// trace_generation per generation, the two counters read back (16 bytes, one stream synchronisation) and the two generation
+// buffers swapped — the loop the Python shell used to run with a dozen ctypes conversions per turn.  It stops when the
+// queue is empty, when the next generation does not fit the buffers or the segment arrays (the caller grows them and calls
+// again with the pending generation as input), or when the wall clock runs out.
+template <class T>
+static int trace_tree(ot_ctx* c, const ot_rays* rays, const int32_t* tree, int64_t n, int32_t* budget, const ot_segments* out,
+                      int64_t out_capacity, int64_t* state, const ot_rays* buf_a, int32_t* tree_a, const ot_rays* buf_b, int32_t* tree_b,
+                      int64_t buf_capacity, int32_t* counts, int32_t n_classes, double max_seconds, int64_t* result) {
+    if (!c || !state || !result || !buf_a || !buf_b || !tree_a || !tree_b) return fail(OT_ERR_INVALID, "NULL argument");
+    if (!c->has_scene) return fail(OT_ERR_NOSCENE, "ot_scene_upload has not been called");
+    HIP_TRY(hipSetDevice(c->device));
+    const int fan = c->max_children < 1 ? 1 : c->max_children;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!c->pinned_state) HIP_TRY(hipHostMalloc((void**)&c->pinned_state, 2 * sizeof(int64_t), hipHostMallocDefault));
+    int64_t* const host_state = c->pinned_state;  // (page-locked: the copy is a DMA the stream waits for, not a staged memcpy)
+    HIP_TRY(hipMemcpyAsync(host_state, state, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int64_t written = host_state[0], cur_n = n, generations = 0;
+    const ot_rays* cur = rays;
+    const int32_t* cur_tree = tree;
+    int where = 0;  // which buffer holds the pending generation: 0 the caller's rays, 1 buf_a, 2 buf_b
+    int64_t reason = 0;
+    while (cur_n > 0) {
+        if (written + cur_n > out_capacity) { reason = 1; break; }        // the segment arrays are too small for this generation
+        if (cur_n * fan > buf_capacity) { reason = 2; break; }           // ... the generation buffers for the next one
+        const bool to_a = where != 1;
+        int rc = trace_generation<T>(c, cur, cur_tree, cur_n, budget, out, out_capacity, state, to_a ? buf_a : buf_b, to_a ? tree_a : tree_b,
+                                     buf_capacity, state + 1, counts, n_classes);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(host_state, state, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));  // the one host synchronisation per generation
+        written = host_state[0];
+        cur_n = host_state[1];
+        ++generations;
+        where = to_a ? 1 : 2;
+        cur = to_a ? buf_a : buf_b;
+        cur_tree = to_a ? tree_a : tree_b;
+        if (max_seconds >= 0 && cur_n > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() >= max_seconds) { reason = 3; break; }
+    }
+    result[0] = written; result[1] = cur_n; result[2] = where; result[3] = generations; result[4] = reason;
+    return 0;
+}
+
 extern "C" {
+
+int ot_trace_tree_f64(ot_ctx* c, const ot_rays* rays, const int32_t* tree, int64_t n, int32_t* budget, const ot_segments* out,
+                      int64_t out_capacity, int64_t* state, const ot_rays* buf_a, int32_t* tree_a, const ot_rays* buf_b, int32_t* tree_b,
+                      int64_t buf_capacity, int32_t* counts, int32_t n_classes, double max_seconds, int64_t* result) {
+    return trace_tree<double>(c, rays, tree, n, budget, out, out_capacity, state, buf_a, tree_a, buf_b, tree_b, buf_capacity, counts, n_classes,
+                              max_seconds, result);
+}
+int ot_trace_tree_f32(ot_ctx* c, const ot_rays* rays, const int32_t* tree, int64_t n, int32_t* budget, const ot_segments* out,
+                      int64_t out_capacity, int64_t* state, const ot_rays* buf_a, int32_t* tree_a, const ot_rays* buf_b, int32_t* tree_b,
+                      int64_t buf_capacity, int32_t* counts, int32_t n_classes, double max_seconds, int64_t* result) {
+    return trace_tree<float>(c, rays, tree, n, budget, out, out_capacity, state, buf_a, tree_a, buf_b, tree_b, buf_capacity, counts, n_classes,
+                             max_seconds, result);
+}
 
 int ot_trace_generation_f64(ot_ctx* c, const ot_rays* rays, const int32_t* tree, int64_t n, int32_t* budget,
                             const ot_segments* out, int64_t out_capacity, int64_t* seg_cursor, const ot_rays* next,

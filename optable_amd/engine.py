@@ -214,34 +214,41 @@ class Engine:
         if n_slots and counts is None:
             counts = torch.zeros((n_slots, n), dtype=torch.int32, device=dev)
         n_classes = 0 if counts is None else counts.shape[1]
-        # two ping-pong generation buffers, grown when a generation outgrows them (no per-generation allocation)
+        # The generation loop runs inside the library (ot_trace_tree_*: one 16-byte read-back per generation); it comes back
+        # when the queue is empty, when the time is up, or when the pending generation needs more room — then the
+        # buffers are grown here and the call repeated with that generation as input.
+        tree_fn = self.lib.ot_trace_tree_f64 if prec == "f64" else self.lib.ot_trace_tree_f32
         cap = max(n * fan, 1024)
-        spare, spare_tree = RayBatch(cap, prec, dev, initialise=False), torch.empty(cap, dtype=torch.int32, device=dev)
-        other, other_tree = None, None
+        bufs = [RayBatch(cap, prec, dev, initialise=False), RayBatch(cap, prec, dev, initialise=False)]
+        trees = [torch.empty(cap, dtype=torch.int32, device=dev), torch.empty(cap, dtype=torch.int32, device=dev)]
+        result = (C.c_int64 * 5)()
         cur, cur_n, written = rays, n, 0
+        timed_out = None
         while cur_n > 0:
-            if written + cur_n > out.capacity:
-                out = _grow(out, max(written + cur_n, 2 * out.capacity), written)
-            if cur_n * fan > spare.n:
-                cap = max(cur_n * fan, 2 * spare.n)
-                spare, spare_tree = RayBatch(cap, prec, dev, initialise=False), torch.empty(cap, dtype=torch.int32, device=dev)
-            rs, ss, ns = cur.c_struct(), out.c_struct(), spare.c_struct()
-            abi.check(gen_fn(
-                self._ctx, C.byref(rs), tree.data_ptr(), cur_n, budget.data_ptr(), C.byref(ss), out.capacity,
-                state.data_ptr(), C.byref(ns), spare_tree.data_ptr(), spare.n, state.data_ptr() + 8,
-                None if counts is None else counts.data_ptr(), n_classes), self.lib)
-            written, cur_n = state.tolist()  # the one host synchronisation per generation
-            nxt, nxt_tree = spare, spare_tree
-            if other is None or other.n < nxt.n:
-                other, other_tree = RayBatch(nxt.n, prec, dev, initialise=False), torch.empty(nxt.n, dtype=torch.int32, device=dev)
-            spare, spare_tree, other, other_tree = other, other_tree, nxt, nxt_tree
-            cur, tree = nxt.slice(0, cur_n), nxt_tree[:cur_n]
-            if max_trace_time is not None and cur_n > 0 and time.time() - t_start >= max_trace_time:
+            left = -1.0 if max_trace_time is None else max(max_trace_time - (time.time() - t_start), 0.0)
+            rs, ss, sa, sb = cur.c_struct(), out.c_struct(), bufs[0].c_struct(), bufs[1].c_struct()
+            abi.check(tree_fn(self._ctx, C.byref(rs), tree.data_ptr(), cur_n, budget.data_ptr(), C.byref(ss), out.capacity,
+                              state.data_ptr(), C.byref(sa), trees[0].data_ptr(), C.byref(sb), trees[1].data_ptr(), bufs[0].n,
+                              None if counts is None else counts.data_ptr(), n_classes, left, result), self.lib)
+            written, cur_n, where, _, reason = (int(x) for x in result)
+            if where:  # the pending generation sits in one of the buffers
+                cur, tree = bufs[where - 1].slice(0, cur_n), trees[where - 1][:cur_n]
+                if where == 1:  # a call writes its first generation into buf_a: the pending one must be in the other buffer
+                    bufs.reverse()
+                    trees.reverse()
+            if cur_n == 0:
+                break
+            if reason == 3:
                 timed_out = torch.zeros(n, dtype=torch.bool, device=dev)
                 timed_out[tree.long()] = True  # trees with rays still queued
                 break
-        else:
-            timed_out = None
+            if reason == 1:
+                out = _grow(out, max(written + cur_n, 2 * out.capacity), written)
+            elif reason == 2:  # new, larger buffers; the pending generation stays where it is until the next call has read it
+                cap = max(cur_n * fan, 2 * bufs[0].n)
+                keep = (cur, tree)  # noqa: F841 - holds the old buffer alive across the call
+                bufs = [RayBatch(cap, prec, dev, initialise=False), RayBatch(cap, prec, dev, initialise=False)]
+                trees = [torch.empty(cap, dtype=torch.int32, device=dev), torch.empty(cap, dtype=torch.int32, device=dev)]
         out.n_valid = int(written)
         out.counts_table = counts
         out.capped = budget <= 0  # cap reached: queued rays were dropped (optical_table.py:138-144)
