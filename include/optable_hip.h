@@ -377,6 +377,9 @@ enum ot_option {
                                   ray) instead of searching the scene again: -1 auto (scenes of 12 nodes or more), 0 never, 1 always */
     OT_OPT_BLOCK_POOL = 14,    /* heavy scenes with curved surfaces, fp32: the live rays of a workgroup in one pool of 64-ray blocks in
                                   LDS, shared by its sixteen waves (k_trace_pool), instead of a list per wave: -1 auto, 0 never, 1 whenever it fits */
+    OT_OPT_REFILL = 16,        /* heavy scenes under a top-level grid (mixed generations): the live rays in registers, every lane takes its
+                                  next fresh ray in place (k_trace_refill) instead of a list per wave: 0 (default: the lists; the two tie on cfg 3), 1 whenever a kernel exists */
+    OT_OPT_REFILL_TICKET = 17, /* ... rays a wave draws from the device-wide queue per atomic: 0 = by batch size (64..256), or a multiple of 64 */
     OT_OPT_GEN_DROP_DOOMED = 15 /* ot_trace_generation_*: a tree whose budget ends with this generation gets no children in `next` (they
                                   could never be processed: optical_table.py:138-144) — 1 (default) / 0: emit them, for a caller who
                                   wants to go on with a larger budget */

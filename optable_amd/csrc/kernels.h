@@ -683,6 +683,245 @@ __global__ __launch_bounds__((rolling_threads<T, F, REC_LDS>()), (rolling_minw<T
 #endif
 }
 
+// ------------------------------------------------------------------------------------------
+// k_trace_refill — mixed scenes (everything under a top-level grid: the rays of a wave are unrelated after their first
+// bounce — cfg 3) with the live rays IN REGISTERS.  A lane keeps its ray from segment to segment; when the ray ends the
+// lane takes the next fresh ray of the wave's ticket IN PLACE (one atomic on the device-wide queue per TICKET rays, the
+// fresh rays of a pass are consecutive: their loads coalesce).  No list, no compaction, no records in LDS or in global
+// scratch: the only LDS a wave owns is the pair queue's key table and markers (1.5 KB), so the workgroups that fit a CU
+// are decided by registers alone — the round-4 calibration (profiles/r04_issue_calibration.json) showed k_trace_rolling at
+// 4 waves per SIMD issuing one vector instruction per 5.1 cycles where the pipe takes one per 2.3: latency-bound, and its
+// 8.9 KB of LDS per wave were what kept more waves out.  Every pass is full until the queue runs dry (a lane is idle for
+// at most the pass in which its ticket ran out); the drain at the end is the same as the lists'.
+// Output and order contract as k_trace_rolling: a ray never leaves its wave, a wave's passes claim slots in address
+// order, so the records of one ray lie at increasing slots (append layout: a stable sort by `ray` is the reference's
+// order, optical_table.py:125-134); [k][ray] slots are what they are.  Nothing about a ray's arithmetic depends on the
+// lane or pass that carries it: bit-identical to the lists (tests/test_gpu_refill.py).
+#ifndef OT_REFILL_FLAT_WG
+#define OT_REFILL_FLAT_WG 256
+#define OT_REFILL_FLAT_MINW 4
+#endif
+// set bits of a wave-uniform mask below this lane (v_mbcnt: the mask comes from scalar registers, no per-lane lane-mask constant to keep)
+__device__ __forceinline__ int rank_below(unsigned long long m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+template <class T, uint32_t F> constexpr int refill_threads() {
+    // (whole multiples of four waves, one per SIMD: the waves of a workgroup are dealt to the SIMDs in turn, and two workgroups of
+    // ten waves put six on the first SIMD — where five fit — so only one of them ran: 2.4 waves per SIMD measured, for 5 asked)
+    if (sizeof(T) == 4) return (F & F_FLAT) != 0 ? OT_REFILL_FLAT_WG : 256;
+    return 256;
+}
+template <class T, uint32_t F> constexpr int refill_minw() {  // waves per SIMD the registers are capped for
+    if (sizeof(T) == 4) return (F & F_FLAT) != 0 ? OT_REFILL_FLAT_MINW : (F == F_ALL ? 2 : 5);
+    return F == F_ALL ? 1 : ((F & F_FLAT) != 0 ? 3 : 2);
+}
+template <class T, uint32_t F, bool NT, class OUT>
+__global__ __launch_bounds__((refill_threads<T, F>()), (refill_minw<T, F>())) void k_trace_refill(
+    SceneBlob blob, T unit, RaysT<T> in, int64_t n, int32_t K, OUT out, AppendCtl ac, int32_t* __restrict__ seg_count, int32_t* counts,
+    int32_t n_classes, WaveScratch<T> ws, int32_t TICKET, int32_t capl_arg, unsigned long long* queue, int32_t mix, int32_t flat_cap) {
+    constexpr bool APPEND = std::is_same<OUT, SegPlanes<T>>::value;
+    struct LeadArgs {  // the parameter list: the layout of the kernel-argument segment (see k_trace_rolling)
+        SceneBlob blob; T unit; RaysT<T> in; int64_t n; int32_t K; OUT out; AppendCtl ac; int32_t* seg_count; int32_t* counts;
+        int32_t n_classes; WaveScratch<T> ws; int32_t CAP; int32_t capl; unsigned long long* queue; int32_t mix; int32_t flat_cap;
+    };
+    (void)ac; (void)seg_count; (void)queue; (void)in; (void)ws; (void)capl_arg; (void)mix;
+    typedef const __attribute__((address_space(4))) RaysT<T>* RaysArgPtr;
+    const RaysArgPtr in_arg = (RaysArgPtr)((uintptr_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(LeadArgs, in));
+    extern __shared__ __align__(16) uint32_t lds[];
+    for (int w = threadIdx.x; w < blob.n_words; w += blockDim.x) lds[w] = blob.words[w];
+    uint32_t* const lds_tail = lds + ((blob.n_words + 3) & ~3);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    FlatLds<T> flat = {nullptr, nullptr, nullptr, 0};
+    if constexpr ((F & F_FLAT) != 0) {
+        const int per_wave = (FlatLds<T>::fixed_bytes + flat_cap * 2 + 15) & ~15;
+        uint8_t* fb = reinterpret_cast<uint8_t*>(lds_tail) + wave * per_wave;
+        flat.key = reinterpret_cast<unsigned long long*>(fb);
+        if constexpr (sizeof(T) == 8) flat.node = reinterpret_cast<int32_t*>(fb + 64 * 8);
+        flat.queue = reinterpret_cast<uint16_t*>(fb + FlatLds<T>::fixed_bytes);
+        flat.queue_cap = flat_cap;
+        for (int q = lane; q < flat_cap; q += 64) flat.queue[q] = 0;  // markers only; every round leaves it zeroed again
+    }
+    // PARK: what only rides along to the interaction and the next record (wavelength, q, intensity, index, path length) waits
+    // in LDS while the search runs — [6][64] reals per wave, a lane's own column — instead of in six of the registers that
+    // decide how many waves fit a SIMD (12 LDS instructions per pass; the lists read and wrote 26)
+    constexpr bool PARK = (F & F_FLAT) != 0;
+    T* park = nullptr;
+    if constexpr (PARK) {
+        const int per_wave_flat = (FlatLds<T>::fixed_bytes + flat_cap * 2 + 15) & ~15;
+        park = reinterpret_cast<T*>(reinterpret_cast<uint8_t*>(lds_tail) + (blockDim.x >> 6) * per_wave_flat) + wave * (6 * 64) + lane;
+    }
+    __syncthreads();  // the only workgroup barrier: the scene image is staged
+    const Scene<T> sc = bind_scene<T>(lds, blob, unit);
+    FlatGrid<T> flat_grid = {};
+    if constexpr ((F & F_FLAT) != 0) flat_grid = flat_grid_header<T, true>(sc);
+    RayState<T> r = {};
+    int32_t i = 0, k = 0, cls = 0, fl = 0;
+    bool busy = false;
+    uint32_t tk_next = 0, tk_end = 0;  // this wave's ticket: fresh rays [tk_next, tk_end) (wave-uniform)
+    bool exhausted = false;
+    int64_t chunk_pos = 0;  // append layout: next free slot of this wave's chunk, and how many are left in it
+    int32_t chunk_left = 0;
+    // Fresh rays are fetched ONE PASS AHEAD into registers of their own (f*), as soon as the interaction has told which lanes
+    // will not carry their ray on, and BEFORE the pass's fourteen segment stores: gfx9 retires a wave's loads and stores through one
+    // in-order counter, so a load issued behind the stores has its data held back until every one of them is acknowledged by
+    // memory — with the fetch at the top of the loop every pass waited for the stores of the pass before (2.24 ms at 4 waves
+    // per SIMD where the lists, which only load in one pass of five, took 2.10).  The stores cover the fetch; the lanes take
+    // their fresh rays over at the top of the next pass.  (Fetching before the interaction, for the lanes without a hit, would
+    // cover more of it, but sixteen more registers are live through the interaction then: 23 spilled at 96.)
+    T fox = T(0), foy = T(0), foz = T(0), fdx = T(0), fdy = T(0), fdz = T(0), fwl = T(0), fqr = T(0), fqi = T(0), fI = T(0), fn = T(0), fpl = T(0), flen = T(0);
+    int32_t fi = 0, ffl = 0, fcls = 0;
+    bool pending = false;
+    auto fetch = [&](const unsigned long long freem) {  // freem: the lanes that take a fresh ray (wave-uniform mask)
+        // (the registers hold nothing between the take-over at the top of a pass and here: said explicitly, or they would be
+        // carried around the loop, through the search, for the lanes the fetch below does not write)
+        fox = foy = foz = fdx = fdy = fdz = fwl = fqr = fqi = fI = fn = fpl = flen = T(0);
+        fi = ffl = fcls = 0;
+        if (freem == 0ull || exhausted) return;
+        if (tk_next == tk_end) {
+            unsigned long long first = 0;
+            if (lane == 0) first = atomicAdd(OT_KARG(queue), (unsigned long long)TICKET);
+            first = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(first >> 32)) << 32) |
+                    (uint32_t)__builtin_amdgcn_readfirstlane((int)(first & 0xffffffffull));
+            const unsigned long long n_now = (unsigned long long)n;
+            if (first >= n_now) { exhausted = true; return; }
+            tk_next = (uint32_t)first;
+            tk_end = (uint32_t)(first + (unsigned long long)TICKET < n_now ? first + (unsigned long long)TICKET : n_now);
+        }
+        const int need = __popcll(freem), avail = (int)(tk_end - tk_next), take = need < avail ? need : avail;
+        const int rank = rank_below(freem);
+        if (((freem >> lane) & 1ull) && rank < take) {
+            fi = (int32_t)(tk_next + (uint32_t)rank);
+            RaysArgPtr ip = in_arg;
+            asm volatile("" : "+s"(ip));  // opaque here: the pointers are loaded now, not hoisted out of the pass loop
+            RaysT<T> in_now;
+            {
+                static_assert(sizeof(RaysT<T>) == 15 * sizeof(uint64_t), "RaysT is fifteen pointers");
+                const __attribute__((address_space(4))) uint64_t* src = (const __attribute__((address_space(4))) uint64_t*)ip;
+                uint64_t words[15];
+#pragma unroll
+                for (int w = 0; w < 15; ++w) words[w] = src[w];
+                __builtin_memcpy(&in_now, words, sizeof(in_now));
+            }
+            // (plain loads: the fresh rays of a pass are a dozen consecutive records, a fraction of a cache line per field — the
+            // rest of the line is wanted a pass or two later and should still be in L2 then; non-temporal loads fetched every
+            // line three times: 1.55 GB read for 0.52 GB of rays)
+            ffl = in_now.flags[fi];
+            if constexpr ((F & F_LIMIT) != 0) fcls = in_now.id[fi];
+            fox = in_now.ox[fi]; foy = in_now.oy[fi]; foz = in_now.oz[fi];
+            fdx = in_now.dx[fi]; fdy = in_now.dy[fi]; fdz = in_now.dz[fi];
+            fwl = in_now.wl[fi]; fqr = in_now.qr[fi]; fqi = in_now.qi[fi];
+            fI = in_now.I[fi]; fn = in_now.n[fi]; fpl = in_now.pl[fi];
+            flen = in_now.len ? in_now.len[fi] : Num<T>::inf();
+            pending = true;
+        }
+        tk_next += (uint32_t)take;
+    };
+#ifdef OT_STAMP
+    unsigned long long st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long st_last = __builtin_amdgcn_s_memtime();
+#endif
+    fetch(~0ull);
+    for (;;) {
+        if (pending) {  // the rays fetched during the last pass
+            r.ox = fox; r.oy = foy; r.oz = foz; r.dx = fdx; r.dy = fdy; r.dz = fdz;
+            r.wl = fwl; r.qr = fqr; r.qi = fqi; r.I = fI; r.n = fn; r.pl = fpl; r.len = flen;
+            i = fi; k = 0; cls = fcls;
+            r.has_q = (ffl & OT_RAY_HAS_Q) != 0;
+            r.last = (int32_t)((uint32_t)ffl >> 8) - 1;  // bits 8..31: node the ray was emitted on, plus one (generation buffers; 0 for a caller's ray)
+            if ((uint32_t)r.last >= (uint32_t)sc.n_nodes) r.last = -1;  // ... that name no node of this scene
+            fl = ffl & 0xff;
+            busy = true;
+            pending = false;
+        }
+        if (!__any(busy)) {
+            if (exhausted) break;  // the queue is exhausted and every ray of this wave has ended
+            fetch(~0ull);          // (the ticket ran out in the middle of a fetch and no ray was left alive)
+            continue;
+        }
+        // ---- one pass: one segment of every live ray
+        OT_STAMP_AT(0);
+        const bool entry = busy;
+        const bool active = entry && !(fl & OT_RAY_DEAD);  // optical_component.py:349: a dead ray is returned as it came
+        const GateCtx gate = {counts, n_classes, cls, nullptr, nullptr, 0, 0};
+        Hit<T> h;
+        if constexpr (PARK) {
+            park[0] = r.wl; park[64] = r.qr; park[128] = r.qi; park[192] = r.I; park[256] = r.n; park[320] = r.pl;
+        }
+        if constexpr ((F & F_FLAT) != 0) h = flat_grid_hit<T, F, GATE_PLAIN>(sc, flat_grid, r, active, gate, flat, lane OT_FLAT_STAMP_ARGS);
+        else {
+#ifdef OT_STAMP
+            h = nearest_hit<T, F, GATE_PLAIN>(sc, r, active, gate, st_acc, &st_last);
+#else
+            h = nearest_hit<T, F, GATE_PLAIN>(sc, r, active, gate);
+#endif
+        }
+        if constexpr (PARK) {
+            r.wl = park[0]; r.qr = park[64]; r.qi = park[128]; r.I = park[192]; r.n = park[256]; r.pl = park[320];
+        }
+        OT_STAMP_AT(1);
+        const bool hit = active && h.node >= 0;
+        // the interaction first: it tells which lanes carry a ray on, and the fresh rays for the others are fetched BEFORE
+        // the segment stores (see above); the parent is kept for its record
+        bool survive = false;
+        RayState<T> child = {};
+        int32_t used = k + 1;
+        if (hit) {
+            MatCache<T> mc = {T(1)};
+            if constexpr (F & F_REFRACT) mc = make_matcache<T, F>(sc, r.wl);
+            const int nk = interact<T, F, 1>(sc, r, h, &child, mc);
+            if (nk == 1) survive = k + 1 < K;
+            else if (nk > 1) used = -(k + 1);  // the tree branches here: the caller re-traces it generation by generation
+        }
+        OT_STAMP_AT(2);
+        fetch(__ballot(!survive));
+        OT_STAMP_AT(3);
+        // the segment record: every entry of the pass writes exactly one
+        int64_t slot = APPEND ? 0 : (int64_t)k * n + (int64_t)i;
+        bool room = true;
+        if constexpr (APPEND) {
+            const unsigned long long writers = __ballot(entry);
+            const int need = __popcll(writers), rank = rank_below(writers);
+            int64_t fresh_pos = 0;
+            if (need > chunk_left) {  // wave-uniform: claim the next chunk; the pass may straddle the two
+                const unsigned long long c0 = lane == 0 ? atomicAdd(OT_KARG(ac.cursor), (unsigned long long)OT_KARG(ac.chunk)) : 0ull;
+                fresh_pos = (int64_t)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(c0 >> 32)) << 32) |
+                                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(c0 & 0xffffffffull)));
+            }
+            slot = rank < chunk_left ? chunk_pos + rank : fresh_pos + (rank - chunk_left);
+            if (need > chunk_left) { chunk_pos = fresh_pos + (need - chunk_left); chunk_left = OT_KARG(ac.chunk) - (need - chunk_left); }
+            else { chunk_pos += need; chunk_left -= need; }
+            room = slot < OT_KARG(ac.capacity);  // an output that is too small loses records, never writes outside (the cursor tells)
+            if (entry && room) store_segment<T, NT>(out, slot, r, hit ? h.t : r.len, (int32_t)i, hit ? leaf_id_of<T, F>(sc, h.node) : (active ? -1 : -2));
+        } else {  // the fourteen [k][ray] array pointers: from the kernel-argument segment, like the caller's ray pointers
+            typedef const __attribute__((address_space(4))) uint64_t* ArgWords;
+            ArgWords src = (ArgWords)((uintptr_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(LeadArgs, out));
+            asm volatile("" : "+s"(src));
+            static_assert(sizeof(SegsT<T>) == 14 * sizeof(uint64_t), "SegsT is fourteen pointers");
+            uint64_t words[14];
+#pragma unroll
+            for (int w = 0; w < 14; ++w) words[w] = src[w];
+            SegsT<T> out_now;
+            __builtin_memcpy(&out_now, words, sizeof(out_now));
+            if (entry) store_segment<T, NT>(out_now, slot, r, hit ? h.t : r.len, (int32_t)i, hit ? leaf_id_of<T, F>(sc, h.node) : (active ? -1 : -2));
+        }
+        if (entry && !survive) OT_KARG(seg_count)[i] = used;
+        if (survive) { r = child; ++k; }  // (child.wl, .has_q are the parent's; .len = inf, .last = the node it was emitted on)
+        busy = survive;
+        OT_STAMP_AT(3);  // (stores, waited: charged to the fetch / store phase)
+#ifdef OT_STAMP
+        st_acc[4] += 1;
+#endif
+    }
+    if constexpr (APPEND) {  // the unused tail of this wave's last chunk: holes
+        int32_t* rp = ray_plane(out);
+        for (int64_t s = chunk_pos + lane; s < chunk_pos + chunk_left; s += 64)
+            if (s < OT_KARG(ac.capacity)) rp[s] = -1;
+    }
+#ifdef OT_STAMP
+    if (lane == 0) for (int q = 0; q < 12; ++q) atomicAdd(&queue[8 + q], st_acc[q]);
+#endif
+}
+
 // k_trace_pool — generation-pure tracing with the live rays of a WORKGROUP in one pool of blocks (single precision, the
 // curved-surface preset: cfg 5).
 // k_trace_rolling's generation-pure lists are private to a wave: 256 rays that die at different times, worked off in

@@ -84,6 +84,9 @@ struct ot_ctx {
     struct RollingPlan { uint64_t epoch = 0; int wpb = 4, per_cu = 1; int32_t cap = 128, capl = 0; bool lds = false, rec_lds = false; size_t lds_bytes = 0; };
     RollingPlan plan[2][2];  // [precision][output layout]
     uint64_t plan_epoch = 1;
+    int32_t opt_refill = 0;      // mixed scenes: rays in registers, refilled in place (k_trace_refill): 0 never (the lists; default: the two tie on cfg 3
+                                 // in the append layout, 2.08-2.11 ms, and the lists win into [k][ray] slots, 3.7 against 4.7 ms), 1 whenever a kernel exists
+    int32_t opt_refill_ticket = 0;  // rays per ticket of k_trace_refill (0 = by batch size)
     int32_t opt_pool = -1;       // curved-surface scenes, fp32: workgroup-wide block pool (-1 auto, 0 never, 1 whenever it fits)
     int32_t opt_rec_lds = -1;    // pair-queue scenes: records of the live rays in LDS (-1 auto, 0 never, 1 whenever it fits)
     int32_t opt_list_cap = 128;  // k_trace_rolling: live rays per wave (cfg 3: 128 beats 256 and 512)
@@ -684,6 +687,50 @@ static int launch_rolling(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, 
     // pass at 128 entries, 53 at 256, 58 at 512 on cfg 5), but only the first 128 positions keep their records in LDS and a
     // pass over the global part waits for its loads behind the segment stores of the pass before (one in-order counter):
     // cfg 5 fp32, append layout, 16 waves per CU: 14.9 ms at 128, 13.5 at 256, 16+ at 384 and beyond.
+    // Mixed scenes: the live rays in registers, refilled in place (k_trace_refill) — no list, no records, 1.5 KB of LDS per wave
+    // (pair queue) + 1.5 KB (the parked ride-along fields), so registers alone decide how many waves share a CU.
+    if (mix && img_fits && c->opt_refill > 0) {
+        const auto kf = refill_kernel<T, OUT>(fr, flat_ok);
+        if (kf) {
+            const int threads = refill_max_threads<T>(fr, flat_ok), waves = threads / 64;
+            const size_t park_bytes = flat_ok ? 6 * 64 * sizeof(T) : 0;
+            const size_t lds_f = img + (size_t)waves * (flat_bytes + park_bytes);
+            int per_cu = 0;
+            if (lds_f <= 158 * 1024) {
+                if (lds_f > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_f));
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kf, threads, lds_f) != hipSuccess) per_cu = 0;
+            }
+            if (per_cu >= 1) {
+                if (c->opt_blocks_per_cu > 0) per_cu = c->opt_blocks_per_cu;
+                const int64_t want = (n + 64 * (int64_t)waves - 1) / (64 * (int64_t)waves);
+                const int64_t capf = (int64_t)c->n_cus * per_cu;
+                const int gridf = (int)(want < capf ? want : capf);
+                // rays per ticket (one atomic on the device-wide queue each): 256, less when the batch is small enough that
+                // whole tickets would leave waves without work
+                int64_t per_wave4 = n / ((int64_t)gridf * waves * 4);
+                int32_t ticket = c->opt_refill_ticket > 0 ? c->opt_refill_ticket : (int32_t)(per_wave4 >= 256 ? 256 : (per_wave4 < 64 ? 64 : (per_wave4 / 64) * 64));
+                if (c->blocked.ensure(256)) return fail(OT_ERR_HIP, "hipMalloc of the ticket counter failed");
+                c->blocked_queue_off = 0;
+                unsigned long long* queue = (unsigned long long*)c->blocked.p;
+#ifdef OT_STAMP
+                HIP_TRY(hipMemsetAsync(queue, 0, 24 * sizeof(unsigned long long), c->stream));
+#else
+                HIP_TRY(hipMemsetAsync(queue, 0, sizeof(unsigned long long), c->stream));
+#endif
+                if (append) HIP_TRY(hipMemsetAsync(ac.cursor, 0, sizeof(unsigned long long), c->stream));
+                hipEvent_t ev0, ev1;
+                int rc = timing_pair(c, &ev0, &ev1);
+                if (rc) return rc;
+                WaveScratch<T> ws = {nullptr, 0};
+                hipExtLaunchKernelGGL(kf, dim3(gridf), dim3(threads), (uint32_t)lds_f, c->stream, ev0, ev1, 0u, blob, (T)c->unit, view<T>(rays), n, K, out,
+                                      ac, seg_count, counts, n_classes, ws, ticket, 0, queue, 1, flat_ok ? flat_cap : 0);
+                HIP_TRY(hipGetLastError());
+                const int32_t shape[8] = {2, threads, per_cu, gridf, (int32_t)lds_f, ticket, 1, (flat_ok ? 1 : 0) | (append ? 4 : 0) | 32};  // bit 5: rays in registers
+                for (int q = 0; q < 8; ++q) c->last_launch[q] = shape[q];
+                return 0;
+            }
+        }
+    }
     const int32_t cap0 = mix ? c->opt_list_cap : (c->opt_list_cap_pure > 0 ? c->opt_list_cap_pure : 256);
     // Generation-pure scenes of the curved-surface preset, single precision, append layout: the workgroup-wide block pool
     // (k_trace_pool) when at least 24 blocks of 64 records fit next to the image (cfg 5: 15 KB image, 41 blocks; 12.1 ms
@@ -1216,6 +1263,12 @@ int ot_set_option(ot_ctx* c, int32_t option, int32_t value) {
             if (value < -1 || value > 1) return fail(OT_ERR_INVALID, "OT_OPT_BLOCK_POOL takes -1 (auto), 0 or 1");
             c->opt_pool = value; return 0;
         case OT_OPT_INSTANCING: c->opt_instancing = value != 0; return 0;  // takes effect at the next ot_scene_upload
+        case OT_OPT_REFILL:
+            if (value < 0 || value > 1) return fail(OT_ERR_INVALID, "OT_OPT_REFILL takes 0 or 1");
+            c->opt_refill = value; return 0;
+        case OT_OPT_REFILL_TICKET:
+            if (value < 0 || value > 4096 || value % 64) return fail(OT_ERR_INVALID, "OT_OPT_REFILL_TICKET takes 0 (by batch size) or a multiple of 64 up to 4096");
+            c->opt_refill_ticket = value; return 0;
         case OT_OPT_BLOCKS_PER_CU:
             if (value < 0 || value > 65536) return fail(OT_ERR_INVALID, "OT_OPT_BLOCKS_PER_CU out of range");
             c->opt_blocks_per_cu = value; return 0;

@@ -39,6 +39,10 @@ template <class T, class OUT> RollingKern<T, OUT> rolling_kernel(int fr, bool fl
 template <class T> int rolling_max_threads(int fr, bool flat, bool rec_lds);
 // k_trace_pool (same arguments; CAP carries the number of blocks): the curved-surface preset FD in single precision, else nullptr
 template <class T, class OUT> RollingKern<T, OUT> pool_kernel(int fr);
+// k_trace_refill (same arguments; CAP carries the rays per ticket): mixed scenes, rays in registers.  fr / flat as above;
+// nullptr where no instantiation exists (the lists take the scene then)
+template <class T, class OUT> RollingKern<T, OUT> refill_kernel(int fr, bool flat);
+template <class T> int refill_max_threads(int fr, bool flat);
 // k_gen_pass / k_gen_probe: fg = 0 the planar preset FB, 1 FC (planar scenes under grids: cfg 3 with splitting slabs), 2 F_ALL
 template <class T> GenKern<T> gen_kernel(int fg, bool lds, bool emit);
 template <class T> ProbeKern<T> probe_kernel(bool lds);
@@ -51,6 +55,9 @@ template <class T> ProbeKern<T> probe_kernel(bool lds);
     template <> int rolling_max_threads<T>(int, bool, bool);                       \
     template <> RollingKern<T, SegsT<T>> pool_kernel<T, SegsT<T>>(int);            \
     template <> RollingKern<T, SegPlanes<T>> pool_kernel<T, SegPlanes<T>>(int);    \
+    template <> RollingKern<T, SegsT<T>> refill_kernel<T, SegsT<T>>(int, bool);       \
+    template <> RollingKern<T, SegPlanes<T>> refill_kernel<T, SegPlanes<T>>(int, bool); \
+    template <> int refill_max_threads<T>(int, bool);                              \
     template <> GenKern<T> gen_kernel<T>(int, bool, bool);                         \
     template <> ProbeKern<T> probe_kernel<T>(bool);
 OT_DECLARE_TABLES(double)

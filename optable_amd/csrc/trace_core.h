@@ -1077,13 +1077,27 @@ template <class T> struct FlatGrid {
     const T* items;
     const T* cellpack;  // cells as (first item | count << 11)
 };
-template <class T> __device__ __forceinline__ FlatGrid<T> flat_grid_header(const Scene<T>& sc) {
+// a wave-uniform value the compiler cannot know to be uniform (it came out of LDS): into a scalar register
+__device__ __forceinline__ int uniform_t(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uniform_t(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ double uniform_t(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+// SCALAR = true: the header's thirteen numbers go through readfirstlane — they sit in scalar registers (or their spill lanes)
+// instead of thirteen vector registers for the whole pass loop (k_trace_refill, whose occupancy is decided by vector registers)
+template <class T, bool SCALAR = false> __device__ __forceinline__ FlatGrid<T> flat_grid_header(const Scene<T>& sc) {
     FlatGrid<T> G;
     const T* g = sc.aux + sc.root;
     G.a0 = (int)g[0]; G.a1 = (int)g[1]; G.g0 = (int)g[2]; G.g1 = (int)g[3];
     G.org0 = g[4]; G.org1 = g[5]; G.inv0 = g[6]; G.inv1 = g[7]; G.size0 = g[9]; G.size1 = g[10];
-    G.hi0 = G.org0 + G.size0 * T(G.g0); G.hi1 = G.org1 + G.size1 * T(G.g1);
     G.slack = T(4) * g[8];
+    if constexpr (SCALAR) {
+        G.a0 = uniform_t(G.a0); G.a1 = uniform_t(G.a1); G.g0 = uniform_t(G.g0); G.g1 = uniform_t(G.g1);
+        G.org0 = uniform_t(G.org0); G.org1 = uniform_t(G.org1); G.inv0 = uniform_t(G.inv0); G.inv1 = uniform_t(G.inv1);
+        G.size0 = uniform_t(G.size0); G.size1 = uniform_t(G.size1); G.slack = uniform_t(G.slack);
+    }
+    G.hi0 = G.org0 + G.size0 * T(G.g0); G.hi1 = G.org1 + G.size1 * T(G.g1);
+    if constexpr (SCALAR) { G.hi0 = uniform_t(G.hi0); G.hi1 = uniform_t(G.hi1); }
     G.items = g + 11 + (G.g0 * G.g1 + 1);
     G.cellpack = sc.aux + sc.root_pack;  // (the host launches this walk only when the packed cells exist)
     return G;
@@ -1306,12 +1320,14 @@ __device__ __forceinline__ Hit<T> flat_grid_hit(const Scene<T>& sc, const FlatGr
         T u1, u2;
         if (nd.flags & OT_NODE_CHECK_AABB) redo = !slab_inv(r.ox, r.oy, r.oz, ri, nd.aabb, u1, u2);
     }
+#ifndef OT_EXP_NOREDO
     if (__any(redo)) {
         if (redo) {
             best.t = Num<T>::inf(); best.node = -1; best.px = best.py = best.pz = T(0);
             root_grid_hit<T, F, GATE>(sc, r, ri, best, gate);
         }
     }
+#endif
     // the hit point of the winner, from the ray's own values and the winner's t: the expressions of the test, the same bits
     if (best.node >= 0 && !redo) return rebuild_hit<T, F>(sc, r, best.node, best.t);
     return best;

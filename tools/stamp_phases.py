@@ -23,7 +23,7 @@ prec = sys.argv[2] if len(sys.argv) > 2 else "f32"
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 3_000_000
 wl = W.baseline_workloads(oa)[name]
 eng = get_engine()
-for k, v in (("CAP", abi.OPT_LIST_CAP), ("KERNEL", abi.OPT_KERNEL), ("RECLDS", abi.OPT_LDS_RECORDS), ("FLAT", abi.OPT_FLAT_QUEUE), ("INST", abi.OPT_INSTANCING)):
+for k, v in (("CAP", abi.OPT_LIST_CAP), ("KERNEL", abi.OPT_KERNEL), ("RECLDS", abi.OPT_LDS_RECORDS), ("FLAT", abi.OPT_FLAT_QUEUE), ("INST", abi.OPT_INSTANCING), ("REFILL", abi.OPT_REFILL)):
     if os.environ.get(k):
         eng.set_option(v, int(os.environ[k]))
 table = oa.OpticalTable()
@@ -31,11 +31,12 @@ table.add_components(wl.components())
 eng.upload(table.compile())
 o, d, lam = wl.rays(n, 0)
 batch = RayBatch.from_arrays(o, d, wavelength=lam, q=1j * np.pi * W.W0**2 / lam, precision=prec)
-out = SegmentBatch(n * wl.max_segments, prec, batch.device)
+LAYOUT = os.environ.get("LAYOUT", "slots")
+out = SegmentBatch(n * wl.max_segments, prec, batch.device, block=(LAYOUT == "append"))
 for _ in range(3):
-    eng.trace(batch, wl.max_segments, out=out)
+    eng.trace(batch, wl.max_segments, out=out, layout=LAYOUT)
 eng.timing(True)
-eng.trace(batch, wl.max_segments, out=out)
+eng.trace(batch, wl.max_segments, out=out, layout=LAYOUT)
 ms, cnt = eng.timing_read()
 eng.timing(False)
 acc = (C.c_ulonglong * 12)()
@@ -45,6 +46,7 @@ load, hit, inter, comp, passes = [int(x) for x in acc][:5]
 walk, queue, test, verdict, slots, rounds = [int(x) for x in acc][5:11]
 tot = load + hit + inter + comp
 segs = int(out.count.abs().sum().item())
+print(f"launch {eng.last_launch()}")
 print(f"{name} {prec} n={n}: {ms / cnt:.3f} ms (stamped build), {passes} passes for {segs} segments = {segs / passes:.1f} lanes per pass")
 for label, v in (("list + loads (waited)", load), ("nearest hit", hit), ("record + interact + state (waited)", inter), ("compaction", comp)):
     print(f"   {label:36s} {v / passes:9.0f} cycles per pass  {100 * v / tot:5.1f} %")

@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Condense tools/profile_r04.sh output into small files fit for profiles/:
+     r04_issue_calibration.json        the microkernels of tools/issue_calibration.hip: s_memtime ground truth next to the SQ
+                                       counters of the same launches, per (kind, waves per SIMD)
+     r04_<workload>_kernel_stats.csv   rows of rocprofv3's --stats summary for this library's kernels (verbatim columns)
+     r04_<workload>_counters.json      per-launch averages of the PMC passes for the dominant kernel + derived figures
+   usage: summarize_r04.py <raw dir> <out dir>     (then copy <out dir>/* into profiles/)
+HBM bytes follow MI355X_MICROARCH.md §HBM: FETCH_SIZE (KiB) x 2 on gfx950, WRITE_SIZE (KiB) as read.
+Issue figures use the CALIBRATED cost of a wave64 vector instruction (profiles/r04_issue_calibration.json): the pipe of a
+SIMD is full at one plain VALU instruction per `VALU_CYCLES` cycles."""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+raw, dst = sys.argv[1], sys.argv[2]
+os.makedirs(dst, exist_ok=True)
+OURS = ("k_trace_", "k_gen_", "k_mon_", "k_stream_")
+RECORD_BYTES = {"cfg2": 104, "cfg4": 104, "cfg3": 56, "cfg5": 56}  # per ray record and per segment record
+N_SIMD, N_XCD, N_CU = 1024, 8, 256
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def short_name(n):
+    return n.split("(")[0].replace("void ", "").strip()
+
+
+def counter_rows(wdir):
+    for f in glob.glob(os.path.join(wdir, "*", "*", "*_counter_collection.csv")):
+        if os.sep + "trace" + os.sep in f:
+            continue
+        for r in csv.DictReader(open(f)):
+            yield r
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# calibration
+def calibration(wdir):
+    plain = json.load(open(os.path.join(wdir, "plain.json")))
+    runs = {(r["kind"], r["waves_per_simd"]): r for r in plain["runs"]}
+    kind_of = {r.get("kernel", "k_" + r["kind"]): r["kind"] for r in plain["runs"]}
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in counter_rows(wdir):
+        fn = short_name(r["Kernel_Name"])
+        if fn not in kind_of:
+            continue
+        wps = int(r["Grid_Size"]) // (N_CU * 256)
+        acc[(kind_of[fn], wps)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    out = []
+    for key, run in sorted(runs.items()):
+        c = {k: sum(v) / len(v) for k, v in acc.get(key, {}).items()}
+        rec = dict(run)
+        rec["counters_per_launch"] = c
+        d = {}
+        wps = run["waves_per_simd"]
+        total = run["valu_per_wave"] + run["salu_per_wave"] + run["lds_per_wave"]
+        d["memtime_ticks_per_valu_per_simd"] = (run["memtime_ticks_median"] / run["valu_per_wave"] / wps) if run["valu_per_wave"] else None
+        d["memtime_ticks_per_instruction_per_simd"] = run["memtime_ticks_median"] / total / wps
+        d["memtime_ticks_per_instruction_per_wave"] = run["memtime_ticks_median"] / total
+        cyc = c.get("GRBM_GUI_ACTIVE")
+        if cyc:
+            cyc /= N_XCD  # summed over the XCDs
+            d["gpu_cycles_per_launch"] = cyc
+            if c.get("SQ_INSTS_VALU"):
+                d["cycles_per_valu_per_simd"] = cyc * N_SIMD / c["SQ_INSTS_VALU"]
+            if c.get("SQ_ACTIVE_INST_VALU"):
+                d["r03_valu_issue_fraction"] = 4 * c["SQ_ACTIVE_INST_VALU"] / (cyc * N_SIMD)  # what summarize_r03.py called the VALU issue fraction
+        if c.get("SQ_ACTIVE_INST_VALU") and c.get("SQ_INSTS_VALU"):
+            d["active_inst_valu_per_valu_instruction"] = c["SQ_ACTIVE_INST_VALU"] / c["SQ_INSTS_VALU"]
+        if c.get("SQ_WAVE_CYCLES") and c.get("SQ_WAVES"):
+            d["wave_cycles_counter_per_memtime_tick"] = c["SQ_WAVE_CYCLES"] / c["SQ_WAVES"] / run["memtime_ticks_median"]
+        if c.get("SQ_BUSY_CYCLES") and cyc:
+            d["sq_busy_cycles_over_gpu_cycles"] = c["SQ_BUSY_CYCLES"] / cyc
+        if c.get("SQ_ACTIVE_INST_SCA") and c.get("SQ_INSTS_SALU"):
+            d["active_inst_sca_per_salu_instruction"] = c["SQ_ACTIVE_INST_SCA"] / c["SQ_INSTS_SALU"]
+        rec["derived"] = d
+        out.append(rec)
+    doc = {"device": plain.get("device"), "cus": plain.get("cus"), "clock_mhz": plain.get("clock_mhz"), "turns": plain.get("turns"),
+           "what": "tools/issue_calibration.hip: inline-assembly microkernels at exactly 1 / 2 / 4 / 8 waves per SIMD; s_memtime per wave "
+                   "(ground truth) and rocprofv3 --pmc counters of the same launches (tools/profile_r04.sh calib)",
+           "runs": out}
+    json.dump(doc, open(os.path.join(dst, "r04_issue_calibration.json"), "w"), indent=1)
+    for rec in out:
+        d = rec["derived"]
+        print("calib", rec["kind"], rec["waves_per_simd"], {k: (round(v, 4) if isinstance(v, float) else v) for k, v in d.items()})
+    return doc
+
+
+def valu_cost_from(doc):
+    """shader cycles one plain wave64 VALU instruction occupies a SIMD's vector pipe when the pipe is full (>= 2 waves)"""
+    best = None
+    for rec in doc["runs"]:
+        if rec["kind"] == "valu" and rec["waves_per_simd"] >= 2:
+            v = rec["derived"].get("cycles_per_valu_per_simd") or rec["derived"].get("memtime_ticks_per_valu_per_simd")
+            if v and (best is None or v < best):
+                best = v
+    return best
+
+
+cal_doc = None
+cal_dir = os.path.join(raw, "calib")
+if os.path.exists(os.path.join(cal_dir, "plain.json")):
+    try:
+        cal_doc = calibration(cal_dir)
+    except Exception as exc:  # noqa: BLE001
+        print("calibration summary failed:", exc)
+if cal_doc is None:
+    committed = os.path.join(HERE, "..", "profiles", "r04_issue_calibration.json")
+    if os.path.exists(committed):
+        cal_doc = json.load(open(committed))
+VALU_CYCLES = (valu_cost_from(cal_doc) if cal_doc else None) or 2.0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# workloads
+def algorithmic_bytes(wdir, w):
+    """(rays + segments) x record bytes per launch, from what the profiled program printed (tools/profile_workload.py)."""
+    if w not in RECORD_BYTES:
+        return None
+    try:
+        text = open(os.path.join(wdir, "trace.log")).read()
+    except OSError:
+        return None
+    m = re.search(r"(\d+) (?:rays|ray-wavelength pairs), (\d+) segments per trace", text)
+    return (int(m.group(1)) + int(m.group(2))) * RECORD_BYTES[w] if m else None
+
+
+for wdir in sorted(glob.glob(os.path.join(raw, "*"))):
+    w = os.path.basename(wdir)
+    if w == "calib" or not os.path.isdir(wdir):
+        continue
+    stats = glob.glob(os.path.join(wdir, "trace", "*", "*_kernel_stats.csv"))
+    if not stats:
+        continue
+    rows = [r for r in csv.DictReader(open(stats[0])) if any(k in r["Name"] for k in OURS)]
+    if not rows:
+        continue
+    with open(os.path.join(dst, f"r04_{w}_kernel_stats.csv"), "w", newline="") as fh:
+        wr = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
+        wr.writeheader()
+        wr.writerows(rows)
+    top = max(rows, key=lambda r: float(r["TotalDurationNs"]))
+    short = short_name(top["Name"])
+    rec = {"workload": w, "kernel": short, "calls": int(top["Calls"]), "avg_ns": float(top["AverageNs"]),
+           "min_ns": float(top["MinNs"]), "max_ns": float(top["MaxNs"]),
+           "all_kernels_ns_per_run": {short_name(r["Name"]): float(r["TotalDurationNs"]) for r in rows}}
+    acc = collections.defaultdict(list)
+    for r in counter_rows(wdir):
+        if short_name(r["Kernel_Name"]) == short:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            rec.setdefault("dispatch", {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size") if k in r})
+    c = {k: sum(v) / len(v) for k, v in acc.items()}
+    rec["counters_per_launch"] = c
+    d = {"valu_cycles_per_instruction_calibrated": VALU_CYCLES}
+    cyc = c.get("GRBM_GUI_ACTIVE", 0) / N_XCD
+    if "SQ_ACTIVE_INST_VALU" in c and "SQ_THREAD_CYCLES_VALU" in c and c["SQ_ACTIVE_INST_VALU"]:
+        d["active_lane_fraction"] = c["SQ_THREAD_CYCLES_VALU"] / (64 * c["SQ_ACTIVE_INST_VALU"])
+    if "SQ_WAIT_ANY" in c and c.get("SQ_WAVE_CYCLES"):
+        d["wait_share_of_wave_cycles"] = c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]
+    if "SQ_WAIT_INST_ANY" in c and c.get("SQ_WAVE_CYCLES"):
+        d["issue_stall_share_of_wave_cycles"] = c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"]
+    if "SQ_ACTIVE_INST_ANY" in c and c.get("SQ_WAVE_CYCLES"):
+        d["active_share_of_wave_cycles"] = c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"]
+    if cyc and c.get("SQ_INSTS_VALU"):
+        d["gpu_cycles_per_launch"] = cyc
+        d["cycles_per_valu_per_simd"] = cyc * N_SIMD / c["SQ_INSTS_VALU"]
+        d["valu_pipe_busy"] = c["SQ_INSTS_VALU"] * VALU_CYCLES / (cyc * N_SIMD)  # calibrated: 1.0 = the microkernel's rate
+        d["r03_valu_issue_fraction"] = 4 * c.get("SQ_ACTIVE_INST_VALU", 0) / (cyc * N_SIMD)
+        if c.get("SQ_INSTS_SALU"):
+            d["salu_per_cycle_per_cu"] = c["SQ_INSTS_SALU"] / (cyc * N_CU)
+        if c.get("SQ_INSTS_LDS"):
+            d["lds_insts_per_cycle_per_cu"] = c["SQ_INSTS_LDS"] / (cyc * N_CU)
+    if c.get("SQ_WAVE_CYCLES") and cyc:
+        d["mean_waves_per_simd"] = 4 * c["SQ_WAVE_CYCLES"] / (cyc * N_SIMD)  # SQ_WAVE_CYCLES counts quad-cycles
+    if "SQ_INSTS_VALU" in c and c.get("SQ_WAVES"):
+        d["valu_insts_per_wave"] = c["SQ_INSTS_VALU"] / c["SQ_WAVES"]
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        d["hbm_read_bytes_fetch_x2"] = c["FETCH_SIZE"] * 1024 * 2
+        d["hbm_write_bytes"] = c["WRITE_SIZE"] * 1024
+        d["hbm_bytes"] = d["hbm_read_bytes_fetch_x2"] + d["hbm_write_bytes"]
+        d["hbm_gbs"] = d["hbm_bytes"] / rec["avg_ns"]
+        alg = algorithmic_bytes(wdir, w)
+        if alg:
+            d["algorithmic_bytes"] = alg
+            d["traffic_over_algorithmic"] = d["hbm_bytes"] / alg
+            d["hbm_frac_algorithmic"] = alg / rec["avg_ns"] / 8000.0
+    rec["derived"] = d
+    json.dump(rec, open(os.path.join(dst, f"r04_{w}_counters.json"), "w"), indent=1)
+    print(w, short, f"{rec['avg_ns'] / 1e6:.3f} ms", {k: round(v, 4) for k, v in d.items() if k not in ("hbm_read_bytes_fetch_x2", "hbm_write_bytes", "hbm_bytes")})
