@@ -15,11 +15,14 @@ process is one rank.  cfg 2 / cfg 3 scale weakly (every rank traces the config's
 TOTAL (6.4e8 ray-wavelength pairs, 1e8 rays) that is sharded over the ranks (`"scaling": "strong"`).  No
 collective in the data path; the single end-of-job gather of the per-ray final state over RCCL is timed
 separately (`gather_ms`).  The default N = 1 run also measures the other BASELINE configs at the size one GPU sees
-(`configs`), a >= 1 s sustained loop (`sustained`), the cold-start figure (`cold`) and the CPU baseline.
+(`configs`), a >= 6 s sustained loop (`sustained`), the cold-start figure (`cold`), call latencies at the
+reference's own sizes (`latency`) and the CPU baseline.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import contextlib
+import io
 import json
 import os
 import socket
@@ -54,7 +57,13 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the cfg3/cfg4/cfg5 survey of the default run")
     ap.add_argument("--no-sustained", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the small-N call latencies of the default run")
+    ap.add_argument("--sustained-seconds", type=float, default=6.0, help="length of the back-to-back loop after the timed region")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU time spent on the oracle baseline (bounded sample)")
+    ap.add_argument("--sharded-configs", default="auto",
+                    help="with --gpus N > 1 on the default workload: the configs BASELINE quotes multi-GPU, at their quoted totals, as "
+                         "`sharded_configs` of the line: auto (cfg4 on 2 / 4 ranks, cfg5 on 8), none, or a comma list")
+    ap.add_argument("--sharded-rays", type=int, default=None, help="rays per rank for --sharded-configs (rehearsals on one card)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the real thing) or gloo (rehearsal: ranks may share a card)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and run the collectives even with one rank (rehearsal of the RCCL calls on a 1-GPU box)")
@@ -216,16 +225,31 @@ def survey_config(oa, eng, name, device):
     b = BYTES[wl.precision]
     reps = 5 if name == "cfg3" else 3
 
+    default_call = {}
+
     def measure(layout):
         """device time per trace with the output in `layout`: [k][ray] slots (ot_trace_*) or the dense append-order list
-        (ot_trace_append_*, sized like a caller who knows the job: by the records of a first trace)"""
+        (ot_trace_append_*) in the block the DEFAULT call allocates: `table.trace_batch(batch, K)` with no layout and no
+        capacity sizes it from a 1 % sample of the batch (Engine._append_estimate), not from a second full trace"""
         torch.cuda.empty_cache()
         if layout == "append":
-            probe = eng.trace(batch, wl.max_segments, layout="append")
-            cap = eng.append_capacity(int(probe.count.abs().sum().item()))  # records + one chunk per wave (where the holes can be)
-            del probe
-            torch.cuda.empty_cache()
-            out = SegmentBatch(cap, wl.precision, batch.device, block=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = table.trace_batch(batch, wl.max_segments, scene=scene)  # first call: sample trace + allocation + trace
+            valid = int(out.n_valid)
+            first_ms = (time.perf_counter() - t0) * 1e3
+            assert out.layout == "append", out.layout
+            records = int(out.count.abs().sum().item())
+            del out
+            t0 = time.perf_counter()
+            out = table.trace_batch(batch, wl.max_segments, scene=scene)  # later calls: the estimate is remembered per scene
+            valid = int(out.n_valid)
+            next_ms = (time.perf_counter() - t0) * 1e3
+            default_call.update(first_call_ms=first_ms, next_call_ms=next_ms, capacity_slots=out.capacity, records=records,
+                                capacity_over_records=out.capacity / max(records, 1), slots_claimed=valid,
+                                note="wall clock of table.trace_batch(batch, K, scene=compiled) with no layout and no capacity, read-back of "
+                                     "the slot count included: first call = 1 % sample trace + block allocation + trace; next = trace into "
+                                     "a fresh block of the remembered estimate")
         else:
             out = SegmentBatch(n * wl.max_segments, wl.precision, batch.device)
         t_load = time.perf_counter()
@@ -274,6 +298,10 @@ def survey_config(oa, eng, name, device):
         t, cnt, _, slots, launch = measure_tiled()
         kern = kernel_name(scene, wl)
         layout = "tiled: slot k * n_rays + i in tile / 64, lane % 64 (ot_trace_tiled_*)"
+        chosen = eng.plan(wl.precision, n, wl.max_segments)["layout"]
+        if chosen == "slots":  # this device streams the 14 arrays faster: they are the config's figure, the tiles the companion
+            (t, cnt, slots, launch), (ts, cnts, slots_s, launch_s) = (ts, cnts, slots_s, launch_s), (t, cnt, slots, launch)
+            layout = "slots: segment k of ray i at k * n_rays + i (ot_trace_*)"
     rec = {"workload": wl.label, "rays": n, "dtype": wl.precision, "kernel": kern, "leaf_surfaces": scene.n_leaves,
            "layout": layout, "output_slots": slots, "launches": cnt, "ms_per_trace": t * 1e3, "segments_per_ray": segs / n,
            "segments_per_s": segs / t, "intersections_per_s": segs * scene.n_leaves / t, "algorithmic_gbs": alg / t / 1e9,
@@ -281,7 +309,9 @@ def survey_config(oa, eng, name, device):
            "bound": "hbm" if not heavy else "valu (S >= 24, SURVEY.md §8d): the HBM fraction is for comparison"}
     if heavy:
         rec["holes"] = slots - segs
-    rec["slots_layout"] = {"layout": "slots: segment k of ray i at k * n_rays + i (ot_trace_*)", "kernel": kernel_name(scene, wl),
+        rec["default_call"] = default_call
+    other_name = ("tiled: 64-slot tiles (ot_trace_tiled_*)" if (not heavy and layout.startswith("slots")) else "slots: segment k of ray i at k * n_rays + i (ot_trace_*)")
+    rec["other_layout"] = {"layout": other_name, "kernel": kernel_name(scene, wl),
                            "output_slots": slots_s, "launches": cnts, "ms_per_trace": ts * 1e3, "segments_per_s": segs / ts,
                            "intersections_per_s": segs * scene.n_leaves / ts, "algorithmic_gbs": alg / ts / 1e9,
                            "hbm_frac": alg / ts / 1e9 / HBM_PEAK_GBS, "launch": launch_s}
@@ -331,6 +361,123 @@ def survey_branching(oa, eng, device):
     del segs, batch, base
     torch.cuda.empty_cache()
     return rec
+
+
+def sharded_config(oa, eng, dist, name, world, rank, device, comm_dev, rays_override=None, min_region_s=0.05):
+    """One of the configs BASELINE quotes on several GPUs (cfg 4 on 2 and 4, cfg 5 on 8), at its quoted TOTAL sharded over the
+    ranks (contiguous ray shards, scene replicated, no collective in the trace).  Every rank traces its shard in the layout
+    the default call uses; the timed region is at least `min_region_s` long (as many launches as that takes, the same on
+    every rank) between barrier + synchronize on both sides, the maximum over the ranks counts.  Called by ALL ranks;
+    returns the record on rank 0."""
+    import math
+
+    import torch
+    from optable_amd import workloads as W
+    from optable_amd.batch import SegmentBatch
+
+    wl = W.baseline_workloads(oa)[name]
+    n_wanted = wl.rays_per_rank(world, rays_override)
+    n = min(n_wanted, MAX_PER_RANK[name])
+    if name == "cfg4":
+        n = max(n // W.CFG4_WAVELENGTHS, 1) * W.CFG4_WAVELENGTHS
+    table = oa.OpticalTable()
+    table.add_components(wl.components())
+    scene = table.compile()
+    eng.upload(scene)
+    batch = make_batch(oa, wl, n, rank, device)
+    n, K = batch.n, wl.max_segments
+    first = table.trace_batch(batch, K, scene=scene)  # the default call: sizes an append block from a sample, picks the light layout by the device probe
+    layout = first.layout
+    segs_step = int(first.count.abs().sum().item())
+    out = first if layout == "append" else SegmentBatch(n * K, wl.precision, batch.device, tiled=(layout == "tiled"))
+    if out is not first:
+        del first
+    for _ in range(2):
+        eng.trace(batch, K, out=out, layout=layout)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.trace(batch, K, out=out, layout=layout)
+    torch.cuda.synchronize()
+    mine = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=comm_dev)
+    dist.all_reduce(mine, op=dist.ReduceOp.MAX)
+    steps = max(3, int(math.ceil(min_region_s / max(float(mine.item()), 1e-6))))
+    for attempt in range(4):  # (back-to-back launches run faster than the lone one the step count was guessed from: lengthen until the region is long enough)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            eng.trace(batch, K, out=out, layout=layout)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        longest = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
+        dist.all_reduce(longest, op=dist.ReduceOp.MAX)
+        if float(longest.item()) >= min_region_s or attempt == 3:
+            break
+        steps = int(steps * min_region_s / max(float(longest.item()), 1e-6) * 1.25) + 1
+    row = torch.tensor([dt, float(segs_step), float(n)], dtype=torch.float64, device=comm_dev)
+    rows = [torch.zeros_like(row) for _ in range(world)]
+    dist.all_gather(rows, row)
+    per_rank = [[float(x) for x in r.tolist()] for r in rows]
+    launch = eng.last_launch()
+    del out, batch
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
+    dt_max = max(r[0] for r in per_rank)
+    segs_total, rays_total = sum(r[1] for r in per_rank), sum(r[2] for r in per_rank)
+    b = BYTES[wl.precision]
+    return {"workload": wl.label, "n_gpus": world, "rays_total": int(rays_total), "total_requested": wl.total_rays,
+            "clamped": bool(n < n_wanted), "rays_per_gpu": n, "dtype": wl.precision, "layout": layout, "steps": steps,
+            "timed_region_ms": dt_max * 1e3, "ms_per_step": dt_max / steps * 1e3, "segments_per_s": segs_total * steps / dt_max,
+            "value": segs_total * scene.n_leaves * steps / dt_max, "unit": "intersections/s (whole job, all ranks)",
+            "algorithmic_gbs_per_gpu": (n * b + segs_step * b) * steps / dt_max / 1e9,
+            "ranks": {"ms_per_step_by_rank": [r[0] / steps * 1e3 for r in per_rank], "segments_by_rank": [int(r[1]) for r in per_rank],
+                      "rays_by_rank": [int(r[2]) for r in per_rank]},
+            "launch": launch}
+
+
+def survey_latency(oa):
+    """Milliseconds per `table.ray_tracing(rays)` call at the sizes the reference is actually used at: its GUI re-runs the whole
+    script on every slider event (interact.py:455-457, 20 frames per second: :202-208), with a handful of Ray objects.  Median
+    over 200 calls after 20 warm-up calls; Ray objects in, Ray objects out (packing, launch(es), read-back, object rebuild)."""
+    import statistics
+
+    import numpy as np
+    from optable_amd import workloads as W
+
+    def cfg2_small(ns):
+        o, d = W.cfg2_rays(100, 0)
+        return W.cfg2_components(ns), [ns.Ray(o[i], d[i], wavelength=W.WL, w0=W.W0, id=i) for i in range(100)]
+
+    # the reference's own time for the same call: cfg 1 measured (BASELINE.md §2: 11.5 ms for 13 segments); the others from its
+    # measured segment rates (2.7e3 / 3.0e3 segments per second, BASELINE.md §2), build container, single thread
+    cases = [("cfg1 examples/gaussian_beam.py: 6 rays -> 13 segments (non-branching, one launch)", W.gaussian_beam_scene, None, 11.5),
+             ("examples/chromatic_aberration.py: 3 rays, every hit branches -> 59 segments (ray trees)", W.chromatic_scene, None, 59 / 2.7e3 * 1e3),
+             ("cfg2 scene at 100 rays, cap 5 -> 500 segments", cfg2_small, {"max_trace_num": 5}, 500 / 3.0e3 * 1e3)]
+    out = []
+    for label, make, limit, ref_ms in cases:
+        comps, rays = make(oa)
+        table = oa.OpticalTable()
+        table.add_components(comps)
+        res = None
+        ts = []
+        with contextlib.redirect_stdout(io.StringIO()):  # (a capped trace prints the reference's message, optical_table.py:138-143)
+            for _ in range(20):
+                table.rays = []
+                res = table.ray_tracing(rays, perfomance_limit=limit)
+            for _ in range(200):
+                table.rays = []
+                t0 = time.perf_counter()
+                res = table.ray_tracing(rays, perfomance_limit=limit)
+                ts.append((time.perf_counter() - t0) * 1e3)
+        ts.sort()
+        out.append({"workload": label, "rays": len(rays), "segments": len(res), "calls": len(ts), "median_ms_per_call": statistics.median(ts),
+                    "p10_ms": ts[len(ts) // 10], "p90_ms": ts[9 * len(ts) // 10], "reference_python_ms": ref_ms,
+                    "speedup_vs_reference": ref_ms / statistics.median(ts)})
+    return out
 
 
 def main():
@@ -403,8 +550,17 @@ def main():
         # Output layout: light scenes (the lane-per-ray kernel: cfg 2, cfg 4) write their [k][ray] slots in 64-slot tiles
         # (ot_trace_tiled_*: one contiguous block per wave and segment; the same records, tests/test_gpu_append.py); heavy
         # scenes write the 14 slot arrays here (their dense output, ot_trace_append_*, is measured in `configs`).
-        layout = "tiled" if scene.n_nodes < 24 else "slots"
+        # Which of the two the DEVICE streams faster differs by box (tiles +12 % on some, -8 % on others, stable within a box:
+        # tools/stream_layouts2.hip), so it is what the library recommends after measuring both once (ot_trace_plan /
+        # ot_probe_layouts: what trace_batch's default layout="auto" uses); the other layout is timed beside it.
+        heavy_wl = scene.n_nodes >= 24
+        plan = eng.plan(prec, n, MAX_SEG)
+        layout = "slots" if heavy_wl else plan["layout"]
         extra["output_layout"] = layout
+        if not heavy_wl:
+            extra["layout_probe"] = {"slots_us": plan["probe_us"][0], "tiled_us": plan["probe_us"][1], "chosen": layout,
+                                     "note": "cfg 2's streams with no tracing, 2^20 rays, through both slot layouts on this device "
+                                             "(ot_probe_layouts, once per context); tiles are taken where they win by more than 1.5 %"}
         outs = [SegmentBatch(n * MAX_SEG, prec, batches[0].device, tiled=(layout == "tiled")) for _ in range(n_inputs)]
 
         def step(s):
@@ -473,39 +629,40 @@ def main():
                 eng.stream_ceiling(batches[s % n_inputs], MAX_SEG, outs[s % n_inputs])
             ceil_ms, ceil_n = eng.timing_read()
         eng.timing(False)
-        if layout == "tiled" and world == 1:
-            # the same K launches into the 14 [k][ray] arrays of ot_trace_* (the layout of rounds 1-2), for comparison
-            outs_slots = [SegmentBatch(n * MAX_SEG, prec, batches[0].device) for _ in range(n_inputs)]
+        if not heavy_wl and world == 1:
+            # the same K launches into the OTHER slot layout (the one the probe did not choose), for comparison
+            other = "slots" if layout == "tiled" else "tiled"
+            outs_o = [SegmentBatch(n * MAX_SEG, prec, batches[0].device, tiled=(other == "tiled")) for _ in range(n_inputs)]
             for s in range(args.warmup + 3):
-                eng.trace(batches[s % n_inputs], MAX_SEG, out=outs_slots[s % n_inputs])
+                eng.trace(batches[s % n_inputs], MAX_SEG, out=outs_o[s % n_inputs], layout=other)
             torch.cuda.synchronize()
             ev0.record()
             for s in range(args.steps):
-                eng.trace(batches[s % n_inputs], MAX_SEG, out=outs_slots[s % n_inputs])
+                eng.trace(batches[s % n_inputs], MAX_SEG, out=outs_o[s % n_inputs], layout=other)
             ev1.record()
             torch.cuda.synchronize()
-            slots_us = ev0.elapsed_time(ev1) / args.steps * 1e3
+            other_us = ev0.elapsed_time(ev1) / args.steps * 1e3
             for s in range(3):
-                eng.stream_ceiling(batches[s % n_inputs], MAX_SEG, outs_slots[s % n_inputs])
+                eng.stream_ceiling(batches[s % n_inputs], MAX_SEG, outs_o[s % n_inputs])
             eng.timing(True)
             for s in range(10 if wl.name == "cfg2" else 3):
-                eng.stream_ceiling(batches[s % n_inputs], MAX_SEG, outs_slots[s % n_inputs])
+                eng.stream_ceiling(batches[s % n_inputs], MAX_SEG, outs_o[s % n_inputs])
             sc_ms, sc_n = eng.timing_read()
             eng.timing(False)
-            extra["slots_layout"] = {"kernel_us": slots_us, "stream_ceiling_us": sc_ms / max(sc_n, 1) * 1e3,
-                                     "note": "the same trace into the 14 [k][ray] arrays of ot_trace_* (the output layout of rounds 1-2)"}
-            del outs_slots
+            extra["other_layout"] = {"layout": other, "kernel_us": other_us, "stream_ceiling_us": sc_ms / max(sc_n, 1) * 1e3,
+                                     "note": "the same trace into the slot layout the device probe did NOT choose"}
+            del outs_o
             torch.cuda.empty_cache()
         if world == 1 and not args.no_sustained:
-            # >= 1 s of back-to-back launches: long enough for any outside sampler to see the GPU busy, and the
-            # figure a long job gets
+            # >= 6 s of back-to-back launches: long enough for any outside sampler (the driver polls the card every few seconds)
+            # to see the GPU busy, and the figure a long job gets
             clocks = {}
             sampler = threading.Thread(target=sample_device_clocks, args=(clocks,), daemon=True)
             sampler.start()  # reads the clocks the chip runs at WHILE this loop keeps it busy (boxes of a pool differ)
             t_s = time.perf_counter()
             done = 0
             chunk = max(1, int(0.02 / max(dt / args.steps, 1e-6)))  # ~20 ms of launches between host syncs
-            while time.perf_counter() - t_s < 1.0:
+            while time.perf_counter() - t_s < args.sustained_seconds:
                 for s in range(chunk):
                     step(done + s)
                 done += chunk
@@ -562,6 +719,24 @@ def main():
     else:
         segs_total_step, rays_total = segs_step, n
 
+    # The configs BASELINE quotes on several GPUs, at their quoted totals: cfg 4 on 2 and 4 ranks, cfg 5 on 8 (every rank takes part)
+    sharded = []
+    if distributed and world > 1 and not args.dry_run and wl.name == "cfg2" and args.sharded_configs != "none" \
+            and (args.sharded_configs != "auto" or args.rays is None):
+        names = (["cfg4"] if world in (2, 4) else []) + (["cfg5"] if world == 8 else []) if args.sharded_configs == "auto" \
+            else [c for c in args.sharded_configs.split(",") if c]
+        del batches, outs
+        torch.cuda.empty_cache()
+        for name in names:
+            try:
+                rec = sharded_config(oa, eng, dist, name, world, rank, device, comm_dev, rays_override=args.sharded_rays)
+            except Exception as exc:  # noqa: BLE001 — reported; the other ranks raise alike (same code, same sizes)
+                rec = {"workload": name, "error": f"{type(exc).__name__}: {exc}"}
+            if rank == 0:
+                sharded.append(rec)
+        batches = [make_batch(oa, wl, min(n, 200_000), rank, device)]
+        eng.upload(scene)
+
     if rank == 0:
         value = segs_total_step * S_LEAVES * args.steps / dt
         avg_kernel_s = region_ms / args.steps / 1e3             # HIP events over the timed region, incl. launch gaps
@@ -611,8 +786,8 @@ def main():
             sus["hbm_frac"] = alg_bytes / (sus["ms_per_step"] / 1e3) / 1e9 / HBM_PEAK_GBS
         if "cold" in extra:
             extra["cold"]["hbm_frac"] = alg_bytes / (extra["cold"]["us_per_step"] / 1e6) / 1e9 / HBM_PEAK_GBS
-        if "slots_layout" in extra:
-            sl = extra["slots_layout"]
+        if "other_layout" in extra:
+            sl = extra["other_layout"]
             sl["hbm_frac"] = alg_bytes / (sl["kernel_us"] / 1e6) / 1e9 / HBM_PEAK_GBS
             sl["stream_ceiling_gbs"] = alg_bytes / (sl["stream_ceiling_us"] / 1e6) / 1e9
         line.update(extra)
@@ -625,6 +800,8 @@ def main():
                 line["gather"] = {"sizes_ms": gather_split["sizes_ms"], "payload_ms": gather_split["payload_ms"],
                                   "payload_bytes": int(sum(gather_split["shard_sizes"])) * 12 * (8 if prec == "f64" else 4),
                                   "shard_sizes": gather_split["shard_sizes"]}
+        if sharded:
+            line["sharded_configs"] = sharded
         if ranks_info is not None:
             line["ranks"] = ranks_info
             line["comm"] = {"backend": "rccl" if use_nccl else "gloo",
@@ -644,6 +821,12 @@ def main():
             except Exception as exc:  # noqa: BLE001
                 line["configs"].append({"workload": "cfg4 branching", "error": f"{type(exc).__name__}: {exc}"})
             batches = [make_batch(oa, wl, min(n, 200_000), rank, device)]
+            eng.upload(scene)
+        if world == 1 and not args.dry_run and wl.name == "cfg2" and not args.no_latency and args.rays is None:
+            try:
+                line["latency"] = survey_latency(oa)
+            except Exception as exc:  # noqa: BLE001
+                line["latency"] = [{"error": f"{type(exc).__name__}: {exc}"}]
             eng.upload(scene)
         if world == 1 and not args.no_cpu_baseline and not args.dry_run:
             try:

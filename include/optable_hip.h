@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define OT_ABI_VERSION 9  /* 9: ot_trace_tree_*, OT_OPT_BLOCK_POOL, OT_OPT_GEN_DROP_DOOMED, ot_trace_append_* holes per workgroup chunk; 8: OT_SHAPE_ASPHERE_CHEB, OT_MAT_CHEB, OT_NODE_BOX_TRUSTED, ot_trace_tiled_*, ot_bench_stream_tiled_*; 3: ot_trace_generation_f32; 4: ot_bench_stream_f32; 5: OT_OPT_LIST_CAP, ray flags bits 8..31, ot_debug_generation_mismatches; 6: ot_debug_last_launch, OT_OPT_FLAT_QUEUE, OT_OPT_LDS_RECORDS; 7: ot_trace_append_*, ot_segment_block, OT_OPT_APPEND_CHUNK, OT_OPT_INSTANCING */
+#define OT_ABI_VERSION 10  /* 10: ot_trace_plan, ot_probe_layouts, OT_OPT_REFILL, OT_OPT_REFILL_TICKET; 9: ot_trace_tree_*, OT_OPT_BLOCK_POOL, OT_OPT_GEN_DROP_DOOMED, ot_trace_append_* holes per workgroup chunk; 8: OT_SHAPE_ASPHERE_CHEB, OT_MAT_CHEB, OT_NODE_BOX_TRUSTED, ot_trace_tiled_*, ot_bench_stream_tiled_*; 3: ot_trace_generation_f32; 4: ot_bench_stream_f32; 5: OT_OPT_LIST_CAP, ray flags bits 8..31, ot_debug_generation_mismatches; 6: ot_debug_last_launch, OT_OPT_FLAT_QUEUE, OT_OPT_LDS_RECORDS; 7: ot_trace_append_*, ot_segment_block, OT_OPT_APPEND_CHUNK, OT_OPT_INSTANCING */
 
 /* ---- status codes ------------------------------------------------------------------- */
 enum ot_status {
@@ -322,6 +322,20 @@ int ot_trace_tree_f32(ot_ctx* ctx, const ot_rays* rays, const int32_t* rays_tree
                       const ot_segments* out, int64_t out_capacity, int64_t* state, const ot_rays* buf_a, int32_t* tree_a,
                       const ot_rays* buf_b, int32_t* tree_b, int64_t buf_capacity, int32_t* counts, int32_t n_count_classes,
                       double max_seconds, int64_t* result);
+
+/* What the library would launch for the uploaded scene and a batch of n_rays rays of `real_bytes` (4 / 8) precision, and
+ * which output layout its kernels write fastest — what a caller with no preference should ask for:
+ * info[0] kernel family of ot_trace_* (1 lane per ray, 2 rolling lists / block pool); [1] 1 = ot_trace_tiled_* accepts the
+ * scene; [2] log2 of the first capacity ot_trace_append_* refuses (30 / 29); [3] the recommended layout: 0 slot arrays
+ * (ot_trace_*), 1 tiles (ot_trace_tiled_*), 2 append (ot_trace_append_*); [5], [6] light scenes: hundredths of a microsecond
+ * per launch of the stream companion in slot arrays / tiles (ot_probe_layouts).  Heavy scenes: append, unless the worst case
+ * max_segments * n_rays would not fit the capacity limit (then slots, which have none).  Light scenes: the layout this DEVICE
+ * streams faster — the 64-slot tiles run up to 12 % faster than the 14 arrays on some boxes and 8 % slower on others, so
+ * it is measured (once per context and precision, ~15 ms, 1.3 GB of temporary buffers in double precision). */
+int ot_trace_plan(ot_ctx* ctx, int32_t real_bytes, int64_t n_rays, int32_t max_segments, int32_t info[8]);
+/* The measurement behind it: microseconds per launch of cfg 2's streams (2^20 rays, 5 segments, no tracing) into the 14 slot
+ * arrays and into 64-slot tiles; cached in the context. */
+int ot_probe_layouts(ot_ctx* ctx, int32_t real_bytes, double* us_slots, double* us_tiled);
 
 /* Diagnostic: how often the two passes of a generation (count, then emit: both run the same trace) disagreed about a
  * ray since the ctx was created.  Expected 0; a disagreement is contained (nothing is written outside the slots the

@@ -7,7 +7,7 @@ __graft_entry__ as g; g.build()"` or `make -C optable_amd/csrc`).
 import ctypes as C
 import os
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "liboptable_hip.so")
 
@@ -109,6 +109,8 @@ SYMBOLS = {
     "ot_set_option": (C.c_int, [_vp, _i32, _i32]),
     "ot_debug_generation_mismatches": (C.c_int, [_vp, C.POINTER(_i64)]),
     "ot_debug_last_launch": (C.c_int, [_vp, C.POINTER(_i32 * 8)]),
+    "ot_trace_plan": (C.c_int, [_vp, _i32, _i64, _i32, C.POINTER(_i32 * 8)]),
+    "ot_probe_layouts": (C.c_int, [_vp, _i32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ot_bench_stream_f64": (C.c_int, [_vp, C.POINTER(OtRays), _i64, _i32, C.POINTER(OtSegments), _vp]),
     "ot_bench_stream_f32": (C.c_int, [_vp, C.POINTER(OtRays), _i64, _i32, C.POINTER(OtSegments), _vp]),
 }

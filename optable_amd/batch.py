@@ -311,6 +311,33 @@ class SegmentBatch:
                 setattr(out, extra, getattr(self, extra))
         return out
 
+    def as_kray_slots(self, max_segments=None):
+        """The history of a non-branching trace as plain [k][ray] slot arrays whatever layout it was written in: slots and
+        tiled batches as `to_slots()` gives them, an append-order list scattered into fresh arrays (slot = k * n_rays + ray, k =
+        the record's rank among its ray's records: a stable sort by ray is segment order).  For checks and tools that index
+        segments by (k, ray); the trace itself never needs it."""
+        if not self.append:
+            return self.to_slots()
+        n = self.n_rays
+        K = int(max_segments) if max_segments is not None else int(self.count.abs().max().item())
+        m = self.n_valid
+        idx = torch.nonzero(self.ray[:m] >= 0).flatten()
+        ray = self.ray[idx].long()
+        order = torch.argsort(ray, stable=True)
+        idx, ray = idx[order], ray[order]
+        cnt = self.count.abs().long()
+        start = torch.cumsum(cnt, 0) - cnt
+        k = torch.arange(ray.numel(), device=self.device) - start[ray]
+        slot = k * n + ray
+        out = SegmentBatch(n * K, self.precision, self.device)
+        for f in abi.SEG_FIELDS + ("ray", "surface"):
+            out.field(f)[slot] = self.field(f)[idx]
+        out.count, out.n_rays = self.count, n
+        for extra in ("counts_table", "count_ids"):
+            if hasattr(self, extra):
+                setattr(out, extra, getattr(self, extra))
+        return out
+
     def c_struct(self):
         if self.tiled:
             raise ValueError("a tiled SegmentBatch has no 14-array form: use to_slots()")

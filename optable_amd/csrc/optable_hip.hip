@@ -98,6 +98,7 @@ struct ot_ctx {
     int32_t opt_pair = 1;  // paired 16-byte segment stores in the lane-per-ray kernel
     int32_t opt_nt = 1, opt_minw = 4, opt_blocks_per_cu = 0;  // defaults from tools/tune.py on MI355X
     Scratch gen, scan_tmp, mon;
+    double probe_us[2][2] = {{0, 0}, {0, 0}};  // ot_probe_layouts: [precision][0 slot arrays, 1 tiles] microseconds per launch of the stream companion; 0 = not measured
     unsigned long long* gen_mismatch = nullptr;  // count / emit disagreements of k_gen_pass (expected: 0)
     int64_t* pinned_state = nullptr;             // ot_trace_tree_*: page-locked landing place of the per-generation read-back
 };
@@ -1225,6 +1226,116 @@ int ot_debug_generation_mismatches(ot_ctx* c, int64_t* out) {
     *out = (int64_t)v;
     return 0;
 }
+
+}  // extern "C"
+
+// Which of the two [k][ray] slot layouts do THIS device's memory channels like better?  The lane-per-ray kernel is bound by
+// its streams, and the stream rate of the two layouts differs by box: on some the 64-slot tiles run 12 % faster than the 14
+// arrays, on others 8 % slower (same code, same clocks; stable within a box to half a percent: tools/stream_layouts2.hip).
+// So it is measured, once per context and precision: cfg 2's shape (2^20 rays, 5 segments) through k_stream_ceiling in
+// both layouts, interleaved, on buffers of the library's own that are freed again (1.3 GB in double precision, ~15 ms).
+template <class T> static int probe_layouts(ot_ctx* c) {
+    constexpr int64_t n = 1 << 20;
+    constexpr int32_t K = 5;
+    const int pi = sizeof(T) == 8 ? 1 : 0;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t in_bytes = (size_t)n * (12 * sizeof(T) + 8), slots_bytes = (size_t)n * K * (12 * sizeof(T) + 8);
+    const size_t tiles_bytes = (size_t)(n * K / 64) * SegTiles<T>::TILE_BYTES;
+    uint8_t* buf = nullptr;
+    if (hipMalloc((void**)&buf, in_bytes + slots_bytes + tiles_bytes + 4 * n + 4096) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(OT_ERR_HIP, "ot_probe_layouts: no room for the probe buffers");
+    }
+    HIP_TRY(hipMemsetAsync(buf, 0, in_bytes, c->stream));
+    ot_rays in;
+    void** inf[12] = {&in.ox, &in.oy, &in.oz, &in.dx, &in.dy, &in.dz, &in.wavelength, &in.q_re, &in.q_im, &in.intensity, &in.n, &in.pathlength};
+    uint8_t* p = buf;
+    for (int f = 0; f < 12; ++f) { *inf[f] = p; p += n * sizeof(T); }
+    in.id = (int32_t*)p; p += 4 * n;
+    in.flags = (int32_t*)p; p += 4 * n;
+    in.length = nullptr;
+    ot_segments sg;
+    void** of[12] = {&sg.ox, &sg.oy, &sg.oz, &sg.dx, &sg.dy, &sg.dz, &sg.length, &sg.intensity, &sg.q_re, &sg.q_im, &sg.n, &sg.pathlength};
+    for (int f = 0; f < 12; ++f) { *of[f] = p; p += n * K * sizeof(T); }
+    sg.ray = (int32_t*)p; p += 4 * n * K;
+    sg.surface = (int32_t*)p; p += 4 * n * K;
+    p = (uint8_t*)(((uintptr_t)p + 4095) & ~(uintptr_t)4095);
+    uint8_t* tiles = p; p += tiles_bytes;
+    int32_t* seg_count = (int32_t*)p;
+    const int block = 256, grid = (int)((n + block - 1) / block);
+    const int32_t pair = (c->opt_pair && sizeof(T) == 8) ? 1 : 0;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    double best[2] = {1e30, 1e30};
+    auto launch = [&](int layout) {
+        if (layout == 0) hipLaunchKernelGGL((k_stream_ceiling<T, true, SegsT<T>>), dim3(grid), dim3(block), 0, c->stream, view<T>(&in), n, K, view<T>(&sg), seg_count, pair);
+        else hipLaunchKernelGGL((k_stream_ceiling<T, true, SegTiles<T>>), dim3(grid), dim3(block), 0, c->stream, view<T>(&in), n, K, SegTiles<T>{tiles}, seg_count, pair);
+    };
+    int rc = 0;
+    for (int round = 0; round < 3 && !rc; ++round)
+        for (int layout = 0; layout < 2 && !rc; ++layout) {
+            for (int w = 0; w < (round == 0 ? 30 : 5); ++w) launch(layout);  // clocks up, code object loaded
+            if (hipEventRecord(e0, c->stream) != hipSuccess) { rc = 1; break; }
+            for (int w = 0; w < 10; ++w) launch(layout);
+            float ms = 0.f;
+            if (hipEventRecord(e1, c->stream) != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { rc = 1; break; }
+            const double us = ms * 1e3 / 10;
+            if (us < best[layout]) best[layout] = us;
+        }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(buf);
+    if (rc || hipGetLastError() != hipSuccess) return fail(OT_ERR_HIP, "ot_probe_layouts: a probe launch failed");
+    c->probe_us[pi][0] = best[0];
+    c->probe_us[pi][1] = best[1];
+    return 0;
+}
+
+extern "C" int ot_probe_layouts(ot_ctx* c, int32_t real_bytes, double* us_slots, double* us_tiled) {
+    if (!c || (real_bytes != 4 && real_bytes != 8)) return fail(OT_ERR_INVALID, "ot_probe_layouts: ctx / real_bytes (4 or 8)");
+    const int pi = real_bytes == 8 ? 1 : 0;
+    if (c->probe_us[pi][0] == 0) {
+        const int rc = real_bytes == 8 ? probe_layouts<double>(c) : probe_layouts<float>(c);
+        if (rc) return rc;
+    }
+    if (us_slots) *us_slots = c->probe_us[pi][0];
+    if (us_tiled) *us_tiled = c->probe_us[pi][1];
+    return 0;
+}
+
+// What would the library launch for this scene and batch, and which output layout do its kernels write fastest?
+extern "C" int ot_trace_plan(ot_ctx* c, int32_t real_bytes, int64_t n, int32_t K, int32_t info[8]) {
+    if (!c || !info || (real_bytes != 4 && real_bytes != 8) || n < 0 || K < 1) return fail(OT_ERR_INVALID, "ot_trace_plan: bad argument");
+    if (!c->has_scene) return fail(OT_ERR_NOSCENE, "ot_scene_upload has not been called");
+    const bool f64 = real_bytes == 8;
+    const bool heavy = f64 ? wants_rolling<double>(c, K) : wants_rolling<float>(c, K);
+    const int64_t limit = ((int64_t)1 << 30) / (f64 ? 2 : 1);  // append capacity: the byte offset of a slot inside a plane stays below 2^32
+    for (int q = 0; q < 8; ++q) info[q] = 0;
+    info[0] = heavy ? 2 : 1;
+    info[1] = heavy ? 0 : 1;                      // ot_trace_tiled_* takes the scene
+    info[2] = f64 ? 29 : 30;                      // log2 of the first append capacity that is refused
+    int layout = 0;
+    if (heavy) {
+        // the dense list — unless even a tight block could not hold the worst case of this batch (the caller then falls back
+        // to the slots, which have no such limit, or splits the batch)
+        layout = (n * (int64_t)K + ((int64_t)1 << 23) < limit) ? 2 : 0;
+    } else {
+        const int pi = f64 ? 1 : 0;
+        if (c->probe_us[pi][0] == 0) {
+            const int rc = f64 ? probe_layouts<double>(c) : probe_layouts<float>(c);
+            if (rc) return rc;
+        }
+        layout = c->probe_us[pi][1] < 0.985 * c->probe_us[pi][0] ? 1 : 0;  // tiles only where they win by more than the probe's noise
+        info[5] = (int32_t)(c->probe_us[pi][0] * 100);  // hundredths of a microsecond per probe launch: slot arrays, tiles
+        info[6] = (int32_t)(c->probe_us[pi][1] * 100);
+    }
+    info[3] = layout;  // 0 slot arrays (ot_trace_*), 1 tiles (ot_trace_tiled_*), 2 append (ot_trace_append_*)
+    return 0;
+}
+
+extern "C" {
 
 int ot_set_option(ot_ctx* c, int32_t option, int32_t value) {
     if (!c) return fail(OT_ERR_INVALID, "ctx is NULL");

@@ -41,6 +41,7 @@ class Engine:
         abi.check(self.lib.ot_ctx_create(device, C.c_void_p(stream), C.byref(self._ctx)), self.lib)
         self.scene = None
         self.append_chunk = 512  # OT_OPT_APPEND_CHUNK as last set through set_option (the library's default)
+        self._records_per_ray = {}  # (scene, cap, precision) -> records per ray seen in a sample trace (append capacity estimates)
         # An ot_ctx holds one scene and one set of scratch buffers: calls on it are serialised (include/
         # optable_hip.h).  The table-level entry points hold this lock across their upload + trace sequence so that
         # Python threads sharing the engine cannot interleave them (ctypes releases the GIL during a call).
@@ -63,6 +64,7 @@ class Engine:
         desc = scene.desc()
         abi.check(self.lib.ot_scene_upload(self._ctx, C.byref(desc)), self.lib)
         self.scene = scene
+        self._records_per_ray = {}
 
     def _check_wavelengths(self, rays):
         """Scenes with a dispersion SERIES (Material(n = callable), fitted over a wavelength interval: materials.py) say
@@ -72,25 +74,43 @@ class Engine:
             return
         wl = rays.wavelength.double() * self.scene.unit
         lo, hi = float(wl.min().item()), float(wl.max().item())
-        if lo < rng[0] * (1 - 1e-12) or hi > rng[1] * (1 + 1e-12):
+        tol = 1e-12 if rays.precision == "f64" else 1e-6  # (a single-precision wavelength exactly at an edge of the interval has moved by its rounding)
+        if lo < rng[0] * (1 - tol) or hi > rng[1] * (1 + tol):
             raise ValueError(f"ray wavelengths {lo:.4g} .. {hi:.4g} m leave the interval {rng[0]:.4g} .. {rng[1]:.4g} m on which the "
                              "scene's dispersion functions have their device form (Material(..., wavelength_range=(lo, hi)) widens it)")
+
+    def plan(self, precision, n_rays, max_segments):
+        """What the library would launch for the uploaded scene and such a batch, and the output layout its kernels write
+        fastest (include/optable_hip.h: ot_trace_plan).  The first call for a light scene measures the device's stream rate in
+        both slot layouts (ot_probe_layouts: ~15 ms, once per engine and precision)."""
+        info = (C.c_int32 * 8)()
+        abi.check(self.lib.ot_trace_plan(self._ctx, 8 if precision == "f64" else 4, int(n_rays), int(max_segments), C.byref(info)), self.lib)
+        return {"kernel": int(info[0]), "tiled_ok": bool(info[1]), "append_limit": 1 << int(info[2]),
+                "layout": ("slots", "tiled", "append")[int(info[3])], "probe_us": (info[5] / 100.0, info[6] / 100.0)}
+
+    def probe_layouts(self, precision="f64"):
+        """(microseconds per launch into the 14 slot arrays, into 64-slot tiles) of cfg 2's streams on this device."""
+        a, b = C.c_double(), C.c_double()
+        abi.check(self.lib.ot_probe_layouts(self._ctx, 8 if precision == "f64" else 4, C.byref(a), C.byref(b)), self.lib)
+        return a.value, b.value
 
     # -- non-branching trace ---------------------------------------------------------------
     def trace(self, rays: RayBatch, max_segments, out: SegmentBatch = None, counts=None, layout="slots", capacity=None):
         """All segments of every ray in one launch; returns the SegmentBatch.
-        layout="slots": [k][ray] slots (ot_trace_*).  layout="auto": "append" for heavy scenes (24 nodes or more: the
-        rolling-list / block-pool kernels), "tiled" for light ones — every reader of a SegmentBatch (to_host, monitors,
-        exports, final_state) takes all layouts.  layout="append": a dense list in append order
-        (ot_trace_append_*, include/optable_hip.h) — `capacity` slots (default: max_segments * n_rays plus the
-        chunk slack, which always suffices; pass what the job needs to save memory: if it turns out too small a
-        RuntimeError names the size that fits)."""
+        layout="slots": [k][ray] slots (ot_trace_*).  layout="auto": what the library recommends for this scene, batch and
+        device (`plan`): "append" for scenes that take the rolling-list / block-pool kernels, for light ones "tiled" or
+        "slots", whichever this device streams faster — every reader of a SegmentBatch (to_host, monitors, exports,
+        final_state) takes all layouts.  layout="append": a dense list in append order (ot_trace_append_*,
+        include/optable_hip.h) — `capacity` slots; default: estimated from a 1 % sample of the batch (records per ray x
+        1.15 + the launch's chunk slack; the rare batch that needs more is traced again into a block of the size the
+        first launch reported); pass what the job needs to skip the estimate: if that turns out too small a RuntimeError
+        names the size that fits."""
         if self.scene is None:
             raise RuntimeError("upload a scene first")
         n, K = rays.n, int(max_segments)
         self._check_wavelengths(rays)
-        if layout == "auto":  # what this scene's kernels write fastest: dense list for heavy scenes, tiles for light ones
-            layout = "append" if self.scene.n_nodes >= 24 else "tiled"
+        if layout == "auto":  # what this scene's kernels write fastest ON THIS DEVICE: the library's own rule (ot_trace_plan)
+            layout = self.plan(rays.precision, n, K)["layout"] if n else "slots"
         if layout == "append":
             return self._trace_append(rays, K, out, counts, capacity)
         if layout == "tiled":
@@ -147,20 +167,50 @@ class Engine:
         is taken from it); `sum(|count|)` of that trace is the record count."""
         return append_slots(n_records, self.last_launch(), self.append_chunk)
 
-    APPEND_SLACK = 1 << 23  # slots beyond the records: chunk (512) x waves of the launch (at most 256 CUs x 16 x 2)
+    MAX_WAVES = 256 * 32  # most waves a launch can have resident (256 CUs x 8 per SIMD): each may leave one chunk's tail unused
+
+    def _append_worst_case(self, n, K):
+        """Slots that hold the records of ANY trace of n rays capped at K segments, holes included: the tail of every wave's last
+        chunk (one wave per ticket of 64 rays at most); with the block pool (curved scenes, fp32) 63 slots per workgroup chunk
+        and the last chunk of every workgroup."""
+        wg_chunk = min(16 * self.append_chunk, 1 << 19)
+        waves = min(self.MAX_WAVES, (n + 63) // 64 + 1)
+        return (n * K + 64 * (n * K // (wg_chunk - 64) + 1)
+                + max(self.append_chunk * waves, (wg_chunk + 64) * min((n + 1023) // 1024, 512)))
+
+    def _append_estimate(self, rays, K, counts):
+        """Capacity for an append trace without tracing the batch twice: records per ray from a strided 1 % sample (its own
+        small trace), x 1.15, plus the slack of the launch; remembered per scene and cap, so the next batch skips the sample."""
+        n = rays.n
+        worst = self._append_worst_case(n, K)
+        if n * K <= 1 << 22 or counts is not None:  # small: the worst case costs nothing; count tables: one ray per id per launch, never sampled
+            return worst, None
+        key = (id(self.scene), K, rays.precision)
+        rpr = self._records_per_ray.get(key)
+        if rpr is None:
+            m = max(n // 100, 4096)
+            idx = torch.arange(0, n, max(n // m, 1), device=rays.device)
+            sample = self.trace(rays.take(idx), K, layout="append", capacity=self._append_worst_case(int(idx.numel()), K))
+            rpr = float(sample.count.abs().sum().item()) / float(idx.numel())
+            self._records_per_ray = {key: rpr}  # (one scene at a time)
+        wg_chunk = min(16 * self.append_chunk, 1 << 19)
+        slack = max(self.append_chunk * self.MAX_WAVES, (wg_chunk + 64) * 256)
+        est = int(n * rpr * 1.15) + int(n * rpr * 1.15) // 128 + slack
+        return (min(est, worst) + 63) // 64 * 64, rpr
 
     def _trace_append(self, rays, K, out, counts, capacity):
         n = rays.n
-        if capacity is None:
-            # holes: the tail of every wave's last chunk of 512 slots (one wave per ticket of 64 rays at most); with the
-            # block pool (curved scenes, fp32) 63 slots per chunk of 8192 and the last chunk of every workgroup
-            wg_chunk = min(16 * self.append_chunk, 1 << 19)
-            capacity = (n * K + 64 * (n * K // (wg_chunk - 64) + 1)
-                        + max(min(self.APPEND_SLACK, self.append_chunk * ((n + 63) // 64 + 1)), (wg_chunk + 64) * min((n + 1023) // 1024, 512)))
+        estimated = False
+        if capacity is None and out is None:
+            capacity, rpr = self._append_estimate(rays, K, counts)
+            estimated = rpr is not None
+        elif capacity is None:
+            capacity = out.capacity
         if out is None:
             out = SegmentBatch(capacity, rays.precision, rays.device, block=True)
-        elif out.block is None or out.precision != rays.precision:
+        elif out.block is None or out.tiled or out.precision != rays.precision:
             raise ValueError("append layout needs a SegmentBatch(block=True) of the rays' precision")
+        out.tiled = False
         if out.count is None or out.count.numel() != n:
             out.count = torch.empty(n, dtype=torch.int32, device=rays.device)
         out.n_rays, out.append, out.n_valid, out.counts_table = n, True, 0, counts
@@ -178,6 +228,16 @@ class Engine:
         out.cursor = cursor  # device scalar: read lazily (n_valid) so that back-to-back launches do not synchronise
         out.n_valid = None
         out.counts_table = counts
+        if estimated:  # an estimated block can be too small: look (one 8-byte read-back), and trace again into what the launch asked for
+            for _ in range(3):
+                need = int(cursor.item())
+                if need <= out.capacity or need >= 1 << 62:
+                    break
+                # (plus room for the holes to fall differently: which wave claims which chunk is not the same from run to run)
+                self._records_per_ray = {}
+                del out
+                out = self._trace_append(rays, K, None, counts, (int(need * 1.02) + (1 << 20) + 63) // 64 * 64)
+                cursor = out.cursor
         return out
 
     # -- branching trace: breadth-first, one generation per launch ------------------------------
@@ -265,6 +325,7 @@ class Engine:
         if self.scene is None:
             raise RuntimeError("upload a scene first")
         prec = rays.precision
+        self._check_wavelengths(rays)
         gen_fn = self.lib.ot_trace_generation_f64 if prec == "f64" else self.lib.ot_trace_generation_f32
         dev, n = rays.device, rays.n
         out = SegmentBatch(n, prec, dev)

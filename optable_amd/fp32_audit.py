@@ -29,10 +29,11 @@ def _edge_margin(comp, P):
 
 
 def audit(scene, s64, s32, K):
-    """s64 / s32: SegmentBatch of the same rays ([k][ray] layout).  Returns arrays over the diverged rays:
+    """s64 / s32: SegmentBatch of the same rays (any layout of the non-branching trace).  Returns arrays over the diverged rays:
     ray, kstar (first differing segment), leaf64 / leaf32 (leaf ids, -1 = escaped), margin (smallest edge margin of
     the hit points involved), pos_err (|origin64 - origin32| of segment kstar: how far apart the two traces were
     when they disagreed), plus `same` (bool per ray)."""
+    s64, s32 = s64.as_kray_slots(K), s32.as_kray_slots(K)  # (whatever layout the traces were written in)
     n = s64.n_rays
     c64, c32 = np.abs(s64.count.cpu().numpy()), np.abs(s32.count.cpu().numpy())
     def f(s, name):

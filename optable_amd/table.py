@@ -110,17 +110,18 @@ class OpticalTable:
             print(f"Ray tracing time exceeds the maximum tracing time after 0 traces. ({len(rays)} ray tree(s) truncated)")
         return _clone_rays(self.rays)
 
-    def trace_batch(self, batch, max_segments=None, counts=None, scene=None, layout="slots", capacity=None):
+    def trace_batch(self, batch, max_segments=None, counts=None, scene=None, layout="auto", capacity=None):
         """Scalable entry: `RayBatch` in, `SegmentBatch` out, no Python objects.  Non-branching
         scenes run as one launch with [segment][ray] output slots; branching scenes run generation by
         generation; both in the batch's precision.
         `scene`: a `table.compile()` result to reuse when the components have not changed since (flattening
         a few hundred components in Python costs milliseconds — 10 ms for cfg 5 — and the engine skips the
         upload when it already holds that very scene); default: compile now, poses are read at call time.
-        `layout`: "auto" (what the scene's kernels write fastest: "append" for heavy scenes, "tiled" for light ones),
-        "slots" ([segment][ray] slots, the default), "tiled" (the same slots in 64-slot tiles: light scenes, 9 % faster
-        streams) or "append" (a dense list in append order, `capacity` slots: see Engine.trace) for the non-branching
-        launch; ray trees always come back as a list in generation order."""
+        `layout`: "auto" (the default: what the scene's kernels write fastest on this device, Engine.plan — the dense
+        "append" list for heavy scenes, "tiled" or "slots" for light ones, whichever the device streams faster), "slots"
+        ([segment][ray] slots), "tiled" (the same slots in 64-slot tiles) or "append" (a dense list in append order,
+        `capacity` slots: see Engine.trace) for the non-branching launch; ray trees always come back as a list in
+        generation order.  Every reader of a SegmentBatch takes all of them."""
         eng = _engine()
         if scene is None:
             scene = self.compile()

@@ -96,6 +96,27 @@ def cfg5_rays(n, seed=3):
     return o, d
 
 
+def gaussian_beam_scene(ns):
+    """BASELINE configs[0], examples/gaussian_beam.py:16-44: mirror, three thin lenses, slab n = 2, mirror; 6 rays -> 13 segments.
+    Returns (components, rays): the reference's own use — a handful of Ray objects through `table.ray_tracing`."""
+    wl, w0 = 780e-9, 10e-6
+    rays = [ns.Ray([-10, y, 0], [1, 0, 0], wavelength=wl, w0=w0) for y in (0, 2, 4, 6, 9)]
+    rays.append(ns.Ray([-10, 21, 0], [1, 0, 0], wavelength=wl, w0=w0).RotZ(-np.pi / 4))
+    comps = [ns.Mirror([0, 0, 0]).RotZ(np.pi / 6), ns.Lens([0, 2, 0], radius=0.8, focal_length=5),
+             ns.Lens([0, 4, 0], radius=0.8, focal_length=10), ns.Lens([0, 6.5, 0], radius=0.8, focal_length=10),
+             ns.GlassSlab([0, 9, 0], n1=1, n2=2, thickness=5), ns.Mirror([0, 11, 0]).RotZ(-np.pi / 2)]
+    return comps, rays
+
+
+def chromatic_scene(ns):
+    """examples/chromatic_aberration.py:16-40: an N-BK7 slab with reflectivity 0.2 (every hit branches), three wavelengths of
+    one ray (shared _id) -> 59 segments.  Returns (components, rays)."""
+    r0 = [ns.Ray([-3, 2, 0], [np.cos(np.pi / 6), -np.sin(np.pi / 6), 0], wavelength=780e-7, w0=20e-4).Propagate(-2)]
+    rays = ns.multiplex_rays_in_wavelength(r0, [780e-7, 560e-7, 400e-7])
+    slab = ns.GlassSlab([0, 0, 0], width=2, height=2, thickness=0.5, n1=ns.Vacuum(), n2=ns.Glass_NBK7(), reflectivity=0.2)
+    return [slab], rays
+
+
 class Workload:
     """One BASELINE config: what to build, what to trace, at which total size and precision."""
 

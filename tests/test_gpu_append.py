@@ -48,7 +48,7 @@ def test_append_layout_equals_slots(case, precision):
     eng = get_engine()
     eng.set_option(abi.OPT_KERNEL, 2)  # the slots through the same (rolling-list) kernel family
     try:
-        slots = table.trace_batch(batch, max_segments=K)
+        slots = table.trace_batch(batch, max_segments=K, layout="slots")
     finally:
         eng.set_option(abi.OPT_KERNEL, 0)
     app = table.trace_batch(batch, max_segments=K, layout="append")
@@ -96,7 +96,7 @@ def test_append_monitor_and_export_follow_the_list_contract(tmp_path):
     table = _table(comps)
     mon = oa.Monitor(origin=[7.5, 0, 0], width=6, height=6)
     batch = _batch(*scenes.cfg2_rays(5000, 0))
-    slots = table.trace_batch(batch, max_segments=5)
+    slots = table.trace_batch(batch, max_segments=5, layout="slots")
     app = table.trace_batch(batch, max_segments=5, layout="append")
     h0, h1 = table.record_batch(mon, slots), table.record_batch(mon, app)
     assert len(h0) == len(h1) > 0
@@ -183,7 +183,7 @@ def test_tiled_layout_equals_slots(precision, n):
         from optable_amd.batch import RayBatch
 
         batch = RayBatch.from_arrays(o, d, wavelength=wl, q=1j * np.pi * scenes.W0**2 / wl, precision=precision)
-        slots = table.trace_batch(batch, max_segments=K)
+        slots = table.trace_batch(batch, max_segments=K, layout="slots")
         tiled = table.trace_batch(batch, max_segments=K, layout="tiled")
         assert tiled.layout == "tiled" and tiled.capacity % 64 == 0
         a, b = slots.to_host(reference_order=True), tiled.to_host(reference_order=True)
@@ -207,15 +207,84 @@ def test_tiled_layout_is_for_light_scenes():
 
 @pytest.mark.parametrize("case", ["cfg2", "cfg3", "cfg5"])
 def test_auto_layout_holds_the_same_records(case):
-    """layout="auto": tiles for light scenes, the dense list for heavy ones — the records of the slots either way."""
+    """layout="auto" (the default): for light scenes the slot layout this device streams faster, the dense list for heavy ones
+    — the records of the slots either way."""
     import optable_amd as oa
+    from optable_amd.engine import get_engine
 
     comps, gen, n, K = CASES[case]
     table = _table(comps(oa))
     batch = _batch(*gen(n), precision="f32")
-    slots = table.trace_batch(batch, max_segments=K)
-    auto = table.trace_batch(batch, max_segments=K, layout="auto")
-    assert auto.layout == ("tiled" if case == "cfg2" else "append")
+    slots = table.trace_batch(batch, max_segments=K, layout="slots")
+    auto = table.trace_batch(batch, max_segments=K)  # (the default IS "auto")
+    assert auto.layout == (get_engine().plan("f32", batch.n, K)["layout"] if case == "cfg2" else "append")
+    assert auto.layout in (("tiled", "slots") if case == "cfg2" else ("append",))
     a, b = slots.to_host(reference_order=True), auto.to_host(reference_order=True)
     for f in abi.SEG_FIELDS + ("ray", "surface"):
         np.testing.assert_array_equal(a[f], b[f], err_msg=f)
+
+
+def test_auto_layout_follows_the_library_rule():
+    """layout="auto" asks the library (ot_trace_plan): an fp64 table with one spherical lens is a LIGHT scene by node count
+    but takes the rolling lists (the double-precision curved preset has no lane-per-ray form), where the tiled entry point
+    refuses it — auto must come out as the dense list, with the records of the slots; a worst case beyond the append
+    capacity limit falls back to the slot arrays."""
+    import optable_amd as oa
+    from optable_amd.engine import get_engine
+
+    table = _table([oa.BiConvexLens([5, 0, 0], CT=0.6, R1=12.0, R2=-12.0, diameter=3.0, n=1.5), oa.Mirror([12, 0, 0], radius=2.0).RotZ(np.pi)])
+    rng = np.random.default_rng(5)
+    n, K = 20_000, 8
+    o = np.stack([np.zeros(n), rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)], 1)
+    d = np.stack([np.ones(n), rng.uniform(-0.02, 0.02, n), rng.uniform(-0.02, 0.02, n)], 1)
+    batch = _batch(o, d, precision="f64")
+    slots = table.trace_batch(batch, max_segments=K, layout="slots")
+    auto = table.trace_batch(batch, max_segments=K)
+    eng = get_engine()
+    plan = eng.plan("f64", n, K)
+    assert plan["kernel"] == 2 and not plan["tiled_ok"] and plan["layout"] == "append" and auto.layout == "append", plan
+    a, b = slots.to_host(reference_order=True), auto.to_host(reference_order=True)
+    for f in abi.SEG_FIELDS + ("ray", "surface"):
+        np.testing.assert_array_equal(a[f], b[f], err_msg=f)
+    # the same scene in single precision is a lane-per-ray scene: tiles or slot arrays, by what this device streams faster
+    p32 = eng.plan("f32", n, K)
+    us_slots, us_tiled = eng.probe_layouts("f32")
+    assert p32["kernel"] == 1 and p32["tiled_ok"] and p32["layout"] == ("tiled" if us_tiled < 0.985 * us_slots else "slots"), (p32, us_slots, us_tiled)
+    # heavy scene, worst case beyond the capacity limit of the append block (2^30 slots in single precision): slots
+    eng.upload(_table(scenes.cfg3_components(oa)).compile())
+    assert eng.plan("f32", 1 << 20, 20)["layout"] == "append"
+    assert eng.plan("f32", 1 << 26, 20)["layout"] == "slots"
+    assert eng.plan("f64", 1 << 25, 20)["layout"] == "slots"
+
+
+def test_append_block_sized_from_a_sample_and_retried_when_too_small():
+    """The default append call sizes its block from a 1 % sample (records per ray x 1.15 + slack) instead of the worst case,
+    and a block that turns out too small is not an error: the launch reports what it needed and the trace runs again."""
+    import optable_amd as oa
+    from optable_amd.engine import get_engine
+
+    comps, gen, n, K = CASES["cfg3"]
+    n = 600_000  # (beyond the size below which the worst case is simply allocated)
+    table = _table(comps(oa))
+    batch = _batch(*gen(n), precision="f32")
+    eng = get_engine()
+    ref = table.trace_batch(batch, max_segments=K, layout="slots").to_host(reference_order=True)
+    segs = table.trace_batch(batch, max_segments=K)
+    records = int(segs.count.abs().sum().item())
+    assert segs.layout == "append" and segs.capacity < n * K and segs.capacity <= 1.3 * records + (1 << 23), (segs.capacity, records)
+    got = segs.to_host(reference_order=True)
+    for f in abi.SEG_FIELDS + ("ray", "surface"):
+        np.testing.assert_array_equal(got[f], ref[f], err_msg=f)
+    # an estimate that is far too low (as if the sample had seen only rays that leave at once)
+    scene = eng.scene
+    eng._records_per_ray = {(id(scene), K, "f32"): 0.01}
+    old_waves = eng.MAX_WAVES
+    eng.MAX_WAVES = 16  # (no slack to hide behind)
+    try:
+        again = eng.trace(batch, K, layout="append")
+    finally:
+        eng.MAX_WAVES = old_waves
+    assert again.n_valid >= records and again.capacity >= records
+    got = again.to_host(reference_order=True)
+    for f in abi.SEG_FIELDS + ("ray", "surface"):
+        np.testing.assert_array_equal(got[f], ref[f], err_msg=f)

@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _run(*extra):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--cpu-seconds", "1", *extra],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--cpu-seconds", "1",
+                          "--sustained-seconds", "1", *extra],
                          capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
@@ -60,6 +61,22 @@ def test_two_ranks_on_one_card_gloo_rehearsal():
     assert line["n_gpus"] == 2 and line["config"]["rays_per_gpu"] == 20000 and line["config"]["rays_total"] == 40000
     assert line["gathered_shape"] == [12, 40000] and line["gather_ms"] > 0 and "gather_error" not in line
     assert line["config"]["segments_per_ray"] == 5.0
+
+
+def test_sharded_configs_of_the_multi_gpu_line_gloo_rehearsal():
+    """With N > 1 the line also carries the configs BASELINE quotes on several GPUs (cfg 4 on 2 / 4, cfg 5 on 8) at their
+    quoted totals, each with a timed region of at least 50 ms between its barriers; rehearsed here with two ranks on the one
+    card, over gloo, at a few thousand rays per rank."""
+    line = _run("--gpus", "2", "--backend", "gloo", "--rays", "20000", "--no-cpu-baseline", "--sharded-configs", "cfg4,cfg5",
+                "--sharded-rays", "64000")
+    recs = line["sharded_configs"]
+    assert [r.get("error") for r in recs] == [None, None], recs
+    assert recs[0]["workload"].startswith("cfg4") and recs[1]["workload"].startswith("cfg5")
+    for r in recs:
+        assert r["n_gpus"] == 2 and r["rays_total"] == 128000 and r["timed_region_ms"] >= 50.0 and r["steps"] >= 3
+        assert len(r["ranks"]["ms_per_step_by_rank"]) == 2 and min(r["ranks"]["segments_by_rank"]) > 64000
+        assert r["value"] / r["segments_per_s"] == pytest.approx(2 if r["workload"].startswith("cfg4") else 260)  # x leaf surfaces
+    assert recs[0]["layout"] in ("tiled", "slots") and recs[1]["layout"] == "append"
 
 
 def test_four_ranks_on_one_card_gloo_rehearsal():

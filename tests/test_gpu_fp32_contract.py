@@ -33,6 +33,7 @@ def test_fp32_leaves_the_fp64_path_only_at_edge_cases(name, n):
     K = wl.max_segments
     s64 = table.trace_batch(RayBatch.from_arrays(o, d, wavelength=lam, q=q), max_segments=K)
     s32 = table.trace_batch(RayBatch.from_arrays(o, d, wavelength=lam, q=q, precision="f32"), max_segments=K)
+    s64, s32 = s64.as_kray_slots(K), s32.as_kray_slots(K)  # (the default layout of these scenes is the dense append-order list)
     rep = audit(table.compile(), s64, s32, K)
     assert rep["same"].mean() >= 0.9995, rep["same"].mean()
     edge = (rep["margin"] < EDGE) | (np.minimum(rep["len64"], rep["len32"]) < SHORT)

@@ -54,13 +54,13 @@ def _shard_equals_whole(table, batch, segs, lo, hi, K):
     import torch
 
     n = batch.n
-    part = table.trace_batch(batch.slice(lo, hi), max_segments=K)
+    part = table.trace_batch(batch.slice(lo, hi), max_segments=K).as_kray_slots(K)  # (the default layout, whatever it is for this scene)
     assert torch.equal(part.count, segs.count[lo:hi])
     m = hi - lo
     keep = torch.arange(K, device=part.count.device).unsqueeze(1) < part.count.unsqueeze(0)
     for name in abi.SEG_FIELDS + ("surface",):
-        whole = segs.field(name).view(K, n)[:, lo:hi]
-        mine = part.field(name).view(K, m)
+        whole = segs.field(name).reshape(K, n)[:, lo:hi]
+        mine = part.field(name).reshape(K, m)
         assert torch.equal(whole[keep], mine[keep]), name
 
 
@@ -75,11 +75,18 @@ def test_cfg3_full_size_fp32():
     o, d = scenes.cfg3_rays(n, 2)
     batch = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=1j * np.pi * scenes.W0**2 / scenes.WL, precision="f32")
     del o, d
-    segs = table.trace_batch(batch, max_segments=K)
+    from optable_amd.engine import get_engine
+
+    segs = table.trace_batch(batch, max_segments=K)  # the DEFAULT call: the dense append-order list through the pair queue
+    info = get_engine().last_launch()
+    assert segs.layout == "append" and info["pair_queue"] & 1 and info["pair_queue"] & 4, info
+    records = int(segs.count.abs().sum().item())
+    assert segs.capacity <= 1.3 * records + (1 << 23), (segs.capacity, records)  # sized from a 1 % sample, not for the worst case
     cnt = segs.count
     assert int(cnt.min()) >= 1 and int(cnt.max()) <= K
     mean = float(cnt.double().mean())
     assert 4.6 < mean < 5.2, mean        # mean 4.8 segments per ray (oracle-validated)
+    segs = segs.as_kray_slots(K)         # (indexable by segment and ray for the checks below)
     _chain_properties(segs, n, K, tol=6e-3, unit_tol=1e-6)
     _shard_equals_whole(table, batch, segs, 3_000_000, 4_250_000, K)
     torch.cuda.empty_cache()
@@ -111,10 +118,16 @@ def test_cfg4_shard_closed_form_fp64(nb):
     n = nb * nwl
     glass = oa.Glass_NBK7()
     table = _table([oa.GlassSlab([0, 0, 0], width=2, height=2, thickness=thickness, n1=oa.Vacuum(), n2=glass, reflectivity=0)])
-    segs = table.trace_batch(batch, max_segments=K)
+    segs = table.trace_batch(batch, max_segments=K)  # the DEFAULT call: tiles or slot arrays, whichever this device streams faster
+    assert segs.layout in ("tiled", "slots")
     assert int(segs.count.min()) == K and int(segs.count.max()) == K
-    f = {name: segs.field(name).view(K, n) for name in abi.SEG_FIELDS}
-    surf = segs.surface.view(K, n)
+
+    class Fields:  # field -> [K, n]: a view of a slot array, a copy out of the tiles — made when asked for, one at a time
+        def __getitem__(self, name):
+            return segs.field(name).reshape(K, n)
+
+    f = Fields()
+    surf = segs.surface.reshape(K, n)
     assert bool((surf[:2] >= 0).all()) and bool((surf[2] == -1).all())
     # host-side Sellmeier (wavelength in model units x unit 1e-2 m -> micrometres)
     um = wls * 1e-2 * 1e6
@@ -158,9 +171,16 @@ def test_cfg5_shard_fp32():
     o, d = scenes.cfg5_rays(n, 3)
     batch = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=1j * np.pi * scenes.W0**2 / scenes.WL, precision="f32")
     del o, d
-    segs = table.trace_batch(batch, max_segments=K)
+    from optable_amd.engine import get_engine
+
+    segs = table.trace_batch(batch, max_segments=K)  # the DEFAULT call: the workgroup-wide block pool into the dense append-order list
+    info = get_engine().last_launch()
+    assert segs.layout == "append" and info["pair_queue"] & 16 and info["pair_queue"] & 4, info
+    records = int(segs.count.abs().sum().item())
+    assert segs.capacity <= 1.3 * records + (1 << 23), (segs.capacity, records)  # 17 GB of records, not the worst case's 35
     cnt = segs.count
     assert int(cnt.min()) >= 1 and int(cnt.max()) == K      # some rays ring between mirror and MMA to the cap
+    segs = segs.as_kray_slots(K)                             # (indexable by segment and ray for the checks below)
     mean = float(cnt.double().mean())
     assert 20 < mean < 28, mean                              # 24.1 at 4e5 rays (oracle-validated at small n)
     _chain_properties(segs, n, K, tol=6e-3, unit_tol=1e-6)

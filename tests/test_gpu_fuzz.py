@@ -59,7 +59,7 @@ def test_random_scene_matches_oracle(seed, oracle):
     o = np.stack([np.zeros(n), rng.uniform(-4, 4, n), rng.uniform(-0.4, 0.4, n)], 1)
     d = np.stack([np.ones(n), rng.uniform(-0.15, 0.15, n), rng.uniform(-0.03, 0.03, n)], 1)
     batch = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=1j * np.pi * scenes.W0**2 / scenes.WL)
-    got = table.trace_batch(batch, max_segments=K).to_host(reference_order=True)
+    got = table.trace_batch(batch, max_segments=K, layout="slots").to_host(reference_order=True)
     ref = oracle.trace(scene, batch.to_host(), max_trace_num=K)
     # per-ray surface sequences
     def sequences(x):
@@ -109,7 +109,7 @@ def test_random_branching_scene_matches_oracle(seed, oracle):
     o = np.stack([np.zeros(n), rng.uniform(-3, 3, n), rng.uniform(-0.3, 0.3, n)], 1)
     d = np.stack([np.ones(n), rng.uniform(-0.12, 0.12, n), rng.uniform(-0.02, 0.02, n)], 1)
     batch = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=1j * np.pi * scenes.W0**2 / scenes.WL)
-    segs = table.trace_batch(batch, max_segments=cap)
+    segs = table.trace_batch(batch, max_segments=cap, layout="slots")
     got = segs.to_host(reference_order=True)
     ref = oracle.trace(scene, batch.to_host(), max_trace_num=cap)
 
@@ -203,7 +203,7 @@ def test_random_large_scene_matches_oracle(seed, oracle):
     assert scene.root_grid >= 0
     n, K = len(o), 16
     batch = RayBatch.from_arrays(o, d, wavelength=wl, q=1j * np.pi * scenes.W0**2 / wl)
-    got = table.trace_batch(batch, max_segments=K).to_host(reference_order=True)
+    got = table.trace_batch(batch, max_segments=K, layout="slots").to_host(reference_order=True)
     ref = oracle.trace(scene, batch.to_host(), max_trace_num=K)
     a, b = _sequences(got, n), _sequences(ref, n)
     same = np.array([x == y for x, y in zip(a, b)])
@@ -230,7 +230,7 @@ def test_random_large_scene_fp32_tracks_fp64(seed):
     out = {}
     for prec in ("f64", "f32"):
         batch = RayBatch.from_arrays(o, d, wavelength=wl, q=1j * np.pi * scenes.W0**2 / wl, precision=prec)
-        out[prec] = table.trace_batch(batch, max_segments=K).to_host(reference_order=True)
+        out[prec] = table.trace_batch(batch, max_segments=K, layout="slots").to_host(reference_order=True)
     a, b = _sequences(out["f64"], n), _sequences(out["f32"], n)
     same = np.array([x == y for x, y in zip(a, b)])
     assert same.mean() >= 0.95, same.mean()
@@ -302,7 +302,7 @@ def test_random_planar_scene_pair_queue_variants_agree(seed, oracle):
                 eng.set_option(abi.OPT_KERNEL, kern)
                 eng.set_option(abi.OPT_FLAT_QUEUE, flat)
                 eng.set_option(abi.OPT_LDS_RECORDS, rec)
-                outs.append(table.trace_batch(batch, max_segments=K))
+                outs.append(table.trace_batch(batch, max_segments=K, layout="slots"))
                 shapes.append(eng.last_launch()["pair_queue"])
         finally:
             eng.set_option(abi.OPT_KERNEL, 0)
@@ -317,7 +317,7 @@ def test_random_planar_scene_pair_queue_variants_agree(seed, oracle):
                 assert torch.equal(outs[0].field(f)[valid], other.field(f)[valid]), (prec, f)
     # and the scene itself, in double precision, against the oracle
     b64 = RayBatch.from_arrays(o, d, wavelength=wl, q=1j * np.pi * scenes.W0**2 / wl)
-    got = table.trace_batch(b64, max_segments=K).to_host(reference_order=True)
+    got = table.trace_batch(b64, max_segments=K, layout="slots").to_host(reference_order=True)
     ref = oracle.trace(scene, b64.to_host(), max_trace_num=K)
     a, b = _sequences(got, n), _sequences(ref, n)
     same = np.array([x == y for x, y in zip(a, b)])

@@ -90,7 +90,7 @@ def test_batch_trace_matches_oracle(case, oracle):
     table = _table(comps(oa))
     o, d = gen(n)
     batch = _batch(o, d)
-    segs = table.trace_batch(batch, max_segments=K)
+    segs = table.trace_batch(batch, max_segments=K, layout="slots")
     got = segs.to_host(reference_order=True)
     scene, host = table.compile(), batch.to_host()
     ref = oracle.trace(scene, host, max_trace_num=K)
@@ -122,7 +122,7 @@ def test_cfg4_dispersion_matches_oracle(oracle):
     o, d = np.tile(o, (nwl, 1)), np.tile(d, (nwl, 1))
     table = _table([oa.GlassSlab([0, 0, 0], width=2, height=2, thickness=0.5, n1=oa.Vacuum(), n2=oa.Glass_NBK7(), reflectivity=0)])
     batch = RayBatch.from_arrays(o, d, wavelength=wl, q=1j * np.pi * scenes.W0**2 / wl)
-    got = table.trace_batch(batch, max_segments=8).to_host(reference_order=True)
+    got = table.trace_batch(batch, max_segments=8, layout="slots").to_host(reference_order=True)
     ref = oracle.trace(table.compile(), batch.to_host(), max_trace_num=8)
     np.testing.assert_array_equal(got["count"], 3)  # exactly 3 segments per ray-wavelength pair
     for f in abi.SEG_FIELDS:
@@ -140,7 +140,7 @@ def test_branching_batch_matches_oracle(oracle):
     table = _table([oa.GlassSlab([0, 0, 0], width=2, height=2, thickness=0.5, n1=1, n2=1.5, reflectivity=0.2),
                     oa.BeamSplitter([3, 0, 0], width=3, height=3, eta=0.4).RotZ(0.3)])
     batch = _batch(o, d)
-    segs = table.trace_batch(batch, max_segments=40)
+    segs = table.trace_batch(batch, max_segments=40, layout="slots")
     got = segs.to_host(reference_order=True)
     ref = oracle.trace(table.compile(), batch.to_host(), max_trace_num=40)
     assert len(got["ray"]) == len(ref["ray"])
@@ -160,7 +160,7 @@ def test_cfg2_full_size_properties():
     table = _table(scenes.cfg2_components(oa))
     o, d = scenes.cfg2_rays(n, 0)
     batch = _batch(o, d)
-    segs = table.trace_batch(batch, max_segments=K)
+    segs = table.trace_batch(batch, max_segments=K, layout="slots")
     assert int(segs.count.min()) == K and int(segs.count.max()) == K  # lens, mirror, mirror, lens, escape
     f = {name: segs.field(name).reshape(K, n) for name in abi.SEG_FIELDS}
     surf = segs.surface.reshape(K, n)
@@ -180,8 +180,8 @@ def test_cfg2_full_size_properties():
     assert float((f["intensity"] - 1).abs().max()) == 0.0
     # shard invariance: two half batches reproduce the full batch bit for bit (rays are independent)
     half = n // 2
-    a = table.trace_batch(batch.slice(0, half), max_segments=K)
-    b = table.trace_batch(batch.slice(half, n), max_segments=K)
+    a = table.trace_batch(batch.slice(0, half), max_segments=K, layout="slots")
+    b = table.trace_batch(batch.slice(half, n), max_segments=K, layout="slots")
     for name in abi.SEG_FIELDS:
         whole = segs.field(name).reshape(K, n)
         assert torch.equal(whole[:, :half], a.field(name).reshape(K, half))
@@ -195,7 +195,7 @@ def test_empty_and_ragged_inputs():
     assert table.ray_tracing([]) == []
     for n in (1, 63, 65, 257):  # partial waves / partial blocks
         o, d = scenes.cfg2_rays(n, 5)
-        segs = table.trace_batch(_batch(o, d), max_segments=5)
+        segs = table.trace_batch(_batch(o, d), max_segments=5, layout="slots")
         assert segs.count.tolist() == [5] * n
 
 
@@ -211,8 +211,8 @@ def test_fp32_trace_tracks_fp64():
     q = 1j * np.pi * scenes.W0**2 / scenes.WL
     b64 = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=q)
     b32 = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=q, precision="f32")
-    s64 = table.trace_batch(b64, max_segments=K).to_host()
-    s32 = table.trace_batch(b32, max_segments=K).to_host()
+    s64 = table.trace_batch(b64, max_segments=K, layout="slots").to_host()
+    s32 = table.trace_batch(b32, max_segments=K, layout="slots").to_host()
     np.testing.assert_array_equal(s64["surface"], s32["surface"])
     for f in ("ox", "oy", "oz", "dx", "dy", "dz", "length"):
         np.testing.assert_allclose(s32[f], s64[f], rtol=2e-4, atol=2e-4, err_msg=f)
@@ -256,7 +256,7 @@ def test_record_batch_matches_object_api():
     from optable_amd.table import _pack
 
     batch = _pack(sc["rays"], np.arange(len(sc["rays"]), dtype=np.int32), "cuda")
-    segs = table.trace_batch(batch, max_segments=16)
+    segs = table.trace_batch(batch, max_segments=16, layout="slots")
     hits = table.record_batch(mon, segs)
     assert len(hits) == mon.ndata
     raw_P = np.array([d[0] for d in mon._data_raw])
@@ -280,13 +280,13 @@ def test_launch_options_do_not_change_results():
     o, d = scenes.cfg2_rays(n, 1)
     batch = _batch(o, d)
     eng = get_engine()
-    base = table.trace_batch(batch, max_segments=K)
+    base = table.trace_batch(batch, max_segments=K, layout="slots")
     try:
         for nt, mw, bpc in ((0, 0, 2), (1, 0, 8), (0, 4, 1), (1, 4, 16)):
             eng.set_option(abi.OPT_NT_STORES, nt)
             eng.set_option(abi.OPT_MIN_WAVES, mw)
             eng.set_option(abi.OPT_BLOCKS_PER_CU, bpc)
-            other = table.trace_batch(batch, max_segments=K)
+            other = table.trace_batch(batch, max_segments=K, layout="slots")
             for f in abi.SEG_FIELDS + ("ray", "surface"):
                 assert torch.equal(base.field(f), other.field(f)), (f, nt, mw, bpc)
     finally:
@@ -311,9 +311,9 @@ def test_blocked_kernel_equals_lane_per_ray_kernel(case):
     eng = get_engine()
     try:
         eng.set_option(abi.OPT_KERNEL, 1)
-        a = table.trace_batch(batch, max_segments=K)
+        a = table.trace_batch(batch, max_segments=K, layout="slots")
         eng.set_option(abi.OPT_KERNEL, 2)
-        b = table.trace_batch(batch, max_segments=K)
+        b = table.trace_batch(batch, max_segments=K, layout="slots")
     finally:
         eng.set_option(abi.OPT_KERNEL, 0)
     assert torch.equal(a.count, b.count)
@@ -346,9 +346,9 @@ def test_heavy_kernel_edge_sizes_dead_rays_and_finite_lengths(case, prec):
             length[1::5] = 6.0  # shorter than the way to most components: those rays end as escapes of finite length
             batch.length = length
             eng.set_option(abi.OPT_KERNEL, 1)
-            a = table.trace_batch(batch, max_segments=cap)
+            a = table.trace_batch(batch, max_segments=cap, layout="slots")
             eng.set_option(abi.OPT_KERNEL, 2)
-            b = table.trace_batch(batch, max_segments=cap)
+            b = table.trace_batch(batch, max_segments=cap, layout="slots")
             assert torch.equal(a.count, b.count), (n, cap)
             valid = a.valid_mask()
             for f in abi.SEG_FIELDS + ("ray", "surface"):
@@ -383,9 +383,9 @@ def test_pair_queue_walk_equals_per_lane_walk(prec):
             o, d = gen(n)
             batch = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=q, precision=prec)
             eng.set_option(abi.OPT_FLAT_QUEUE, 0)
-            a = table.trace_batch(batch, max_segments=K)
+            a = table.trace_batch(batch, max_segments=K, layout="slots")
             eng.set_option(abi.OPT_FLAT_QUEUE, 1)
-            b = table.trace_batch(batch, max_segments=K)
+            b = table.trace_batch(batch, max_segments=K, layout="slots")
             assert torch.equal(a.count, b.count), n
             valid = a.valid_mask()
             for f in abi.SEG_FIELDS + ("ray", "surface"):
@@ -393,10 +393,10 @@ def test_pair_queue_walk_equals_per_lane_walk(prec):
             # the same kernel with the records of the live rays in LDS instead of the per-wave global scratch, and the launch
             # shape says which variant ran
             eng.set_option(abi.OPT_LDS_RECORDS, 0)
-            c0 = table.trace_batch(batch, max_segments=K)
+            c0 = table.trace_batch(batch, max_segments=K, layout="slots")
             shape0 = eng.last_launch()
             eng.set_option(abi.OPT_LDS_RECORDS, 1)
-            c1 = table.trace_batch(batch, max_segments=K)
+            c1 = table.trace_batch(batch, max_segments=K, layout="slots")
             shape1 = eng.last_launch()
             assert shape0["kernel"] == 2 and shape0["pair_queue"] == 1
             assert shape1["pair_queue"] == (3 if prec == "f32" else 1)  # fp64 records (108 bytes) stay in global memory
@@ -430,12 +430,12 @@ def test_pair_queue_round_that_does_not_fit_defers_lanes(prec):
     try:
         eng.set_option(abi.OPT_KERNEL, 2)
         eng.set_option(abi.OPT_FLAT_QUEUE, 0)
-        a = table.trace_batch(batch, max_segments=K)
+        a = table.trace_batch(batch, max_segments=K, layout="slots")
         eng.set_option(abi.OPT_FLAT_QUEUE, 192)
-        b = table.trace_batch(batch, max_segments=K)
+        b = table.trace_batch(batch, max_segments=K, layout="slots")
         assert eng.last_launch()["pair_queue"] & 1
         eng.set_option(abi.OPT_FLAT_QUEUE, 1)
-        c = table.trace_batch(batch, max_segments=K)
+        c = table.trace_batch(batch, max_segments=K, layout="slots")
     finally:
         eng.set_option(abi.OPT_KERNEL, 0)
         eng.set_option(abi.OPT_FLAT_QUEUE, 1)
@@ -476,11 +476,11 @@ def test_pair_queue_winner_that_fails_its_own_box_takes_the_per_lane_walk(prec, 
     try:
         eng.set_option(abi.OPT_KERNEL, 2)
         eng.set_option(abi.OPT_FLAT_QUEUE, 0)
-        a = table.trace_batch(batch, max_segments=K, scene=scene)
+        a = table.trace_batch(batch, max_segments=K, scene=scene, layout="slots")
         eng.set_option(abi.OPT_FLAT_QUEUE, 1)
-        b = table.trace_batch(batch, max_segments=K, scene=scene)
+        b = table.trace_batch(batch, max_segments=K, scene=scene, layout="slots")
         assert eng.last_launch()["pair_queue"] & 1
-        whole = table.trace_batch(batch, max_segments=K, scene=honest)
+        whole = table.trace_batch(batch, max_segments=K, scene=honest, layout="slots")
     finally:
         eng.set_option(abi.OPT_KERNEL, 0)
         eng.set_option(abi.OPT_FLAT_QUEUE, 1)
@@ -512,9 +512,9 @@ def test_acceleration_grids_do_not_change_results(case):
     o, d = gen(n)
     batch = _batch(o, d)
     table = _table(comps(oa))
-    fast = table.trace_batch(batch, max_segments=K)
+    fast = table.trace_batch(batch, max_segments=K, layout="slots")
     table.accelerate = False
-    plain = table.trace_batch(batch, max_segments=K)
+    plain = table.trace_batch(batch, max_segments=K, layout="slots")
     assert torch.equal(fast.count, plain.count)
     valid = fast.valid_mask()
     for f in abi.SEG_FIELDS + ("ray", "surface"):
@@ -536,8 +536,8 @@ def test_fp32_heavy_scenes_track_fp64(case, min_same):
     table = _table(comps(oa))
     o, d = gen(n)
     q = 1j * np.pi * scenes.W0**2 / scenes.WL
-    s64 = table.trace_batch(RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=q), max_segments=K)
-    s32 = table.trace_batch(RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=q, precision="f32"), max_segments=K)
+    s64 = table.trace_batch(RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=q), max_segments=K, layout="slots")
+    s32 = table.trace_batch(RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=q, precision="f32"), max_segments=K, layout="slots")
     c64, c32 = s64.count.cpu().numpy(), s32.count.cpu().numpy()
     surf64 = s64.surface.cpu().numpy().reshape(K, n)
     surf32 = s32.surface.cpu().numpy().reshape(K, n)
@@ -565,7 +565,7 @@ def test_segment_chain_is_continuous(case, prec, tol):
     table = _table(comps(oa))
     o, d = gen(n)
     q = 1j * np.pi * scenes.W0**2 / scenes.WL
-    segs = table.trace_batch(RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=q, precision=prec), max_segments=K)
+    segs = table.trace_batch(RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=q, precision=prec), max_segments=K, layout="slots")
     cnt = segs.count.cpu().numpy()
     assert (cnt > 0).all()
     f = {name: segs.field(name).cpu().numpy().reshape(K, n).astype(np.float64) for name in ("ox", "oy", "oz", "dx", "dy", "dz", "length")}
@@ -595,7 +595,7 @@ def test_fused_path_honours_input_length_and_dead_flags(oracle):
     flags[::7] |= abi.RAY_DEAD
     batch.flags.copy_(torch.from_numpy(flags))
     batch.length = torch.from_numpy(length).to(batch.device)
-    got = table.trace_batch(batch, max_segments=K).to_host(reference_order=True)
+    got = table.trace_batch(batch, max_segments=K, layout="slots").to_host(reference_order=True)
     host = batch.to_host()
     host["length"] = length
     ref = oracle.trace(table.compile(), host, max_trace_num=K)
@@ -611,11 +611,11 @@ def test_zero_rays_and_empty_scene():
     from optable_amd.batch import RayBatch
 
     table = _table(scenes.cfg2_components(oa))
-    empty = table.trace_batch(RayBatch(0), max_segments=5)
+    empty = table.trace_batch(RayBatch(0), max_segments=5, layout="slots")
     assert empty.to_host()["ox"].size == 0
     void = oa.OpticalTable()  # no components: every ray escapes unchanged
     o, d = scenes.cfg2_rays(100, 3)
-    segs = void.trace_batch(_batch(o, d), max_segments=3).to_host()
+    segs = void.trace_batch(_batch(o, d), max_segments=3, layout="slots").to_host()
     assert segs["count"].tolist() == [1] * 100 and (segs["surface"] == -1).all()
     np.testing.assert_allclose(segs["dx"], d[:, 0], rtol=0, atol=1e-15)
 
@@ -629,7 +629,7 @@ def test_lazy_materialisation_and_csv_export(tmp_path):
     rays = sc["rays"]
     full = table.ray_tracing(rays)
     batch = _pack(rays, np.arange(len(rays), dtype=np.int32), "cuda")
-    segs = table.trace_batch(batch, max_segments=8)
+    segs = table.trace_batch(batch, max_segments=8, layout="slots")
     some = table.materialize(segs, rays, select=[1, 4])
     want = [r for r in full if r._id in (rays[1]._id, rays[4]._id)]
     assert len(some) == len(want) == 5
@@ -655,8 +655,8 @@ def test_sorted_spatially_is_a_pure_reordering():
     batch = _batch(o, d)
     ordered, order = batch.sorted_spatially()
     assert torch.equal(torch.sort(order).values, torch.arange(n, device=order.device))
-    a = table.trace_batch(batch, max_segments=K)
-    b = table.trace_batch(ordered, max_segments=K)
+    a = table.trace_batch(batch, max_segments=K, layout="slots")
+    b = table.trace_batch(ordered, max_segments=K, layout="slots")
     assert torch.equal(a.count[order], b.count)
     for f in abi.SEG_FIELDS + ("surface",):
         x, y = a.field(f).reshape(K, n)[:, order], b.field(f).reshape(K, n)
@@ -689,7 +689,7 @@ def test_batch_limited_scene_with_shared_ids(branching, oracle):
     ids = 1000 + 7 * rng.permutation(nb)               # arbitrary, unordered, not 0..n-1
     base = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=1j * np.pi * scenes.W0**2 / scenes.WL, ids=ids)
     batch = base.multiplexed_in_wavelength([780e-7, 560e-7, 400e-7])
-    segs = table.trace_batch(batch, max_segments=K)
+    segs = table.trace_batch(batch, max_segments=K, layout="slots")
     got = segs.to_host(reference_order=True)
     host = batch.to_host()
     uniq, inverse = np.unique(host["id"], return_inverse=True)
@@ -716,8 +716,8 @@ def test_fp32_ray_trees_track_fp64():
                     oa.GlassSlab([-2, 0, 0], width=3, height=3, thickness=0.4, n1=1, n2=1.5, reflectivity=0.2).RotZ(0.1)])
     o, d = scenes.cfg2_rays(2000, 3)
     q = 1j * np.pi * scenes.W0**2 / scenes.WL
-    s32 = table.trace_batch(RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=q, precision="f32"), max_segments=10)
-    s64 = table.trace_batch(RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=q, precision="f64"), max_segments=10)
+    s32 = table.trace_batch(RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=q, precision="f32"), max_segments=10, layout="slots")
+    s64 = table.trace_batch(RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=q, precision="f64"), max_segments=10, layout="slots")
     assert s32.precision == "f32" and s64.precision == "f64"
     a, b = s32.to_host(), s64.to_host()
     n = 2000
@@ -744,15 +744,15 @@ def test_compiled_scene_can_be_reused_and_is_not_uploaded_twice():
     o, d = scenes.cfg2_rays(2000, 1)
     batch = _batch(o, d)
     scene = table.compile()
-    a = table.trace_batch(batch, max_segments=5, scene=scene)
+    a = table.trace_batch(batch, max_segments=5, scene=scene, layout="slots")
     assert get_engine().scene is scene
-    b = table.trace_batch(batch, max_segments=5, scene=scene)
-    fresh = table.trace_batch(batch, max_segments=5)
+    b = table.trace_batch(batch, max_segments=5, scene=scene, layout="slots")
+    fresh = table.trace_batch(batch, max_segments=5, layout="slots")
     for f in abi.SEG_FIELDS:
         assert torch.equal(a.field(f), b.field(f)) and torch.equal(a.field(f), fresh.field(f))
     comps[0]._Translate([0.5, 0, 0])                       # move the lens
-    stale = table.trace_batch(batch, max_segments=5, scene=scene)
-    moved = table.trace_batch(batch, max_segments=5)
+    stale = table.trace_batch(batch, max_segments=5, scene=scene, layout="slots")
+    moved = table.trace_batch(batch, max_segments=5, layout="slots")
     assert torch.equal(stale.field("length"), a.field("length"))
     assert not torch.equal(moved.field("length"), a.field("length"))
 
@@ -869,7 +869,7 @@ def test_exact_ties_go_to_the_first_component(many, oracle):
     o = np.tile([[0.0, 0.0, 0.0]], (64, 1)) + np.linspace(-0.3, 0.3, 64)[:, None] * np.array([[0, 1, 0]])
     d = np.tile([[1.0, 0.0, 0.0]], (64, 1))
     batch = _batch(o, d)
-    got = table.trace_batch(batch, max_segments=4).to_host(reference_order=True)
+    got = table.trace_batch(batch, max_segments=4, layout="slots").to_host(reference_order=True)
     ref = oracle.trace(scene, batch.to_host(), max_trace_num=4)
     np.testing.assert_array_equal(got["surface"], ref["surface"])
     for f in abi.SEG_FIELDS:
@@ -888,7 +888,7 @@ def test_group_tie_keeps_the_first_child(oracle):
     pair.add_component(oa.Mirror([6, 0, 0], radius=1.0))
     table = _table([pair])
     o, d = np.array([[0.0, 0.2, 0.0]]), np.array([[1.0, 0.0, 0.0]])
-    got = table.trace_batch(_batch(o, d), max_segments=3).to_host()
+    got = table.trace_batch(_batch(o, d), max_segments=3, layout="slots").to_host()
     ref = oracle.trace(table.compile(), _batch(o, d).to_host(), max_trace_num=3)
     np.testing.assert_array_equal(got["surface"], ref["surface"])
     assert got["surface"][0] == 0 and got["dx"][1] > 0                      # the lens won: the ray goes on, bent
@@ -920,7 +920,7 @@ def test_axis_parallel_rays_and_flat_boxes_match_oracle(oracle):
     o[10::20, 2] = 1.0                          # ... on the top edge plane
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     batch = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=1j * np.pi * scenes.W0**2 / scenes.WL, normalize=False)
-    got = table.trace_batch(batch, max_segments=10).to_host(reference_order=True)
+    got = table.trace_batch(batch, max_segments=10, layout="slots").to_host(reference_order=True)
     ref = oracle.trace(table.compile(), batch.to_host(), max_trace_num=10)
     seq = lambda x: [tuple(x["surface"][x["ray"] == i].tolist()) for i in range(n)]
     same = np.array([a == b for a, b in zip(seq(got), seq(ref))])
@@ -941,14 +941,14 @@ def test_two_threads_sharing_the_engine_do_not_interleave():
 
     o, d = scenes.cfg2_rays(20000, 4)
     tables = [_table(scenes.cfg2_components(oa)), _table([oa.Mirror([3, 0, 0], radius=2.0).RotZ(np.pi)])]
-    expect = [t.trace_batch(_batch(o, d), max_segments=5).count.clone() for t in tables]
+    expect = [t.trace_batch(_batch(o, d), max_segments=5, layout="slots").count.clone() for t in tables]
     assert not torch.equal(expect[0], expect[1])
     errors = []
 
     def work(k):
         try:
             for _ in range(30):
-                got = tables[k].trace_batch(_batch(o, d), max_segments=5).count
+                got = tables[k].trace_batch(_batch(o, d), max_segments=5, layout="slots").count
                 if not torch.equal(got, expect[k]):
                     errors.append(k)
         except Exception as exc:  # noqa: BLE001
@@ -976,7 +976,7 @@ def test_streamed_host_api_equals_the_resident_batch(precision):
     table = _table(scenes.cfg2_components(oa))
     o, d = scenes.cfg2_rays(n, 2)
     q = 1j * np.pi * scenes.W0**2 / scenes.WL
-    segs = table.trace_batch(RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=q, precision=precision), max_segments=K)
+    segs = table.trace_batch(RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=q, precision=precision), max_segments=K, layout="slots")
     final = odist.final_state(segs).cpu().numpy()
     tol = 1e-11 if precision == "f64" else 2e-4
     for chunk in (n, 16384, 7001):
@@ -1012,7 +1012,7 @@ def test_large_image_with_every_feature_reads_the_scene_from_l2(oracle):
     o, d = scenes.cfg5_rays(n, 5)
     d = d + np.array([0.0, 0.02, 0.0]) * np.linspace(-1, 1, n)[:, None]      # fan out so that some rays reach the cylinder
     batch = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=1j * np.pi * scenes.W0**2 / scenes.WL)
-    got = table.trace_batch(batch, max_segments=K).to_host(reference_order=True)
+    got = table.trace_batch(batch, max_segments=K, layout="slots").to_host(reference_order=True)
     ref = oracle.trace(scene, batch.to_host(), max_trace_num=K)
     np.testing.assert_array_equal(got["ray"], ref["ray"])
     np.testing.assert_array_equal(got["surface"], ref["surface"])
@@ -1020,7 +1020,7 @@ def test_large_image_with_every_feature_reads_the_scene_from_l2(oracle):
         tol = 2e-3 if f in ("q_re", "q_im") else 1e-9
         np.testing.assert_allclose(got[f], ref[f], rtol=tol, atol=max(tol, 1e-9), err_msg=f)
     cyl_leaf = scene.n_leaves - 1
-    s32 = table.trace_batch(RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=1j, precision="f32"), max_segments=K)
+    s32 = table.trace_batch(RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=1j, precision="f32"), max_segments=K, layout="slots")
     assert int((s32.count > 0).sum()) == n and (got["surface"] == cyl_leaf).sum() >= 0
 
 
@@ -1040,13 +1040,13 @@ def test_very_large_scene_image(oracle):
     d = np.tile([[1.0, 0.0, 0.0]], (n, 1))
     q = 1j * np.pi * scenes.W0**2 / scenes.WL
     batch = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=q)
-    got = table.trace_batch(batch, max_segments=K).to_host(reference_order=True)
+    got = table.trace_batch(batch, max_segments=K, layout="slots").to_host(reference_order=True)
     ref = oracle.trace(scene, batch.to_host(), max_trace_num=K)
     np.testing.assert_array_equal(got["surface"], ref["surface"])
     for f in abi.SEG_FIELDS:
         tol = 2e-3 if f in ("q_re", "q_im") else 1e-9
         np.testing.assert_allclose(got[f], ref[f], rtol=tol, atol=max(tol, 1e-9), err_msg=f)
-    g32 = table.trace_batch(RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=q, precision="f32"), max_segments=K).to_host(reference_order=True)
+    g32 = table.trace_batch(RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=q, precision="f32"), max_segments=K, layout="slots").to_host(reference_order=True)
     seq = lambda x: [tuple(x["surface"][x["ray"] == i].tolist()) for i in range(n)]
     same = np.array([a == b for a, b in zip(seq(g32), seq(ref))])
     assert same.mean() > 0.9, same.mean()
@@ -1114,14 +1114,14 @@ def test_stale_cached_boxes_gate_but_never_prune(kernel, oracle):
     eng = get_engine()
     eng.set_option(abi.OPT_KERNEL, kernel)
     try:
-        first = table.trace_batch(batch, max_segments=6).to_host(reference_order=True)  # caches every box
+        first = table.trace_batch(batch, max_segments=6, layout="slots").to_host(reference_order=True)  # caches every box
         ref0 = oracle.trace(table.compile(), batch.to_host(), max_trace_num=6)
         np.testing.assert_array_equal(first["surface"], ref0["surface"])
         pair._Translate([-5.0, 0.0, 0.0])  # the group and its mirrors move; their cached boxes stay at x ~ 10
         scene = table.compile()
         nodes = scene.node_table()
         assert not all(nodes["flags"] & abi.NODE_BOX_TRUSTED)
-        got = table.trace_batch(batch, max_segments=6).to_host(reference_order=True)
+        got = table.trace_batch(batch, max_segments=6, layout="slots").to_host(reference_order=True)
         ref = oracle.trace(scene, batch.to_host(), max_trace_num=6)
     finally:
         eng.set_option(abi.OPT_KERNEL, 0)
@@ -1164,7 +1164,7 @@ def test_repeated_hits_on_one_curved_surface(shape, oracle):
     out = {}
     for prec in ("f64", "f32"):
         b = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=1j * np.pi * scenes.W0**2 / scenes.WL, precision=prec)
-        out[prec] = table.trace_batch(b, max_segments=K)
+        out[prec] = table.trace_batch(b, max_segments=K, layout="slots")
     got = out["f64"].to_host(reference_order=True)
     host = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=1j * np.pi * scenes.W0**2 / scenes.WL, device="cpu").to_host()
     ref = oracle.trace(table.compile(), host, max_trace_num=K)
@@ -1194,7 +1194,7 @@ def test_generation_emit_pass_reuses_the_count_pass_decision(prec):
     for reuse in (0, 1):
         eng.set_option(abi.OPT_GEN_REUSE, reuse)
         try:
-            got[reuse] = table.trace_batch(batch, max_segments=cap).to_host(reference_order=True)
+            got[reuse] = table.trace_batch(batch, max_segments=cap, layout="slots").to_host(reference_order=True)
         finally:
             eng.set_option(abi.OPT_GEN_REUSE, -1)
     assert len(got[0]["ray"]) > 3 * n  # the trees do branch

@@ -31,10 +31,10 @@ def test_block_pool_equals_per_wave_lists(n, K):
     eng = get_engine()
     try:
         eng.set_option(abi.OPT_BLOCK_POOL, 0)
-        lists = table.trace_batch(batch, max_segments=K)
+        lists = table.trace_batch(batch, max_segments=K, layout="slots")
         assert not eng.last_launch()["pair_queue"] & 16
         eng.set_option(abi.OPT_BLOCK_POOL, 1)  # (the slots take the pool only when asked to: scattered stores)
-        pool = table.trace_batch(batch, max_segments=K)
+        pool = table.trace_batch(batch, max_segments=K, layout="slots")
         info = eng.last_launch()
         assert info["kernel"] == 2 and info["pair_queue"] & 16 and info["pair_queue"] & 2, info
         app = table.trace_batch(batch, max_segments=K, layout="append")
