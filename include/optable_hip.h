@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define OT_ABI_VERSION 10  /* 10: ot_trace_plan, ot_probe_layouts, OT_OPT_REFILL, OT_OPT_REFILL_TICKET; 9: ot_trace_tree_*, OT_OPT_BLOCK_POOL, OT_OPT_GEN_DROP_DOOMED, ot_trace_append_* holes per workgroup chunk; 8: OT_SHAPE_ASPHERE_CHEB, OT_MAT_CHEB, OT_NODE_BOX_TRUSTED, ot_trace_tiled_*, ot_bench_stream_tiled_*; 3: ot_trace_generation_f32; 4: ot_bench_stream_f32; 5: OT_OPT_LIST_CAP, ray flags bits 8..31, ot_debug_generation_mismatches; 6: ot_debug_last_launch, OT_OPT_FLAT_QUEUE, OT_OPT_LDS_RECORDS; 7: ot_trace_append_*, ot_segment_block, OT_OPT_APPEND_CHUNK, OT_OPT_INSTANCING */
+#define OT_ABI_VERSION 10  /* 10: ot_trace_plan, ot_probe_layouts, OT_OPT_REFILL, OT_OPT_REFILL_TICKET, OT_OPT_POOL_JITTER, OT_OPT_GEN_ONEPASS; 9: ot_trace_tree_*, OT_OPT_BLOCK_POOL, OT_OPT_GEN_DROP_DOOMED, ot_trace_append_* holes per workgroup chunk; 8: OT_SHAPE_ASPHERE_CHEB, OT_MAT_CHEB, OT_NODE_BOX_TRUSTED, ot_trace_tiled_*, ot_bench_stream_tiled_*; 3: ot_trace_generation_f32; 4: ot_bench_stream_f32; 5: OT_OPT_LIST_CAP, ray flags bits 8..31, ot_debug_generation_mismatches; 6: ot_debug_last_launch, OT_OPT_FLAT_QUEUE, OT_OPT_LDS_RECORDS; 7: ot_trace_append_*, ot_segment_block, OT_OPT_APPEND_CHUNK, OT_OPT_INSTANCING */
 
 /* ---- status codes ------------------------------------------------------------------- */
 enum ot_status {
@@ -394,6 +394,12 @@ enum ot_option {
     OT_OPT_REFILL = 16,        /* heavy scenes under a top-level grid (mixed generations): the live rays in registers, every lane takes its
                                   next fresh ray in place (k_trace_refill) instead of a list per wave: 0 (default: the lists; the two tie on cfg 3), 1 whenever a kernel exists */
     OT_OPT_REFILL_TICKET = 17, /* ... rays a wave draws from the device-wide queue per atomic: 0 = by batch size (64..256), or a multiple of 64 */
+    OT_OPT_GEN_ONEPASS = 19,   /* ot_trace_tree_*: every generation in ONE pass — each workgroup traces a tile of rays once, keeps the children in
+                                  registers and takes its output offsets from a decoupled look-back over per-tile descriptors (k_gen_one) —
+                                  instead of count + scan + emit: 0 (default: the two passes are faster — every tile of the one-pass kernel waits for
+                                  the slowest of its predecessors), 1 for scenes without count-limited surfaces.  Identical output. */
+    OT_OPT_POOL_JITTER = 18,   /* test knob of the block pool's cross-wave protocol: one in `value` publications of a state or control word is
+                                  held back ~8000 cycles after the records it announces were written (0 = off).  Results must not change. */
     OT_OPT_GEN_DROP_DOOMED = 15 /* ot_trace_generation_*: a tree whose budget ends with this generation gets no children in `next` (they
                                   could never be processed: optical_table.py:138-144) — 1 (default) / 0: emit them, for a caller who
                                   wants to go on with a larger budget */

@@ -20,3 +20,12 @@ template <> GenKern<T> gen_kernel<T>(int fg, bool lds, bool emit) {
     return pick<F_ALL>(lds, emit);
 }
 template <> ProbeKern<T> probe_kernel<T>(bool lds) { return lds ? k_gen_probe<T, F_ALL, true> : k_gen_probe<T, F_ALL, false>; }
+
+// k_gen_one: the same presets
+template <> GenOneKern<T> gen_one_kernel<T>(int fg, bool lds) {
+    if (fg == 0) return lds ? k_gen_one<T, FB, true> : k_gen_one<T, FB, false>;
+    if constexpr (sizeof(T) == 4) {
+        if (fg == 1 && lds) return k_gen_one<T, FC, true>;
+    }
+    return lds ? k_gen_one<T, F_ALL, true> : k_gen_one<T, F_ALL, false>;
+}

@@ -939,10 +939,19 @@ __global__ __launch_bounds__((refill_threads<T, F>()), (refill_minw<T, F>())) vo
 // No wave ever waits for another one while it has anything to do: a wave that finds nothing to trace and nothing to
 // fill sleeps a few hundred cycles and looks again (somebody holds the blocks that are left), and leaves when the queue
 // is exhausted and every block is free.
-// Ordering between waves needs no waiting: the LDS executes the instructions of one wave in the order they were issued, so
-// a state word written after a block's records is seen after them, and records read before a state word is written have
-// been read when it lands; the fences below are wave-scope (they only keep the compiler from reordering).  A
-// workgroup-scope release would also wait for the pass's fourteen global segment stores — 1.8x the pass time.
+// Ordering between waves needs no waiting.  The argument, in the terms of the ISA: every access to a block or to a state /
+// control word is an LDS instruction (ds_read, ds_write, ds_cmpst, ds_add) of SOME wave of this workgroup; a CU has ONE LDS
+// pipeline, it executes the DS instructions it is handed one at a time, and it is handed those of one wave in program order
+// (a wave's DS instructions leave through one in-order queue: that is what lets `s_waitcnt lgkmcnt(N)` mean "all but the
+// N youngest are done").  So (i) a wave's record writes, issued before its state-word write, are executed by the pipeline
+// before it; (ii) any wave whose ds_read of that state word returns the new value had that read executed after the write,
+// hence after the record writes, and its own record reads, issued after the state read (it waits for the value: lgkmcnt),
+// execute later still: they see the records.  (iii) The other direction: a wave reads B's records into registers, then
+// writes B's state word; whoever sees the new word and overwrites B does so after those reads have executed.  No step
+// depends on how long anything takes, only on the order within one wave and on the pipeline being single — which the
+// jitter test (OT_OPT_POOL_JITTER: publications held back by thousands of cycles at random) exercises.  The fences below are
+// therefore wave-scope: they only keep the COMPILER from reordering the accesses.  A workgroup-scope release would also
+// wait for the pass's fourteen global segment stores — 1.8x the pass time.
 // Two policies matter more than anything else here (cfg 5, 12.3 ms as built): refilling EAGERLY, as soon as 16 / 8 / 4 blocks
 // are free instead of when a wave has nothing to trace, makes small cohorts whose generations never meet (13.7 / 15.1 /
 // 16.6 ms); the OLDEST generation first instead of the youngest lets every cohort run ahead on its own (21.7 ms).
@@ -961,7 +970,7 @@ __global__ __launch_bounds__(1024, 1) void k_trace_pool(
         SceneBlob blob; T unit; RaysT<T> in; int64_t n; int32_t K; OUT out; AppendCtl ac; int32_t* seg_count; int32_t* counts;
         int32_t n_classes; WaveScratch<T> ws; int32_t CAP; int32_t capl; unsigned long long* queue; int32_t mix; int32_t flat_cap;
     };
-    (void)ac; (void)seg_count; (void)queue; (void)in; (void)ws; (void)capl_arg; (void)mix; (void)flat_cap;
+    (void)ac; (void)seg_count; (void)queue; (void)in; (void)ws; (void)capl_arg; (void)mix;  // (flat_cap: the jitter period of the protocol test, 0 = off)
     typedef const __attribute__((address_space(4))) RaysT<T>* RaysArgPtr;
     const RaysArgPtr in_arg = (RaysArgPtr)((uintptr_t)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(LeadArgs, in));
     extern __shared__ __align__(16) uint32_t lds[];
@@ -994,6 +1003,18 @@ __global__ __launch_bounds__(1024, 1) void k_trace_pool(
     const uint32_t wg_chunk = APPEND ? (uint32_t)min(16 * OT_KARG(ac.chunk), 1 << 19) : 0u;
     // (ctl[1] starts as epoch 0, offset wg_chunk — a full chunk: the first claim opens the first real one)
     bool broken = false;  // a bound that "cannot trigger" did: the launch is reported as failed (see the end of the kernel)
+    uint32_t pass_no = 0;
+    // OT_OPT_POOL_JITTER (tests): before one in `flat_cap` publications of a state or control word the wave stalls for ~8000
+    // cycles — the records are written, the word that says so is late.  Whatever the protocol leaves to timing shows up as
+    // a wrong record under this; with the option off it is one scalar compare per site.
+    auto jitter = [&](uint32_t site) {
+        if (flat_cap > 0) {
+            const uint32_t h = ((pass_no * 2654435761u) ^ (site * 40503u) ^ ((uint32_t)(threadIdx.x >> 6) * 9176u) ^ (blockIdx.x * 131u)) >> 7;
+            if (h % (uint32_t)flat_cap == 0u)
+                for (int q = 0; q < 64; ++q) __builtin_amdgcn_s_sleep(127);
+        }
+    };
+
     auto chunk_base = [&](uint32_t epoch) -> int64_t {
         const uint32_t lo = __hip_atomic_load(&ctl[4 + 2 * (epoch & 3u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const uint32_t hi = __hip_atomic_load(&ctl[5 + 2 * (epoch & 3u)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1020,6 +1041,7 @@ __global__ __launch_bounds__(1024, 1) void k_trace_pool(
                     __hip_atomic_store(&ctl[5 + 2 * ((epoch + 1u) & 3u)], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                jitter(4);
                 if (lane == 0) __hip_atomic_store(&ctl[1], ((epoch + 1u) << 20) | (uint32_t)take, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 return (int64_t)(((unsigned long long)hi << 32) | lo);
             }
@@ -1037,9 +1059,12 @@ __global__ __launch_bounds__(1024, 1) void k_trace_pool(
       }
     };
     int idle = 0;
+    uint32_t prev_st = 0;    // the state word this lane saw at the last poll: a poll that sees ANY word changed is progress
     for (;;) {
         // ---- choose: every lane looks at one block
         const uint32_t st = lane < NB ? __hip_atomic_load(&state[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : POOL_LOCKED;
+        if (__any(st != prev_st)) idle = 0;  // somebody released, filled or advanced a block since the last look: the workgroup is alive
+        prev_st = st;
         const int cnt_l = (int)(st & 127u), gen_l = (int)((st >> 8) & 0xfffffu);
         const bool elig = !(st & POOL_LOCKED) && cnt_l > 0;
         // lowest generation first; among its blocks the first one from a starting point of this wave's own (sixteen waves
@@ -1071,6 +1096,7 @@ __global__ __launch_bounds__(1024, 1) void k_trace_pool(
                         const int c = start >= n_now ? 0 : (int)(n_now - start < 64ull ? n_now - start : 64ull);
                         if (lane < c) pool[b * POOL_BLOCK_WORDS + lane] = (uint32_t)start + (uint32_t)lane;
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        jitter(1);
                         if (lane == 0) __hip_atomic_store(&state[b], (uint32_t)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // generation 0, unlocked (0 rays: free)
                         ++j;
                     }
@@ -1086,7 +1112,9 @@ __global__ __launch_bounds__(1024, 1) void k_trace_pool(
             // blocks exist but other waves hold them (or are filling them): look again shortly
             __builtin_amdgcn_s_sleep(4);
             OT_POOL_COUNT(2, 1);
-            if (++idle > (1 << 22)) { broken = true; break; }  // (a wave never holds a block longer than one pass: this cannot trigger; it bounds a bug)
+            // (only polls that saw NOTHING change count: a long tail in which other waves work off the last blocks — a cavity with
+            // 1e5 bounces — is not a failure; 2^22 polls of an unchanged pool are, a wave never holds a block longer than one pass)
+            if (++idle > (1 << 22)) { broken = true; break; }
             continue;
         }
         idle = 0;
@@ -1164,6 +1192,7 @@ __global__ __launch_bounds__(1024, 1) void k_trace_pool(
             }
             // B's rays are in registers: give it back, shorter (its remaining rays sit where they sat)
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            jitter(2);
             if (B >= 0 && lane == 0) {
                 const int rest = cntB - takeB;
                 __hip_atomic_store(&state[B], rest > 0 ? (uint32_t)((gen << 8) | rest) : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1215,6 +1244,8 @@ __global__ __launch_bounds__(1024, 1) void k_trace_pool(
                 dst[13 * 64] = (uint32_t)((r.has_q ? OT_RAY_HAS_Q : 0) | ((child.last + 1) << 8));
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            jitter(3);
+            ++pass_no;
             if (lane == 0) {
                 const int left = __popcll(mk);
                 __hip_atomic_store(&state[A], left > 0 ? (uint32_t)(((gen + 1) << 8) | left) : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1460,4 +1491,182 @@ __global__ __launch_bounds__(256) void k_gen_pass(SceneBlob blob, T unit, RaysT<
     };
     if (c_nk > 0) put(nk > 0 ? ch[0] : r, d0, nk > 0);
     if (c_nk > 1) put(nk > 1 ? ch[1] : r, d0 + 1, nk > 1);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_gen_one: a generation in ONE pass (round 4).  Every WAVE traces a tile of 64 consecutive rays of the generation
+// once, keeps the 0-2 children of each ray in registers, and learns where its segments and children go from a DECOUPLED
+// LOOK-BACK over one 64-bit descriptor per tile (flag | segments << 31 | children): the tile publishes its aggregate as
+// soon as its trace is done, then reads the descriptors of its predecessors 64 at a time until it meets one that
+// already holds an inclusive prefix, publishes its own inclusive prefix and writes.  Tiles are numbered by workgroup and
+// wave and workgroups are dispatched in index order, so every predecessor of a running tile is itself running or finished: no
+// wait can last longer than a predecessor's trace, and nothing is serial per workgroup — the difference to round 1's
+// single-pass kernel (persistent workgroups that loaded, traced, looked back and stored tile after tile: 26.6 ms on cfg 4
+// with reflectivity 0.2).  Against the two passes of k_gen_pass a generation's rays are read and traced ONCE (375 instead of
+// 484 bytes per processed ray in double precision), there is no scan, no totals kernel, no code byte, no stored decision,
+// and count and emit cannot disagree because there is only one of them.
+// Budgets (optical_table.py:138-144).  The two-pass kernels read budget[tree] in the count pass and let the tree's last ray
+// write it in the emit pass; in one pass that is a race (a tree's rays can span workgroups).  Here every RAY carries what is
+// left of its tree's budget at the start of the generation (rem[], 4 bytes per ray: seeded from budget[] by k_gen_seed_rem
+// before the first generation of a call, handed to the children as rem - min(rays of the tree in this generation, rem));
+// budget[] itself is only WRITTEN (by the tree's last ray) and stays what callers read between calls.
+// Scenes with count-limited leaves keep the two-pass path (their gate needs the per-slot scans between probe and trace).
+static constexpr unsigned long long GEN1_AGG = 1ull << 62, GEN1_INC = 2ull << 62, GEN1_MASK = (1ull << 62) - 1ull;
+// index one past the last ray of ray i's tree (tree[] is non-decreasing): neighbours first, then a binary search
+__device__ __forceinline__ int64_t tree_tail(const int32_t* __restrict__ tree, int64_t i, int64_t n) {
+    const int32_t t = tree[i];
+    for (int k = 1; k <= 3; ++k)
+        if (i + k >= n || tree[i + k] != t) return i + k;
+    int64_t lo = i + 3, hi = n;  // tree[lo] == t; first index in (lo, n] whose tree differs
+    while (lo + 1 < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (tree[mid] == t) lo = mid; else hi = mid;
+    }
+    return hi;
+}
+template <class T, uint32_t F> constexpr int gen_one_minw() { return (sizeof(T) == 8 && F == (F_AABB | F_LENS | F_REFRACT)) ? 4 : 1; }  // (4 waves per SIMD where 128 registers suffice)
+template <class T, uint32_t F, bool SCENE_IN_LDS>
+__global__ __launch_bounds__(256, (gen_one_minw<T, F>())) void k_gen_one(SceneBlob blob, T unit, RaysT<T> in, const int32_t* __restrict__ tree, const int32_t* __restrict__ rem,
+                                                 int64_t n, int32_t* __restrict__ budget, int64_t* state, SegsT<T> out, int64_t out_capacity,
+                                                 RaysOutT<T> next, int32_t* next_tree, int32_t* next_rem, int64_t next_capacity,
+                                                 unsigned long long* desc, uint32_t* ticket, int32_t* counts, int32_t n_classes, int32_t drop_doomed) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    const uint32_t* base = blob.words;
+    if (SCENE_IN_LDS) {
+        for (int w = threadIdx.x; w < blob.n_words; w += blockDim.x) lds[w] = blob.words[w];
+        __syncthreads();  // the only workgroup barrier: the scene image is staged; from here on the four waves are on their own
+        base = lds;
+    }
+    const Scene<T> sc = bind_scene<T>(base, blob, unit);
+    const int lane = threadIdx.x & 63;
+    // A tile is the 64 rays of ONE WAVE (numbered by workgroup and wave: workgroups are dispatched in index order, so every
+    // predecessor of a running wave is running or done).  With a tile per workgroup, three waves sat at a barrier while
+    // the fourth looked back (cfg 4 R = 0.2: 17.7 ms against 14.7 for the two passes); per wave nothing ever waits for a
+    // neighbour and a CU has sixteen independent look-backs in flight.
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t tile = i >> 6;
+    // (the segment cursor as it stands BEFORE this generation: the last tile rewrites it at the very end, which it can only do
+    // after every other tile has published — so the value is pinned here, ahead of anything this tile publishes)
+    const int64_t cursor = (int64_t)__hip_atomic_load(reinterpret_cast<unsigned long long*>(state), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("" ::"v"((int32_t)cursor), "v"((int32_t)(cursor >> 32)) : "memory");
+    // rank within the tree, budget cut, doomed children: as k_gen_pass, with the ray's own rem[] in place of budget[tree]
+    int32_t my_tree = -1;
+    int start_lane = -1;
+    if (i < n) {
+        my_tree = tree[i];
+        if (lane == 0 || tree[i - 1] != my_tree) start_lane = lane;
+    }
+    const int head_lane = wave_incl_max_i32(start_lane);
+    int64_t head = (i - lane) + head_lane;
+    if (i < n && head_lane == 0) head = tree_head(tree, i - lane);
+    const int64_t bud = i < n ? (int64_t)rem[i] : 0;
+    const bool active = i < n && (i - head) < bud;
+    bool doomed = false;
+    if (active && drop_doomed) {
+        const int64_t last_needed = head + bud - 1;
+        doomed = last_needed < n && tree[last_needed] == my_tree;
+    }
+    RayState<T> r = {};
+    int32_t cls = 0, fl = 0;
+    if (active) {
+        fl = in.flags[i];
+        r = load_ray(in, i, fl);
+        if ((uint32_t)r.last >= (uint32_t)sc.n_nodes) r.last = -1;
+        cls = in.id[i];
+    }
+    const bool dead = active && (fl & OT_RAY_DEAD);
+    const GateCtx gate = {counts, n_classes, cls, nullptr, nullptr, n, i};
+    const Hit<T> h = nearest_hit<T, F, GATE_TABLE>(sc, r, active && !dead, gate);
+    // Double precision: two children are 2 x 11 doubles = 44 registers that would sit through the barrier and the look-back (133
+    // registers, 3 waves per SIMD).  The interaction is therefore run for its COUNT here (its unused results are dead code) and
+    // again for the children after the look-back, behind an opaque copy of one input so that the two calls are not merged:
+    // 124 registers, 4 waves per SIMD, ~5 % more arithmetic in a pass that is bound by its streams.
+    constexpr bool LATE_KIDS = sizeof(T) == 8;
+    int32_t nk = 0;
+    RayState<T> ch[2];  // indexed by constants only
+    if (active && !dead && h.node >= 0) {
+        if constexpr (LATE_KIDS) {
+            RayState<T> unused[2];
+            nk = interact<T, F, 2>(sc, r, h, unused, make_matcache<T, F>(sc, r.wl));
+        } else {
+            nk = interact<T, F, 2>(sc, r, h, ch, make_matcache<T, F>(sc, r.wl));
+        }
+    }
+    if (doomed) nk = 0;
+    // what the tree has left after this generation: for the children, and (its last ray) for budget[]
+    int32_t rem_after = 0;
+    if (i < n && (nk > 0 || i == n - 1 || tree[i + 1] != my_tree)) {
+        const int64_t in_gen = tree_tail(tree, i, n) - head;
+        rem_after = (int32_t)(bud - (in_gen < bud ? in_gen : bud));
+        if (i == n - 1 || tree[i + 1] != my_tree) budget[my_tree] = rem_after;  // one writer per tree, no reader in this kernel
+    }
+    // ---- the tile's aggregate
+    const unsigned long long act_mask = __ballot(active);
+    const int seg_rank = rank_below(act_mask), n_act = __popcll(act_mask);
+    int kids_total;
+    const int kid_excl = wave_excl_scan_i32(nk, kids_total);
+    const unsigned long long agg = ((unsigned long long)n_act << 31) | (unsigned long long)kids_total;
+    // ---- decoupled look-back: exclusive prefix over the tiles before this one
+    unsigned long long excl = 0;
+    if (tile * 64 < n) {  // (wave-uniform; the waves behind the end of the generation have nothing to say)
+        if (tile > 0) {
+            if (lane == 0) __hip_atomic_store(&desc[tile], GEN1_AGG | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int64_t pos = tile - 1;  // nearest predecessor not yet accounted for
+            for (;;) {
+                const int64_t j = pos - lane;
+                const unsigned long long d = j >= 0 ? __hip_atomic_load(&desc[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : GEN1_INC;  // (before tile 0: an inclusive zero)
+                const unsigned long long m_inc = __ballot((d >> 62) == 2ull), m_not = __ballot((d >> 62) == 0ull);
+                const int first_inc = m_inc ? __builtin_ctzll(m_inc) : 64, first_not = m_not ? __builtin_ctzll(m_not) : 64;
+                if (first_not < first_inc) {  // a predecessor in the window has not published yet: it is tracing (it was dispatched before this wave)
+                    __builtin_amdgcn_s_sleep(4);
+                    continue;
+                }
+                unsigned long long v = lane <= first_inc ? (d & GEN1_MASK) : 0ull;  // aggregates up to the first inclusive prefix, and that prefix
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+                excl += v;
+                if (first_inc < 64) break;
+                pos -= 64;
+            }
+        }
+        if (lane == 0) {
+            __hip_atomic_store(&desc[tile], GEN1_INC | (excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((tile + 1) * 64 >= n) {  // the last tile: the generation's totals (every other tile has read the cursor: it published before this one could finish)
+                const unsigned long long all = excl + agg;
+                state[0] = cursor + (int64_t)(all >> 31);
+                state[1] = (int64_t)(all & 0x7fffffffull);
+            }
+        }
+    }
+    const unsigned long long mine = excl;
+    // ---- write: segment record and children, once, in stable order
+    if (active) {
+        const int64_t slot = cursor + (int64_t)(mine >> 31) + seg_rank;
+        if (slot < out_capacity) {
+            if (dead) store_segment<T, GEN_NT>(out, slot, r, r.len, my_tree, -2);
+            else if (h.node < 0) store_segment<T, GEN_NT>(out, slot, r, r.len, my_tree, -1);
+            else store_segment<T, GEN_NT>(out, slot, r, h.t, my_tree, leaf_id_of<T, F>(sc, h.node));
+        }
+    }
+    const int64_t d0 = (int64_t)(mine & 0x7fffffffull) + kid_excl;
+    if constexpr (LATE_KIDS) {
+        if (nk > 0) {
+            RayState<T> r2 = r;
+            asm volatile("" : "+v"(r2.dx));  // (the same value, opaque to the optimiser: this call is not the one above)
+            (void)interact<T, F, 2>(sc, r2, h, ch, make_matcache<T, F>(sc, r2.wl));
+        }
+    }
+    auto put = [&](const RayState<T>& k, int64_t d) {
+        if (d >= next_capacity) return;
+        st<GEN_NT>(next.ox + d, k.ox); st<GEN_NT>(next.oy + d, k.oy); st<GEN_NT>(next.oz + d, k.oz);
+        st<GEN_NT>(next.dx + d, k.dx); st<GEN_NT>(next.dy + d, k.dy); st<GEN_NT>(next.dz + d, k.dz);
+        st<GEN_NT>(next.wl + d, k.wl); st<GEN_NT>(next.qr + d, k.qr); st<GEN_NT>(next.qi + d, k.qi);
+        st<GEN_NT>(next.I + d, k.I); st<GEN_NT>(next.n + d, k.n); st<GEN_NT>(next.pl + d, k.pl);
+        next.flags[d] = (fl & OT_RAY_HAS_Q) | ((k.last + 1) << 8);
+        next.id[d] = cls;
+        next_tree[d] = my_tree;
+        next_rem[d] = rem_after;
+    };
+    if (nk > 0) put(ch[0], d0);
+    if (nk > 1) put(ch[1], d0 + 1);
 }

@@ -109,6 +109,12 @@ __global__ void k_gen_totals(const unsigned long long* wave_total, const unsigne
     }
 }
 
+// k_gen_one's per-ray budgets, seeded from the per-tree table before the first generation of a call (kernels.h)
+__global__ void k_gen_seed_rem(const int32_t* __restrict__ tree, const int32_t* __restrict__ budget, int64_t n, int32_t* __restrict__ rem) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rem[i] = budget[tree[i]];
+}
+
 // rank[slot][i] = how many earlier rays of i's tree (this generation) hit limited leaf `slot`
 __global__ void k_gen_rank(const int32_t* tree, int64_t n, int32_t n_slots, const int32_t* ex, int32_t* rank) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -87,6 +87,7 @@ struct ot_ctx {
     int32_t opt_refill = 0;      // mixed scenes: rays in registers, refilled in place (k_trace_refill): 0 never (the lists; default: the two tie on cfg 3
                                  // in the append layout, 2.08-2.11 ms, and the lists win into [k][ray] slots, 3.7 against 4.7 ms), 1 whenever a kernel exists
     int32_t opt_refill_ticket = 0;  // rays per ticket of k_trace_refill (0 = by batch size)
+    int32_t opt_pool_jitter = 0; // k_trace_pool: one in this many state-word publications is held back ~8000 cycles (protocol test; 0 = off)
     int32_t opt_pool = -1;       // curved-surface scenes, fp32: workgroup-wide block pool (-1 auto, 0 never, 1 whenever it fits)
     int32_t opt_rec_lds = -1;    // pair-queue scenes: records of the live rays in LDS (-1 auto, 0 never, 1 whenever it fits)
     int32_t opt_list_cap = 128;  // k_trace_rolling: live rays per wave (cfg 3: 128 beats 256 and 512)
@@ -97,7 +98,10 @@ struct ot_ctx {
     size_t blocked_queue_off = 0;
     int32_t opt_pair = 1;  // paired 16-byte segment stores in the lane-per-ray kernel
     int32_t opt_nt = 1, opt_minw = 4, opt_blocks_per_cu = 0;  // defaults from tools/tune.py on MI355X
-    Scratch gen, scan_tmp, mon;
+    Scratch gen, scan_tmp, mon, gen_rem;
+    int32_t opt_gen_onepass = 0;   // ot_trace_tree_*: one pass per generation with a decoupled look-back (k_gen_one): 0 (default: count + scan + emit —
+                                   // the one-pass kernel moves 22 % fewer bytes but every tile waits for the slowest of its predecessors: cfg 4 with
+                                   // R = 0.2 18.4 ms against 13.6, tools/ab_onepass.py), 1 whenever the scene has no count-limited surface
     double probe_us[2][2] = {{0, 0}, {0, 0}};  // ot_probe_layouts: [precision][0 slot arrays, 1 tiles] microseconds per launch of the stream companion; 0 = not measured
     unsigned long long* gen_mismatch = nullptr;  // count / emit disagreements of k_gen_pass (expected: 0)
     int64_t* pinned_state = nullptr;             // ot_trace_tree_*: page-locked landing place of the per-generation read-back
@@ -518,6 +522,7 @@ int ot_ctx_destroy(ot_ctx* c) {
     if (c->blob32) (void)hipFree(c->blob32);
     if (c->slot_max) (void)hipFree(c->slot_max);
     if (c->gen.p) (void)hipFree(c->gen.p);
+    if (c->gen_rem.p) (void)hipFree(c->gen_rem.p);
     if (c->gen_mismatch) (void)hipFree(c->gen_mismatch);
     if (c->pinned_state) (void)hipHostFree(c->pinned_state);
     if (c->scan_tmp.p) (void)hipFree(c->scan_tmp.p);
@@ -762,7 +767,7 @@ static int launch_rolling(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, 
             if (rc) return rc;
             WaveScratch<T> ws = {nullptr, 0};
             hipExtLaunchKernelGGL(kp, dim3(gridp), dim3(1024), (uint32_t)lds_p, c->stream, ev0, ev1, 0u, blob, (T)c->unit, view<T>(rays), n, K, out,
-                                  ac, seg_count, counts, n_classes, ws, NB, 0, queue, 0, 0);
+                                  ac, seg_count, counts, n_classes, ws, NB, 0, queue, 0, c->opt_pool_jitter);
             HIP_TRY(hipGetLastError());
             const int32_t shape[8] = {2, 1024, 1, gridp, (int32_t)lds_p, NB * 64, 0, 2 | 16 | (append ? 4 : 0)};  // bit 4: block pool
             for (int q = 0; q < 8; ++q) c->last_launch[q] = shape[q];
@@ -1105,6 +1110,35 @@ static int trace_generation(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
     return timing_end(c);
 }
 
+// One generation in one pass (kernels.h k_gen_one): zero the tile descriptors and the ticket, launch.  `rem`: what is left of
+// its tree's budget for every ray of the generation; `next_rem` receives the children's.
+template <class T>
+static int trace_generation_one(ot_ctx* c, const ot_rays* rays, const int32_t* tree, const int32_t* rem, int64_t n, int32_t* budget, const ot_segments* out,
+                                int64_t out_capacity, int64_t* state, const ot_rays* next, int32_t* next_tree, int32_t* next_rem, int64_t next_capacity,
+                                int32_t* counts, int32_t n_classes) {
+    constexpr bool f64 = sizeof(T) == 8;
+    const int64_t n_tiles = (n + 63) / 64, n_groups = (n + 255) / 256;  // a tile = the 64 rays of one wave
+    const size_t sz_desc = align_up(sizeof(unsigned long long) * n_tiles + 8);
+    if (c->gen.ensure(sz_desc)) return fail(OT_ERR_HIP, "hipMalloc of generation scratch failed");
+    unsigned long long* desc = (unsigned long long*)c->gen.p;
+    uint32_t* ticket = (uint32_t*)(desc + n_tiles);
+    int rc = timing_begin(c);
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(desc, 0, sizeof(unsigned long long) * n_tiles + 8, c->stream));
+    const size_t bytes = f64 ? c->bytes64 : c->bytes32;
+    const SceneBlob blob = make_blob<T>(c);
+    const bool in_lds = bytes <= (size_t)c->opt_lds_limit_kb * 1024;
+    const size_t lds_bytes = in_lds ? bytes : 0;
+    const bool small = (c->features & ~preset::FB) == 0;
+    const int fg = small ? 0 : ((c->features & ~preset::FC) == 0 ? 1 : 2);
+    const GenOneKern<T> k = gen_one_kernel<T>(fg, in_lds);
+    if (lds_bytes > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL(k, dim3((unsigned)n_groups), dim3(256), lds_bytes, c->stream, blob, (T)c->unit, view<T>(rays), tree, rem, n, budget, state, view<T>(out),
+                       out_capacity, view_out<T>(next), next_tree, next_rem, next_capacity, desc, ticket, counts, n_classes, c->opt_gen_drop ? 1 : 0);
+    HIP_TRY(hipGetLastError());
+    return timing_end(c);
+}
+
 // The generation loop of a whole ray tree batch (optical_table.py:115-147) on the host side of the library: one
 // trace_generation per generation, the two counters read back (16 bytes, one stream synchronisation) and the two generation
 // buffers swapped — the loop the Python shell used to run with a dozen ctypes conversions per turn.  It stops when the
@@ -1128,12 +1162,32 @@ static int trace_tree(ot_ctx* c, const ot_rays* rays, const int32_t* tree, int64
     const int32_t* cur_tree = tree;
     int where = 0;  // which buffer holds the pending generation: 0 the caller's rays, 1 buf_a, 2 buf_b
     int64_t reason = 0;
+    // One pass per generation (k_gen_one) when OT_OPT_GEN_ONEPASS asks for it and the scene has no count-limited leaves (their
+    // gate needs the scans between a probe pass and the trace).  Its per-ray budgets live in the library: seeded from budget[]
+    // for the first generation of this call, two buffers of buf_capacity for the children.
+    const bool one_pass = c->n_slots == 0 && c->opt_gen_onepass > 0 && n > 0;
+    int32_t *rem_cur = nullptr, *rem_a = nullptr, *rem_b = nullptr;
+    if (one_pass) {
+        if (c->gen_rem.ensure(sizeof(int32_t) * (size_t)(n + 2 * buf_capacity) + 256)) return fail(OT_ERR_HIP, "hipMalloc of the per-ray budgets failed");
+        rem_cur = (int32_t*)c->gen_rem.p;
+        rem_a = rem_cur + n;
+        rem_b = rem_a + buf_capacity;
+        hipLaunchKernelGGL(k_gen_seed_rem, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, tree, (const int32_t*)budget, n, rem_cur);
+        HIP_TRY(hipGetLastError());
+    }
     while (cur_n > 0) {
         if (written + cur_n > out_capacity) { reason = 1; break; }        // the segment arrays are too small for this generation
         if (cur_n * fan > buf_capacity) { reason = 2; break; }           // ... the generation buffers for the next one
         const bool to_a = where != 1;
-        int rc = trace_generation<T>(c, cur, cur_tree, cur_n, budget, out, out_capacity, state, to_a ? buf_a : buf_b, to_a ? tree_a : tree_b,
+        int rc;
+        if (one_pass) {
+            rc = trace_generation_one<T>(c, cur, cur_tree, rem_cur, cur_n, budget, out, out_capacity, state, to_a ? buf_a : buf_b, to_a ? tree_a : tree_b,
+                                         to_a ? rem_a : rem_b, buf_capacity, counts, n_classes);
+            rem_cur = to_a ? rem_a : rem_b;
+        } else {
+            rc = trace_generation<T>(c, cur, cur_tree, cur_n, budget, out, out_capacity, state, to_a ? buf_a : buf_b, to_a ? tree_a : tree_b,
                                      buf_capacity, state + 1, counts, n_classes);
+        }
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(host_state, state, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));  // the one host synchronisation per generation
@@ -1374,6 +1428,12 @@ int ot_set_option(ot_ctx* c, int32_t option, int32_t value) {
             if (value < -1 || value > 1) return fail(OT_ERR_INVALID, "OT_OPT_BLOCK_POOL takes -1 (auto), 0 or 1");
             c->opt_pool = value; return 0;
         case OT_OPT_INSTANCING: c->opt_instancing = value != 0; return 0;  // takes effect at the next ot_scene_upload
+        case OT_OPT_GEN_ONEPASS:
+            if (value < 0 || value > 1) return fail(OT_ERR_INVALID, "OT_OPT_GEN_ONEPASS takes 0 or 1");
+            c->opt_gen_onepass = value; return 0;
+        case OT_OPT_POOL_JITTER:
+            if (value < 0 || value > (1 << 20)) return fail(OT_ERR_INVALID, "OT_OPT_POOL_JITTER takes 0 (off) or a period up to 2^20");
+            c->opt_pool_jitter = value; return 0;
         case OT_OPT_REFILL:
             if (value < 0 || value > 1) return fail(OT_ERR_INVALID, "OT_OPT_REFILL takes 0 or 1");
             c->opt_refill = value; return 0;

@@ -27,6 +27,9 @@ using GenKern = void (*)(SceneBlob, T, RaysT<T>, const int32_t*, int64_t, int32_
                          int64_t, uint8_t*, unsigned long long*, const unsigned long long*, int32_t*, int32_t, const int32_t*,
                          unsigned long long*, int32_t*, T*, int32_t);
 template <class T>
+using GenOneKern = void (*)(SceneBlob, T, RaysT<T>, const int32_t*, const int32_t*, int64_t, int32_t*, int64_t*, SegsT<T>, int64_t, RaysOutT<T>, int32_t*,
+                            int32_t*, int64_t, unsigned long long*, uint32_t*, int32_t*, int32_t, int32_t);
+template <class T>
 using ProbeKern = void (*)(SceneBlob, T, RaysT<T>, const int32_t*, int64_t, const int32_t*, int32_t*, int32_t, int32_t*);
 
 // k_trace_fused: fi = 0 FA, 1 FB, 2 F_ALL; image in LDS; 128-register cap (4 waves per SIMD); non-temporal segment stores
@@ -46,6 +49,8 @@ template <class T> int refill_max_threads(int fr, bool flat);
 // k_gen_pass / k_gen_probe: fg = 0 the planar preset FB, 1 FC (planar scenes under grids: cfg 3 with splitting slabs), 2 F_ALL
 template <class T> GenKern<T> gen_kernel(int fg, bool lds, bool emit);
 template <class T> ProbeKern<T> probe_kernel(bool lds);
+// k_gen_one (one pass per generation, decoupled look-back): fg as above; nullptr where no instantiation exists
+template <class T> GenOneKern<T> gen_one_kernel(int fg, bool lds);
 
 #define OT_DECLARE_TABLES(T)                                                       \
     template <> FusedKern<T, SegsT<T>> fused_kernel<T, SegsT<T>>(int, bool, bool, bool);         \
@@ -59,7 +64,8 @@ template <class T> ProbeKern<T> probe_kernel(bool lds);
     template <> RollingKern<T, SegPlanes<T>> refill_kernel<T, SegPlanes<T>>(int, bool); \
     template <> int refill_max_threads<T>(int, bool);                              \
     template <> GenKern<T> gen_kernel<T>(int, bool, bool);                         \
-    template <> ProbeKern<T> probe_kernel<T>(bool);
+    template <> ProbeKern<T> probe_kernel<T>(bool);                               \
+    template <> GenOneKern<T> gen_one_kernel<T>(int, bool);
 OT_DECLARE_TABLES(double)
 OT_DECLARE_TABLES(float)
 #undef OT_DECLARE_TABLES

@@ -128,7 +128,10 @@ def test_two_pass_generations_agree_with_themselves():
     for every ray.  2e6 trees of the branching cfg 4 variant (every hit splits, TIR inside the slab) and the cavity."""
     from optable_amd import workloads as W
 
+    from optable_amd import abi
+
     eng = get_engine()
+    eng.set_option(abi.OPT_GEN_ONEPASS, 0)  # (the two-pass kernels: the one-pass kernel has no second pass to disagree with)
     before = eng.generation_mismatches()
     table = oa.OpticalTable()
     table.add_components(W.cfg4_components(oa, reflectivity=0.2))
@@ -144,6 +147,7 @@ def test_two_pass_generations_agree_with_themselves():
                                  np.tile([1.0, 0, 0], (4096, 1)), precision=prec)
         eng.upload(t2.compile())
         eng.trace_tree(b, 300)
+    eng.set_option(abi.OPT_GEN_ONEPASS, 0)
     assert eng.generation_mismatches() == before
 
 

@@ -162,3 +162,65 @@ def test_block_pool_block_too_small_loses_records_not_memory():
     assert torch.equal(small.count, full.count)
     fits = table.trace_batch(batch, max_segments=K, layout="append", capacity=get_engine().append_capacity(records))
     assert fits.n_valid >= records
+
+
+def test_block_pool_stress_random_sizes_caps_and_chunks():
+    """The pool's lock-free scheduling under sixty launches of random batch size, segment cap and append chunk size (what
+    tools/pool_stress.py runs by the hundred): every launch holds exactly the records of the per-wave lists, in the
+    reference's order."""
+    import optable_amd as oa
+    from optable_amd.batch import RayBatch
+    from optable_amd.engine import get_engine
+
+    rng = np.random.default_rng(20260405)
+    table = oa.OpticalTable()
+    table.add_components(scenes.cfg5_components(oa))
+    eng = get_engine()
+    eng.upload(table.compile())
+    q = 1j * np.pi * scenes.W0**2 / scenes.WL
+    try:
+        for it in range(60):
+            n = int(rng.choice([1, 63, 64, 65, 1000, 4097, 30_000, 100_003]))
+            K = int(rng.integers(2, 51))
+            chunk = int(rng.choice([64, 128, 512, 2048]))
+            o, d = scenes.cfg5_rays(n, int(rng.integers(0, 1000)))
+            batch = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=q, precision="f32", device="cuda")
+            eng.set_option(abi.OPT_BLOCK_POOL, 0)
+            a = eng.trace(batch, K).to_host(reference_order=True)
+            eng.set_option(abi.OPT_BLOCK_POOL, -1)
+            eng.set_option(abi.OPT_APPEND_CHUNK, chunk)
+            out = eng.trace(batch, K, layout="append")
+            assert eng.last_launch()["pair_queue"] & 16
+            b = out.to_host(reference_order=True)
+            for f in abi.SEG_FIELDS + ("ray", "surface"):
+                np.testing.assert_array_equal(a[f], b[f], err_msg=f"launch {it}: n={n} K={K} chunk={chunk}: {f}")
+    finally:
+        eng.set_option(abi.OPT_BLOCK_POOL, -1)
+        eng.set_option(abi.OPT_APPEND_CHUNK, 512)
+
+
+@pytest.mark.parametrize("period", [1000, 37])
+def test_block_pool_protocol_under_delayed_publications(period):
+    """The cross-wave protocol of the pool rests on ORDER (one wave's LDS instructions execute in program order on the CU's one
+    LDS pipeline), never on timing: with one in `period` publications of a state or control word held back ~8000 cycles after
+    the records it announces (OT_OPT_POOL_JITTER) the records must not change — nor the slot order contract."""
+    from optable_amd.engine import get_engine
+
+    table, batch = _setup(150_001)
+    K = 30
+    eng = get_engine()
+    try:
+        eng.set_option(abi.OPT_BLOCK_POOL, 0)
+        lists = table.trace_batch(batch, max_segments=K, layout="slots").to_host(reference_order=True)
+        eng.set_option(abi.OPT_BLOCK_POOL, -1)
+        eng.set_option(abi.OPT_APPEND_CHUNK, 64)      # a workgroup opens a new chunk every 16 passes: the claim path is busy too
+        eng.set_option(abi.OPT_POOL_JITTER, period)
+        app = table.trace_batch(batch, max_segments=K, layout="append")
+        assert eng.last_launch()["pair_queue"] & 16
+        got = app.to_host(reference_order=True)
+    finally:
+        eng.set_option(abi.OPT_POOL_JITTER, 0)
+        eng.set_option(abi.OPT_APPEND_CHUNK, 512)
+        eng.set_option(abi.OPT_BLOCK_POOL, -1)
+    for f in abi.SEG_FIELDS + ("ray", "surface", "count"):
+        np.testing.assert_array_equal(lists[f], got[f], err_msg=f)
