@@ -17,15 +17,23 @@ template <> GenKern<T> gen_kernel<T>(int fg, bool lds, bool emit) {
     if constexpr (sizeof(T) == 4) {  // (single precision, image in LDS: the combinations whose count / emit pair compiles without a stack slot)
         if (fg == 1 && lds) return emit ? k_gen_pass<T, FC, true, true> : k_gen_pass<T, FC, true, false>;
     }
+    // the everyday parts (count gates, polygons, spheres, aspheres; + the rarer shapes): 94 / 114 registers in single precision
+    // (the all-features emit kernel: 150-161), 148 / 236 in double (255-262); image in LDS only
+    if (fg == 2 && lds) return emit ? k_gen_pass<T, FE, true, true> : k_gen_pass<T, FE, true, false>;
+    if (fg == 3 && lds) return emit ? k_gen_pass<T, FM, true, true> : k_gen_pass<T, FM, true, false>;
     return pick<F_ALL>(lds, emit);
 }
-template <> ProbeKern<T> probe_kernel<T>(bool lds) { return lds ? k_gen_probe<T, F_ALL, true> : k_gen_probe<T, F_ALL, false>; }
+template <> ProbeKern<T> probe_kernel<T>(int fg, bool lds) {
+    if (fg == 2 && lds) return k_gen_probe<T, FE, true>;
+    if (fg == 3 && lds) return k_gen_probe<T, FM, true>;
+    return lds ? k_gen_probe<T, F_ALL, true> : k_gen_probe<T, F_ALL, false>;
+}
 
-// k_gen_one: the same presets
+// k_gen_one (opt-in, OT_OPT_GEN_ONEPASS): the planar presets; nullptr elsewhere (the two passes take the generation)
 template <> GenOneKern<T> gen_one_kernel<T>(int fg, bool lds) {
     if (fg == 0) return lds ? k_gen_one<T, FB, true> : k_gen_one<T, FB, false>;
     if constexpr (sizeof(T) == 4) {
         if (fg == 1 && lds) return k_gen_one<T, FC, true>;
     }
-    return lds ? k_gen_one<T, F_ALL, true> : k_gen_one<T, F_ALL, false>;
+    return nullptr;
 }

@@ -1,35 +1,16 @@
-// inst_refill.hip — the k_trace_refill instantiations of one precision and one output layout and their lookup
-// (-DOT_REAL=double | float, -DOT_APPEND=0 | 1).
+// inst_refill.hip — the k_trace_refill instantiations of one precision and their lookup (-DOT_REAL=double | float).
 #include "tables.h"
 
 using T = OT_REAL;
 using namespace preset;
-#ifndef OT_APPEND
-#define OT_APPEND 0
-#endif
-#if OT_APPEND
-using OUT = SegPlanes<T>;
-#else
-using OUT = SegsT<T>;
-#endif
-constexpr bool APPEND = OT_APPEND != 0;
 
-// fr as for rolling_kernel (0 FR, 1 FC, 3 F_ALL, 4 FRP); flat = the pair-queue walk (FR / FRP).  Non-temporal stores as for the
-// lists: the sparse [k][ray] slots want plain stores (partial lines merge in L2), the dense append list streams.
-template <> RollingKern<T, OUT> refill_kernel<T, OUT>(int fr, bool flat) {
-    constexpr bool NT = APPEND;
-    if (flat) {
-        if (fr == 0) return k_trace_refill<T, FR | F_FLAT, NT, OUT>;
-        if (fr == 4) return k_trace_refill<T, FRP | F_FLAT, NT, OUT>;
-        return nullptr;
-    }
-    if (fr == 1) return k_trace_refill<T, FC, NT, OUT>;
-    if (fr == 3) return k_trace_refill<T, F_ALL, true, OUT>;
+// fr as for rolling_kernel (0 FR, 4 FRP); the pair-queue walk only, and only the append layout: into the sparse [k][ray] slots the
+// lists are faster (3.7 against 4.7 ms on cfg 3), and an opt-in kernel that ties with the default is not worth twelve more
+// instantiations.  nullptr: the lists take the launch.
+template <> RollingKern<T, SegPlanes<T>> refill_kernel<T, SegPlanes<T>>(int fr, bool flat) {
+    if (flat && fr == 0) return k_trace_refill<T, FR | F_FLAT, true, SegPlanes<T>>;
+    if (flat && fr == 4) return k_trace_refill<T, FRP | F_FLAT, true, SegPlanes<T>>;
     return nullptr;
 }
-#if !OT_APPEND
-template <> int refill_max_threads<T>(int fr, bool flat) {
-    if (flat) return refill_threads<T, FR | F_FLAT>();
-    return fr == 1 ? refill_threads<T, FC>() : refill_threads<T, F_ALL>();
-}
-#endif
+template <> RollingKern<T, SegsT<T>> refill_kernel<T, SegsT<T>>(int, bool) { return nullptr; }
+template <> int refill_max_threads<T>(int, bool) { return refill_threads<T, FR | F_FLAT>(); }

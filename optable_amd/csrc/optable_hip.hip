@@ -873,13 +873,17 @@ static int check_trace_args(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K
 // does this scene take the rolling lists (heavy: many nodes per segment => VALU-bound, uneven path lengths) or one lane per
 // ray with perfectly coalesced streams (light: HBM-bound)?  The all-features preset has no lane-per-ray form in double
 // precision (it would need more than 256 registers): those scenes always take the lists.
+static int fused_preset(uint32_t need) {  // smallest lane-per-ray preset that covers the scene (tables.h): 0 FA, 1 FB, 2 FE, 3 FM, 4 F_ALL
+    using namespace preset;
+    return (need & ~FA) == 0 ? 0 : ((need & ~FB) == 0 ? 1 : ((need & ~FE) == 0 ? 2 : ((need & ~FM) == 0 ? 3 : 4)));
+}
 template <class T> static bool wants_rolling(const ot_ctx* c, int32_t K) {
     using namespace preset;
     const bool f64 = sizeof(T) == 8;
-    const int fi = (c->features & ~FA) == 0 ? 0 : ((c->features & ~FB) == 0 ? 1 : 2);
+    const int fi = fused_preset(c->features);
     const size_t bytes = f64 ? c->bytes64 : c->bytes32;
     const bool in_lds = bytes <= (size_t)c->opt_lds_limit_kb * 1024;
-    return c->opt_kernel == 2 || (c->opt_kernel == 0 && c->n_nodes >= 24 && K > 2) || (f64 && (fi == 2 || !in_lds));
+    return c->opt_kernel == 2 || (c->opt_kernel == 0 && c->n_nodes >= 24 && K > 2) || (f64 && (fi == 4 || !in_lds));
 }
 
 // one lane per ray (k_trace_fused); OUT = SegsT<T> or SegTiles<T>
@@ -890,7 +894,7 @@ static int launch_fused(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, co
     using namespace preset;  // tables.h
     const bool f64 = sizeof(T) == 8;
     const uint32_t need = c->features;
-    const int fi = (need & ~FA) == 0 ? 0 : ((need & ~FB) == 0 ? 1 : 2);
+    const int fi = fused_preset(need);
     const size_t bytes = f64 ? c->bytes64 : c->bytes32;
     const bool in_lds = bytes <= (size_t)c->opt_lds_limit_kb * 1024;
     const SceneBlob blob = make_blob<T>(c);
@@ -1011,6 +1015,11 @@ int ot_trace_append_f32(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, co
 
 }  // extern "C"
 
+static int gen_preset(uint32_t need) {  // 0 FB (planar, no count gates), 1 FC (planar under grids), 2 FE, 3 FM, 4 F_ALL
+    using namespace preset;
+    return (need & ~FB) == 0 ? 0 : ((need & ~FC) == 0 ? 1 : ((need & ~FE) == 0 ? 2 : ((need & ~FM) == 0 ? 3 : 4)));
+}
+
 template <class T>
 static int trace_generation(ot_ctx* c, const ot_rays* rays, const int32_t* tree, int64_t n, int32_t* budget,
                             const ot_segments* out, int64_t out_capacity, int64_t* seg_cursor, const ot_rays* next,
@@ -1074,9 +1083,8 @@ static int trace_generation(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
     const SceneBlob blob = make_blob<T>(c);
     const bool in_lds = bytes <= (size_t)c->opt_lds_limit_kb * 1024;
     const size_t lds_bytes = in_lds ? bytes : 0;
-    const bool small = (c->features & ~preset::FB) == 0;  // planar scenes without count gates: the small instantiation (tables.h)
-    const int fg = small ? 0 : ((c->features & ~preset::FC) == 0 ? 1 : 2);  // ... with grids: the planar preset that walks them
-    const ProbeKern<T> k_probe = probe_kernel<T>(in_lds);
+    const int fg = gen_preset(c->features);  // smallest generation preset that covers the scene (tables.h)
+    const ProbeKern<T> k_probe = probe_kernel<T>(fg, in_lds);
     const GenKern<T> k_count = gen_kernel<T>(fg, in_lds, false), k_emit = gen_kernel<T>(fg, in_lds, true);
     if (lds_bytes > 48 * 1024) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -1129,8 +1137,7 @@ static int trace_generation_one(ot_ctx* c, const ot_rays* rays, const int32_t* t
     const SceneBlob blob = make_blob<T>(c);
     const bool in_lds = bytes <= (size_t)c->opt_lds_limit_kb * 1024;
     const size_t lds_bytes = in_lds ? bytes : 0;
-    const bool small = (c->features & ~preset::FB) == 0;
-    const int fg = small ? 0 : ((c->features & ~preset::FC) == 0 ? 1 : 2);
+    const int fg = gen_preset(c->features);
     const GenOneKern<T> k = gen_one_kernel<T>(fg, in_lds);
     if (lds_bytes > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipLaunchKernelGGL(k, dim3((unsigned)n_groups), dim3(256), lds_bytes, c->stream, blob, (T)c->unit, view<T>(rays), tree, rem, n, budget, state, view<T>(out),
@@ -1165,7 +1172,11 @@ static int trace_tree(ot_ctx* c, const ot_rays* rays, const int32_t* tree, int64
     // One pass per generation (k_gen_one) when OT_OPT_GEN_ONEPASS asks for it and the scene has no count-limited leaves (their
     // gate needs the scans between a probe pass and the trace).  Its per-ray budgets live in the library: seeded from budget[]
     // for the first generation of this call, two buffers of buf_capacity for the children.
-    const bool one_pass = c->n_slots == 0 && c->opt_gen_onepass > 0 && n > 0;
+    const bool one_pass_kernel = [&] {
+        const size_t image = sizeof(T) == 8 ? c->bytes64 : c->bytes32;
+        return gen_one_kernel<T>(gen_preset(c->features), image <= (size_t)c->opt_lds_limit_kb * 1024) != nullptr;
+    }();
+    const bool one_pass = c->n_slots == 0 && c->opt_gen_onepass > 0 && n > 0 && one_pass_kernel;
     int32_t *rem_cur = nullptr, *rem_a = nullptr, *rem_b = nullptr;
     if (one_pass) {
         if (c->gen_rem.ensure(sizeof(int32_t) * (size_t)(n + 2 * buf_capacity) + 256)) return fail(OT_ERR_HIP, "hipMalloc of the per-ray budgets failed");

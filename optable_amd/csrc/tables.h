@@ -15,6 +15,11 @@ constexpr uint32_t FC = FB | F_GRID | F_ROOT | F_SUBTREE;      // planar scenes 
 constexpr uint32_t FR = FB | F_ROOT;                           // planar scenes under a top-level grid that lists leaves only (cfg 3)
 constexpr uint32_t FRP = FR | F_POLY;                          // ... with polygon / boolean apertures
 constexpr uint32_t FD = F_AABB | F_REFRACT | F_CURVED | F_GRID;  // spherical / aspheric optics in gridded groups (cfg 5)
+// light scenes made of the reference's everyday parts — what used to fall into the all-features preset (169-181 registers and
+// 146-186 scalar spills in single precision, no lane-per-ray form at all in double):
+constexpr uint32_t FE = FB | F_POLY | F_CURVED | F_LIMIT;      // + polygon / boolean apertures, spheres and aspheres, count gates: TriangularPrism,
+                                                               //   Block(hole=), BiConvexLens, doublets (fp32 118 registers, fp64 186)
+constexpr uint32_t FM = FE | F_MISC;                           // + cylinders, polygons in tilted planes (DovePrism), sag / index series (138 / 244)
 }  // namespace preset
 
 template <class T, class OUT>
@@ -32,7 +37,7 @@ using GenOneKern = void (*)(SceneBlob, T, RaysT<T>, const int32_t*, const int32_
 template <class T>
 using ProbeKern = void (*)(SceneBlob, T, RaysT<T>, const int32_t*, int64_t, const int32_t*, int32_t*, int32_t, int32_t*);
 
-// k_trace_fused: fi = 0 FA, 1 FB, 2 F_ALL; image in LDS; 128-register cap (4 waves per SIMD); non-temporal segment stores
+// k_trace_fused: fi = 0 FA, 1 FB, 2 FE, 3 FM, 4 F_ALL (single precision only); image in LDS; 128-register cap (4 waves per SIMD); non-temporal segment stores
 template <class T, class OUT> FusedKern<T, OUT> fused_kernel(int fi, bool lds, bool minw4, bool nt);
 // k_trace_rolling: fr = 0 FR, 1 FC, 2 FD, 3 F_ALL, 4 FRP; flat = the pair-queue walk (FR / FRP only); image in LDS or read
 // from L2 (all-features preset only); records of the live rays in LDS (fp32: pair queue and FD) or in the global scratch.
@@ -46,9 +51,9 @@ template <class T, class OUT> RollingKern<T, OUT> pool_kernel(int fr);
 // nullptr where no instantiation exists (the lists take the scene then)
 template <class T, class OUT> RollingKern<T, OUT> refill_kernel(int fr, bool flat);
 template <class T> int refill_max_threads(int fr, bool flat);
-// k_gen_pass / k_gen_probe: fg = 0 the planar preset FB, 1 FC (planar scenes under grids: cfg 3 with splitting slabs), 2 F_ALL
+// k_gen_pass / k_gen_probe: fg = 0 the planar preset FB, 1 FC (planar scenes under grids: cfg 3 with splitting slabs), 2 FE, 3 FM, 4 F_ALL
 template <class T> GenKern<T> gen_kernel(int fg, bool lds, bool emit);
-template <class T> ProbeKern<T> probe_kernel(bool lds);
+template <class T> ProbeKern<T> probe_kernel(int fg, bool lds);
 // k_gen_one (one pass per generation, decoupled look-back): fg as above; nullptr where no instantiation exists
 template <class T> GenOneKern<T> gen_one_kernel(int fg, bool lds);
 
@@ -64,7 +69,7 @@ template <class T> GenOneKern<T> gen_one_kernel(int fg, bool lds);
     template <> RollingKern<T, SegPlanes<T>> refill_kernel<T, SegPlanes<T>>(int, bool); \
     template <> int refill_max_threads<T>(int, bool);                              \
     template <> GenKern<T> gen_kernel<T>(int, bool, bool);                         \
-    template <> ProbeKern<T> probe_kernel<T>(bool);                               \
+    template <> ProbeKern<T> probe_kernel<T>(int, bool);                          \
     template <> GenOneKern<T> gen_one_kernel<T>(int, bool);
 OT_DECLARE_TABLES(double)
 OT_DECLARE_TABLES(float)

@@ -84,3 +84,23 @@ def test_rolling_kernel_argument_segment_is_laid_out_like_the_struct_the_kernel_
             at += size
         sizes = [s for _, s in explicit]
         assert sizes[6] == 24 and sizes[7] == 8 and sizes[13] == 8, (k["name"], sizes)  # AppendCtl, seg_count, queue
+
+
+def test_everyday_presets_keep_their_register_budgets(kernels):
+    """The presets that light scenes made of the reference's everyday parts select (tables.h FE = 63: polygon / boolean
+    apertures, spheres, aspheres, count gates; FM = 319: + cylinders, tilted polygons, series) instead of the all-features
+    instantiation: FE within 128 registers in single precision (4 waves per SIMD) and 192 in double (2), FM within 144 /
+    256; the all-features lane-per-ray kernel they replace sits at 169-181 with 146-186 scalar spills."""
+    def of(family, real, mask):
+        return [k for k in kernels if re.match(rf"_Z\d+{family}I{real}Lj{mask}E", k["name"])]
+
+    for family in ("k_trace_fused", "k_gen_pass", "k_gen_probe"):
+        fe32, fe64 = of(family, "f", 63), of(family, "d", 63)
+        fm32, fm64 = of(family, "f", 319), of(family, "d", 319)
+        assert fe32 and fe64 and fm32 and fm64, family
+        assert max(k["vgpr"] for k in fe32) <= 128, [(k["name"][:40], k["vgpr"]) for k in fe32]
+        assert max(k["vgpr"] for k in fe64) <= 192, [(k["name"][:40], k["vgpr"]) for k in fe64]
+        assert max(k["vgpr"] for k in fm32) <= 144, [(k["name"][:40], k["vgpr"]) for k in fm32]
+        assert max(k["vgpr"] for k in fm64) <= 256, [(k["name"][:40], k["vgpr"]) for k in fm64]
+    all32 = of("k_trace_fused", "f", 1023)
+    assert all32 and min(k["vgpr"] for k in all32) > 150  # (what the split is measured against)

@@ -225,36 +225,45 @@ def test_auto_layout_holds_the_same_records(case):
 
 
 def test_auto_layout_follows_the_library_rule():
-    """layout="auto" asks the library (ot_trace_plan): an fp64 table with one spherical lens is a LIGHT scene by node count
-    but takes the rolling lists (the double-precision curved preset has no lane-per-ray form), where the tiled entry point
-    refuses it — auto must come out as the dense list, with the records of the slots; a worst case beyond the append
-    capacity limit falls back to the slot arrays."""
+    """layout="auto" asks the library (ot_trace_plan) instead of counting nodes: a heavy scene traced with a cap of two
+    segments runs on the lane-per-ray kernel (tiles or slot arrays, never the append list its node count suggests); a light
+    scene sent to the rolling lists (OT_OPT_KERNEL = 2) is refused by the tiled entry point and must come out as the dense
+    list; a worst case beyond the append capacity limit falls back to the slot arrays.  Same records every time."""
     import optable_amd as oa
     from optable_amd.engine import get_engine
 
-    table = _table([oa.BiConvexLens([5, 0, 0], CT=0.6, R1=12.0, R2=-12.0, diameter=3.0, n=1.5), oa.Mirror([12, 0, 0], radius=2.0).RotZ(np.pi)])
-    rng = np.random.default_rng(5)
-    n, K = 20_000, 8
-    o = np.stack([np.zeros(n), rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)], 1)
-    d = np.stack([np.ones(n), rng.uniform(-0.02, 0.02, n), rng.uniform(-0.02, 0.02, n)], 1)
-    batch = _batch(o, d, precision="f64")
-    slots = table.trace_batch(batch, max_segments=K, layout="slots")
-    auto = table.trace_batch(batch, max_segments=K)
     eng = get_engine()
-    plan = eng.plan("f64", n, K)
-    assert plan["kernel"] == 2 and not plan["tiled_ok"] and plan["layout"] == "append" and auto.layout == "append", plan
+    comps, gen, n, K = CASES["cfg3"]
+    table = _table(comps(oa))
+    batch = _batch(*gen(n), precision="f32")  # (single precision: in double this scene's grids leave only the lists)
+    slots = table.trace_batch(batch, max_segments=2, layout="slots")
+    auto = table.trace_batch(batch, max_segments=2)
+    plan = eng.plan("f32", n, 2)
+    assert plan["kernel"] == 1 and plan["tiled_ok"] and auto.layout == plan["layout"] and auto.layout in ("tiled", "slots"), plan
     a, b = slots.to_host(reference_order=True), auto.to_host(reference_order=True)
     for f in abi.SEG_FIELDS + ("ray", "surface"):
         np.testing.assert_array_equal(a[f], b[f], err_msg=f)
-    # the same scene in single precision is a lane-per-ray scene: tiles or slot arrays, by what this device streams faster
-    p32 = eng.plan("f32", n, K)
     us_slots, us_tiled = eng.probe_layouts("f32")
-    assert p32["kernel"] == 1 and p32["tiled_ok"] and p32["layout"] == ("tiled" if us_tiled < 0.985 * us_slots else "slots"), (p32, us_slots, us_tiled)
-    # heavy scene, worst case beyond the capacity limit of the append block (2^30 slots in single precision): slots
-    eng.upload(_table(scenes.cfg3_components(oa)).compile())
+    assert plan["layout"] == ("tiled" if us_tiled < 0.985 * us_slots else "slots"), (plan, us_slots, us_tiled)
+    assert eng.plan("f64", n, 2)["kernel"] == 2 and eng.plan("f64", n, 2)["layout"] == "append"
     assert eng.plan("f32", 1 << 20, 20)["layout"] == "append"
-    assert eng.plan("f32", 1 << 26, 20)["layout"] == "slots"
+    assert eng.plan("f32", 1 << 26, 20)["layout"] == "slots"  # 20 x 2^26 slots: beyond the 2^30 an append block may hold
     assert eng.plan("f64", 1 << 25, 20)["layout"] == "slots"
+    # a light scene on the rolling lists
+    comps, gen, n, K = CASES["cfg2"]
+    table = _table(comps(oa))
+    batch = _batch(*gen(n), precision="f64")
+    slots = table.trace_batch(batch, max_segments=K, layout="slots")
+    try:
+        eng.set_option(abi.OPT_KERNEL, 2)
+        auto = table.trace_batch(batch, max_segments=K)
+        plan = eng.plan("f64", n, K)
+    finally:
+        eng.set_option(abi.OPT_KERNEL, 0)
+    assert plan["kernel"] == 2 and not plan["tiled_ok"] and auto.layout == "append", plan
+    a, b = slots.to_host(reference_order=True), auto.to_host(reference_order=True)
+    for f in abi.SEG_FIELDS + ("ray", "surface"):
+        np.testing.assert_array_equal(a[f], b[f], err_msg=f)
 
 
 def test_append_block_sized_from_a_sample_and_retried_when_too_small():

@@ -114,32 +114,6 @@ def test_one_pass_equals_two_pass_on_a_heavy_planar_scene():
     _both(table.compile(), batch, 20)
 
 
-@pytest.mark.parametrize("precision", ["f64", "f32"])
-def test_one_pass_equals_two_pass_on_curved_splitting_surfaces(precision, oracle):
-    """The all-features preset: an aspheric lens and a micro-mirror array whose caps split every ray (R = 0.6, T = 0.4)."""
-    comps = [oa.ASphericParametricLens([5, 0, 0], CT=0.8, diameter=5, n=1.5, R=10, kappa=-1, a4=1e-5),
-             oa.MMA(origin=[15, 0, 0], N=(6, 6), pitch=0.4, roc=28, n=1.5, thickness=0.1, reflectivity=0.6, transmission=0.4)]
-    table = oa.OpticalTable()
-    table.add_components(comps)
-    scene = table.compile()
-    n = 20_000
-    rng = np.random.default_rng(9)
-    o = np.stack([np.zeros(n), rng.uniform(-1.0, 1.0, n), rng.uniform(-1.0, 1.0, n)], 1)
-    batch = RayBatch.from_arrays(o, np.tile([1.0, 0, 0], (n, 1)), wavelength=W.WL, q=Q, precision=precision)
-    _both(scene, batch, 16)
-    if precision == "f64":
-        small = batch.slice(0, 300)
-        get_engine().set_option(abi.OPT_GEN_ONEPASS, 1)
-        try:
-            got = get_engine().trace_tree(small, 16).to_host(reference_order=True)
-        finally:
-            get_engine().set_option(abi.OPT_GEN_ONEPASS, 0)
-        ref = oracle.trace(scene, small.to_host(), max_trace_num=16)
-        np.testing.assert_array_equal(got["ray"], ref["ray"])
-        np.testing.assert_array_equal(got["surface"], ref["surface"])
-        np.testing.assert_allclose(got["ox"], ref["ox"], rtol=1e-9, atol=1e-9)
-
-
 def test_one_pass_resumes_after_its_buffers_grow():
     """Segment arrays and generation buffers that are too small at first: the library hands the pending generation back, the
     engine grows the buffers and calls again — the per-ray budgets of the one-pass kernels are re-seeded from the tree
