@@ -298,7 +298,7 @@ def survey_config(oa, eng, name, device):
         t, cnt, _, slots, launch = measure_tiled()
         kern = kernel_name(scene, wl)
         layout = "tiled: slot k * n_rays + i in tile / 64, lane % 64 (ot_trace_tiled_*)"
-        chosen = eng.plan(wl.precision, n, wl.max_segments)["layout"]
+        chosen = "tiled" if t <= ts else "slots"  # (both were just measured on this very workload: the faster one is the config's figure)
         if chosen == "slots":  # this device streams the 14 arrays faster: they are the config's figure, the tiles the companion
             (t, cnt, slots, launch), (ts, cnts, slots_s, launch_s) = (ts, cnts, slots_s, launch_s), (t, cnt, slots, launch)
             layout = "slots: segment k of ray i at k * n_rays + i (ot_trace_*)"
@@ -556,11 +556,19 @@ def main():
         heavy_wl = scene.n_nodes >= 24
         plan = eng.plan(prec, n, MAX_SEG)
         layout = "slots" if heavy_wl else plan["layout"]
-        extra["output_layout"] = layout
         if not heavy_wl:
-            extra["layout_probe"] = {"slots_us": plan["probe_us"][0], "tiled_us": plan["probe_us"][1], "chosen": layout,
-                                     "note": "cfg 2's streams with no tracing, 2^20 rays, through both slot layouts on this device "
-                                             "(ot_probe_layouts, once per context); tiles are taken where they win by more than 1.5 %"}
+            # ... and since the real trace on the real buffers can come out the other way round than the generic stream probe
+            # (seen: probe 119 vs 136 us for tiles, trace 126 vs 118 against them), the workload itself is measured in both
+            # layouts first (Engine.tune_layout: 20 launches each, what a caller who cares would do) and the faster one runs
+            tuned = eng.tune_layout(batches[0], MAX_SEG)
+            layout = tuned["chosen"]
+            extra["layout_probe"] = {"stream_probe_slots_us": plan["probe_us"][0], "stream_probe_tiled_us": plan["probe_us"][1],
+                                     "stream_probe_says": plan["layout"], "trace_slots_us": tuned.get("slots"), "trace_tiled_us": tuned.get("tiled"),
+                                     "chosen": layout,
+                                     "note": "stream probe: cfg 2's streams with no tracing, 2^20 rays, both slot layouts (ot_probe_layouts, once per "
+                                             "context: what layout=\"auto\" uses by default); trace: this workload, 20 launches per layout before "
+                                             "the warm-up (Engine.tune_layout) — the faster one is the layout of the timed region"}
+        extra["output_layout"] = layout
         outs = [SegmentBatch(n * MAX_SEG, prec, batches[0].device, tiled=(layout == "tiled")) for _ in range(n_inputs)]
 
         def step(s):

@@ -396,8 +396,10 @@ enum ot_option {
     OT_OPT_REFILL_TICKET = 17, /* ... rays a wave draws from the device-wide queue per atomic: 0 = by batch size (64..256), or a multiple of 64 */
     OT_OPT_GEN_ONEPASS = 19,   /* ot_trace_tree_*: every generation in ONE pass — each workgroup traces a tile of rays once, keeps the children in
                                   registers and takes its output offsets from a decoupled look-back over per-tile descriptors (k_gen_one) —
-                                  instead of count + scan + emit: 0 (default: the two passes are faster — every tile of the one-pass kernel waits for
-                                  the slowest of its predecessors), 1 for scenes without count-limited surfaces.  Identical output. */
+                                  instead of count + scan + emit: -1 (default) for generations of up to 65536 rays (one launch instead of six: what
+                                  small ray trees cost), 0 never, 1 always.  Large generations are faster in two passes (every tile of the one-pass
+                                  kernel waits for the slowest of its predecessors).  Scenes with count-limited surfaces always take the two
+                                  passes.  Identical output either way. */
     OT_OPT_POOL_JITTER = 18,   /* test knob of the block pool's cross-wave protocol: one in `value` publications of a state or control word is
                                   held back ~8000 cycles after the records it announces were written (0 = off).  Results must not change. */
     OT_OPT_GEN_DROP_DOOMED = 15 /* ot_trace_generation_*: a tree whose budget ends with this generation gets no children in `next` (they

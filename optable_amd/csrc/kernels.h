@@ -1529,7 +1529,20 @@ template <class T, uint32_t F, bool SCENE_IN_LDS>
 __global__ __launch_bounds__(256, (gen_one_minw<T, F>())) void k_gen_one(SceneBlob blob, T unit, RaysT<T> in, const int32_t* __restrict__ tree, const int32_t* __restrict__ rem,
                                                  int64_t n, int32_t* __restrict__ budget, int64_t* state, SegsT<T> out, int64_t out_capacity,
                                                  RaysOutT<T> next, int32_t* next_tree, int32_t* next_rem, int64_t next_capacity,
-                                                 unsigned long long* desc, uint32_t* ticket, int32_t* counts, int32_t n_classes, int32_t drop_doomed) {
+                                                 unsigned long long* desc, uint32_t* ticket, int32_t* counts, int32_t n_classes, int32_t drop_doomed,
+                                                 const int64_t* n_in, int64_t* n_out) {
+    // CHAINED launches (small ray trees: ot_trace_tree_* enqueues several generations before it reads anything back): the
+    // generation's size is not known on the host when the launch is enqueued — the grid covers an upper bound (`n`), the real
+    // size comes from where the generation before left it (*n_in) and this one leaves its own in *n_out (two words used in
+    // turn, so that a late wave of this launch never reads what its last tile has just written).
+    if (n_in) {
+        const int64_t n_real = *n_in;
+        if (n_real <= 0) {  // the trees ended generations ago: nothing to trace, nothing follows
+            if (blockIdx.x == 0 && threadIdx.x == 0) { state[1] = 0; *n_out = 0; }
+            return;
+        }
+        n = n_real < n ? n_real : n;
+    }
     extern __shared__ __align__(16) uint32_t lds[];
     const uint32_t* base = blob.words;
     if (SCENE_IN_LDS) {
@@ -1635,6 +1648,7 @@ __global__ __launch_bounds__(256, (gen_one_minw<T, F>())) void k_gen_one(SceneBl
                 const unsigned long long all = excl + agg;
                 state[0] = cursor + (int64_t)(all >> 31);
                 state[1] = (int64_t)(all & 0x7fffffffull);
+                if (n_out) *n_out = (int64_t)(all & 0x7fffffffull);
             }
         }
     }

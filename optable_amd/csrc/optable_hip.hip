@@ -99,10 +99,12 @@ struct ot_ctx {
     int32_t opt_pair = 1;  // paired 16-byte segment stores in the lane-per-ray kernel
     int32_t opt_nt = 1, opt_minw = 4, opt_blocks_per_cu = 0;  // defaults from tools/tune.py on MI355X
     Scratch gen, scan_tmp, mon, gen_rem;
-    int32_t opt_gen_onepass = 0;   // ot_trace_tree_*: one pass per generation with a decoupled look-back (k_gen_one): 0 (default: count + scan + emit —
-                                   // the one-pass kernel moves 22 % fewer bytes but every tile waits for the slowest of its predecessors: cfg 4 with
-                                   // R = 0.2 18.4 ms against 13.6, tools/ab_onepass.py), 1 whenever the scene has no count-limited surface
+    int32_t opt_gen_onepass = -1;  // ot_trace_tree_*: one pass per generation with a decoupled look-back (k_gen_one): -1 (default) generations of up to
+                                   // 65536 rays (one launch instead of six), 0 never, 1 always.  Large generations keep count + scan + emit: the
+                                   // one-pass kernel moves 22 % fewer bytes but every tile waits for the slowest of its predecessors (cfg 4 with
+                                   // R = 0.2: 18.4 ms against 13.6, tools/ab_onepass.py).  Scenes with count-limited surfaces: always two passes
     double probe_us[2][2] = {{0, 0}, {0, 0}};  // ot_probe_layouts: [precision][0 slot arrays, 1 tiles] microseconds per launch of the stream companion; 0 = not measured
+    int64_t* gen_chain = nullptr;                // k_gen_one in chained launches: the generation sizes, on the device
     unsigned long long* gen_mismatch = nullptr;  // count / emit disagreements of k_gen_pass (expected: 0)
     int64_t* pinned_state = nullptr;             // ot_trace_tree_*: page-locked landing place of the per-generation read-back
 };
@@ -524,6 +526,7 @@ int ot_ctx_destroy(ot_ctx* c) {
     if (c->gen.p) (void)hipFree(c->gen.p);
     if (c->gen_rem.p) (void)hipFree(c->gen_rem.p);
     if (c->gen_mismatch) (void)hipFree(c->gen_mismatch);
+    if (c->gen_chain) (void)hipFree(c->gen_chain);
     if (c->pinned_state) (void)hipHostFree(c->pinned_state);
     if (c->scan_tmp.p) (void)hipFree(c->scan_tmp.p);
     if (c->mon.p) (void)hipFree(c->mon.p);
@@ -1123,11 +1126,12 @@ static int trace_generation(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
 template <class T>
 static int trace_generation_one(ot_ctx* c, const ot_rays* rays, const int32_t* tree, const int32_t* rem, int64_t n, int32_t* budget, const ot_segments* out,
                                 int64_t out_capacity, int64_t* state, const ot_rays* next, int32_t* next_tree, int32_t* next_rem, int64_t next_capacity,
-                                int32_t* counts, int32_t n_classes) {
+                                int32_t* counts, int32_t n_classes, const int64_t* n_in = nullptr, int64_t* n_out = nullptr) {
     constexpr bool f64 = sizeof(T) == 8;
     const int64_t n_tiles = (n + 63) / 64, n_groups = (n + 255) / 256;  // a tile = the 64 rays of one wave
     const size_t sz_desc = align_up(sizeof(unsigned long long) * n_tiles + 8);
-    if (c->gen.ensure(sz_desc)) return fail(OT_ERR_HIP, "hipMalloc of generation scratch failed");
+    // (at least 64 KB: growing the scratch frees it, which waits for the device — not between the launches of a chain)
+    if (c->gen.ensure(sz_desc < 65536 ? 65536 : sz_desc)) return fail(OT_ERR_HIP, "hipMalloc of generation scratch failed");
     unsigned long long* desc = (unsigned long long*)c->gen.p;
     uint32_t* ticket = (uint32_t*)(desc + n_tiles);
     int rc = timing_begin(c);
@@ -1141,7 +1145,7 @@ static int trace_generation_one(ot_ctx* c, const ot_rays* rays, const int32_t* t
     const GenOneKern<T> k = gen_one_kernel<T>(fg, in_lds);
     if (lds_bytes > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     hipLaunchKernelGGL(k, dim3((unsigned)n_groups), dim3(256), lds_bytes, c->stream, blob, (T)c->unit, view<T>(rays), tree, rem, n, budget, state, view<T>(out),
-                       out_capacity, view_out<T>(next), next_tree, next_rem, next_capacity, desc, ticket, counts, n_classes, c->opt_gen_drop ? 1 : 0);
+                       out_capacity, view_out<T>(next), next_tree, next_rem, next_capacity, desc, ticket, counts, n_classes, c->opt_gen_drop ? 1 : 0, n_in, n_out);
     HIP_TRY(hipGetLastError());
     return timing_end(c);
 }
@@ -1169,45 +1173,83 @@ static int trace_tree(ot_ctx* c, const ot_rays* rays, const int32_t* tree, int64
     const int32_t* cur_tree = tree;
     int where = 0;  // which buffer holds the pending generation: 0 the caller's rays, 1 buf_a, 2 buf_b
     int64_t reason = 0;
-    // One pass per generation (k_gen_one) when OT_OPT_GEN_ONEPASS asks for it and the scene has no count-limited leaves (their
+    // One pass per generation (k_gen_one) where OT_OPT_GEN_ONEPASS allows it and the scene has no count-limited leaves (their
     // gate needs the scans between a probe pass and the trace).  Its per-ray budgets live in the library: seeded from budget[]
     // for the first generation of this call, two buffers of buf_capacity for the children.
     const bool one_pass_kernel = [&] {
         const size_t image = sizeof(T) == 8 ? c->bytes64 : c->bytes32;
         return gen_one_kernel<T>(gen_preset(c->features), image <= (size_t)c->opt_lds_limit_kb * 1024) != nullptr;
     }();
-    const bool one_pass = c->n_slots == 0 && c->opt_gen_onepass > 0 && n > 0 && one_pass_kernel;
-    int32_t *rem_cur = nullptr, *rem_a = nullptr, *rem_b = nullptr;
-    if (one_pass) {
+    // OT_OPT_GEN_ONEPASS: 1 every generation, 0 none, -1 (default) the SMALL ones: a generation of a few thousand rays is a
+    // handful of tiles that are all resident at once — nothing to wait for in the look-back — and one launch instead of six
+    // (count, three scan kernels, totals, emit) is what a tree of six rays costs: 1.08 -> ms per table.ray_tracing call.
+    constexpr int64_t ONE_PASS_SMALL = 1 << 16;
+    const bool one_pass_ok = c->n_slots == 0 && c->opt_gen_onepass != 0 && n > 0 && one_pass_kernel;
+    int32_t *rem_cur = nullptr, *rem_in = nullptr, *rem_a = nullptr, *rem_b = nullptr;
+    bool rem_valid = false;  // rem_cur holds the budgets of the CURRENT generation's rays (seeded, or written by a one-pass generation)
+    int chained_to = 0;      // buffer (1 / 2) the last generation of a chain of small generations left its children in, 0 = no chain ran
+    int64_t* chain_n = nullptr;  // two device words: sizes handed from one chained generation to the next
+    if (one_pass_ok) {
         if (c->gen_rem.ensure(sizeof(int32_t) * (size_t)(n + 2 * buf_capacity) + 256)) return fail(OT_ERR_HIP, "hipMalloc of the per-ray budgets failed");
-        rem_cur = (int32_t*)c->gen_rem.p;
-        rem_a = rem_cur + n;
+        rem_in = (int32_t*)c->gen_rem.p;
+        rem_a = rem_in + n;
         rem_b = rem_a + buf_capacity;
-        hipLaunchKernelGGL(k_gen_seed_rem, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, tree, (const int32_t*)budget, n, rem_cur);
-        HIP_TRY(hipGetLastError());
+        if (!c->gen_chain) HIP_TRY(hipMalloc((void**)&c->gen_chain, 2 * sizeof(int64_t)));
+        chain_n = c->gen_chain;
     }
     while (cur_n > 0) {
         if (written + cur_n > out_capacity) { reason = 1; break; }        // the segment arrays are too small for this generation
         if (cur_n * fan > buf_capacity) { reason = 2; break; }           // ... the generation buffers for the next one
         const bool to_a = where != 1;
+        const bool one_pass = one_pass_ok && (c->opt_gen_onepass > 0 || cur_n <= ONE_PASS_SMALL);
         int rc;
         if (one_pass) {
+            if (!rem_valid) {  // first generation of the call, or the one before took the two passes: per-ray budgets from the tree table
+                rem_cur = where == 0 ? rem_in : (where == 1 ? rem_a : rem_b);
+                hipLaunchKernelGGL(k_gen_seed_rem, dim3((unsigned)((cur_n + 255) / 256)), dim3(256), 0, c->stream, cur_tree, (const int32_t*)budget, cur_n, rem_cur);
+                HIP_TRY(hipGetLastError());
+            }
             rc = trace_generation_one<T>(c, cur, cur_tree, rem_cur, cur_n, budget, out, out_capacity, state, to_a ? buf_a : buf_b, to_a ? tree_a : tree_b,
-                                         to_a ? rem_a : rem_b, buf_capacity, counts, n_classes);
+                                         to_a ? rem_a : rem_b, buf_capacity, counts, n_classes, nullptr, chain_n);
             rem_cur = to_a ? rem_a : rem_b;
+            rem_valid = true;
+            // Small trees: further generations are enqueued WITHOUT reading anything back — each launch sized for the most rays
+            // the one before can have emitted, its real size taken on the device from where that one left it (k_gen_one's n_in /
+            // n_out).  One read-back per chain instead of one per generation: a tree of a handful of rays is launch and
+            // synchronisation latency, nothing else.
+            if (rc == 0 && (max_seconds < 0 || max_seconds > 1.0)) {  // (a chain is at most fifteen launches of a few microseconds)
+                int64_t bound = cur_n * fan, written_bound = written + cur_n;
+                int here = to_a ? 1 : 2, slot = 0;
+                for (int link = 0; link < 15 && bound <= 4096 && bound * fan <= buf_capacity && written_bound + bound <= out_capacity; ++link) {
+                    const bool from_a = here == 1;
+                    rc = trace_generation_one<T>(c, from_a ? buf_a : buf_b, from_a ? tree_a : tree_b, from_a ? rem_a : rem_b, bound, budget, out, out_capacity,
+                                                 state, from_a ? buf_b : buf_a, from_a ? tree_b : tree_a, from_a ? rem_b : rem_a, buf_capacity, counts, n_classes,
+                                                 chain_n + slot, chain_n + (slot ^ 1));
+                    if (rc) break;
+                    written_bound += bound;
+                    bound *= fan;
+                    here = from_a ? 2 : 1;
+                    slot ^= 1;
+                    ++generations;
+                    chained_to = here;
+                }
+            }
         } else {
             rc = trace_generation<T>(c, cur, cur_tree, cur_n, budget, out, out_capacity, state, to_a ? buf_a : buf_b, to_a ? tree_a : tree_b,
                                      buf_capacity, state + 1, counts, n_classes);
+            rem_valid = false;
         }
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(host_state, state, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));  // the one host synchronisation per generation
+        HIP_TRY(hipStreamSynchronize(c->stream));  // the one host synchronisation per generation (per chain of small generations)
         written = host_state[0];
         cur_n = host_state[1];
         ++generations;
-        where = to_a ? 1 : 2;
-        cur = to_a ? buf_a : buf_b;
-        cur_tree = to_a ? tree_a : tree_b;
+        where = chained_to ? chained_to : (to_a ? 1 : 2);
+        if (chained_to) rem_cur = where == 1 ? rem_a : rem_b;
+        chained_to = 0;
+        cur = where == 1 ? buf_a : buf_b;
+        cur_tree = where == 1 ? tree_a : tree_b;
         if (max_seconds >= 0 && cur_n > 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() >= max_seconds) { reason = 3; break; }
     }
     result[0] = written; result[1] = cur_n; result[2] = where; result[3] = generations; result[4] = reason;
@@ -1440,7 +1482,7 @@ int ot_set_option(ot_ctx* c, int32_t option, int32_t value) {
             c->opt_pool = value; return 0;
         case OT_OPT_INSTANCING: c->opt_instancing = value != 0; return 0;  // takes effect at the next ot_scene_upload
         case OT_OPT_GEN_ONEPASS:
-            if (value < 0 || value > 1) return fail(OT_ERR_INVALID, "OT_OPT_GEN_ONEPASS takes 0 or 1");
+            if (value < -1 || value > 1) return fail(OT_ERR_INVALID, "OT_OPT_GEN_ONEPASS takes -1 (small generations), 0 or 1");
             c->opt_gen_onepass = value; return 0;
         case OT_OPT_POOL_JITTER:
             if (value < 0 || value > (1 << 20)) return fail(OT_ERR_INVALID, "OT_OPT_POOL_JITTER takes 0 (off) or a period up to 2^20");

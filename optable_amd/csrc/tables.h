@@ -33,7 +33,7 @@ using GenKern = void (*)(SceneBlob, T, RaysT<T>, const int32_t*, int64_t, int32_
                          unsigned long long*, int32_t*, T*, int32_t);
 template <class T>
 using GenOneKern = void (*)(SceneBlob, T, RaysT<T>, const int32_t*, const int32_t*, int64_t, int32_t*, int64_t*, SegsT<T>, int64_t, RaysOutT<T>, int32_t*,
-                            int32_t*, int64_t, unsigned long long*, uint32_t*, int32_t*, int32_t, int32_t);
+                            int32_t*, int64_t, unsigned long long*, uint32_t*, int32_t*, int32_t, int32_t, const int64_t*, int64_t*);
 template <class T>
 using ProbeKern = void (*)(SceneBlob, T, RaysT<T>, const int32_t*, int64_t, const int32_t*, int32_t*, int32_t, int32_t*);
 

@@ -42,6 +42,7 @@ class Engine:
         self.scene = None
         self.append_chunk = 512  # OT_OPT_APPEND_CHUNK as last set through set_option (the library's default)
         self._records_per_ray = {}  # (scene, cap, precision) -> records per ray seen in a sample trace (append capacity estimates)
+        self._layout_choice = {}    # (scene, precision) -> "slots" | "tiled" measured on the workload itself (tune_layout)
         # An ot_ctx holds one scene and one set of scratch buffers: calls on it are serialised (include/
         # optable_hip.h).  The table-level entry points hold this lock across their upload + trace sequence so that
         # Python threads sharing the engine cannot interleave them (ctypes releases the GIL during a call).
@@ -65,6 +66,7 @@ class Engine:
         abi.check(self.lib.ot_scene_upload(self._ctx, C.byref(desc)), self.lib)
         self.scene = scene
         self._records_per_ray = {}
+        self._layout_choice = {}
 
     def _check_wavelengths(self, rays):
         """Scenes with a dispersion SERIES (Material(n = callable), fitted over a wavelength interval: materials.py) say
@@ -88,6 +90,33 @@ class Engine:
         return {"kernel": int(info[0]), "tiled_ok": bool(info[1]), "append_limit": 1 << int(info[2]),
                 "layout": ("slots", "tiled", "append")[int(info[3])], "probe_us": (info[5] / 100.0, info[6] / 100.0)}
 
+    def tune_layout(self, rays, max_segments, launches=20):
+        """Measure THIS workload in both slot layouts and keep the faster one for the uploaded scene: `layout="auto"` then
+        takes it instead of the generic stream probe (which times a copy-like kernel on buffers of its own; the real trace on
+        the caller's buffers can come out the other way round — the two layouts differ by how their streams fall on the
+        memory channels, and that depends on the box and on where the buffers lie).  Light scenes only (heavy ones have one
+        dense layout); returns {"slots": us per launch, "tiled": us per launch, "chosen": ...}."""
+        K = int(max_segments)
+        plan = self.plan(rays.precision, rays.n, K)
+        if plan["kernel"] != 1 or not plan["tiled_ok"] or rays.n == 0:
+            return {"chosen": plan["layout"]}
+        res = {}
+        for layout in ("slots", "tiled"):
+            out = SegmentBatch(rays.n * K, rays.precision, rays.device, tiled=(layout == "tiled"))
+            for _ in range(max(launches // 2, 3)):
+                self.trace(rays, K, out=out, layout=layout)
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            for _ in range(launches):
+                self.trace(rays, K, out=out, layout=layout)
+            ev1.record()
+            torch.cuda.synchronize()
+            res[layout] = ev0.elapsed_time(ev1) / launches * 1e3
+            del out
+        res["chosen"] = "tiled" if res["tiled"] < res["slots"] else "slots"
+        self._layout_choice = {(id(self.scene), rays.precision): res["chosen"]}
+        return res
+
     def probe_layouts(self, precision="f64"):
         """(microseconds per launch into the 14 slot arrays, into 64-slot tiles) of cfg 2's streams on this device."""
         a, b = C.c_double(), C.c_double()
@@ -109,8 +138,11 @@ class Engine:
             raise RuntimeError("upload a scene first")
         n, K = rays.n, int(max_segments)
         self._check_wavelengths(rays)
-        if layout == "auto":  # what this scene's kernels write fastest ON THIS DEVICE: the library's own rule (ot_trace_plan)
-            layout = self.plan(rays.precision, n, K)["layout"] if n else "slots"
+        if layout == "auto":  # what this scene's kernels write fastest ON THIS DEVICE: a measurement of this very workload
+            # (tune_layout) where there is one, else the library's own rule (ot_trace_plan: a generic stream probe for light scenes)
+            tuned = self._layout_choice.get((id(self.scene), rays.precision))
+            plan = self.plan(rays.precision, n, K) if n else None
+            layout = "slots" if plan is None else (tuned if (tuned and plan["kernel"] == 1 and plan["tiled_ok"]) else plan["layout"])
         if layout == "append":
             return self._trace_append(rays, K, out, counts, capacity)
         if layout == "tiled":

@@ -254,6 +254,12 @@ def test_auto_layout_follows_the_library_rule():
     table = _table(comps(oa))
     batch = _batch(*gen(n), precision="f64")
     slots = table.trace_batch(batch, max_segments=K, layout="slots")
+    # ... and, before that, the same scene with its layout MEASURED on the workload itself (Engine.tune_layout): auto follows it
+    scene = table.compile()
+    eng.upload(scene)
+    tuned = eng.tune_layout(batch, K, launches=6)
+    assert tuned["chosen"] == ("tiled" if tuned["tiled"] < tuned["slots"] else "slots")
+    assert table.trace_batch(batch, max_segments=K, scene=scene).layout == tuned["chosen"]
     try:
         eng.set_option(abi.OPT_KERNEL, 2)
         auto = table.trace_batch(batch, max_segments=K)

@@ -147,7 +147,7 @@ def test_two_pass_generations_agree_with_themselves():
                                  np.tile([1.0, 0, 0], (4096, 1)), precision=prec)
         eng.upload(t2.compile())
         eng.trace_tree(b, 300)
-    eng.set_option(abi.OPT_GEN_ONEPASS, 0)
+    eng.set_option(abi.OPT_GEN_ONEPASS, -1)
     assert eng.generation_mismatches() == before
 
 

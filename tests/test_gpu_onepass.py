@@ -26,13 +26,16 @@ def _both(scene, batch, cap, **kw):
         two = eng.trace_tree(batch, cap, **kw)
         eng.set_option(abi.OPT_GEN_ONEPASS, 1)
         one = eng.trace_tree(batch, cap, **kw)
+        eng.set_option(abi.OPT_GEN_ONEPASS, -1)  # the default: one pass for generations of up to 65536 rays, two above — the
+        mixed = eng.trace_tree(batch, cap, **kw)  # per-ray budgets are re-seeded from the tree table at every change-over
     finally:
-        eng.set_option(abi.OPT_GEN_ONEPASS, 0)
-    assert one.n_valid == two.n_valid and one.n_valid > 0
+        eng.set_option(abi.OPT_GEN_ONEPASS, -1)
+    assert one.n_valid == two.n_valid == mixed.n_valid and one.n_valid > 0
     m = one.n_valid
     for f in abi.SEG_FIELDS + ("ray", "surface"):
         assert torch.equal(one.field(f)[:m], two.field(f)[:m]), f
-    assert torch.equal(one.capped, two.capped)
+        assert torch.equal(mixed.field(f)[:m], two.field(f)[:m]), f
+    assert torch.equal(one.capped, two.capped) and torch.equal(mixed.capped, two.capped)
     return one
 
 
@@ -62,7 +65,7 @@ def test_one_pass_equals_two_pass_on_cfg4_with_reflectivity(precision, oracle):
         try:
             got = get_engine().trace_tree(small, 12).to_host(reference_order=True)
         finally:
-            get_engine().set_option(abi.OPT_GEN_ONEPASS, 0)
+            get_engine().set_option(abi.OPT_GEN_ONEPASS, -1)
         ref = oracle.trace(scene, small.to_host(), max_trace_num=12)
         np.testing.assert_array_equal(got["ray"], ref["ray"])
         np.testing.assert_array_equal(got["surface"], ref["surface"])
@@ -76,7 +79,7 @@ def test_one_pass_equals_two_pass_on_bushy_trees(cap, drop):
     """A lattice of beam splitters: trees that double every generation, spanning many tiles of a generation, capped in their
     largest generation — the per-ray budgets, the doomed-children rule and the look-back across hundreds of tiles."""
     scene = _lattice()
-    n = 3000
+    n = 3000 if cap != 40 else 12_000  # (cap 40 at 12 000 trees: generations grow past 65 536 rays and shrink again — both change-overs of the default mode)
     rng = np.random.default_rng(5)
     o = np.stack([np.zeros(n), rng.uniform(-0.3, 0.3, n), rng.uniform(-0.2, 0.2, n)], 1)
     d = np.stack([np.ones(n), rng.uniform(-0.02, 0.02, n), rng.uniform(-0.01, 0.01, n)], 1)
@@ -131,7 +134,7 @@ def test_one_pass_resumes_after_its_buffers_grow():
         big = eng.trace_tree(batch, 40, out_capacity=80 * n)
         small = eng.trace_tree(batch, 40, out_capacity=1024)  # grows the segment arrays (and, the trees doubling, the buffers) several times
     finally:
-        eng.set_option(abi.OPT_GEN_ONEPASS, 0)
+        eng.set_option(abi.OPT_GEN_ONEPASS, -1)
     assert small.n_valid == big.n_valid
     for f in abi.SEG_FIELDS + ("ray", "surface"):
         assert torch.equal(small.field(f)[: small.n_valid], big.field(f)[: big.n_valid]), f

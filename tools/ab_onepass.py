@@ -39,7 +39,7 @@ def run(label, comps, batch, cap, out_cap):
             eng.timing(False)
             print(f"{label:44s} round {rnd} {'one pass ' if mode else 'two passes'}  device {ms:8.3f} ms  wall {wall:8.3f} ms  {launches:4d} timed regions  {segs.n_valid} segments", flush=True)
             del segs
-    eng.set_option(abi.OPT_GEN_ONEPASS, 0)
+    eng.set_option(abi.OPT_GEN_ONEPASS, -1)
 
 
 only = set(filter(None, os.environ.get("ONLY", "").split(",")))
