@@ -195,9 +195,9 @@ def kernel_name(scene, wl):
 
 
 def committed_counters(name):
-    """SQ-counter summary of this workload committed under profiles/ (tools/profile_r03.sh; the newest round that has
+    """SQ-counter summary of this workload committed under profiles/ (tools/profile_r04.sh; the newest round that has
     one), or None."""
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03", "r02"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_{name}_counters.json")
         if os.path.exists(path):
             rec = json.load(open(path))

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define OT_ABI_VERSION 10  /* 10: ot_trace_plan, ot_probe_layouts, OT_OPT_REFILL, OT_OPT_REFILL_TICKET, OT_OPT_POOL_JITTER, OT_OPT_GEN_ONEPASS; 9: ot_trace_tree_*, OT_OPT_BLOCK_POOL, OT_OPT_GEN_DROP_DOOMED, ot_trace_append_* holes per workgroup chunk; 8: OT_SHAPE_ASPHERE_CHEB, OT_MAT_CHEB, OT_NODE_BOX_TRUSTED, ot_trace_tiled_*, ot_bench_stream_tiled_*; 3: ot_trace_generation_f32; 4: ot_bench_stream_f32; 5: OT_OPT_LIST_CAP, ray flags bits 8..31, ot_debug_generation_mismatches; 6: ot_debug_last_launch, OT_OPT_FLAT_QUEUE, OT_OPT_LDS_RECORDS; 7: ot_trace_append_*, ot_segment_block, OT_OPT_APPEND_CHUNK, OT_OPT_INSTANCING */
+#define OT_ABI_VERSION 10  /* 10: ot_trace_plan, ot_probe_layouts, ot_runtime_info, OT_OPT_REFILL, OT_OPT_REFILL_TICKET, OT_OPT_POOL_JITTER, OT_OPT_GEN_ONEPASS; 9: ot_trace_tree_*, OT_OPT_BLOCK_POOL, OT_OPT_GEN_DROP_DOOMED, ot_trace_append_* holes per workgroup chunk; 8: OT_SHAPE_ASPHERE_CHEB, OT_MAT_CHEB, OT_NODE_BOX_TRUSTED, ot_trace_tiled_*, ot_bench_stream_tiled_*; 3: ot_trace_generation_f32; 4: ot_bench_stream_f32; 5: OT_OPT_LIST_CAP, ray flags bits 8..31, ot_debug_generation_mismatches; 6: ot_debug_last_launch, OT_OPT_FLAT_QUEUE, OT_OPT_LDS_RECORDS; 7: ot_trace_append_*, ot_segment_block, OT_OPT_APPEND_CHUNK, OT_OPT_INSTANCING */
 
 /* ---- status codes ------------------------------------------------------------------- */
 enum ot_status {
@@ -200,6 +200,11 @@ typedef struct ot_ctx ot_ctx;
 /* ---- lifecycle ------------------------------------------------------------------------ */
 int ot_abi_version(void);
 const char* ot_last_error(void);
+/* The HIP runtime this library is bound to: file name of the libamdhip64 that resolves its symbols, and hipRuntimeGetVersion.
+ * A process must hold ONE HIP runtime.  The library names libamdhip64.so.7 by soname, so a copy that is already in the process
+ * is used (PyTorch ships its own: load it, or `import torch`, BEFORE this library — INTEGRATION.md); loaded first and alone, the
+ * library falls back to the ROCm installation's copy.  Never touches the device. */
+int ot_runtime_info(char* path, int32_t path_capacity, int32_t* runtime_version);
 
 /* stream: a hipStream_t the caller owns (e.g. torch.cuda.current_stream().cuda_stream);
  * NULL is the device's default (null) stream — which is what torch uses unless told otherwise.

@@ -80,6 +80,7 @@ _TRACE_ARGS = [_vp, C.POINTER(OtRays), _i64, _i32, C.POINTER(OtSegments), _vp, _
 SYMBOLS = {
     "ot_abi_version": (C.c_int, []),
     "ot_last_error": (C.c_char_p, []),
+    "ot_runtime_info": (C.c_int, [C.c_char_p, _i32, C.POINTER(_i32)]),
     "ot_ctx_create": (C.c_int, [C.c_int, _vp, C.POINTER(_vp)]),
     "ot_ctx_destroy": (C.c_int, [_vp]),
     "ot_ctx_synchronize": (C.c_int, [_vp]),
@@ -145,8 +146,35 @@ def load():
         fn.restype, fn.argtypes = restype, argtypes
     if lib.ot_abi_version() != ABI_VERSION:
         raise EngineUnavailable(f"ABI mismatch: library {lib.ot_abi_version()} != binding {ABI_VERSION}")
+    # one HIP runtime per process: if PyTorch's copy and another one are both mapped, device arrays of one are foreign to the other
+    copies = hip_runtimes_in_process()
+    if len(copies) > 1:
+        raise EngineUnavailable("two HIP runtimes are loaded in this process: " + ", ".join(sorted(copies)) + " — liboptable_hip.so binds to the "
+                                "libamdhip64.so.7 that is loaded first; import torch (or dlopen its lib/libamdhip64.so) before anything that "
+                                "pulls in the ROCm installation's copy (INTEGRATION.md)")
     _lib = lib
     return lib
+
+
+def hip_runtimes_in_process():
+    """Paths of the libamdhip64 copies mapped into this process (/proc/self/maps)."""
+    found = set()
+    try:
+        with open("/proc/self/maps") as fh:
+            for line in fh:
+                if "libamdhip64" in line:
+                    found.add(os.path.realpath(line.split()[-1]))
+    except OSError:
+        pass
+    return found
+
+
+def runtime_info():
+    """(path of the libamdhip64 the engine is bound to, hipRuntimeGetVersion)."""
+    lib = load()
+    buf, ver = C.create_string_buffer(1024), _i32()
+    check(lib.ot_runtime_info(buf, 1024, C.byref(ver)), lib)
+    return buf.value.decode(), int(ver.value)
 
 
 def check(status, lib=None):

@@ -3,6 +3,7 @@
 // No CPU fallback lives here: without a GPU every entry point fails with OT_ERR_HIP.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdio>
@@ -495,6 +496,25 @@ static int validate_scene(const ot_scene_desc* s) {
 extern "C" {
 
 int ot_abi_version(void) { return OT_ABI_VERSION; }
+
+// Which HIP runtime did the dynamic linker bind this library to?  (a process must hold ONE libamdhip64; the
+// library names it by soname only, so a copy that is already loaded — PyTorch ships its own — is the one that is used.)
+int ot_runtime_info(char* path, int32_t path_capacity, int32_t* runtime_version) {
+    if (runtime_version) {
+        int v = 0;
+        if (hipRuntimeGetVersion(&v) != hipSuccess) { v = 0; (void)hipGetLastError(); }
+        *runtime_version = v;
+    }
+    if (path && path_capacity > 0) {
+        path[0] = 0;
+        Dl_info info;
+        if (dladdr((const void*)&hipGetDeviceCount, &info) && info.dli_fname) {
+            std::strncpy(path, info.dli_fname, (size_t)path_capacity - 1);
+            path[path_capacity - 1] = 0;
+        }
+    }
+    return 0;
+}
 const char* ot_last_error(void) { return g_err.c_str(); }
 
 int ot_ctx_create(int device, void* stream, ot_ctx** out) {

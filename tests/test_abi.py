@@ -125,3 +125,18 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(abi, "_lib", None)
     with pytest.raises(abi.EngineUnavailable, match="no CPU fallback"):
         abi.load()
+
+
+def test_library_binds_to_the_hip_runtime_that_is_already_in_the_process():
+    """One HIP runtime per process: the library names libamdhip64.so.7 by soname, abi.load() brings torch's
+    copy in first, so that copy is the one the library's symbols resolve to — and it is the only one mapped."""
+    import subprocess
+
+    from optable_amd import abi
+
+    path, version = abi.runtime_info()
+    copies = abi.hip_runtimes_in_process()
+    assert len(copies) == 1 and os.path.realpath(path) in copies, (path, copies)
+    assert version > 0
+    needed = subprocess.check_output(["readelf", "-d", abi.LIB_PATH], text=True)
+    assert "Shared library: [libamdhip64.so.7]" in needed  # by soname: no absolute path baked in

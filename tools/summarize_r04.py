@@ -19,7 +19,7 @@ import sys
 raw, dst = sys.argv[1], sys.argv[2]
 os.makedirs(dst, exist_ok=True)
 OURS = ("k_trace_", "k_gen_", "k_mon_", "k_stream_")
-RECORD_BYTES = {"cfg2": 104, "cfg4": 104, "cfg3": 56, "cfg5": 56}  # per ray record and per segment record
+RECORD_BYTES = {"cfg2": 104, "cfg4": 104, "cfg3": 56, "cfg5": 56, "allfeat64": 104, "allfeat32": 56}  # per ray record and per segment record
 N_SIMD, N_XCD, N_CU = 1024, 8, 256
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -167,12 +167,33 @@ for wdir in sorted(glob.glob(os.path.join(raw, "*"))):
     if cyc and c.get("SQ_INSTS_VALU"):
         d["gpu_cycles_per_launch"] = cyc
         d["cycles_per_valu_per_simd"] = cyc * N_SIMD / c["SQ_INSTS_VALU"]
-        d["valu_pipe_busy"] = c["SQ_INSTS_VALU"] * VALU_CYCLES / (cyc * N_SIMD)  # calibrated: 1.0 = the microkernel's rate
+        d["valu_pipe_busy_if_all_plain"] = c["SQ_INSTS_VALU"] * VALU_CYCLES / (cyc * N_SIMD)  # every instruction at the plain-fma cost: a floor
         d["r03_valu_issue_fraction"] = 4 * c.get("SQ_ACTIVE_INST_VALU", 0) / (cyc * N_SIMD)
         if c.get("SQ_INSTS_SALU"):
             d["salu_per_cycle_per_cu"] = c["SQ_INSTS_SALU"] / (cyc * N_CU)
         if c.get("SQ_INSTS_LDS"):
             d["lds_insts_per_cycle_per_cu"] = c["SQ_INSTS_LDS"] / (cyc * N_CU)
+    if cyc and c.get("SQ_INSTS_VALU") and "SQ_INSTS_VALU_INT32" in c:
+        # How busy is the vector pipe really?  The calibration (profiles/r04_issue_calibration.json) puts every instruction form in
+        # one of three classes on gfx950: 2 cycles per wave64 instruction (v_add / v_mul / v_fma / v_fmac _f32, v_mov, v_add_u32,
+        # v_and / v_or), 4 cycles (compares, v_cndmask, v_min / v_max / v_med3, shifts, v_lshl_add, v_mad_u32_u24, v_mul_lo, DPP,
+        # v_readlane, v_mbcnt, conversions, every packed and every double-precision form) and 8 (v_rcp / v_sqrt / v_rsq ...).
+        # The type counters split the stream into f32 arithmetic, TRANS, CVT, INT32, INT64 and a rest (moves, compares, selects,
+        # min / max, logic); INT32 and the rest mix both classes, so the figure is a bracket: everything unknown at 2 cycles (low)
+        # or at 4 (high).  Double-precision arithmetic is in the 4-cycle class.
+        n = c["SQ_INSTS_VALU"]
+        f32 = c.get("SQ_INSTS_VALU_ADD_F32", 0) + c.get("SQ_INSTS_VALU_MUL_F32", 0) + c.get("SQ_INSTS_VALU_FMA_F32", 0)
+        f64 = c.get("SQ_INSTS_VALU_ADD_F64", 0) + c.get("SQ_INSTS_VALU_MUL_F64", 0) + c.get("SQ_INSTS_VALU_FMA_F64", 0)
+        trans = c.get("SQ_INSTS_VALU_TRANS_F32", 0) + c.get("SQ_INSTS_VALU_TRANS_F64", 0)
+        cvt, i32, i64 = c.get("SQ_INSTS_VALU_CVT", 0), c.get("SQ_INSTS_VALU_INT32", 0), c.get("SQ_INSTS_VALU_INT64", 0)
+        rest = max(n - f32 - f64 - trans - cvt - i32 - i64, 0)
+        two, four, eight = VALU_CYCLES, 2 * VALU_CYCLES, 4 * VALU_CYCLES
+        low = two * (f32 + i32 + rest) + four * (f64 + cvt + i64) + eight * trans
+        high = two * f32 + four * (f64 + cvt + i64 + i32 + rest) + eight * trans
+        d["valu_mix"] = {"f32_arithmetic": f32 / n, "f64_arithmetic": f64 / n, "transcendental": trans / n, "conversions": cvt / n,
+                         "int32": i32 / n, "int64": i64 / n, "moves_compares_selects_minmax_logic": rest / n}
+        d["valu_pipe_busy_low"] = low / (cyc * N_SIMD)
+        d["valu_pipe_busy_high"] = high / (cyc * N_SIMD)
     if c.get("SQ_WAVE_CYCLES") and cyc:
         d["mean_waves_per_simd"] = 4 * c["SQ_WAVE_CYCLES"] / (cyc * N_SIMD)  # SQ_WAVE_CYCLES counts quad-cycles
     if "SQ_INSTS_VALU" in c and c.get("SQ_WAVES"):
@@ -189,4 +210,4 @@ for wdir in sorted(glob.glob(os.path.join(raw, "*"))):
             d["hbm_frac_algorithmic"] = alg / rec["avg_ns"] / 8000.0
     rec["derived"] = d
     json.dump(rec, open(os.path.join(dst, f"r04_{w}_counters.json"), "w"), indent=1)
-    print(w, short, f"{rec['avg_ns'] / 1e6:.3f} ms", {k: round(v, 4) for k, v in d.items() if k not in ("hbm_read_bytes_fetch_x2", "hbm_write_bytes", "hbm_bytes")})
+    print(w, short, f"{rec['avg_ns'] / 1e6:.3f} ms", {k: round(v, 4) for k, v in d.items() if k not in ("hbm_read_bytes_fetch_x2", "hbm_write_bytes", "hbm_bytes") and not isinstance(v, dict)})
