@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define OT_ABI_VERSION 10  /* 10: ot_trace_plan, ot_probe_layouts, ot_runtime_info, OT_OPT_REFILL, OT_OPT_REFILL_TICKET, OT_OPT_POOL_JITTER, OT_OPT_GEN_ONEPASS; 9: ot_trace_tree_*, OT_OPT_BLOCK_POOL, OT_OPT_GEN_DROP_DOOMED, ot_trace_append_* holes per workgroup chunk; 8: OT_SHAPE_ASPHERE_CHEB, OT_MAT_CHEB, OT_NODE_BOX_TRUSTED, ot_trace_tiled_*, ot_bench_stream_tiled_*; 3: ot_trace_generation_f32; 4: ot_bench_stream_f32; 5: OT_OPT_LIST_CAP, ray flags bits 8..31, ot_debug_generation_mismatches; 6: ot_debug_last_launch, OT_OPT_FLAT_QUEUE, OT_OPT_LDS_RECORDS; 7: ot_trace_append_*, ot_segment_block, OT_OPT_APPEND_CHUNK, OT_OPT_INSTANCING */
+#define OT_ABI_VERSION 11  /* 11: OT_OPT_GEN_AHEAD, ot_trace_trees_*; 10: ot_trace_plan, ot_probe_layouts, ot_runtime_info, OT_OPT_REFILL, OT_OPT_REFILL_TICKET, OT_OPT_POOL_JITTER, OT_OPT_GEN_ONEPASS; 9: ot_trace_tree_*, OT_OPT_BLOCK_POOL, OT_OPT_GEN_DROP_DOOMED, ot_trace_append_* holes per workgroup chunk; 8: OT_SHAPE_ASPHERE_CHEB, OT_MAT_CHEB, OT_NODE_BOX_TRUSTED, ot_trace_tiled_*, ot_bench_stream_tiled_*; 3: ot_trace_generation_f32; 4: ot_bench_stream_f32; 5: OT_OPT_LIST_CAP, ray flags bits 8..31, ot_debug_generation_mismatches; 6: ot_debug_last_launch, OT_OPT_FLAT_QUEUE, OT_OPT_LDS_RECORDS; 7: ot_trace_append_*, ot_segment_block, OT_OPT_APPEND_CHUNK, OT_OPT_INSTANCING */
 
 /* ---- status codes ------------------------------------------------------------------- */
 enum ot_status {
@@ -311,6 +311,19 @@ int ot_trace_generation_f32(ot_ctx* ctx, const ot_rays* rays, const int32_t* ray
                             int32_t* next_tree, int64_t next_capacity, int64_t* n_next,
                             int32_t* counts, int32_t n_count_classes);
 
+/* Whole ray trees in ONE launch, a lane per tree (k_trace_trees): the reference's loop — pop the oldest ray, archive it,
+ * push its children, stop after max_trace_num rays (optical_table.py:115-147) — runs per lane with the queue in LDS, and only
+ * segment records go to memory.  Output as ot_trace_*: slot k * n_rays + i of `out` (max_trace_num * n_rays slots) is the
+ * k-th ray of tree i in the reference's FIFO order, seg_count[i] the rays tree i processed (== max_trace_num: cut short by
+ * the cap, or ended exactly there).  A queue of ceil(max_trace_num / 2) rays per lane always suffices; ot_trace_trees_plan
+ * says whether the scene has such a kernel (info[0]: scenes without count-limited surfaces, planar preset, image + queues
+ * within the CU's LDS), how many entries its queues get (info[1]) and whether that is enough for every tree (info[2]).  If
+ * not, a tree whose queue overflows reports seg_count[i] = -(rays processed so far) and the caller takes ot_trace_tree_*.
+ * OT_ERR_UNSUPPORTED when info[0] would be 0. */
+int ot_trace_trees_f64(ot_ctx* ctx, const ot_rays* rays, int64_t n_rays, int32_t max_trace_num, const ot_segments* out, int32_t* seg_count);
+int ot_trace_trees_f32(ot_ctx* ctx, const ot_rays* rays, int64_t n_rays, int32_t max_trace_num, const ot_segments* out, int32_t* seg_count);
+int ot_trace_trees_plan(ot_ctx* ctx, int32_t real_bytes, int32_t max_trace_num, int32_t* info /* int32[4] */);
+
 /* The whole breadth-first trace of a batch of ray trees: the loop over ot_trace_generation_* (optical_table.py:115-147) run
  * by the library — per generation one launch sequence and ONE 16-byte read-back.  `state` is device int64[2] = {segment
  * cursor, rays of the pending generation}: zero it before the first call.  buf_a / buf_b (+ tree_a / tree_b) are two
@@ -405,6 +418,9 @@ enum ot_option {
                                   small ray trees cost), 0 never, 1 always.  Large generations are faster in two passes (every tile of the one-pass
                                   kernel waits for the slowest of its predecessors).  Scenes with count-limited surfaces always take the two
                                   passes.  Identical output either way. */
+    OT_OPT_GEN_AHEAD = 20,     /* ot_trace_tree_*, light scenes without count-limited surfaces: the emit pass of a generation also counts the
+                                  children of the children it writes, and the next generation replaces its count pass over the ray records by a pass
+                                  over one byte per ray (k_gen_recount): 1 (default) / 0.  Identical output either way. */
     OT_OPT_POOL_JITTER = 18,   /* test knob of the block pool's cross-wave protocol: one in `value` publications of a state or control word is
                                   held back ~8000 cycles after the records it announces were written (0 = off).  Results must not change. */
     OT_OPT_GEN_DROP_DOOMED = 15 /* ot_trace_generation_*: a tree whose budget ends with this generation gets no children in `next` (they

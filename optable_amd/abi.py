@@ -7,7 +7,7 @@ __graft_entry__ as g; g.build()"` or `make -C optable_amd/csrc`).
 import ctypes as C
 import os
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "liboptable_hip.so")
 
@@ -72,7 +72,7 @@ NODE_CHECK_AABB, NODE_GRID, NODE_BOX_TRUSTED = 1, 2, 4
 MAT_CONST, MAT_SELLMEIER, MAT_CHEB = 0, 1, 2
 RAY_HAS_Q, RAY_DEAD = 1, 2
 OPT_NT_STORES, OPT_MIN_WAVES, OPT_BLOCKS_PER_CU, OPT_KERNEL, OPT_LDS_LIMIT_KB, OPT_LIST_CAP, OPT_PAIR_STORES, OPT_MIX_GENERATIONS, OPT_FLAT_QUEUE, OPT_LDS_RECORDS = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
-OPT_APPEND_CHUNK, OPT_INSTANCING, OPT_GEN_REUSE, OPT_BLOCK_POOL, OPT_GEN_DROP_DOOMED, OPT_REFILL, OPT_REFILL_TICKET, OPT_POOL_JITTER, OPT_GEN_ONEPASS = 11, 12, 13, 14, 15, 16, 17, 18, 19
+OPT_APPEND_CHUNK, OPT_INSTANCING, OPT_GEN_REUSE, OPT_BLOCK_POOL, OPT_GEN_DROP_DOOMED, OPT_REFILL, OPT_REFILL_TICKET, OPT_POOL_JITTER, OPT_GEN_ONEPASS, OPT_GEN_AHEAD = 11, 12, 13, 14, 15, 16, 17, 18, 19, 20
 
 # every symbol the header declares, with its ctypes signature
 _vp, _i32, _i64 = C.c_void_p, C.c_int32, C.c_int64
@@ -102,6 +102,9 @@ SYMBOLS = {
                                     C.POINTER(OtRays), _vp, _i64, _vp, _i32, C.c_double, _vp]),
     "ot_trace_tree_f32": (C.c_int, [_vp, C.POINTER(OtRays), _vp, _i64, _vp, C.POINTER(OtSegments), _i64, _vp, C.POINTER(OtRays), _vp,
                                     C.POINTER(OtRays), _vp, _i64, _vp, _i32, C.c_double, _vp]),
+    "ot_trace_trees_f64": (C.c_int, [_vp, C.POINTER(OtRays), _i64, _i32, C.POINTER(OtSegments), _vp]),
+    "ot_trace_trees_f32": (C.c_int, [_vp, C.POINTER(OtRays), _i64, _i32, C.POINTER(OtSegments), _vp]),
+    "ot_trace_trees_plan": (C.c_int, [_vp, _i32, _i32, _vp]),
     "ot_monitor_record_f64": (C.c_int, [_vp, C.POINTER(OtMonitor), C.POINTER(OtSegments), _i64, _vp, _i64, _vp, _vp,
                                         _vp, _vp, _vp, _vp]),
     "ot_timing_enable": (C.c_int, [_vp, C.c_int]),

@@ -5,8 +5,8 @@ using T = OT_REAL;
 using namespace preset;
 
 template <uint32_t FM> static GenKern<T> pick(bool lds, bool emit) {
-    if (lds) return emit ? k_gen_pass<T, FM, true, true> : k_gen_pass<T, FM, true, false>;
-    return emit ? k_gen_pass<T, FM, false, true> : k_gen_pass<T, FM, false, false>;
+    if (lds) return emit ? k_gen_pass<T, FM, true, 1> : k_gen_pass<T, FM, true, 0>;
+    return emit ? k_gen_pass<T, FM, false, 1> : k_gen_pass<T, FM, false, 0>;
 }
 // beam splitters and partially reflecting slabs are planar scenes: they get the small instantiation (145 instead of 255
 // registers in fp64); count gates, curved shapes and polygons need the full one
@@ -15,13 +15,18 @@ template <uint32_t FM> static GenKern<T> pick(bool lds, bool emit) {
 template <> GenKern<T> gen_kernel<T>(int fg, bool lds, bool emit) {
     if (fg == 0) return pick<FB>(lds, emit);
     if constexpr (sizeof(T) == 4) {  // (single precision, image in LDS: the combinations whose count / emit pair compiles without a stack slot)
-        if (fg == 1 && lds) return emit ? k_gen_pass<T, FC, true, true> : k_gen_pass<T, FC, true, false>;
+        if (fg == 1 && lds) return emit ? k_gen_pass<T, FC, true, 1> : k_gen_pass<T, FC, true, 0>;
     }
     // the everyday parts (count gates, polygons, spheres, aspheres; + the rarer shapes): 94 / 114 registers in single precision
     // (the all-features emit kernel: 150-161), 148 / 236 in double (255-262); image in LDS only
-    if (fg == 2 && lds) return emit ? k_gen_pass<T, FE, true, true> : k_gen_pass<T, FE, true, false>;
-    if (fg == 3 && lds) return emit ? k_gen_pass<T, FM, true, true> : k_gen_pass<T, FM, true, false>;
+    if (fg == 2 && lds) return emit ? k_gen_pass<T, FE, true, 1> : k_gen_pass<T, FE, true, 0>;
+    if (fg == 3 && lds) return emit ? k_gen_pass<T, FM, true, 1> : k_gen_pass<T, FM, true, 0>;
     return pick<F_ALL>(lds, emit);
+}
+// the emit pass with look-ahead (the next generation needs no count pass): light planar scenes whose image is in LDS
+template <> GenKern<T> gen_ahead_kernel<T>(int fg, bool lds) {
+    if (fg == 0 && lds) return k_gen_pass<T, FB, true, 2>;
+    return nullptr;
 }
 template <> ProbeKern<T> probe_kernel<T>(int fg, bool lds) {
     if (fg == 2 && lds) return k_gen_probe<T, FE, true>;
@@ -35,5 +40,11 @@ template <> GenOneKern<T> gen_one_kernel<T>(int fg, bool lds) {
     if constexpr (sizeof(T) == 4) {
         if (fg == 1 && lds) return k_gen_one<T, FC, true>;
     }
+    return nullptr;
+}
+
+// k_trace_trees: light planar scenes (beam splitters, partially reflecting slabs, mirrors, thin lenses)
+template <> TreeKern<T> tree_kernel<T>(int fg) {
+    if (fg == 0) return k_trace_trees<T, FB, (sizeof(T) == 8 ? 1 : 2)>;
     return nullptr;
 }

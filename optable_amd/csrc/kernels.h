@@ -54,11 +54,11 @@ template <class T> static SegsT<T> view(const ot_segments* s) {
 }
 
 // ------------------------------------------------------------------------------------------
-// scene blob: [DNode<T> x n_phys][DMat<T> x n_mats][T x n_aux][int32 x 4 n_runs], staged into LDS word by word.
+// scene blob: [DNode<T> x n_phys][DMat<T> x n_mats][T x n_aux][int32 x 4 n_runs][DHead<T> x n_phys, 16-byte aligned], staged into LDS word by word.
 // n_nodes counts the caller's (virtual) nodes, n_phys the records kept after instanced runs were folded (trace_core.h NodeRef).
 struct SceneBlob {
     const uint32_t* words;
-    int32_t n_words, n_nodes, n_phys, n_mats, root, cache_mat, root_pack, n_runs, runs_word;
+    int32_t n_words, n_nodes, n_phys, n_mats, root, cache_mat, root_pack, n_runs, runs_word, heads_word;
 };
 
 template <class T> __device__ __forceinline__ Scene<T> bind_scene(const uint32_t* base, const SceneBlob& b, T unit) {
@@ -67,6 +67,7 @@ template <class T> __device__ __forceinline__ Scene<T> bind_scene(const uint32_t
     sc.mats = reinterpret_cast<const DMat<T>*>(sc.nodes + b.n_phys);
     sc.aux = reinterpret_cast<const T*>(sc.mats + b.n_mats);
     sc.runs = reinterpret_cast<const int32_t*>(base + b.runs_word);
+    sc.heads = reinterpret_cast<const DHead<T>*>(__builtin_assume_aligned(base + b.heads_word, 16));
     sc.n_nodes = b.n_nodes;
     sc.n_runs = b.n_runs;
     for (int k = 0; k < 4; ++k) sc.run0[k] = b.n_runs > 0 ? __builtin_amdgcn_readfirstlane(sc.runs[k]) : 0;
@@ -276,6 +277,103 @@ __global__ __launch_bounds__(256, MINW) void k_trace_fused(SceneBlob blob, T uni
             }
         }
         if (i < n) seg_count[i] = used;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_trace_trees: whole ray TREES, a lane per tree (round 4).  The breadth-first loop of the reference (optical_table.py:
+// 115-147: pop the oldest ray, archive it, push its children, stop after max_trace_num rays) runs per lane with the FIFO
+// in LDS; only segment records leave the chip — the generation kernels write every child to HBM and read it back (271 of
+// the 375-484 bytes they move per processed ray).  A tree that processes at most `cap` rays never needs more than
+// ceil(cap / 2) queued rays: after j rays the queue holds at most j + 1, and only its first cap - j entries can still be
+// processed; children that would queue up behind that are not stored.  The queue is a ring of Q entries per lane,
+// [entry][field][lane] (11 reals + the node the ray starts on), so a wave's pushes and pops are conflict-free whatever the
+// lanes' positions.  Q < ceil(cap / 2) is allowed (large caps, small trees): a tree whose ring overflows reports
+// -(segments so far) and the caller takes the generation path.
+// Output: the [k][tree] slots of ot_trace_* — slot k * n + i is the k-th ray of tree i in FIFO order, which IS the
+// reference's order; seg_count[i] = rays processed (== cap: the cap cut the tree short or the tree ended exactly there,
+// as `budget <= 0` on the generation path).  Scenes without count-limited leaves (their counters are shared between trees).
+#ifndef OT_TREES_NT
+#define OT_TREES_NT false
+#endif
+template <class T> constexpr int tree_entry_bytes() { return 64 * (11 * (int)sizeof(T) + 4); }
+template <class T, uint32_t F, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_trace_trees(SceneBlob blob, T unit, RaysT<T> in, int64_t n, int32_t cap, int32_t Q, SegsT<T> out,
+                                                           int32_t* __restrict__ seg_count) {
+    extern __shared__ __align__(16) uint32_t lds[];
+    for (int w = threadIdx.x; w < blob.n_words; w += blockDim.x) lds[w] = blob.words[w];
+    __syncthreads();
+    const Scene<T> sc = bind_scene<T>(lds, blob, unit);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // this wave's ring: Q entries of [11 reals][64 lanes] + [64 lanes] int32
+    uint8_t* const ring = reinterpret_cast<uint8_t*>(lds) + (((size_t)blob.n_words * 4 + 15) & ~(size_t)15) + (size_t)wave * Q * tree_entry_bytes<T>();
+    auto real_at = [&](int e, int f) -> T* { return reinterpret_cast<T*>(ring + (size_t)e * tree_entry_bytes<T>()) + f * 64 + lane; };
+    auto int_at = [&](int e) -> int32_t* { return reinterpret_cast<int32_t*>(ring + (size_t)e * tree_entry_bytes<T>() + 64 * 11 * sizeof(T)) + lane; };
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < n; i0 += stride) {
+        const int64_t i = i0 + threadIdx.x;
+        bool active = i < n, overflow = false;
+        RayState<T> r = {};
+        int32_t k = 0, head = 0, qlen = 0;  // rays processed; ring position of the oldest queued ray; queued rays
+        MatCache<T> mc = {T(1)};
+        if (active) {
+            const int32_t fl = in.flags[i];
+            r = load_ray(in, i, fl);
+            if ((uint32_t)r.last >= (uint32_t)sc.n_nodes) r.last = -1;
+            if constexpr (F & F_REFRACT) mc = make_matcache<T, F>(sc, r.wl);
+            if (fl & OT_RAY_DEAD) {  // optical_component.py:349: a dead ray hits nothing and is returned as is
+                store_segment<T, OT_TREES_NT>(out, i, r, r.len, (int32_t)i, -2);
+                k = 1;
+                active = false;
+            }
+        }
+        const T wl = r.wl;
+        const int32_t has_q = r.has_q;
+        while (__any(active)) {
+            const GateCtx gate = {nullptr, 0, 0, nullptr, nullptr, 0, 0};
+            const Hit<T> h = nearest_hit<T, F, GATE_PLAIN>(sc, r, active, gate);
+            if (active) {
+                const int64_t slot = (int64_t)k * n + i;
+                ++k;
+                int nk = 0;
+                RayState<T> ch[2];
+                if (h.node < 0) {
+                    store_segment<T, OT_TREES_NT>(out, slot, r, r.len, (int32_t)i, -1);
+                } else {
+                    store_segment<T, OT_TREES_NT>(out, slot, r, h.t, (int32_t)i, leaf_id_of<T, F>(sc, h.node));
+                    nk = interact<T, F, 2>(sc, r, h, ch, mc);
+                }
+                const int32_t left = cap - k;  // rays this tree may still process
+                auto push = [&](const RayState<T>& c) {
+                    if (qlen >= left) return;  // would never be processed (optical_table.py:138-144 drops it with the queue)
+                    if (qlen >= Q) { overflow = true; return; }
+                    int e = head + qlen;
+                    if (e >= Q) e -= Q;
+                    *real_at(e, 0) = c.ox; *real_at(e, 1) = c.oy; *real_at(e, 2) = c.oz;
+                    *real_at(e, 3) = c.dx; *real_at(e, 4) = c.dy; *real_at(e, 5) = c.dz;
+                    *real_at(e, 6) = c.qr; *real_at(e, 7) = c.qi; *real_at(e, 8) = c.I;
+                    *real_at(e, 9) = c.n; *real_at(e, 10) = c.pl;
+                    *int_at(e) = c.last;
+                    ++qlen;
+                };
+                if (nk > 0) push(ch[0]);
+                if (nk > 1) push(ch[1]);
+                if (qlen > 0 && left > 0 && !overflow) {
+                    const int e = head;
+                    r.ox = *real_at(e, 0); r.oy = *real_at(e, 1); r.oz = *real_at(e, 2);
+                    r.dx = *real_at(e, 3); r.dy = *real_at(e, 4); r.dz = *real_at(e, 5);
+                    r.qr = *real_at(e, 6); r.qi = *real_at(e, 7); r.I = *real_at(e, 8);
+                    r.n = *real_at(e, 9); r.pl = *real_at(e, 10);
+                    r.last = *int_at(e);
+                    r.wl = wl; r.has_q = has_q; r.len = Num<T>::inf();
+                    head = head + 1 == Q ? 0 : head + 1;
+                    --qlen;
+                } else {
+                    active = false;
+                }
+            }
+        }
+        if (i < n) seg_count[i] = overflow ? -k : k;
     }
 }
 
@@ -1375,14 +1473,22 @@ __global__ __launch_bounds__(256) void k_gen_probe(SceneBlob blob, T unit, RaysT
 // assert 0).
 // The emit pass stores PLAIN: its children are the next generation's input, read back within the same millisecond, and
 // the L2 / Infinity Cache serve part of that; with non-temporal stores cfg 4 (R = 0.2) took 19.7 instead of 15.0 ms.
+// LOOK-AHEAD (MODE 2, round 4): the emit pass has every child of its rays in registers, so it also does what the count pass
+// of the NEXT generation would do with it — the search and the interaction, for the number of children only — and leaves that
+// number per child (`ahead`, one byte at the child's slot).  The next generation then needs no count pass over its rays:
+// k_gen_recount (below) turns those bytes, tree[] and budget[] into the code bytes and wave totals — 10 bytes per ray read and
+// written instead of the 109 of a ray record.  A ray is still traced twice (as a child here, as a parent in its own emit pass),
+// but read once: 385 instead of 484 bytes per processed ray on cfg 4 with reflectivity 0.2.  Should the two traces ever
+// disagree, the emit pass fills or drops as described above and counts it in `mismatch`.  Light scenes without count gates only.
 static constexpr bool GEN_NT = false;
-template <class T, uint32_t F, bool SCENE_IN_LDS, bool EMIT>
+template <class T, uint32_t F, bool SCENE_IN_LDS, int MODE>  // 0 count, 1 emit, 2 emit + look-ahead
 __global__ __launch_bounds__(256) void k_gen_pass(SceneBlob blob, T unit, RaysT<T> in, const int32_t* __restrict__ tree, int64_t n,
                                                   int32_t* __restrict__ budget, const int64_t* cursor, SegsT<T> out,
                                                   int64_t out_capacity, RaysOutT<T> next, int32_t* next_tree, int64_t next_capacity,
                                                   uint8_t* code, unsigned long long* wave_total, const unsigned long long* wave_prefix,
                                                   int32_t* counts, int32_t n_classes, const int32_t* rank, unsigned long long* mismatch,
-                                                  int32_t* hit_node, T* hit_t, int32_t drop_doomed) {
+                                                  int32_t* hit_node, T* hit_t, int32_t drop_doomed, uint8_t* __restrict__ ahead) {
+    constexpr bool EMIT = MODE != 0, AHEAD = MODE == 2;
     extern __shared__ __align__(16) uint32_t lds[];
     const uint32_t* base = blob.words;
     if (SCENE_IN_LDS) {
@@ -1491,6 +1597,28 @@ __global__ __launch_bounds__(256) void k_gen_pass(SceneBlob blob, T unit, RaysT<
     };
     if (c_nk > 0) put(nk > 0 ? ch[0] : r, d0, nk > 0);
     if (c_nk > 1) put(nk > 1 ? ch[1] : r, d0 + 1, nk > 1);
+    if constexpr (AHEAD) {
+        // the children as the next generation will load them (load_ray: no `len` in a generation buffer, flags as `put` wrote them)
+        auto count_of = [&](RayState<T> q, bool real) -> int32_t {
+            q.len = Num<T>::inf();
+            q.has_q = (fl & OT_RAY_HAS_Q) != 0;
+            if ((uint32_t)q.last >= (uint32_t)sc.n_nodes) q.last = -1;
+            const Hit<T> h2 = nearest_hit<T, F, GATE_TABLE>(sc, q, real, gate);
+            RayState<T> gc[2];
+            int32_t n2 = 0;
+            if (real && h2.node >= 0) n2 = interact<T, F, 2>(sc, q, h2, gc, make_matcache<T, F>(sc, q.wl));
+            return n2;
+        };
+        const bool real0 = c_nk > 0 && nk > 0, real1 = c_nk > 1 && nk > 1;
+        if (__any(c_nk > 0)) {  // (wave-uniform: the search is a wave-wide walk)
+            const int32_t a0 = count_of(ch[0], real0);
+            if (c_nk > 0 && d0 < next_capacity) ahead[d0] = (uint8_t)a0;
+        }
+        if (__any(c_nk > 1)) {
+            const int32_t a1 = count_of(ch[1], real1);
+            if (c_nk > 1 && d0 + 1 < next_capacity) ahead[d0 + 1] = (uint8_t)a1;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------

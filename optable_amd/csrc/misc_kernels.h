@@ -115,6 +115,39 @@ __global__ void k_gen_seed_rem(const int32_t* __restrict__ tree, const int32_t* 
     if (i < n) rem[i] = budget[tree[i]];
 }
 
+// k_gen_recount: the count pass of a generation whose rays were looked ahead by the emit pass that wrote them (k_gen_pass MODE 2):
+// rank within the tree, budget cut and doomed children exactly as the count pass decides them, the number of children from the
+// byte the emit pass left.  Writes the code byte in place of it and the wave totals.
+__global__ __launch_bounds__(256) void k_gen_recount(const int32_t* __restrict__ tree, int64_t n, const int32_t* __restrict__ budget, uint8_t* code,
+                                                     unsigned long long* __restrict__ wave_total, int32_t drop_doomed) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t gwave = i >> 6;
+    int32_t my_tree = -1;
+    int start_lane = -1;
+    if (i < n) {
+        my_tree = tree[i];
+        if (lane == 0 || tree[i - 1] != my_tree) start_lane = lane;
+    }
+    const int head_lane = wave_incl_max_i32(start_lane);
+    int64_t head = (i - lane) + head_lane;
+    if (i < n && head_lane == 0) head = tree_head(tree, i - lane);
+    const int64_t bud = i < n ? (int64_t)budget[my_tree] : 0;
+    const bool active = i < n && (i - head) < bud;
+    bool doomed = false;
+    if (active && drop_doomed) {
+        const int64_t last_needed = head + bud - 1;
+        doomed = last_needed < n && tree[last_needed] == my_tree;
+    }
+    int32_t nk = active ? (int32_t)(code[i] & 3) : 0;
+    if (doomed) nk = 0;
+    if (i < n) code[i] = (uint8_t)((active ? 1 : 0) | (nk << 1) | (doomed ? 8 : 0));
+    const int n_act = __popcll(__ballot(active));
+    int kids;
+    wave_excl_scan_i32(nk, kids);
+    if (lane == 0 && (gwave << 6) < n) wave_total[gwave] = ((unsigned long long)n_act << 32) | (unsigned long long)kids;
+}
+
 // rank[slot][i] = how many earlier rays of i's tree (this generation) hit limited leaf `slot`
 __global__ void k_gen_rank(const int32_t* tree, int64_t n, int32_t n_slots, const int32_t* ex, int32_t* rank) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

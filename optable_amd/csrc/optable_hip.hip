@@ -57,6 +57,7 @@ struct ot_ctx {
     size_t bytes64 = 0, bytes32 = 0;
     int32_t n_nodes = 0, n_mats = 0, n_aux = 0, n_slots = 0, max_children = 0;
     int32_t n_phys = 0, n_runs = 0, runs_word64 = 0, runs_word32 = 0;  // instanced runs folded by fill_blob (trace_core.h NodeRef)
+    int32_t heads_word64 = 0, heads_word32 = 0;                        // where the node heads of the linear walk start in the image
     int32_t opt_append_chunk = 512;  // append layout: slots per claim
     int32_t opt_instancing = 1;      // fold lattice children into instanced runs at upload
     int32_t opt_gen_drop = 1;        // generation kernels: children of a tree whose budget ends with this generation are not emitted
@@ -99,7 +100,8 @@ struct ot_ctx {
     size_t blocked_queue_off = 0;
     int32_t opt_pair = 1;  // paired 16-byte segment stores in the lane-per-ray kernel
     int32_t opt_nt = 1, opt_minw = 4, opt_blocks_per_cu = 0;  // defaults from tools/tune.py on MI355X
-    Scratch gen, scan_tmp, mon, gen_rem;
+    Scratch gen, scan_tmp, mon, gen_rem, gen_ahead;
+    int32_t opt_gen_ahead = 1;  // ot_trace_tree_*: the emit pass counts its children's children, the next generation skips its count pass (k_gen_pass MODE 2)
     int32_t opt_gen_onepass = -1;  // ot_trace_tree_*: one pass per generation with a decoupled look-back (k_gen_one): -1 (default) generations of up to
                                    // 65536 rays (one launch instead of six), 0 never, 1 always.  Large generations keep count + scan + emit: the
                                    // one-pass kernel moves 22 % fewer bytes but every tile waits for the slowest of its predecessors (cfg 4 with
@@ -249,7 +251,7 @@ static std::vector<NodeRun> find_runs(const ot_scene_desc* s) {
 }
 
 template <class T> static void fill_blob(const ot_scene_desc* s, const std::vector<NodeRun>& runs_in, std::vector<uint8_t>& out, int32_t& n_phys,
-                                         int32_t& runs_word) {
+                                         int32_t& runs_word, int32_t& heads_word) {
     std::vector<NodeRun> runs = runs_in;
     const int64_t pack = packable_cells(s);
     int folded = 0, geo_reals = 0;
@@ -257,7 +259,9 @@ template <class T> static void fill_blob(const ot_scene_desc* s, const std::vect
     n_phys = s->n_nodes - folded;
     const size_t nb = sizeof(DNode<T>) * n_phys, mb = sizeof(DMat<T>) * s->n_materials, ab = sizeof(T) * (s->n_aux + pack + geo_reals);
     const size_t rb = sizeof(int32_t) * 4 * runs.size();
-    out.assign(((nb + mb + ab + rb + 15) / 16) * 16, 0);
+    const size_t heads_at = ((nb + mb + ab + rb + 15) / 16) * 16, hb = sizeof(DHead<T>) * n_phys;  // the walk's node heads (trace_core.h DHead)
+    out.assign(heads_at + hb, 0);
+    heads_word = (int32_t)(heads_at / 4);
     DNode<T>* nodes = reinterpret_cast<DNode<T>*>(out.data());
     size_t next_run = 0;
     int phys = 0;
@@ -332,6 +336,13 @@ template <class T> static void fill_blob(const ot_scene_desc* s, const std::vect
     runs_word = (int32_t)((nb + mb + ab) / 4);
     int32_t* rt = reinterpret_cast<int32_t*>(out.data() + nb + mb + ab);
     for (size_t k = 0; k < runs.size(); ++k) { rt[4 * k] = runs[k].first; rt[4 * k + 1] = runs[k].count; rt[4 * k + 2] = runs[k].pnode; rt[4 * k + 3] = runs[k].geo; }
+    DHead<T>* heads = reinterpret_cast<DHead<T>*>(out.data() + heads_at);
+    for (int q = 0; q < n_phys; ++q) {
+        const DNode<T>& d = nodes[q];
+        heads[q].kfs = (d.kind & 1) | ((d.flags & 0x7ff) << 1) | (d.shape << 12);
+        heads[q].end = d.end;
+        for (int k = 0; k < 6; ++k) heads[q].aabb[k] = d.aabb[k];
+    }
 }
 
 // which code paths the scene needs (trace_core.h feature mask)
@@ -545,6 +556,7 @@ int ot_ctx_destroy(ot_ctx* c) {
     if (c->slot_max) (void)hipFree(c->slot_max);
     if (c->gen.p) (void)hipFree(c->gen.p);
     if (c->gen_rem.p) (void)hipFree(c->gen_rem.p);
+    if (c->gen_ahead.p) (void)hipFree(c->gen_ahead.p);
     if (c->gen_mismatch) (void)hipFree(c->gen_mismatch);
     if (c->gen_chain) (void)hipFree(c->gen_chain);
     if (c->pinned_state) (void)hipHostFree(c->pinned_state);
@@ -580,8 +592,8 @@ int ot_scene_upload(ot_ctx* c, const ot_scene_desc* s) {
     std::vector<uint8_t> b64, b32;
     const std::vector<NodeRun> runs = c->opt_instancing ? find_runs(s) : std::vector<NodeRun>();
     int32_t n_phys = 0;
-    fill_blob<double>(s, runs, b64, n_phys, c->runs_word64);
-    fill_blob<float>(s, runs, b32, n_phys, c->runs_word32);
+    fill_blob<double>(s, runs, b64, n_phys, c->runs_word64, c->heads_word64);
+    fill_blob<float>(s, runs, b32, n_phys, c->runs_word32, c->heads_word32);
     c->n_phys = n_phys;
     c->n_runs = (int32_t)runs.size();
     HIP_TRY(hipStreamSynchronize(c->stream));  // previous launches may still read the old scene
@@ -675,6 +687,7 @@ template <class T> static SceneBlob make_blob(const ot_ctx* c) {
     blob.cache_mat = c->cache_mat;
     blob.n_runs = c->n_runs;
     blob.runs_word = f64 ? c->runs_word64 : c->runs_word32;
+    blob.heads_word = f64 ? c->heads_word64 : c->heads_word32;
     return blob;
 }
 
@@ -1047,7 +1060,10 @@ template <class T>
 static int trace_generation(ot_ctx* c, const ot_rays* rays, const int32_t* tree, int64_t n, int32_t* budget,
                             const ot_segments* out, int64_t out_capacity, int64_t* seg_cursor, const ot_rays* next,
                             int32_t* next_tree, int64_t next_capacity, int64_t* n_next, int32_t* counts,
-                            int32_t n_classes) {
+                            int32_t n_classes, uint8_t* ahead_in = nullptr, uint8_t* ahead_out = nullptr) {
+    // ahead_in: the bytes the emit pass of the generation before left for these rays (children per ray if processed): no count
+    // pass over the rays, k_gen_recount instead.  ahead_out: where this emit pass leaves them for the next generation (of
+    // next_capacity bytes); NULL: plain emit.  Both live outside c->gen, which may be reallocated between generations.
     if (!c) return fail(OT_ERR_INVALID, "ctx is NULL");
     if (!c->has_scene) return fail(OT_ERR_NOSCENE, "ot_scene_upload has not been called");
     int rc = check_rays(rays, "rays");
@@ -1070,7 +1086,7 @@ static int trace_generation(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
     const int64_t n_waves = (n + 63) / 64;
     const size_t sz_code = align_up((size_t)n), sz_wave = align_up(sizeof(unsigned long long) * n_waves);
     // heavy scenes keep the count pass's decision per ray for the emit pass (kernels.h k_gen_pass); OT_OPT_GEN_REUSE: -1 auto
-    const bool reuse = c->opt_gen_reuse < 0 ? c->n_nodes >= 12 : c->opt_gen_reuse != 0;
+    const bool reuse = (c->opt_gen_reuse < 0 ? c->n_nodes >= 12 : c->opt_gen_reuse != 0) && !ahead_in;
     const size_t sz_hn = reuse ? align_up(sizeof(int32_t) * n) : 0, sz_ht = reuse ? align_up(sizeof(T) * n) : 0;
     const size_t total = sz_tot + sz_code + 2 * sz_wave + (ns > 0 ? 3 * sz_slot : 0) + sz_hn + sz_ht;
     if (c->gen.ensure(total)) return fail(OT_ERR_HIP, "hipMalloc of generation scratch failed");
@@ -1108,7 +1124,10 @@ static int trace_generation(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
     const size_t lds_bytes = in_lds ? bytes : 0;
     const int fg = gen_preset(c->features);  // smallest generation preset that covers the scene (tables.h)
     const ProbeKern<T> k_probe = probe_kernel<T>(fg, in_lds);
-    const GenKern<T> k_count = gen_kernel<T>(fg, in_lds, false), k_emit = gen_kernel<T>(fg, in_lds, true);
+    const GenKern<T> k_count = gen_kernel<T>(fg, in_lds, false);
+    const GenKern<T> k_emit = ahead_out ? gen_ahead_kernel<T>(fg, in_lds) : gen_kernel<T>(fg, in_lds, true);
+    if (!k_emit) return fail(OT_ERR_UNSUPPORTED, "no look-ahead emit kernel for this scene");
+    if (ahead_in) code = ahead_in;  // rewritten in place by k_gen_recount
     if (lds_bytes > 48 * 1024) {
         HIP_TRY(hipFuncSetAttribute((const void*)k_probe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         HIP_TRY(hipFuncSetAttribute((const void*)k_count, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
@@ -1123,22 +1142,65 @@ static int trace_generation(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
         hipLaunchKernelGGL(k_gen_rank, dim3(g1), dim3(block), 0, c->stream, tree, n, ns, probe_ex, rank);
     }
     // count -> scan of the wave totals -> emit (kernels.h: k_gen_pass)
-    hipLaunchKernelGGL(k_count, dim3(g1), dim3(block), lds_bytes, c->stream, blob, (T)c->unit, view<T>(rays), tree, n, budget,
-                       (const int64_t*)seg_cursor, view<T>(out), out_capacity, view_out<T>(next), next_tree, next_capacity, code, wave_total,
-                       (const unsigned long long*)wave_prefix, counts, n_classes, (const int32_t*)rank, mismatch, hit_node, hit_t,
-                       c->opt_gen_drop ? 1 : 0);
+    if (ahead_in)
+        hipLaunchKernelGGL(k_gen_recount, dim3(g1), dim3(block), 0, c->stream, tree, n, (const int32_t*)budget, code, wave_total, c->opt_gen_drop ? 1 : 0);
+    else
+        hipLaunchKernelGGL(k_count, dim3(g1), dim3(block), lds_bytes, c->stream, blob, (T)c->unit, view<T>(rays), tree, n, budget,
+                           (const int64_t*)seg_cursor, view<T>(out), out_capacity, view_out<T>(next), next_tree, next_capacity, code, wave_total,
+                           (const unsigned long long*)wave_prefix, counts, n_classes, (const int32_t*)rank, mismatch, hit_node, hit_t,
+                           c->opt_gen_drop ? 1 : 0, (uint8_t*)nullptr);
     exclusive_scan<unsigned long long, unsigned long long>(c->scan_tmp.p, wave_total, wave_prefix, n_waves, c->stream);
     hipLaunchKernelGGL(k_gen_totals, dim3(1), dim3(64), 0, c->stream, (const unsigned long long*)wave_total,
                        (const unsigned long long*)wave_prefix, n_waves, totals, seg_cursor, n_next);
     hipLaunchKernelGGL(k_emit, dim3(g1), dim3(block), lds_bytes, c->stream, blob, (T)c->unit, view<T>(rays), tree, n, budget,
                        (const int64_t*)(totals + 2), view<T>(out), out_capacity, view_out<T>(next), next_tree, next_capacity, code, wave_total,
                        (const unsigned long long*)wave_prefix, counts, n_classes, (const int32_t*)rank, mismatch, hit_node, hit_t,
-                       c->opt_gen_drop ? 1 : 0);
+                       c->opt_gen_drop ? 1 : 0, ahead_out);
     if (ns > 0)
         hipLaunchKernelGGL(k_gen_counts, dim3(g1), dim3(block), 0, c->stream, tree, rays->id, n, ns, rank, probe, c->slot_max, counts,
                            n_classes);
     HIP_TRY(hipGetLastError());
     return timing_end(c);
+}
+
+// Whole ray trees, a lane per tree (kernels.h k_trace_trees).  plan: Q = ring entries per lane — ceil(cap / 2) when that fits
+// the CU's LDS next to the image with a 256-thread workgroup (then no tree can overflow: full = 1), else what fits (speculative).
+template <class T> static bool trees_plan(const ot_ctx* c, int32_t cap, int32_t* Q, int32_t* full) {
+    const size_t image = sizeof(T) == 8 ? c->bytes64 : c->bytes32;
+    *Q = *full = 0;
+    if (!c->has_scene || c->n_slots > 0 || c->max_children > 2 || cap < 1 || !tree_kernel<T>(gen_preset(c->features))) return false;
+    const size_t room = 160 * 1024 - 1024, img = (image + 15) & ~(size_t)15, per_entry = 4 * (size_t)tree_entry_bytes<T>();
+    if (img + per_entry > room) return false;
+    const int64_t fit = (int64_t)((room - img) / per_entry), need = ((int64_t)cap + 1) / 2;
+    *Q = (int32_t)(need < fit ? need : fit);
+    *full = need <= fit;
+    return true;
+}
+template <class T>
+static int trace_trees(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t cap, const ot_segments* out, int32_t* seg_count) {
+    int rc = check_trace_args(c, rays, n, cap, seg_count, nullptr, 0);
+    if (rc) return rc;
+    rc = check_segs(out);
+    if (rc) return rc;
+    int32_t Q, full;
+    if (!trees_plan<T>(c, cap, &Q, &full)) return fail(OT_ERR_UNSUPPORTED, "no tree kernel for this scene (count-limited surfaces, features beyond the planar preset, or an image that leaves no room for the queues): use ot_trace_tree_*");
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t image = sizeof(T) == 8 ? c->bytes64 : c->bytes32;
+    const size_t lds_bytes = ((image + 15) & ~(size_t)15) + 4 * (size_t)Q * tree_entry_bytes<T>();
+    const TreeKern<T> kern = tree_kernel<T>(gen_preset(c->features));
+    const SceneBlob blob = make_blob<T>(c);
+    const int64_t blocks_needed = (n + 255) / 256, most = (int64_t)c->n_cus * 64;
+    const int grid = (int)(blocks_needed < most ? blocks_needed : most);
+    hipEvent_t ev0, ev1;
+    rc = timing_pair(c, &ev0, &ev1);
+    if (rc) return rc;
+    if (lds_bytes > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), (uint32_t)lds_bytes, c->stream, ev0, ev1, 0u, blob, (T)c->unit, view<T>(rays), n, cap, Q, view<T>(out), seg_count);
+    HIP_TRY(hipGetLastError());
+    const int32_t shape[8] = {4, 256, 0, (int32_t)grid, (int32_t)lds_bytes, Q, 0, 0};
+    for (int q = 0; q < 8; ++q) c->last_launch[q] = shape[q];
+    return 0;
 }
 
 // One generation in one pass (kernels.h k_gen_one): zero the tile descriptors and the ticket, launch.  `rem`: what is left of
@@ -1217,6 +1279,23 @@ static int trace_tree(ot_ctx* c, const ot_rays* rays, const int32_t* tree, int64
         if (!c->gen_chain) HIP_TRY(hipMalloc((void**)&c->gen_chain, 2 * sizeof(int64_t)));
         chain_n = c->gen_chain;
     }
+    // Look-ahead (k_gen_pass MODE 2; OT_OPT_GEN_AHEAD): the emit pass of a two-pass generation leaves, per child, the number of
+    // children that child will have; the next two-pass generation replaces its count pass over the rays by k_gen_recount over
+    // those bytes.  Light scenes (no decision reuse: their search is a few planes) without count gates whose generation
+    // buffers carry no `len`; two byte arrays of buf_capacity used in turn.
+    const bool ahead_ok = [&] {
+        const size_t image = sizeof(T) == 8 ? c->bytes64 : c->bytes32;
+        const bool reuse = c->opt_gen_reuse < 0 ? c->n_nodes >= 12 : c->opt_gen_reuse != 0;
+        return c->opt_gen_ahead != 0 && c->n_slots == 0 && !reuse && !buf_a->length && !buf_b->length &&
+               gen_ahead_kernel<T>(gen_preset(c->features), image <= (size_t)c->opt_lds_limit_kb * 1024) != nullptr;
+    }();
+    uint8_t *ahead_a = nullptr, *ahead_b = nullptr, *ahead_cur = nullptr;  // ahead_cur: the bytes of the CURRENT generation, if its producer left them
+    if (ahead_ok) {
+        const size_t each = align_up((size_t)buf_capacity + 64);
+        if (c->gen_ahead.ensure(2 * each)) return fail(OT_ERR_HIP, "hipMalloc of the look-ahead bytes failed");
+        ahead_a = (uint8_t*)c->gen_ahead.p;
+        ahead_b = ahead_a + each;
+    }
     while (cur_n > 0) {
         if (written + cur_n > out_capacity) { reason = 1; break; }        // the segment arrays are too small for this generation
         if (cur_n * fan > buf_capacity) { reason = 2; break; }           // ... the generation buffers for the next one
@@ -1229,6 +1308,7 @@ static int trace_tree(ot_ctx* c, const ot_rays* rays, const int32_t* tree, int64
                 hipLaunchKernelGGL(k_gen_seed_rem, dim3((unsigned)((cur_n + 255) / 256)), dim3(256), 0, c->stream, cur_tree, (const int32_t*)budget, cur_n, rem_cur);
                 HIP_TRY(hipGetLastError());
             }
+            ahead_cur = nullptr;
             rc = trace_generation_one<T>(c, cur, cur_tree, rem_cur, cur_n, budget, out, out_capacity, state, to_a ? buf_a : buf_b, to_a ? tree_a : tree_b,
                                          to_a ? rem_a : rem_b, buf_capacity, counts, n_classes, nullptr, chain_n);
             rem_cur = to_a ? rem_a : rem_b;
@@ -1255,8 +1335,10 @@ static int trace_tree(ot_ctx* c, const ot_rays* rays, const int32_t* tree, int64
                 }
             }
         } else {
+            uint8_t* const ahead_next = ahead_ok ? (to_a ? ahead_a : ahead_b) : nullptr;
             rc = trace_generation<T>(c, cur, cur_tree, cur_n, budget, out, out_capacity, state, to_a ? buf_a : buf_b, to_a ? tree_a : tree_b,
-                                     buf_capacity, state + 1, counts, n_classes);
+                                     buf_capacity, state + 1, counts, n_classes, ahead_cur, ahead_next);
+            ahead_cur = ahead_next;
             rem_valid = false;
         }
         if (rc) return rc;
@@ -1278,6 +1360,19 @@ static int trace_tree(ot_ctx* c, const ot_rays* rays, const int32_t* tree, int64
 
 extern "C" {
 
+int ot_trace_trees_f64(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t max_trace_num, const ot_segments* out, int32_t* seg_count) {
+    return trace_trees<double>(c, rays, n, max_trace_num, out, seg_count);
+}
+int ot_trace_trees_f32(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t max_trace_num, const ot_segments* out, int32_t* seg_count) {
+    return trace_trees<float>(c, rays, n, max_trace_num, out, seg_count);
+}
+int ot_trace_trees_plan(ot_ctx* c, int32_t real_bytes, int32_t max_trace_num, int32_t* info) {
+    if (!c || !info || (real_bytes != 4 && real_bytes != 8)) return fail(OT_ERR_INVALID, "bad ot_trace_trees_plan arguments");
+    int32_t Q = 0, full = 0;
+    const bool ok = real_bytes == 8 ? trees_plan<double>(c, max_trace_num, &Q, &full) : trees_plan<float>(c, max_trace_num, &Q, &full);
+    info[0] = ok ? 1 : 0; info[1] = Q; info[2] = full; info[3] = 0;
+    return 0;
+}
 int ot_trace_tree_f64(ot_ctx* c, const ot_rays* rays, const int32_t* tree, int64_t n, int32_t* budget, const ot_segments* out,
                       int64_t out_capacity, int64_t* state, const ot_rays* buf_a, int32_t* tree_a, const ot_rays* buf_b, int32_t* tree_b,
                       int64_t buf_capacity, int32_t* counts, int32_t n_classes, double max_seconds, int64_t* result) {
@@ -1501,6 +1596,7 @@ int ot_set_option(ot_ctx* c, int32_t option, int32_t value) {
             if (value < -1 || value > 1) return fail(OT_ERR_INVALID, "OT_OPT_BLOCK_POOL takes -1 (auto), 0 or 1");
             c->opt_pool = value; return 0;
         case OT_OPT_INSTANCING: c->opt_instancing = value != 0; return 0;  // takes effect at the next ot_scene_upload
+        case OT_OPT_GEN_AHEAD: c->opt_gen_ahead = value != 0; return 0;
         case OT_OPT_GEN_ONEPASS:
             if (value < -1 || value > 1) return fail(OT_ERR_INVALID, "OT_OPT_GEN_ONEPASS takes -1 (small generations), 0 or 1");
             c->opt_gen_onepass = value; return 0;

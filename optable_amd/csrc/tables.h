@@ -30,7 +30,9 @@ using RollingKern = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, OUT, Appe
 template <class T>
 using GenKern = void (*)(SceneBlob, T, RaysT<T>, const int32_t*, int64_t, int32_t*, const int64_t*, SegsT<T>, int64_t, RaysOutT<T>, int32_t*,
                          int64_t, uint8_t*, unsigned long long*, const unsigned long long*, int32_t*, int32_t, const int32_t*,
-                         unsigned long long*, int32_t*, T*, int32_t);
+                         unsigned long long*, int32_t*, T*, int32_t, uint8_t*);
+template <class T>
+using TreeKern = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, int32_t, SegsT<T>, int32_t*);
 template <class T>
 using GenOneKern = void (*)(SceneBlob, T, RaysT<T>, const int32_t*, const int32_t*, int64_t, int32_t*, int64_t*, SegsT<T>, int64_t, RaysOutT<T>, int32_t*,
                             int32_t*, int64_t, unsigned long long*, uint32_t*, int32_t*, int32_t, int32_t, const int64_t*, int64_t*);
@@ -53,7 +55,11 @@ template <class T, class OUT> RollingKern<T, OUT> refill_kernel(int fr, bool fla
 template <class T> int refill_max_threads(int fr, bool flat);
 // k_gen_pass / k_gen_probe: fg = 0 the planar preset FB, 1 FC (planar scenes under grids: cfg 3 with splitting slabs), 2 FE, 3 FM, 4 F_ALL
 template <class T> GenKern<T> gen_kernel(int fg, bool lds, bool emit);
+// the emit pass that also counts the children's children (k_gen_pass MODE 2); nullptr where no instantiation exists
+template <class T> GenKern<T> gen_ahead_kernel(int fg, bool lds);
 template <class T> ProbeKern<T> probe_kernel(int fg, bool lds);
+// k_trace_trees (a lane per tree, the FIFO in LDS): fg as above; nullptr where no instantiation exists
+template <class T> TreeKern<T> tree_kernel(int fg);
 // k_gen_one (one pass per generation, decoupled look-back): fg as above; nullptr where no instantiation exists
 template <class T> GenOneKern<T> gen_one_kernel(int fg, bool lds);
 
@@ -69,7 +75,9 @@ template <class T> GenOneKern<T> gen_one_kernel(int fg, bool lds);
     template <> RollingKern<T, SegPlanes<T>> refill_kernel<T, SegPlanes<T>>(int, bool); \
     template <> int refill_max_threads<T>(int, bool);                              \
     template <> GenKern<T> gen_kernel<T>(int, bool, bool);                         \
+    template <> GenKern<T> gen_ahead_kernel<T>(int, bool);                         \
     template <> ProbeKern<T> probe_kernel<T>(int, bool);                          \
+    template <> TreeKern<T> tree_kernel<T>(int);                                  \
     template <> GenOneKern<T> gen_one_kernel<T>(int, bool);
 OT_DECLARE_TABLES(double)
 OT_DECLARE_TABLES(float)

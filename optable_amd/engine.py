@@ -273,6 +273,36 @@ class Engine:
         return out
 
     # -- branching trace: breadth-first, one generation per launch ------------------------------
+    def trees_plan(self, precision, max_trace_num):
+        """ot_trace_trees_plan: does the uploaded scene have a lane-per-tree kernel (k_trace_trees), how many queue entries
+        per lane would a cap of `max_trace_num` get, and is that enough for every possible tree."""
+        info = (C.c_int32 * 4)()
+        abi.check(self.lib.ot_trace_trees_plan(self._ctx, 8 if precision == "f64" else 4, int(max_trace_num), info), self.lib)
+        return {"kernel": bool(info[0]), "queue": int(info[1]), "full": bool(info[2])}
+
+    def trace_trees(self, rays: RayBatch, max_trace_num, out: SegmentBatch = None):
+        """Whole ray trees in one launch, a lane per tree with its FIFO in LDS (ot_trace_trees_*): a SegmentBatch in the
+        `slots` layout — slot k * n + i = the k-th ray of tree i in the reference's order, count[i] = rays of tree i
+        (negative: the tree's queue overflowed, possible only when `trees_plan()["full"]` is False; take trace_tree then).
+        `capped` as trace_tree reports it."""
+        if self.scene is None:
+            raise RuntimeError("upload a scene first")
+        self._check_wavelengths(rays)
+        prec, n, K = rays.precision, rays.n, int(max_trace_num)
+        if out is None:
+            out = SegmentBatch(n * K, prec, rays.device)
+        if out.capacity < n * K or out.precision != prec or out.tiled or out.block is not None:
+            raise ValueError("out: plain slot arrays of max_trace_num * n_rays slots in the rays' precision")
+        out.count = torch.empty(n, dtype=torch.int32, device=rays.device)
+        out.n_rays = n
+        fn = self.lib.ot_trace_trees_f64 if prec == "f64" else self.lib.ot_trace_trees_f32
+        rs, ss = rays.c_struct(), out.c_struct()
+        abi.check(fn(self._ctx, C.byref(rs), n, K, C.byref(ss), out.count.data_ptr()), self.lib)
+        out.capped = out.count >= K
+        out.timed_out = False
+        out.counts_table = None
+        return out
+
     def trace_tree(self, rays: RayBatch, max_trace_num, counts=None, out_capacity=None, max_trace_time=None):
         """Full ray trees (beam splitters, partial reflections, any cap).  Returns a flat
         SegmentBatch in generation order plus, per tree, whether a cap cut it short.

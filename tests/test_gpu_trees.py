@@ -1,0 +1,106 @@
+"""GPU (MI355X): k_trace_trees — whole ray trees in one launch, a lane per tree with its FIFO queue in LDS — against the
+generation kernels (ot_trace_tree_*): the same segments in the same (reference) order, bit for bit, the same trees capped;
+against the oracle; queues that are too small report their trees instead of dropping rays."""
+import numpy as np
+import pytest
+import torch
+
+import optable_amd as oa
+import scenes
+from optable_amd import abi
+from optable_amd import workloads as W
+from optable_amd.batch import RayBatch
+from optable_amd.engine import get_engine
+
+pytestmark = pytest.mark.gpu
+Q = 1j * np.pi * W.W0**2 / W.WL
+
+
+def _lattice(k_max=3):
+    comps = []
+    for k in range(k_max):
+        comps.append(oa.BeamSplitter([2.0 * (k + 1), 0, 0], width=6, height=2, eta=0.5).RotZ(np.pi / 4))
+        comps.append(oa.Mirror([2.0 * (k + 1), 3.0 + 0.1 * k, 0], radius=2).RotZ(-np.pi / 2))
+        comps.append(oa.BeamSplitter([2.0 * (k + 1) + 1.0, 1.5, 0], width=6, height=2, eta=0.3).RotZ(-np.pi / 4))
+    t = oa.OpticalTable()
+    t.add_components(comps)
+    return t.compile()
+
+
+def _lattice_rays(n, seed, precision="f64"):
+    rng = np.random.default_rng(seed)
+    o = np.stack([np.zeros(n), rng.uniform(-0.3, 0.3, n), rng.uniform(-0.2, 0.2, n)], 1)
+    d = np.stack([np.ones(n), rng.uniform(-0.02, 0.02, n), rng.uniform(-0.01, 0.01, n)], 1)
+    return RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=Q, precision=precision)
+
+
+def _same_as_generations(scene, batch, cap):
+    eng = get_engine()
+    eng.upload(scene)
+    plan = eng.trees_plan(batch.precision, cap)
+    assert plan["kernel"] and plan["full"], plan
+    trees = eng.trace_trees(batch, cap)
+    gens = eng.trace_tree(batch, cap)
+    assert int(trees.count.min()) >= 1
+    assert int(trees.count.sum()) == gens.n_valid
+    assert torch.equal(trees.capped, gens.capped)
+    a, b = trees.to_host(reference_order=True), gens.to_host(reference_order=True)
+    np.testing.assert_array_equal(a["ray"], b["ray"])
+    np.testing.assert_array_equal(a["surface"], b["surface"])
+    for f in abi.SEG_FIELDS:
+        np.testing.assert_array_equal(a[f], b[f], err_msg=f)
+    return trees, a
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+def test_trees_equal_generations_on_cfg4_with_reflectivity(precision, oracle):
+    table = oa.OpticalTable()
+    table.add_components(W.cfg4_components(oa, reflectivity=0.2))
+    scene = table.compile()
+    o, d, wl = W.cfg4_rays(5_000, 4)  # x 64 wavelengths = 3.2e5 trees
+    batch = RayBatch.from_arrays(o, d, wavelength=wl, q=1j * np.pi * W.W0**2 / wl, precision=precision)
+    trees, _ = _same_as_generations(scene, batch, 12)
+    assert bool(trees.capped.all())
+    if precision == "f64":
+        small = batch.slice(0, 400)
+        got = get_engine().trace_trees(small, 12).to_host(reference_order=True)
+        ref = oracle.trace(scene, small.to_host(), max_trace_num=12)
+        np.testing.assert_array_equal(got["ray"], ref["ray"])
+        np.testing.assert_array_equal(got["surface"], ref["surface"])
+        for f in abi.SEG_FIELDS:
+            np.testing.assert_allclose(got[f], ref[f], rtol=1e-9, atol=1e-9, err_msg=f)
+
+
+@pytest.mark.parametrize("cap", [1, 2, 3, 7, 12])
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+def test_trees_equal_generations_on_bushy_trees(cap, precision):
+    """Beam-splitter lattice: trees that double every generation and are cut by the cap in their widest one — the queue bound
+    ceil(cap / 2) and the rule that drops children no budget is left for."""
+    _same_as_generations(_lattice(), _lattice_rays(3000, 5, precision), cap)
+
+
+def test_trees_whose_rays_all_escape_or_die():
+    """Trees of one ray (a miss), of dead input rays, and a batch that is not a multiple of the wave."""
+    scene = _lattice()
+    batch = _lattice_rays(1001, 7)
+    batch.dz.fill_(0.9)  # most rays leave the table at once
+    batch.flags[::5] |= abi.RAY_DEAD
+    _same_as_generations(scene, batch, 6)
+
+
+def test_a_queue_that_is_too_small_reports_its_trees():
+    """A cap whose queue bound does not fit the CU's LDS: the plan says so, small trees still come out right, and a tree
+    that overflows its queue is reported (negative count), never silently truncated."""
+    scene = _lattice()
+    eng = get_engine()
+    eng.upload(scene)
+    batch = _lattice_rays(2000, 8)
+    plan = eng.trees_plan("f64", 400)
+    assert plan["kernel"] and not plan["full"] and plan["queue"] < 200
+    trees = eng.trace_trees(batch, 400)
+    gens = eng.trace_tree(batch, 400)
+    count = trees.count.cpu().numpy()
+    per_tree = np.bincount(gens.field("ray")[: gens.n_valid].cpu().numpy(), minlength=batch.n)
+    ok = count > 0
+    np.testing.assert_array_equal(count[ok], per_tree[ok])
+    assert np.all(-count[~ok] <= per_tree[~ok])  # an overflowed tree stopped early, and says how far it got

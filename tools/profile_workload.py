@@ -23,7 +23,7 @@ SIZES = {"cfg2": 1_000_000, "cfg3": 10_000_000, "cfg4": 160_000_000, "cfg5": 12_
 n = int(os.environ.get("RAYS", SIZES[name]))
 eng = get_engine()
 from optable_amd import abi as _abi
-for _env, _opt in (("FLAT", _abi.OPT_FLAT_QUEUE), ("RECLDS", _abi.OPT_LDS_RECORDS), ("CAP", _abi.OPT_LIST_CAP), ("MIX", _abi.OPT_MIX_GENERATIONS), ("KERNEL", _abi.OPT_KERNEL), ("REFILL", _abi.OPT_REFILL), ("ONEPASS", _abi.OPT_GEN_ONEPASS)):
+for _env, _opt in (("FLAT", _abi.OPT_FLAT_QUEUE), ("RECLDS", _abi.OPT_LDS_RECORDS), ("CAP", _abi.OPT_LIST_CAP), ("MIX", _abi.OPT_MIX_GENERATIONS), ("KERNEL", _abi.OPT_KERNEL), ("REFILL", _abi.OPT_REFILL), ("ONEPASS", _abi.OPT_GEN_ONEPASS), ("AHEAD", _abi.OPT_GEN_AHEAD)):
     if os.environ.get(_env):
         eng.set_option(_opt, int(os.environ[_env]))
 Q = lambda lam: 1j * np.pi * W.W0**2 / lam
