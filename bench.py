@@ -324,8 +324,8 @@ def survey_config(oa, eng, name, device):
 
 
 def survey_branching(oa, eng, device):
-    """cfg 4 with reflectivity 0.2 (SURVEY.md §8d branching variant): 1.28e7 ray trees x 12 segments through the
-    generation kernels (count / scan / emit per generation); device time from the library's HIP events."""
+    """cfg 4 with reflectivity 0.2 (SURVEY.md §8d branching variant): 1.28e7 ray trees x 12 segments through the default
+    call (one lane-per-tree launch) and through the generation loop; device time from the library's HIP events."""
     import numpy as np
     import torch
     from optable_amd import workloads as W
@@ -339,26 +339,44 @@ def survey_branching(oa, eng, device):
     o, d, _ = W.cfg4_rays(nb, 4, n_wavelengths=1)
     base = RayBatch.from_arrays(o, d, wavelength=W.WL, q=1j * np.pi * W.W0**2 / W.WL, precision="f64", device=device)
     batch = base.multiplexed_in_wavelength(np.linspace(400e-7, 1100e-7, W.CFG4_WAVELENGTHS))
-    eng.trace_tree(batch, 12, out_capacity=batch.n * 13)  # warm: scratch and generation buffers
-    eng.timing(True)
-    t0 = time.perf_counter()
-    segs = eng.trace_tree(batch, 12, out_capacity=batch.n * 13)
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    ms, launches = eng.timing_read()
-    eng.timing(False)
-    n_seg = int(segs.n_valid)
-    alg = n_seg * 104 * 2 + (n_seg - batch.n) * 104  # per processed ray: record read + segment written; per child: record written
-    rec = {"workload": "cfg4 with reflectivity 0.2: 1.28e7 ray trees (2e5 rays x 64 wavelengths) x 12 segments, fp64, generation kernels",
-           "rays": batch.n, "dtype": "f64", "kernel": "k_gen_pass<double> (count + emit) per generation", "leaf_surfaces": scene.n_leaves,
-           "generations": int(launches), "ms_per_trace": ms, "wall_ms_per_trace": wall * 1e3, "segments_per_ray": n_seg / batch.n,
+    def timed(fn):
+        fn()  # warm: output arrays, scratch and generation buffers
+        eng.timing(True)
+        t0 = time.perf_counter()
+        segs = fn()
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        ms, launches = eng.timing_read()
+        eng.timing(False)
+        return segs, ms, launches, wall
+
+    # the default call (Engine.trace_branching: one launch, a lane per tree with its FIFO in LDS) ...
+    segs, ms, launches, wall = timed(lambda: eng.trace_branching(batch, 12))
+    per_tree = segs.layout == "slots"
+    n_seg = int(segs.count.abs().sum()) if per_tree else int(segs.n_valid)
+    del segs
+    # ... and the generation loop (count / look-ahead, scan, emit per generation): what caps beyond the LDS queues take
+    gsegs, gms, glaunches, gwall = timed(lambda: eng.trace_tree(batch, 12, out_capacity=batch.n * 13))
+    assert int(gsegs.n_valid) == n_seg
+    del gsegs
+    # algorithmic bytes: every tree's first ray read once, every processed ray's segment written once; the generation path
+    # additionally writes and reads back every child (its own algorithmic figure, as round 3 reported it)
+    alg = batch.n * 104 + n_seg * 104
+    alg_gen = n_seg * 104 * 2 + (n_seg - batch.n) * 104
+    rec = {"workload": "cfg4 with reflectivity 0.2: 1.28e7 ray trees (2e5 rays x 64 wavelengths) x 12 segments, fp64",
+           "rays": batch.n, "dtype": "f64", "leaf_surfaces": scene.n_leaves,
+           "kernel": "k_trace_trees<double> (a lane per tree, FIFO in LDS, one launch)" if per_tree else "k_gen_pass<double> per generation",
+           "launches": int(launches), "ms_per_trace": ms, "wall_ms_per_trace": wall * 1e3, "segments_per_ray": n_seg / batch.n,
            "segments_per_s": n_seg / (ms / 1e3), "intersections_per_s": n_seg * scene.n_leaves / (ms / 1e3),
            "algorithmic_gbs": alg / (ms / 1e3) / 1e9, "hbm_frac": alg / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, "bound": "hbm",
+           "generation_loop": {"kernel": "k_gen_pass<double> (count or look-ahead recount + emit) per generation", "generations": int(glaunches),
+                               "ms_per_trace": gms, "wall_ms_per_trace": gwall * 1e3, "algorithmic_gbs": alg_gen / (gms / 1e3) / 1e9,
+                               "hbm_frac": alg_gen / (gms / 1e3) / 1e9 / HBM_PEAK_GBS},
            "generation_mismatches": eng.generation_mismatches()}
     counters = committed_counters("cfg4b")
     if counters:
         rec["sq_counters"] = counters
-    del segs, batch, base
+    del batch, base
     torch.cuda.empty_cache()
     return rec
 

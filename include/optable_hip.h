@@ -312,14 +312,15 @@ int ot_trace_generation_f32(ot_ctx* ctx, const ot_rays* rays, const int32_t* ray
                             int32_t* counts, int32_t n_count_classes);
 
 /* Whole ray trees in ONE launch, a lane per tree (k_trace_trees): the reference's loop — pop the oldest ray, archive it,
- * push its children, stop after max_trace_num rays (optical_table.py:115-147) — runs per lane with the queue in LDS, and only
- * segment records go to memory.  Output as ot_trace_*: slot k * n_rays + i of `out` (max_trace_num * n_rays slots) is the
- * k-th ray of tree i in the reference's FIFO order, seg_count[i] the rays tree i processed (== max_trace_num: cut short by
- * the cap, or ended exactly there).  A queue of ceil(max_trace_num / 2) rays per lane always suffices; ot_trace_trees_plan
- * says whether the scene has such a kernel (info[0]: scenes without count-limited surfaces, planar preset, image + queues
- * within the CU's LDS), how many entries its queues get (info[1]) and whether that is enough for every tree (info[2]).  If
- * not, a tree whose queue overflows reports seg_count[i] = -(rays processed so far) and the caller takes ot_trace_tree_*.
- * OT_ERR_UNSUPPORTED when info[0] would be 0. */
+ * push its children, stop after max_trace_num rays (optical_table.py:115-147) — runs per lane with the queue on the chip (its
+ * front in LDS, the rest in an L2-resident scratch of the library), and only segment records go to memory.  Output as
+ * ot_trace_*: slot k * n_rays + i of `out` (max_trace_num * n_rays slots) is the k-th ray of tree i in the reference's FIFO
+ * order, seg_count[i] the rays tree i processed (== max_trace_num: cut short by the cap, or ended exactly there).  A queue of
+ * ceil(max_trace_num / 2) rays per lane always suffices; ot_trace_trees_plan says whether the scene has such a kernel
+ * (info[0]: scenes without count-limited surfaces, planar preset, image + queue fronts within the CU's LDS), how many entries
+ * its queues get (info[1]), whether that is enough for every tree (info[2]: always, up to caps of ~170 in double precision)
+ * and how many of them are in LDS (info[3]).  If not, a tree whose queue overflows reports seg_count[i] = -(rays processed
+ * so far) and the caller takes ot_trace_tree_*.  OT_ERR_UNSUPPORTED when info[0] would be 0. */
 int ot_trace_trees_f64(ot_ctx* ctx, const ot_rays* rays, int64_t n_rays, int32_t max_trace_num, const ot_segments* out, int32_t* seg_count);
 int ot_trace_trees_f32(ot_ctx* ctx, const ot_rays* rays, int64_t n_rays, int32_t max_trace_num, const ot_segments* out, int32_t* seg_count);
 int ot_trace_trees_plan(ot_ctx* ctx, int32_t real_bytes, int32_t max_trace_num, int32_t* info /* int32[4] */);
@@ -361,7 +362,8 @@ int ot_probe_layouts(ot_ctx* ctx, int32_t real_bytes, double* us_slots, double* 
 int ot_debug_generation_mismatches(ot_ctx* ctx, int64_t* count);
 
 /* Diagnostic: the shape of the last ot_trace_* launch on this ctx, for profiles and tuning notes.
- * info[0] kernel (1 lane per ray, 2 rolling lists), [1] threads per workgroup, [2] workgroups per CU the occupancy
+ * info[0] kernel (1 lane per ray, 2 rolling lists, 3 refill, 4 lane per tree: [5] / [6] = its queue entries in LDS / in the
+ * scratch ring), [1] threads per workgroup, [2] workgroups per CU the occupancy
  * query allowed, [3] workgroups launched, [4] dynamic LDS bytes per workgroup, [5] list capacity per wave (rolling),
  * [6] 1 = mixed generations, [7] bit 0 = candidate pair queue (OT_OPT_FLAT_QUEUE took effect), bit 1 = records in LDS,
  * bit 2 = append layout, bit 3 = tiled layout, bit 4 = workgroup-wide block pool (OT_OPT_BLOCK_POOL; [5] = its slots). */
@@ -421,6 +423,8 @@ enum ot_option {
     OT_OPT_GEN_AHEAD = 20,     /* ot_trace_tree_*, light scenes without count-limited surfaces: the emit pass of a generation also counts the
                                   children of the children it writes, and the next generation replaces its count pass over the ray records by a pass
                                   over one byte per ray (k_gen_recount): 1 (default) / 0.  Identical output either way. */
+    OT_OPT_TREES_LDS_ENTRIES = 21, /* ot_trace_trees_*: queue entries per lane kept in LDS (default 3; the rest of a tree's queue lives in a global
+                                  scratch): more entries, fewer waves per CU */
     OT_OPT_POOL_JITTER = 18,   /* test knob of the block pool's cross-wave protocol: one in `value` publications of a state or control word is
                                   held back ~8000 cycles after the records it announces were written (0 = off).  Results must not change. */
     OT_OPT_GEN_DROP_DOOMED = 15 /* ot_trace_generation_*: a tree whose budget ends with this generation gets no children in `next` (they

@@ -411,8 +411,8 @@ class SegmentBatch:
             out["count"] = np.abs(self.count.cpu().numpy())
             return out
         if self.count is not None:
-            K = self.capacity // self.n_rays
             cnt = np.abs(self.count.cpu().numpy())  # a negative count marks a tree that branched (its slots are still valid)
+            K = min(self.capacity // self.n_rays, int(cnt.max()))  # (only the planes in use: a generous cap costs no copy)
             full = bool(cnt.min() == K)                            # every slot valid: no masking needed
             keep = None if full else np.arange(K)[:, None] < cnt[None, :]            # [K, N]
             out = {}

@@ -45,6 +45,6 @@ template <> GenOneKern<T> gen_one_kernel<T>(int fg, bool lds) {
 
 // k_trace_trees: light planar scenes (beam splitters, partially reflecting slabs, mirrors, thin lenses)
 template <> TreeKern<T> tree_kernel<T>(int fg) {
-    if (fg == 0) return k_trace_trees<T, FB, (sizeof(T) == 8 ? 1 : 2)>;
+    if (fg == 0) return k_trace_trees<T, FB, (sizeof(T) == 8 ? 2 : 3)>;
     return nullptr;
 }

@@ -54,11 +54,11 @@ template <class T> static SegsT<T> view(const ot_segments* s) {
 }
 
 // ------------------------------------------------------------------------------------------
-// scene blob: [DNode<T> x n_phys][DMat<T> x n_mats][T x n_aux][int32 x 4 n_runs][DHead<T> x n_phys, 16-byte aligned], staged into LDS word by word.
+// scene blob: [DNode<T> x n_phys][DMat<T> x n_mats][T x n_aux][int32 x 4 n_runs], staged into LDS word by word.
 // n_nodes counts the caller's (virtual) nodes, n_phys the records kept after instanced runs were folded (trace_core.h NodeRef).
 struct SceneBlob {
     const uint32_t* words;
-    int32_t n_words, n_nodes, n_phys, n_mats, root, cache_mat, root_pack, n_runs, runs_word, heads_word;
+    int32_t n_words, n_nodes, n_phys, n_mats, root, cache_mat, root_pack, n_runs, runs_word;
 };
 
 template <class T> __device__ __forceinline__ Scene<T> bind_scene(const uint32_t* base, const SceneBlob& b, T unit) {
@@ -67,7 +67,6 @@ template <class T> __device__ __forceinline__ Scene<T> bind_scene(const uint32_t
     sc.mats = reinterpret_cast<const DMat<T>*>(sc.nodes + b.n_phys);
     sc.aux = reinterpret_cast<const T*>(sc.mats + b.n_mats);
     sc.runs = reinterpret_cast<const int32_t*>(base + b.runs_word);
-    sc.heads = reinterpret_cast<const DHead<T>*>(__builtin_assume_aligned(base + b.heads_word, 16));
     sc.n_nodes = b.n_nodes;
     sc.n_runs = b.n_runs;
     for (int k = 0; k < 4; ++k) sc.run0[k] = b.n_runs > 0 ? __builtin_amdgcn_readfirstlane(sc.runs[k]) : 0;
@@ -283,38 +282,58 @@ __global__ __launch_bounds__(256, MINW) void k_trace_fused(SceneBlob blob, T uni
 // ------------------------------------------------------------------------------------------
 // k_trace_trees: whole ray TREES, a lane per tree (round 4).  The breadth-first loop of the reference (optical_table.py:
 // 115-147: pop the oldest ray, archive it, push its children, stop after max_trace_num rays) runs per lane with the FIFO
-// in LDS; only segment records leave the chip — the generation kernels write every child to HBM and read it back (271 of
+// on the chip; only segment records leave it — the generation kernels write every child to HBM and read it back (271 of
 // the 375-484 bytes they move per processed ray).  A tree that processes at most `cap` rays never needs more than
 // ceil(cap / 2) queued rays: after j rays the queue holds at most j + 1, and only its first cap - j entries can still be
-// processed; children that would queue up behind that are not stored.  The queue is a ring of Q entries per lane,
-// [entry][field][lane] (11 reals + the node the ray starts on), so a wave's pushes and pops are conflict-free whatever the
-// lanes' positions.  Q < ceil(cap / 2) is allowed (large caps, small trees): a tree whose ring overflows reports
-// -(segments so far) and the caller takes the generation path.
+// processed; children that would queue up behind that are not stored.
+// The queue of a lane is two rings, [entry][field][lane] each (11 reals + the node the ray starts on), so a wave's pushes
+// and pops are conflict-free / coalesced whatever the lanes' positions: QL entries in LDS hold the FRONT of the queue, QG
+// entries in a per-wave global scratch (L2-resident: written and read back by the same lane within microseconds) the rest.
+// A push goes to LDS while nothing is queued in the scratch and LDS has room, else to the scratch; a pop takes LDS first.
+// Short queues — a chain of partial reflections (cfg 4 with R = 0.2: three rays at most) — never leave the LDS, and three
+// entries per lane leave room for 8 waves per CU in double precision and 16 in single, which is what the kernel's speed
+// hangs on (one wave per SIMD issues an instruction every ~4.5 cycles: 5.8 ms on cfg 4 R = 0.2; two: ms).  A ray whose
+// parent left an empty queue is handed over in registers.  QL + QG < ceil(cap / 2) is allowed (large caps, small trees): a
+// tree whose rings overflow reports -(segments so far) and the caller takes the generation path.
 // Output: the [k][tree] slots of ot_trace_* — slot k * n + i is the k-th ray of tree i in FIFO order, which IS the
 // reference's order; seg_count[i] = rays processed (== cap: the cap cut the tree short or the tree ended exactly there,
 // as `budget <= 0` on the generation path).  Scenes without count-limited leaves (their counters are shared between trees).
-#ifndef OT_TREES_NT
-#define OT_TREES_NT false
-#endif
 template <class T> constexpr int tree_entry_bytes() { return 64 * (11 * (int)sizeof(T) + 4); }
 template <class T, uint32_t F, int MINW>
-__global__ __launch_bounds__(256, MINW) void k_trace_trees(SceneBlob blob, T unit, RaysT<T> in, int64_t n, int32_t cap, int32_t Q, SegsT<T> out,
-                                                           int32_t* __restrict__ seg_count) {
+__global__ __launch_bounds__(256, MINW) void k_trace_trees(SceneBlob blob, T unit, RaysT<T> in, int64_t n, int32_t cap, int32_t QL, int32_t QG,
+                                                           uint8_t* __restrict__ scratch, SegsT<T> out, int32_t* __restrict__ seg_count) {
     extern __shared__ __align__(16) uint32_t lds[];
     for (int w = threadIdx.x; w < blob.n_words; w += blockDim.x) lds[w] = blob.words[w];
     __syncthreads();
     const Scene<T> sc = bind_scene<T>(lds, blob, unit);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // this wave's ring: Q entries of [11 reals][64 lanes] + [64 lanes] int32
-    uint8_t* const ring = reinterpret_cast<uint8_t*>(lds) + (((size_t)blob.n_words * 4 + 15) & ~(size_t)15) + (size_t)wave * Q * tree_entry_bytes<T>();
-    auto real_at = [&](int e, int f) -> T* { return reinterpret_cast<T*>(ring + (size_t)e * tree_entry_bytes<T>()) + f * 64 + lane; };
-    auto int_at = [&](int e) -> int32_t* { return reinterpret_cast<int32_t*>(ring + (size_t)e * tree_entry_bytes<T>() + 64 * 11 * sizeof(T)) + lane; };
+    constexpr size_t EB = tree_entry_bytes<T>();
+    uint8_t* const ring = reinterpret_cast<uint8_t*>(lds) + (((size_t)blob.n_words * 4 + 15) & ~(size_t)15) + (size_t)wave * QL * EB;
+    uint8_t* const gring = scratch + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * (size_t)QG * EB;
+    auto real_at = [&](uint8_t* base, int e, int f) -> T* { return reinterpret_cast<T*>(base + (size_t)e * EB) + f * 64 + lane; };
+    auto int_at = [&](uint8_t* base, int e) -> int32_t* { return reinterpret_cast<int32_t*>(base + (size_t)e * EB + 64 * 11 * sizeof(T)) + lane; };
+    auto put = [&](uint8_t* base, int e, const RayState<T>& c) {
+        *real_at(base, e, 0) = c.ox; *real_at(base, e, 1) = c.oy; *real_at(base, e, 2) = c.oz;
+        *real_at(base, e, 3) = c.dx; *real_at(base, e, 4) = c.dy; *real_at(base, e, 5) = c.dz;
+        *real_at(base, e, 6) = c.qr; *real_at(base, e, 7) = c.qi; *real_at(base, e, 8) = c.I;
+        *real_at(base, e, 9) = c.n; *real_at(base, e, 10) = c.pl;
+        *int_at(base, e) = c.last;
+    };
+    auto get = [&](uint8_t* base, int e, RayState<T>& r) {
+        r.ox = *real_at(base, e, 0); r.oy = *real_at(base, e, 1); r.oz = *real_at(base, e, 2);
+        r.dx = *real_at(base, e, 3); r.dy = *real_at(base, e, 4); r.dz = *real_at(base, e, 5);
+        r.qr = *real_at(base, e, 6); r.qi = *real_at(base, e, 7); r.I = *real_at(base, e, 8);
+        r.n = *real_at(base, e, 9); r.pl = *real_at(base, e, 10);
+        r.last = *int_at(base, e);
+    };
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < n; i0 += stride) {
         const int64_t i = i0 + threadIdx.x;
         bool active = i < n, overflow = false;
         RayState<T> r = {};
-        int32_t k = 0, head = 0, qlen = 0;  // rays processed; ring position of the oldest queued ray; queued rays
+        int32_t k = 0;                     // rays processed
+        int32_t lhead = 0, llen = 0;       // LDS ring: position of the oldest entry, entries
+        int32_t ghead = 0, glen = 0;       // scratch ring (the queue behind the LDS entries)
         MatCache<T> mc = {T(1)};
         if (active) {
             const int32_t fl = in.flags[i];
@@ -322,13 +341,11 @@ __global__ __launch_bounds__(256, MINW) void k_trace_trees(SceneBlob blob, T uni
             if ((uint32_t)r.last >= (uint32_t)sc.n_nodes) r.last = -1;
             if constexpr (F & F_REFRACT) mc = make_matcache<T, F>(sc, r.wl);
             if (fl & OT_RAY_DEAD) {  // optical_component.py:349: a dead ray hits nothing and is returned as is
-                store_segment<T, OT_TREES_NT>(out, i, r, r.len, (int32_t)i, -2);
+                store_segment<T, false>(out, i, r, r.len, (int32_t)i, -2);
                 k = 1;
                 active = false;
             }
         }
-        const T wl = r.wl;
-        const int32_t has_q = r.has_q;
         while (__any(active)) {
             const GateCtx gate = {nullptr, 0, 0, nullptr, nullptr, 0, 0};
             const Hit<T> h = nearest_hit<T, F, GATE_PLAIN>(sc, r, active, gate);
@@ -338,39 +355,52 @@ __global__ __launch_bounds__(256, MINW) void k_trace_trees(SceneBlob blob, T uni
                 int nk = 0;
                 RayState<T> ch[2];
                 if (h.node < 0) {
-                    store_segment<T, OT_TREES_NT>(out, slot, r, r.len, (int32_t)i, -1);
+                    store_segment<T, false>(out, slot, r, r.len, (int32_t)i, -1);
                 } else {
-                    store_segment<T, OT_TREES_NT>(out, slot, r, h.t, (int32_t)i, leaf_id_of<T, F>(sc, h.node));
+                    store_segment<T, false>(out, slot, r, h.t, (int32_t)i, leaf_id_of<T, F>(sc, h.node));
                     nk = interact<T, F, 2>(sc, r, h, ch, mc);
                 }
                 const int32_t left = cap - k;  // rays this tree may still process
+                // a first child behind an empty queue is the next ray: it stays in registers
+                const bool direct = nk > 0 && left > 0 && llen + glen == 0;
+                int32_t pos = direct ? 1 : 0;  // queue position the next push would get, counted from the next ray to process
                 auto push = [&](const RayState<T>& c) {
-                    if (qlen >= left) return;  // would never be processed (optical_table.py:138-144 drops it with the queue)
-                    if (qlen >= Q) { overflow = true; return; }
-                    int e = head + qlen;
-                    if (e >= Q) e -= Q;
-                    *real_at(e, 0) = c.ox; *real_at(e, 1) = c.oy; *real_at(e, 2) = c.oz;
-                    *real_at(e, 3) = c.dx; *real_at(e, 4) = c.dy; *real_at(e, 5) = c.dz;
-                    *real_at(e, 6) = c.qr; *real_at(e, 7) = c.qi; *real_at(e, 8) = c.I;
-                    *real_at(e, 9) = c.n; *real_at(e, 10) = c.pl;
-                    *int_at(e) = c.last;
-                    ++qlen;
+                    if (llen + glen + pos >= left) return;  // would never be processed (optical_table.py:138-144 drops it with the queue)
+                    if (glen == 0 && llen < QL) {
+                        int e = lhead + llen;
+                        if (e >= QL) e -= QL;
+                        put(ring, e, c);
+                        ++llen;
+                    } else if (glen < QG) {
+                        int e = ghead + glen;
+                        if (e >= QG) e -= QG;
+                        put(gring, e, c);
+                        ++glen;
+                    } else {
+                        overflow = true;
+                    }
                 };
-                if (nk > 0) push(ch[0]);
+                if (nk > 0 && !direct) push(ch[0]);
                 if (nk > 1) push(ch[1]);
-                if (qlen > 0 && left > 0 && !overflow) {
-                    const int e = head;
-                    r.ox = *real_at(e, 0); r.oy = *real_at(e, 1); r.oz = *real_at(e, 2);
-                    r.dx = *real_at(e, 3); r.dy = *real_at(e, 4); r.dz = *real_at(e, 5);
-                    r.qr = *real_at(e, 6); r.qi = *real_at(e, 7); r.I = *real_at(e, 8);
-                    r.n = *real_at(e, 9); r.pl = *real_at(e, 10);
-                    r.last = *int_at(e);
+                const T wl = r.wl;
+                const int32_t has_q = r.has_q;
+                if (direct) {
+                    r = ch[0];
+                } else if (llen + glen > 0 && left > 0 && !overflow) {
+                    if (llen > 0) {
+                        get(ring, lhead, r);
+                        lhead = lhead + 1 == QL ? 0 : lhead + 1;
+                        --llen;
+                    } else {
+                        get(gring, ghead, r);
+                        ghead = ghead + 1 == QG ? 0 : ghead + 1;
+                        --glen;
+                    }
                     r.wl = wl; r.has_q = has_q; r.len = Num<T>::inf();
-                    head = head + 1 == Q ? 0 : head + 1;
-                    --qlen;
                 } else {
                     active = false;
                 }
+                if (overflow) active = false;
             }
         }
         if (i < n) seg_count[i] = overflow ? -k : k;

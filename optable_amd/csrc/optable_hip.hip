@@ -57,7 +57,6 @@ struct ot_ctx {
     size_t bytes64 = 0, bytes32 = 0;
     int32_t n_nodes = 0, n_mats = 0, n_aux = 0, n_slots = 0, max_children = 0;
     int32_t n_phys = 0, n_runs = 0, runs_word64 = 0, runs_word32 = 0;  // instanced runs folded by fill_blob (trace_core.h NodeRef)
-    int32_t heads_word64 = 0, heads_word32 = 0;                        // where the node heads of the linear walk start in the image
     int32_t opt_append_chunk = 512;  // append layout: slots per claim
     int32_t opt_instancing = 1;      // fold lattice children into instanced runs at upload
     int32_t opt_gen_drop = 1;        // generation kernels: children of a tree whose budget ends with this generation are not emitted
@@ -100,7 +99,8 @@ struct ot_ctx {
     size_t blocked_queue_off = 0;
     int32_t opt_pair = 1;  // paired 16-byte segment stores in the lane-per-ray kernel
     int32_t opt_nt = 1, opt_minw = 4, opt_blocks_per_cu = 0;  // defaults from tools/tune.py on MI355X
-    Scratch gen, scan_tmp, mon, gen_rem, gen_ahead;
+    Scratch gen, scan_tmp, mon, gen_rem, gen_ahead, trees;
+    int32_t opt_trees_lds = 3;  // k_trace_trees: queue entries per lane kept in LDS (the rest of a tree's queue lives in a global scratch)
     int32_t opt_gen_ahead = 1;  // ot_trace_tree_*: the emit pass counts its children's children, the next generation skips its count pass (k_gen_pass MODE 2)
     int32_t opt_gen_onepass = -1;  // ot_trace_tree_*: one pass per generation with a decoupled look-back (k_gen_one): -1 (default) generations of up to
                                    // 65536 rays (one launch instead of six), 0 never, 1 always.  Large generations keep count + scan + emit: the
@@ -251,7 +251,7 @@ static std::vector<NodeRun> find_runs(const ot_scene_desc* s) {
 }
 
 template <class T> static void fill_blob(const ot_scene_desc* s, const std::vector<NodeRun>& runs_in, std::vector<uint8_t>& out, int32_t& n_phys,
-                                         int32_t& runs_word, int32_t& heads_word) {
+                                         int32_t& runs_word) {
     std::vector<NodeRun> runs = runs_in;
     const int64_t pack = packable_cells(s);
     int folded = 0, geo_reals = 0;
@@ -259,9 +259,7 @@ template <class T> static void fill_blob(const ot_scene_desc* s, const std::vect
     n_phys = s->n_nodes - folded;
     const size_t nb = sizeof(DNode<T>) * n_phys, mb = sizeof(DMat<T>) * s->n_materials, ab = sizeof(T) * (s->n_aux + pack + geo_reals);
     const size_t rb = sizeof(int32_t) * 4 * runs.size();
-    const size_t heads_at = ((nb + mb + ab + rb + 15) / 16) * 16, hb = sizeof(DHead<T>) * n_phys;  // the walk's node heads (trace_core.h DHead)
-    out.assign(heads_at + hb, 0);
-    heads_word = (int32_t)(heads_at / 4);
+    out.assign(((nb + mb + ab + rb + 15) / 16) * 16, 0);
     DNode<T>* nodes = reinterpret_cast<DNode<T>*>(out.data());
     size_t next_run = 0;
     int phys = 0;
@@ -336,13 +334,6 @@ template <class T> static void fill_blob(const ot_scene_desc* s, const std::vect
     runs_word = (int32_t)((nb + mb + ab) / 4);
     int32_t* rt = reinterpret_cast<int32_t*>(out.data() + nb + mb + ab);
     for (size_t k = 0; k < runs.size(); ++k) { rt[4 * k] = runs[k].first; rt[4 * k + 1] = runs[k].count; rt[4 * k + 2] = runs[k].pnode; rt[4 * k + 3] = runs[k].geo; }
-    DHead<T>* heads = reinterpret_cast<DHead<T>*>(out.data() + heads_at);
-    for (int q = 0; q < n_phys; ++q) {
-        const DNode<T>& d = nodes[q];
-        heads[q].kfs = (d.kind & 1) | ((d.flags & 0x7ff) << 1) | (d.shape << 12);
-        heads[q].end = d.end;
-        for (int k = 0; k < 6; ++k) heads[q].aabb[k] = d.aabb[k];
-    }
 }
 
 // which code paths the scene needs (trace_core.h feature mask)
@@ -557,6 +548,7 @@ int ot_ctx_destroy(ot_ctx* c) {
     if (c->gen.p) (void)hipFree(c->gen.p);
     if (c->gen_rem.p) (void)hipFree(c->gen_rem.p);
     if (c->gen_ahead.p) (void)hipFree(c->gen_ahead.p);
+    if (c->trees.p) (void)hipFree(c->trees.p);
     if (c->gen_mismatch) (void)hipFree(c->gen_mismatch);
     if (c->gen_chain) (void)hipFree(c->gen_chain);
     if (c->pinned_state) (void)hipHostFree(c->pinned_state);
@@ -592,8 +584,8 @@ int ot_scene_upload(ot_ctx* c, const ot_scene_desc* s) {
     std::vector<uint8_t> b64, b32;
     const std::vector<NodeRun> runs = c->opt_instancing ? find_runs(s) : std::vector<NodeRun>();
     int32_t n_phys = 0;
-    fill_blob<double>(s, runs, b64, n_phys, c->runs_word64, c->heads_word64);
-    fill_blob<float>(s, runs, b32, n_phys, c->runs_word32, c->heads_word32);
+    fill_blob<double>(s, runs, b64, n_phys, c->runs_word64);
+    fill_blob<float>(s, runs, b32, n_phys, c->runs_word32);
     c->n_phys = n_phys;
     c->n_runs = (int32_t)runs.size();
     HIP_TRY(hipStreamSynchronize(c->stream));  // previous launches may still read the old scene
@@ -687,7 +679,6 @@ template <class T> static SceneBlob make_blob(const ot_ctx* c) {
     blob.cache_mat = c->cache_mat;
     blob.n_runs = c->n_runs;
     blob.runs_word = f64 ? c->runs_word64 : c->runs_word32;
-    blob.heads_word = f64 ? c->heads_word64 : c->heads_word32;
     return blob;
 }
 
@@ -1163,17 +1154,30 @@ static int trace_generation(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
     return timing_end(c);
 }
 
-// Whole ray trees, a lane per tree (kernels.h k_trace_trees).  plan: Q = ring entries per lane — ceil(cap / 2) when that fits
-// the CU's LDS next to the image with a 256-thread workgroup (then no tree can overflow: full = 1), else what fits (speculative).
-template <class T> static bool trees_plan(const ot_ctx* c, int32_t cap, int32_t* Q, int32_t* full) {
+// Whole ray trees, a lane per tree (kernels.h k_trace_trees).  The plan: workgroups of 256 threads; QL entries per lane in LDS
+// (OT_OPT_TREES_LDS_ENTRIES, default 3: eight waves per CU in double precision, sixteen in single) and the rest of the
+// ceil(cap / 2) entries a tree can need in a per-wave global scratch, as long as the scratch of all resident waves stays
+// within 1 GiB (caps up to ~170 in double precision); beyond that the queues are what fits and the launch is a speculation
+// on small trees (full = 0).
+struct TreesPlan { int32_t QL, QG, full, groups_per_cu; size_t lds_bytes; };
+template <class T> static bool trees_plan(const ot_ctx* c, int32_t cap, TreesPlan* p) {
     const size_t image = sizeof(T) == 8 ? c->bytes64 : c->bytes32;
-    *Q = *full = 0;
+    *p = TreesPlan{};
     if (!c->has_scene || c->n_slots > 0 || c->max_children > 2 || cap < 1 || !tree_kernel<T>(gen_preset(c->features))) return false;
-    const size_t room = 160 * 1024 - 1024, img = (image + 15) & ~(size_t)15, per_entry = 4 * (size_t)tree_entry_bytes<T>();
-    if (img + per_entry > room) return false;
-    const int64_t fit = (int64_t)((room - img) / per_entry), need = ((int64_t)cap + 1) / 2;
-    *Q = (int32_t)(need < fit ? need : fit);
-    *full = need <= fit;
+    const size_t room = 160 * 1024 - 1024, img = (image + 15) & ~(size_t)15, entry = (size_t)tree_entry_bytes<T>();
+    if (img + 4 * entry > room) return false;
+    const int64_t need = ((int64_t)cap + 1) / 2, fit = (int64_t)((room - img) / (4 * entry));
+    int64_t ql = c->opt_trees_lds < need ? c->opt_trees_lds : need;
+    if (ql > fit) ql = fit;
+    p->QL = (int32_t)ql;
+    p->lds_bytes = img + 4 * (size_t)ql * entry;
+    const int by_lds = (int)((160 * 1024) / (p->lds_bytes + 256)), by_regs = sizeof(T) == 8 ? 2 : 3;  // (launch bounds: 2 / 3 waves per SIMD; single precision at 4 would spill)
+    p->groups_per_cu = by_lds < by_regs ? (by_lds < 1 ? 1 : by_lds) : by_regs;
+    const int64_t waves = (int64_t)c->n_cus * p->groups_per_cu * 4, most = ((int64_t)1 << 30) / (waves * (int64_t)entry);
+    // (the scratch ring alone must hold a whole queue: pushes keep going there while the LDS entries in front of them drain)
+    const int64_t qg = need > ql ? need : 0;
+    p->QG = (int32_t)(qg < most ? qg : most);
+    p->full = qg <= most;
     return true;
 }
 template <class T>
@@ -1182,23 +1186,24 @@ static int trace_trees(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t cap, c
     if (rc) return rc;
     rc = check_segs(out);
     if (rc) return rc;
-    int32_t Q, full;
-    if (!trees_plan<T>(c, cap, &Q, &full)) return fail(OT_ERR_UNSUPPORTED, "no tree kernel for this scene (count-limited surfaces, features beyond the planar preset, or an image that leaves no room for the queues): use ot_trace_tree_*");
+    TreesPlan p;
+    if (!trees_plan<T>(c, cap, &p)) return fail(OT_ERR_UNSUPPORTED, "no tree kernel for this scene (count-limited surfaces, features beyond the planar preset, or an image that leaves no room for the queues): use ot_trace_tree_*");
     if (n == 0) return 0;
     HIP_TRY(hipSetDevice(c->device));
-    const size_t image = sizeof(T) == 8 ? c->bytes64 : c->bytes32;
-    const size_t lds_bytes = ((image + 15) & ~(size_t)15) + 4 * (size_t)Q * tree_entry_bytes<T>();
     const TreeKern<T> kern = tree_kernel<T>(gen_preset(c->features));
     const SceneBlob blob = make_blob<T>(c);
-    const int64_t blocks_needed = (n + 255) / 256, most = (int64_t)c->n_cus * 64;
+    const int64_t blocks_needed = (n + 255) / 256, most = (int64_t)c->n_cus * p.groups_per_cu;  // persistent: the scratch is per workgroup
     const int grid = (int)(blocks_needed < most ? blocks_needed : most);
+    const size_t scratch = (size_t)grid * 4 * (size_t)p.QG * tree_entry_bytes<T>();
+    if (c->trees.ensure(scratch + 256)) return fail(OT_ERR_HIP, "hipMalloc of the tree queues failed");
     hipEvent_t ev0, ev1;
     rc = timing_pair(c, &ev0, &ev1);
     if (rc) return rc;
-    if (lds_bytes > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), (uint32_t)lds_bytes, c->stream, ev0, ev1, 0u, blob, (T)c->unit, view<T>(rays), n, cap, Q, view<T>(out), seg_count);
+    if (p.lds_bytes > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
+    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), (uint32_t)p.lds_bytes, c->stream, ev0, ev1, 0u, blob, (T)c->unit, view<T>(rays), n, cap, p.QL, p.QG,
+                          (uint8_t*)c->trees.p, view<T>(out), seg_count);
     HIP_TRY(hipGetLastError());
-    const int32_t shape[8] = {4, 256, 0, (int32_t)grid, (int32_t)lds_bytes, Q, 0, 0};
+    const int32_t shape[8] = {4, 256, p.groups_per_cu, (int32_t)grid, (int32_t)p.lds_bytes, p.QL, p.QG, 0};
     for (int q = 0; q < 8; ++q) c->last_launch[q] = shape[q];
     return 0;
 }
@@ -1368,9 +1373,9 @@ int ot_trace_trees_f32(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t max_tr
 }
 int ot_trace_trees_plan(ot_ctx* c, int32_t real_bytes, int32_t max_trace_num, int32_t* info) {
     if (!c || !info || (real_bytes != 4 && real_bytes != 8)) return fail(OT_ERR_INVALID, "bad ot_trace_trees_plan arguments");
-    int32_t Q = 0, full = 0;
-    const bool ok = real_bytes == 8 ? trees_plan<double>(c, max_trace_num, &Q, &full) : trees_plan<float>(c, max_trace_num, &Q, &full);
-    info[0] = ok ? 1 : 0; info[1] = Q; info[2] = full; info[3] = 0;
+    TreesPlan p;
+    const bool ok = real_bytes == 8 ? trees_plan<double>(c, max_trace_num, &p) : trees_plan<float>(c, max_trace_num, &p);
+    info[0] = ok ? 1 : 0; info[1] = p.QL + p.QG; info[2] = p.full; info[3] = p.QL;
     return 0;
 }
 int ot_trace_tree_f64(ot_ctx* c, const ot_rays* rays, const int32_t* tree, int64_t n, int32_t* budget, const ot_segments* out,
@@ -1597,6 +1602,9 @@ int ot_set_option(ot_ctx* c, int32_t option, int32_t value) {
             c->opt_pool = value; return 0;
         case OT_OPT_INSTANCING: c->opt_instancing = value != 0; return 0;  // takes effect at the next ot_scene_upload
         case OT_OPT_GEN_AHEAD: c->opt_gen_ahead = value != 0; return 0;
+        case OT_OPT_TREES_LDS_ENTRIES:
+            if (value < 1 || value > 64) return fail(OT_ERR_INVALID, "OT_OPT_TREES_LDS_ENTRIES takes 1..64");
+            c->opt_trees_lds = value; return 0;
         case OT_OPT_GEN_ONEPASS:
             if (value < -1 || value > 1) return fail(OT_ERR_INVALID, "OT_OPT_GEN_ONEPASS takes -1 (small generations), 0 or 1");
             c->opt_gen_onepass = value; return 0;

@@ -89,16 +89,6 @@ template <class T> struct DNode {
     int32_t kind, end, flags, shape, inter, mat1, mat2, roc_kind, max_count, slot, aux, leaf_id;
     int32_t bank_pad[sizeof(T) == 4 ? 1 : 2];
 };
-// What the linear node walk of nearest_hit needs of a node before it decides anything — kind, flags, shape, the end of its
-// subtree and its lab box — in ONE 16-byte aligned record per physical node, behind the run table of the image: two
-// ds_read_b128 issued together and ONE wait per node, where the fields of the 212-byte record (kind and flags first, then the
-// box, then `end`) cost a dependent LDS round trip each; the walk over five or six top-level nodes was the largest phase of a
-// cfg 5 pass (stamps: 5350 of 9800 cycles).  Same bits as the record's own fields (a copy made at upload).
-template <class T> struct alignas(16) DHead {
-    int32_t kfs;  // kind | flags << 1 | shape << 12
-    int32_t end;
-    T aabb[6];
-};
 template <class T> struct DMat {
     T n;
     T B[3];
@@ -110,7 +100,6 @@ template <class T> struct Scene {
     const DNode<T>* nodes;  // PHYSICAL records: every node once, except that a run of instanced leaves keeps one prototype
     const DMat<T>* mats;
     const T* aux;
-    const DHead<T>* heads;  // [physical nodes]: the walk's view of a node (DHead)
     const int32_t* runs;    // [n_runs][4]: first virtual index, count, physical index of the prototype, aux offset of the geo table
     int32_t run0[4];        // the first run, read once per workgroup: node_ref is called a dozen times per pass and an LDS round trip each adds up
     int32_t n_nodes;        // VIRTUAL node count: the caller's depth-first list (indices in hits, ties, skip lists, grid items)
@@ -1388,28 +1377,23 @@ __device__ __forceinline__ Hit<T> nearest_hit(const Scene<T>& sc, const RayState
     for (; i < sc.n_nodes; ++i) {  // virtual indices; the children of an instanced run are only ever reached through their group's grid
         const NodeRef<T> nr = node_ref<T, F>(sc, i);
         const DNode<T>& nd = *nr.nd;
-        // (the node's head: everything the walk decides on, read at once — the nodes this loop visits are never members of an
-        // instanced run, whose boxes live in the run's pose table)
-        const DHead<T>& hd = sc.heads[nr.nd - sc.nodes];
-        const int hd_kfs = hd.kfs, hd_end = hd.end;
-        const int hd_kind = hd_kfs & 1, hd_flags = (hd_kfs >> 1) & 0x7ff, hd_shape = hd_kfs >> 12;
         if constexpr (F & F_AABB) {
             bool inside = false;
             T t1 = T(0), t2 = T(0);
-            if (hd_kind == OT_NODE_GROUP && (hd_flags & OT_NODE_CHECK_AABB)) {
+            if (nd.kind == OT_NODE_GROUP && (nd.flags & OT_NODE_CHECK_AABB)) {
                 if (i >= skip_until) {
-                    inside = slab_inv(r.ox, r.oy, r.oz, ri, hd.aabb, t1, t2);
-                    if (!(F & F_LIMIT) && (hd_flags & OT_NODE_BOX_TRUSTED) && beyond_best(t1, best.t)) inside = false;  // nothing in this group can be nearer
-                    if (!inside) skip_until = hd_end;
+                    inside = slab_inv(r.ox, r.oy, r.oz, ri, nr.geo + 3, t1, t2);
+                    if (!(F & F_LIMIT) && (nd.flags & OT_NODE_BOX_TRUSTED) && beyond_best(t1, best.t)) inside = false;  // nothing in this group can be nearer
+                    if (!inside) skip_until = nd.end;
                 }
             }
-            if (hd_kind == OT_NODE_GROUP) {
+            if (nd.kind == OT_NODE_GROUP) {
                 if constexpr (F & F_GRID) {
-                    if (hd_flags & OT_NODE_GRID) {  // wave-uniform branch; lanes that missed the box idle inside
+                    if (nd.flags & OT_NODE_GRID) {  // wave-uniform branch; lanes that missed the box idle inside
                         OT_NH_AT(5);
                         if (inside) {
                             grid_children<T, F, GATE>(sc, nd, r, ri, t1, t2, best, gate);
-                            skip_until = hd_end;
+                            skip_until = nd.end;
                         }
                         OT_NH_AT(7);
                     }
@@ -1418,12 +1402,12 @@ __device__ __forceinline__ Hit<T> nearest_hit(const Scene<T>& sc, const RayState
                 // wave jumps over the group: a lane that is skipping holds the end of this group or of one that encloses it
                 // (inactive lanes INT_MAX), so none of them has business before nd.end.  One ballot; the first version took
                 // the wave-wide minimum of skip_until here, six dependent cross-lane steps per group node.
-                if (!__any(skip_until <= i + 1)) i = hd_end - 1;
+                if (!__any(skip_until <= i + 1)) i = nd.end - 1;
                 continue;
             }
         }
         if constexpr (DEFER_CURVED) {
-            const int sh = hd_shape;
+            const int sh = nd.shape;
             if (!(sh == OT_SHAPE_CIRCLE || sh == OT_SHAPE_RECT || sh == OT_SHAPE_POLYGON2D || sh == OT_SHAPE_CSG)) {  // wave-uniform
                 const bool want = i >= skip_until;
                 if (__any(want)) {

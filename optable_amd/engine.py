@@ -278,7 +278,7 @@ class Engine:
         per lane would a cap of `max_trace_num` get, and is that enough for every possible tree."""
         info = (C.c_int32 * 4)()
         abi.check(self.lib.ot_trace_trees_plan(self._ctx, 8 if precision == "f64" else 4, int(max_trace_num), info), self.lib)
-        return {"kernel": bool(info[0]), "queue": int(info[1]), "full": bool(info[2])}
+        return {"kernel": bool(info[0]), "queue": int(info[1]), "full": bool(info[2]), "lds_entries": int(info[3])}
 
     def trace_trees(self, rays: RayBatch, max_trace_num, out: SegmentBatch = None):
         """Whole ray trees in one launch, a lane per tree with its FIFO in LDS (ot_trace_trees_*): a SegmentBatch in the
@@ -302,6 +302,27 @@ class Engine:
         out.timed_out = False
         out.counts_table = None
         return out
+
+    # A lane-per-tree launch whose queues may overflow (caps beyond ~170 in double precision) is a speculation on small trees:
+    # small batches only, and it may allocate this many slots at most.
+    TREES_SMALL_BATCH = 64 * 256
+    TREES_SPECULATIVE_SLOTS = 1 << 20
+
+    def trace_branching(self, rays: RayBatch, max_trace_num, counts=None, max_trace_time=None):
+        """Ray trees by whichever path the scene and the cap allow: ONE launch with a lane per tree (`trace_trees`: [k][tree]
+        slots in the reference's order) when the scene has such a kernel and its queues hold every possible tree — or, for
+        larger caps, speculatively when the batch is small (a tree that overflows its queue sends the call to the
+        generations) — else the generation loop (`trace_tree`: a list in generation order).  Readers take both layouts;
+        `capped` / `timed_out` are set either way."""
+        n, K = rays.n, int(max_trace_num)
+        if n and counts is None and not self.scene.limited and (max_trace_time is None or max_trace_time > 1.0):
+            plan = self.trees_plan(rays.precision, K)
+            if plan["kernel"] and (plan["full"] or (n <= self.TREES_SMALL_BATCH and n * K <= self.TREES_SPECULATIVE_SLOTS)):
+                segs = self.trace_trees(rays, K)
+                if plan["full"] or not bool((segs.count < 0).any()):
+                    return segs
+                del segs
+        return self.trace_tree(rays, K, counts=counts, max_trace_time=max_trace_time)
 
     def trace_tree(self, rays: RayBatch, max_trace_num, counts=None, out_capacity=None, max_trace_time=None):
         """Full ray trees (beam splitters, partial reflections, any cap).  Returns a flat

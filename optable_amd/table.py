@@ -120,8 +120,9 @@ class OpticalTable:
         `layout`: "auto" (the default: what the scene's kernels write fastest on this device, Engine.plan — the dense
         "append" list for heavy scenes, "tiled" or "slots" for light ones, whichever the device streams faster), "slots"
         ([segment][ray] slots), "tiled" (the same slots in 64-slot tiles) or "append" (a dense list in append order,
-        `capacity` slots: see Engine.trace) for the non-branching launch; ray trees always come back as a list in
-        generation order.  Every reader of a SegmentBatch takes all of them."""
+        `capacity` slots: see Engine.trace) for the non-branching launch; ray trees come back as [k][tree] slots when one
+        launch takes them (Engine.trace_branching: light scenes, caps whose queues fit the LDS) and as a list in generation
+        order otherwise.  Every reader of a SegmentBatch takes all of them."""
         eng = _engine()
         if scene is None:
             scene = self.compile()
@@ -137,7 +138,7 @@ class OpticalTable:
                 segs = eng.trace(batch, cap, layout=layout, capacity=capacity)
                 if scene.max_children <= 1 or not bool((segs.count < 0).any()):
                     return segs
-            return eng.trace_tree(batch, cap)
+            return eng.trace_branching(batch, cap)
 
     def _trace_batch_limited(self, eng, scene, batch, cap, fused_ok, counts):
         """`trace_batch` for scenes with `max_interact_count` surfaces.  Their counters are keyed by ray id
@@ -392,7 +393,7 @@ class OpticalTable:
                 host_segs = segs.to_host(reference_order=True)
                 capped = _fused_capped(host_segs, cap)
             else:
-                segs = eng.trace_tree(batch, cap, counts=counts, max_trace_time=max_time)
+                segs = eng.trace_branching(batch, cap, counts=counts, max_trace_time=max_time)
                 host_segs = segs.to_host(reference_order=True)
                 capped = int(segs.capped.sum().item())
                 if capped:  # traces done by the largest truncated tree (what the cap message reports)

@@ -79,6 +79,21 @@ def test_trees_equal_generations_on_bushy_trees(cap, precision):
     _same_as_generations(_lattice(), _lattice_rays(3000, 5, precision), cap)
 
 
+@pytest.mark.parametrize("lds_entries", [1, 2, 3, 8])
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+def test_deep_queues_spill_into_the_scratch_ring_and_keep_their_order(lds_entries, precision):
+    """Bushy trees under a cap of 48: queues of up to 24 rays per lane, of which 1-8 live in LDS and the rest in the global
+    scratch ring — FIFO order across the two rings, whatever the split."""
+    eng = get_engine()
+    try:
+        eng.set_option(abi.OPT_TREES_LDS_ENTRIES, lds_entries)
+        _same_as_generations(_lattice(), _lattice_rays(20_000, 11, precision), 48)
+        plan = eng.trees_plan(precision, 48)
+        assert plan["lds_entries"] == min(lds_entries, 6 if precision == "f64" else 13) and plan["queue"] == plan["lds_entries"] + 24
+    finally:
+        eng.set_option(abi.OPT_TREES_LDS_ENTRIES, 3)
+
+
 def test_trees_whose_rays_all_escape_or_die():
     """Trees of one ray (a miss), of dead input rays, and a batch that is not a multiple of the wave."""
     scene = _lattice()
@@ -95,10 +110,10 @@ def test_a_queue_that_is_too_small_reports_its_trees():
     eng = get_engine()
     eng.upload(scene)
     batch = _lattice_rays(2000, 8)
-    plan = eng.trees_plan("f64", 400)
-    assert plan["kernel"] and not plan["full"] and plan["queue"] < 200
-    trees = eng.trace_trees(batch, 400)
-    gens = eng.trace_tree(batch, 400)
+    plan = eng.trees_plan("f64", 2000)
+    assert plan["kernel"] and not plan["full"] and plan["queue"] < 1000
+    trees = eng.trace_trees(batch, 2000)
+    gens = eng.trace_tree(batch, 2000)
     count = trees.count.cpu().numpy()
     per_tree = np.bincount(gens.field("ray")[: gens.n_valid].cpu().numpy(), minlength=batch.n)
     ok = count > 0

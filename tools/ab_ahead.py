@@ -46,21 +46,25 @@ def run(label, comps, batch, cap, out_cap):
             del segs
     eng.set_option(abi.OPT_GEN_ONEPASS, -1)
     eng.set_option(abi.OPT_GEN_AHEAD, 1)
-    plan = eng.trees_plan(batch.precision, cap)
-    if plan["kernel"] and plan["full"]:
-        from optable_amd.batch import SegmentBatch
-        out = SegmentBatch(batch.n * cap, batch.precision, batch.device)
-        for rnd in range(4):
-            eng.timing(True)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            segs = eng.trace_trees(batch, cap, out=out)
-            torch.cuda.synchronize()
-            wall = (time.perf_counter() - t0) * 1e3
-            ms, launches = eng.timing_read()
-            eng.timing(False)
-            print(f"{label:44s} round {rnd} lane per tree  device {ms:8.3f} ms  wall {wall:8.3f} ms  {launches:4d} timed regions  {int(segs.count.abs().sum())} segments  {eng.last_launch()}", flush=True)
-        del out, segs
+    for ql in [int(q) for q in os.environ.get("QL", "3").split(",")]:
+        eng.set_option(abi.OPT_TREES_LDS_ENTRIES, ql)
+        plan = eng.trees_plan(batch.precision, cap)
+        print(f"{label:44s} lane-per-tree plan {plan}")
+        if plan["kernel"] and plan["full"]:
+            from optable_amd.batch import SegmentBatch
+            out = SegmentBatch(batch.n * cap, batch.precision, batch.device)
+            for rnd in range(4):
+                eng.timing(True)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                segs = eng.trace_trees(batch, cap, out=out)
+                torch.cuda.synchronize()
+                wall = (time.perf_counter() - t0) * 1e3
+                ms, launches = eng.timing_read()
+                eng.timing(False)
+                print(f"{label:44s} round {rnd} lane per tree  device {ms:8.3f} ms  wall {wall:8.3f} ms  {launches:4d} timed regions  {int(segs.count.abs().sum())} segments  {eng.last_launch()}", flush=True)
+            del out, segs
+    eng.set_option(abi.OPT_TREES_LDS_ENTRIES, 3)
 
 
 only = set(filter(None, os.environ.get("ONLY", "").split(",")))
@@ -77,7 +81,8 @@ if not only or "cfg3b" in only:
     del batch
 if not only or "lattice" in only:
     comps = []
-    for k in range(5):
+    LK = int(os.environ.get("LATTICE_K", 5))  # 3: nine components, no grids: the planar preset (and the lane-per-tree kernel)
+    for k in range(LK):
         comps.append(oa.BeamSplitter([2.0 * (k + 1), 0, 0], width=6, height=2, eta=0.5).RotZ(np.pi / 4))
         comps.append(oa.Mirror([2.0 * (k + 1), 3.0 + 0.1 * k, 0], radius=2).RotZ(-np.pi / 2))
         comps.append(oa.BeamSplitter([2.0 * (k + 1) + 1.0, 1.5, 0], width=6, height=2, eta=0.3).RotZ(-np.pi / 4))
@@ -86,5 +91,7 @@ if not only or "lattice" in only:
     o = np.stack([np.zeros(n), rng.uniform(-0.3, 0.3, n), rng.uniform(-0.2, 0.2, n)], 1)
     d = np.stack([np.ones(n), rng.uniform(-0.02, 0.02, n), rng.uniform(-0.01, 0.01, n)], 1)
     batch = RayBatch.from_arrays(o, d, wavelength=W.WL, q=Q)
-    for cap in (12, 24):
-        run(f"beam-splitter lattice: 1e6 trees, cap {cap}, fp64", comps, batch, cap, n * (cap + 1))
+    for prec in os.environ.get("PRECS", "f64").split(","):
+        b = batch if prec == "f64" else batch.astype(prec)
+        for cap in [int(c) for c in os.environ.get("CAPS", "12,24").split(",")]:
+            run(f"beam-splitter lattice x{LK}: 1e6 trees, cap {cap}, {prec}", comps, b, cap, n * (cap + 1))
