@@ -43,8 +43,15 @@ template <> GenOneKern<T> gen_one_kernel<T>(int fg, bool lds) {
     return nullptr;
 }
 
-// k_trace_trees: light planar scenes (beam splitters, partially reflecting slabs, mirrors, thin lenses)
+// k_trace_trees: the planar preset, planar scenes under grids (single precision, as their generation kernels) and the everyday
+// parts; 2 waves per SIMD in double precision (the rarer shapes: 1 — 256 registers would spill), 3 in single: the register
+// caps the queues' LDS leaves room for (tables.h tree_minw)
 template <> TreeKern<T> tree_kernel<T>(int fg) {
-    if (fg == 0) return k_trace_trees<T, FB, (sizeof(T) == 8 ? 2 : 3)>;
+    if (fg == 0) return k_trace_trees<T, FB, tree_minw<T>(0)>;
+    if constexpr (sizeof(T) == 4) {
+        if (fg == 1) return k_trace_trees<T, FC, tree_minw<T>(1)>;
+    }
+    if (fg == 2) return k_trace_trees<T, FE, tree_minw<T>(2)>;
+    if (fg == 3) return k_trace_trees<T, FM, tree_minw<T>(3)>;
     return nullptr;
 }

@@ -1171,7 +1171,7 @@ template <class T> static bool trees_plan(const ot_ctx* c, int32_t cap, TreesPla
     if (ql > fit) ql = fit;
     p->QL = (int32_t)ql;
     p->lds_bytes = img + 4 * (size_t)ql * entry;
-    const int by_lds = (int)((160 * 1024) / (p->lds_bytes + 256)), by_regs = sizeof(T) == 8 ? 2 : 3;  // (launch bounds: 2 / 3 waves per SIMD; single precision at 4 would spill)
+    const int by_lds = (int)((160 * 1024) / (p->lds_bytes + 256)), by_regs = tree_minw<T>(gen_preset(c->features));  // (launch bounds: waves per SIMD)
     p->groups_per_cu = by_lds < by_regs ? (by_lds < 1 ? 1 : by_lds) : by_regs;
     const int64_t waves = (int64_t)c->n_cus * p->groups_per_cu * 4, most = ((int64_t)1 << 30) / (waves * (int64_t)entry);
     // (the scratch ring alone must hold a whole queue: pushes keep going there while the LDS entries in front of them drain)

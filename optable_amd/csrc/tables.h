@@ -60,6 +60,9 @@ template <class T> GenKern<T> gen_ahead_kernel(int fg, bool lds);
 template <class T> ProbeKern<T> probe_kernel(int fg, bool lds);
 // k_trace_trees (a lane per tree, the FIFO in LDS): fg as above; nullptr where no instantiation exists
 template <class T> TreeKern<T> tree_kernel(int fg);
+// ... and the waves per SIMD its registers are capped for (its workgroups per CU: 256 threads = one wave per SIMD each)
+// (measured with one wave per SIMD more — 168 / 128 registers, 39 / 2 of them spilled: cfg 4 R = 0.2 6.8 instead of 4.3 ms in double precision, 3-5 % faster in single)
+template <class T> constexpr int tree_minw(int fg) { return sizeof(T) == 4 ? 3 : (fg == 3 ? 1 : 2); }
 // k_gen_one (one pass per generation, decoupled look-back): fg as above; nullptr where no instantiation exists
 template <class T> GenOneKern<T> gen_one_kernel(int fg, bool lds);
 

@@ -119,3 +119,47 @@ def test_a_queue_that_is_too_small_reports_its_trees():
     ok = count > 0
     np.testing.assert_array_equal(count[ok], per_tree[ok])
     assert np.all(-count[~ok] <= per_tree[~ok])  # an overflowed tree stopped early, and says how far it got
+
+
+def _everyday(dove):
+    comps = [oa.BeamSplitter([3.0, 0, 0], width=6, height=3, eta=0.4).RotZ(np.pi / 4),
+             oa.Mirror([3.0, 3.5, 0], radius=3).RotZ(-np.pi / 2),
+             oa.Block([8, 0.4, 0], hole=oa.Circle(0.6), width=3, height=3),
+             oa.BiConvexLens([11, 0.4, 0], CT=0.6, R1=12.0, R2=-12.0, diameter=3.0, n=1.5),
+             oa.BeamSplitter([13.5, 0.4, 0], width=6, height=3, eta=0.7).RotZ(-np.pi / 4),
+             oa.Mirror([16, 0.4, 0], radius=3.0).RotZ(np.pi + 0.05)]
+    if dove:
+        comps.insert(3, oa.DovePrism([9.5, 0.1, 0], L=1.2, D=0.5, Ng=1.5))
+    t = oa.OpticalTable()
+    t.add_components(comps)
+    return t.compile()
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+@pytest.mark.parametrize("dove", [False, True], ids=["FE", "FM"])
+def test_trees_of_everyday_parts(dove, precision, oracle):
+    """Beam splitters around a holed block, a biconvex lens (and a dove prism's tilted polygon faces): the lane-per-tree
+    kernels of the presets FE / FM against the generation kernels, bit for bit, and against the oracle."""
+    scene = _everyday(dove)
+    rng = np.random.default_rng(12)
+    n = 4000
+    o = np.stack([np.zeros(n), rng.uniform(-0.5, 0.5, n), rng.uniform(-0.4, 0.4, n)], 1)
+    d = np.stack([np.ones(n), rng.uniform(-0.03, 0.03, n), rng.uniform(-0.02, 0.02, n)], 1)
+    batch = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=Q, precision=precision)
+    _, got = _same_as_generations(scene, batch, 16)
+    assert len(got["ray"]) > 3 * n
+    if precision == "f64":
+        ref = oracle.trace(scene, batch.to_host(), max_trace_num=16)
+        np.testing.assert_array_equal(got["ray"], ref["ray"])
+        np.testing.assert_array_equal(got["surface"], ref["surface"])
+        for f in abi.SEG_FIELDS:
+            np.testing.assert_allclose(got[f], ref[f], rtol=1e-9, atol=1e-9, err_msg=f)
+
+
+def test_trees_under_grids_in_single_precision():
+    """cfg 3 with 10 % reflecting slab faces: 32 components under a top-level grid (the planar preset with grid walks, fp32)."""
+    table = oa.OpticalTable()
+    table.add_components(W.cfg3_components(oa, slab_reflectivity=0.1))
+    o, d = W.cfg3_rays(100_000, 2)
+    batch = RayBatch.from_arrays(o, d, wavelength=W.WL, q=Q, precision="f32")
+    _same_as_generations(table.compile(), batch, 20)

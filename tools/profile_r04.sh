@@ -32,7 +32,7 @@ for w in $WL; do
   rocprofv3 --pmc $SQ_B --output-format csv -d $OUT/$w/sq_b -- $P > $OUT/$w/sq_b.log 2>&1 || echo "$w sq_b failed"
   rocprofv3 --pmc $SQ_E --output-format csv -d $OUT/$w/sq_e -- $P > $OUT/$w/sq_e.log 2>&1 || echo "$w sq_e failed"
   rocprofv3 --pmc $SQ_F --output-format csv -d $OUT/$w/sq_f -- $P > $OUT/$w/sq_f.log 2>&1 || echo "$w sq_f failed"
-  if [ "$w" = calib ] || [ "$w" = cfg3 ] || [ "$w" = cfg5 ]; then
+  if [ "$w" = calib ] || [ "$w" = cfg3 ] || [ "$w" = cfg5 ] || [ "$w" = cfg4b ]; then
     rocprofv3 --pmc $SQ_C --output-format csv -d $OUT/$w/sq_c -- $P > $OUT/$w/sq_c.log 2>&1 || echo "$w sq_c failed"
     rocprofv3 --pmc $SQ_D --output-format csv -d $OUT/$w/sq_d -- $P > $OUT/$w/sq_d.log 2>&1 || echo "$w sq_d failed"
   fi

@@ -75,11 +75,17 @@ elif name in ("cfg4", "cfg4b"):
         torch.cuda.synchronize()
         print(f"cfg4: {batch.n} ray-wavelength pairs, {int(out.count.abs().sum())} segments per trace, {reps} traces, layout {LAYOUT}")
     else:
-        for _ in range(max(reps // 2, 2)):
+        for _ in range(max(reps, 2)):
             t0 = time.perf_counter()
-            segs = eng.trace_tree(batch, 12, out_capacity=batch.n * 13)
+            if os.environ.get("GENLOOP"):  # the generation loop (count / recount + scan + emit per generation) instead of the default call
+                segs = eng.trace_tree(batch, 12, out_capacity=batch.n * 13)
+                n_seg = segs.n_valid
+            else:  # one launch, a lane per tree (k_trace_trees)
+                segs = eng.trace_branching(batch, 12)
+                n_seg = int(segs.count.abs().sum())
             torch.cuda.synchronize()
-            print(f"cfg4b: {batch.n} trees, {segs.n_valid} segments, {1e3 * (time.perf_counter() - t0):.1f} ms wall")
+            print(f"cfg4b: {batch.n} trees, {n_seg} segments per trace, {1e3 * (time.perf_counter() - t0):.1f} ms wall, layout {segs.layout}")
+            del segs
 elif name == "cfg3b":  # heavy branching: cfg 3 with 10 % reflecting slab faces, trees capped at 20 segments, fp32
     table = oa.OpticalTable()
     table.add_components(W.cfg3_components(oa, slab_reflectivity=0.1))

@@ -19,7 +19,7 @@ import sys
 raw, dst = sys.argv[1], sys.argv[2]
 os.makedirs(dst, exist_ok=True)
 OURS = ("k_trace_", "k_gen_", "k_mon_", "k_stream_")
-RECORD_BYTES = {"cfg2": 104, "cfg4": 104, "cfg3": 56, "cfg5": 56, "allfeat64": 104, "allfeat32": 56}  # per ray record and per segment record
+RECORD_BYTES = {"cfg2": 104, "cfg4": 104, "cfg4b": 104, "cfg3": 56, "cfg5": 56, "allfeat64": 104, "allfeat32": 56}  # per ray record and per segment record
 N_SIMD, N_XCD, N_CU = 1024, 8, 256
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -124,7 +124,7 @@ def algorithmic_bytes(wdir, w):
         text = open(os.path.join(wdir, "trace.log")).read()
     except OSError:
         return None
-    m = re.search(r"(\d+) (?:rays|ray-wavelength pairs), (\d+) segments per trace", text)
+    m = re.search(r"(\d+) (?:rays|ray-wavelength pairs|trees), (\d+) segments per trace", text)
     return (int(m.group(1)) + int(m.group(2))) * RECORD_BYTES[w] if m else None
 
 
