@@ -340,7 +340,9 @@ def survey_branching(oa, eng, device):
     base = RayBatch.from_arrays(o, d, wavelength=W.WL, q=1j * np.pi * W.W0**2 / W.WL, precision="f64", device=device)
     batch = base.multiplexed_in_wavelength(np.linspace(400e-7, 1100e-7, W.CFG4_WAVELENGTHS))
     def timed(fn):
-        fn()  # warm: output arrays, scratch and generation buffers
+        for _ in range(2):  # warm: output arrays (the allocator's cache), scratch and generation buffers
+            fn()
+        torch.cuda.synchronize()
         eng.timing(True)
         t0 = time.perf_counter()
         segs = fn()

@@ -333,8 +333,13 @@ __global__ __launch_bounds__(256, MINW) void k_trace_trees(SceneBlob blob, T uni
         bool active = i < n, overflow = false;
         RayState<T> r = {};
         int32_t k = 0;                     // rays processed
-        int32_t lhead = 0, llen = 0;       // LDS ring: position of the oldest entry, entries
-        int32_t ghead = 0, glen = 0;       // scratch ring (the queue behind the LDS entries)
+        // the two rings in one register (QL, QG <= 255): LDS ring head | entries << 8 | scratch ring head << 16 | entries << 24
+        uint32_t qs = 0;
+        auto lhead = [&]() -> int { return (int)(qs & 255u); };
+        auto llen = [&]() -> int { return (int)((qs >> 8) & 255u); };
+        auto ghead = [&]() -> int { return (int)((qs >> 16) & 255u); };
+        auto glen = [&]() -> int { return (int)(qs >> 24); };
+        auto queued = [&]() -> int { return llen() + glen(); };
         MatCache<T> mc = {T(1)};
         if (active) {
             const int32_t fl = in.flags[i];
@@ -363,20 +368,20 @@ __global__ __launch_bounds__(256, MINW) void k_trace_trees(SceneBlob blob, T uni
                 }
                 const int32_t left = cap - k;  // rays this tree may still process
                 // a first child behind an empty queue is the next ray: it stays in registers
-                const bool direct = nk > 0 && left > 0 && llen + glen == 0;
+                const bool direct = nk > 0 && left > 0 && (qs & 0xff00ff00u) == 0;
                 int32_t pos = direct ? 1 : 0;  // queue position the next push would get, counted from the next ray to process
                 auto push = [&](const RayState<T>& c) {
-                    if (llen + glen + pos >= left) return;  // would never be processed (optical_table.py:138-144 drops it with the queue)
-                    if (glen == 0 && llen < QL) {
-                        int e = lhead + llen;
+                    if (queued() + pos >= left) return;  // would never be processed (optical_table.py:138-144 drops it with the queue)
+                    if (glen() == 0 && llen() < QL) {
+                        int e = lhead() + llen();
                         if (e >= QL) e -= QL;
                         put(ring, e, c);
-                        ++llen;
-                    } else if (glen < QG) {
-                        int e = ghead + glen;
+                        qs += 1u << 8;
+                    } else if (glen() < QG) {
+                        int e = ghead() + glen();
                         if (e >= QG) e -= QG;
                         put(gring, e, c);
-                        ++glen;
+                        qs += 1u << 24;
                     } else {
                         overflow = true;
                     }
@@ -387,15 +392,15 @@ __global__ __launch_bounds__(256, MINW) void k_trace_trees(SceneBlob blob, T uni
                 const int32_t has_q = r.has_q;
                 if (direct) {
                     r = ch[0];
-                } else if (llen + glen > 0 && left > 0 && !overflow) {
-                    if (llen > 0) {
-                        get(ring, lhead, r);
-                        lhead = lhead + 1 == QL ? 0 : lhead + 1;
-                        --llen;
+                } else if ((qs & 0xff00ff00u) != 0 && left > 0 && !overflow) {
+                    if (llen() > 0) {
+                        const int e = lhead();
+                        get(ring, e, r);
+                        qs = ((qs & ~255u) | (uint32_t)(e + 1 == QL ? 0 : e + 1)) - (1u << 8);
                     } else {
-                        get(gring, ghead, r);
-                        ghead = ghead + 1 == QG ? 0 : ghead + 1;
-                        --glen;
+                        const int e = ghead();
+                        get(gring, e, r);
+                        qs = ((qs & ~(255u << 16)) | ((uint32_t)(e + 1 == QG ? 0 : e + 1) << 16)) - (1u << 24);
                     }
                     r.wl = wl; r.has_q = has_q; r.len = Num<T>::inf();
                 } else {

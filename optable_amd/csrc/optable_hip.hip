@@ -1169,11 +1169,14 @@ template <class T> static bool trees_plan(const ot_ctx* c, int32_t cap, TreesPla
     const int64_t need = ((int64_t)cap + 1) / 2, fit = (int64_t)((room - img) / (4 * entry));
     int64_t ql = c->opt_trees_lds < need ? c->opt_trees_lds : need;
     if (ql > fit) ql = fit;
+    if (ql > 255) ql = 255;
     p->QL = (int32_t)ql;
     p->lds_bytes = img + 4 * (size_t)ql * entry;
-    const int by_lds = (int)((160 * 1024) / (p->lds_bytes + 256)), by_regs = tree_minw<T>(gen_preset(c->features));  // (launch bounds: waves per SIMD)
+    const int by_lds = (int)((160 * 1024) / (p->lds_bytes + 256)), by_regs = tree_groups_by_registers<T>(gen_preset(c->features));  // (waves per SIMD the kernel's registers allow)
     p->groups_per_cu = by_lds < by_regs ? (by_lds < 1 ? 1 : by_lds) : by_regs;
-    const int64_t waves = (int64_t)c->n_cus * p->groups_per_cu * 4, most = ((int64_t)1 << 30) / (waves * (int64_t)entry);
+    const int64_t waves = (int64_t)c->n_cus * p->groups_per_cu * 4;
+    int64_t most = ((int64_t)1 << 30) / (waves * (int64_t)entry);
+    if (most > 255) most = 255;  // (the kernel keeps ring positions in bytes)
     // (the scratch ring alone must hold a whole queue: pushes keep going there while the LDS entries in front of them drain)
     const int64_t qg = need > ql ? need : 0;
     p->QG = (int32_t)(qg < most ? qg : most);

@@ -104,3 +104,17 @@ def test_everyday_presets_keep_their_register_budgets(kernels):
         assert max(k["vgpr"] for k in fm64) <= 256, [(k["name"][:40], k["vgpr"]) for k in fm64]
     all32 = of("k_trace_fused", "f", 1023)
     assert all32 and min(k["vgpr"] for k in all32) > 150  # (what the split is measured against)
+
+
+def test_single_precision_tree_kernels_fit_four_waves_per_simd(kernels):
+    """k_trace_trees in single precision (presets FB = 28, FC = 732, FE = 63) is launched with four workgroups of four waves
+    per CU (tables.h tree_groups_by_registers): that needs 128 registers or fewer; double precision two (256)."""
+    def of(real, mask):
+        return [k for k in kernels if re.match(rf"_Z\d+k_trace_treesI{real}Lj{mask}E", k["name"])]
+
+    for mask in (28, 732, 63):
+        ks = of("f", mask)
+        assert ks and max(k["vgpr"] for k in ks) <= 128, (mask, [(k["name"][:40], k["vgpr"]) for k in ks])
+    for mask in (28, 63):
+        ks = of("d", mask)
+        assert ks and max(k["vgpr"] for k in ks) <= 256, (mask, [(k["name"][:40], k["vgpr"]) for k in ks])
