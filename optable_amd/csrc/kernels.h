@@ -298,11 +298,13 @@ __global__ __launch_bounds__(256, MINW) void k_trace_fused(SceneBlob blob, T uni
 // tree whose rings overflow reports -(segments so far) and the caller takes the generation path.
 // Output: the [k][tree] slots of ot_trace_* — slot k * n + i is the k-th ray of tree i in FIFO order, which IS the
 // reference's order; seg_count[i] = rays processed (== cap: the cap cut the tree short or the tree ended exactly there,
-// as `budget <= 0` on the generation path).  Scenes without count-limited leaves (their counters are shared between trees).
+// as `budget <= 0` on the generation path).  Count-limited leaves: one column of the counts table per tree (rays that share
+// an id are the caller's successive launches, as for ot_trace_*).
 template <class T> constexpr int tree_entry_bytes() { return 64 * (11 * (int)sizeof(T) + 4); }
 template <class T, uint32_t F, int MINW>
 __global__ __launch_bounds__(256, MINW) void k_trace_trees(SceneBlob blob, T unit, RaysT<T> in, int64_t n, int32_t cap, int32_t QL, int32_t QG,
-                                                           uint8_t* __restrict__ scratch, SegsT<T> out, int32_t* __restrict__ seg_count) {
+                                                           uint8_t* __restrict__ scratch, SegsT<T> out, int32_t* __restrict__ seg_count,
+                                                           int32_t* counts, int32_t n_classes) {
     extern __shared__ __align__(16) uint32_t lds[];
     for (int w = threadIdx.x; w < blob.n_words; w += blockDim.x) lds[w] = blob.words[w];
     __syncthreads();
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(256, MINW) void k_trace_trees(SceneBlob blob, T uni
         const int64_t i = i0 + threadIdx.x;
         bool active = i < n, overflow = false;
         RayState<T> r = {};
-        int32_t k = 0;                     // rays processed
+        int32_t k = 0, cls = 0;            // rays processed; the tree's column of the interact-count table
         // the two rings in one register (QL, QG <= 255): LDS ring head | entries << 8 | scratch ring head << 16 | entries << 24
         uint32_t qs = 0;
         auto lhead = [&]() -> int { return (int)(qs & 255u); };
@@ -346,6 +348,7 @@ __global__ __launch_bounds__(256, MINW) void k_trace_trees(SceneBlob blob, T uni
             r = load_ray(in, i, fl);
             if ((uint32_t)r.last >= (uint32_t)sc.n_nodes) r.last = -1;
             if constexpr (F & F_REFRACT) mc = make_matcache<T, F>(sc, r.wl);
+            cls = in.id[i];
             if (fl & OT_RAY_DEAD) {  // optical_component.py:349: a dead ray hits nothing and is returned as is
                 store_segment<T, false>(out, i, r, r.len, (int32_t)i, -2);
                 k = 1;
@@ -353,7 +356,9 @@ __global__ __launch_bounds__(256, MINW) void k_trace_trees(SceneBlob blob, T uni
             }
         }
         while (__any(active)) {
-            const GateCtx gate = {nullptr, 0, 0, nullptr, nullptr, 0, 0};
+            // count-limited leaves (optical_component.py:140-149): a tree's rays meet them one after the other in FIFO order, as
+            // the reference's loop does — exact as long as no other tree of the launch shares the column (the host API's rounds)
+            const GateCtx gate = {counts, n_classes, cls, nullptr, nullptr, 0, 0};
             const Hit<T> h = nearest_hit<T, F, GATE_PLAIN>(sc, r, active, gate);
             if (active) {
                 const int64_t slot = (int64_t)k * n + i;

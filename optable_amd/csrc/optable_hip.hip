@@ -1163,7 +1163,7 @@ struct TreesPlan { int32_t QL, QG, full, groups_per_cu; size_t lds_bytes; };
 template <class T> static bool trees_plan(const ot_ctx* c, int32_t cap, TreesPlan* p) {
     const size_t image = sizeof(T) == 8 ? c->bytes64 : c->bytes32;
     *p = TreesPlan{};
-    if (!c->has_scene || c->n_slots > 0 || c->max_children > 2 || cap < 1 || !tree_kernel<T>(gen_preset(c->features))) return false;
+    if (!c->has_scene || c->max_children > 2 || cap < 1 || !tree_kernel<T>(gen_preset(c->features))) return false;
     const size_t room = 160 * 1024 - 1024, img = (image + 15) & ~(size_t)15, entry = (size_t)tree_entry_bytes<T>();
     if (img + 4 * entry > room) return false;
     const int64_t need = ((int64_t)cap + 1) / 2, fit = (int64_t)((room - img) / (4 * entry));
@@ -1184,13 +1184,14 @@ template <class T> static bool trees_plan(const ot_ctx* c, int32_t cap, TreesPla
     return true;
 }
 template <class T>
-static int trace_trees(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t cap, const ot_segments* out, int32_t* seg_count) {
-    int rc = check_trace_args(c, rays, n, cap, seg_count, nullptr, 0);
+static int trace_trees(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t cap, const ot_segments* out, int32_t* seg_count, int32_t* counts,
+                       int32_t n_classes) {
+    int rc = check_trace_args(c, rays, n, cap, seg_count, counts, n_classes);
     if (rc) return rc;
     rc = check_segs(out);
     if (rc) return rc;
     TreesPlan p;
-    if (!trees_plan<T>(c, cap, &p)) return fail(OT_ERR_UNSUPPORTED, "no tree kernel for this scene (count-limited surfaces, features beyond the planar preset, or an image that leaves no room for the queues): use ot_trace_tree_*");
+    if (!trees_plan<T>(c, cap, &p)) return fail(OT_ERR_UNSUPPORTED, "no tree kernel for this scene (features beyond the everyday presets, or an image that leaves no room for the queues): use ot_trace_tree_*");
     if (n == 0) return 0;
     HIP_TRY(hipSetDevice(c->device));
     const TreeKern<T> kern = tree_kernel<T>(gen_preset(c->features));
@@ -1204,7 +1205,7 @@ static int trace_trees(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t cap, c
     if (rc) return rc;
     if (p.lds_bytes > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
     hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), (uint32_t)p.lds_bytes, c->stream, ev0, ev1, 0u, blob, (T)c->unit, view<T>(rays), n, cap, p.QL, p.QG,
-                          (uint8_t*)c->trees.p, view<T>(out), seg_count);
+                          (uint8_t*)c->trees.p, view<T>(out), seg_count, counts, n_classes);
     HIP_TRY(hipGetLastError());
     const int32_t shape[8] = {4, 256, p.groups_per_cu, (int32_t)grid, (int32_t)p.lds_bytes, p.QL, p.QG, 0};
     for (int q = 0; q < 8; ++q) c->last_launch[q] = shape[q];
@@ -1368,11 +1369,13 @@ static int trace_tree(ot_ctx* c, const ot_rays* rays, const int32_t* tree, int64
 
 extern "C" {
 
-int ot_trace_trees_f64(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t max_trace_num, const ot_segments* out, int32_t* seg_count) {
-    return trace_trees<double>(c, rays, n, max_trace_num, out, seg_count);
+int ot_trace_trees_f64(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t max_trace_num, const ot_segments* out, int32_t* seg_count, int32_t* counts,
+                       int32_t n_classes) {
+    return trace_trees<double>(c, rays, n, max_trace_num, out, seg_count, counts, n_classes);
 }
-int ot_trace_trees_f32(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t max_trace_num, const ot_segments* out, int32_t* seg_count) {
-    return trace_trees<float>(c, rays, n, max_trace_num, out, seg_count);
+int ot_trace_trees_f32(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t max_trace_num, const ot_segments* out, int32_t* seg_count, int32_t* counts,
+                       int32_t n_classes) {
+    return trace_trees<float>(c, rays, n, max_trace_num, out, seg_count, counts, n_classes);
 }
 int ot_trace_trees_plan(ot_ctx* c, int32_t real_bytes, int32_t max_trace_num, int32_t* info) {
     if (!c || !info || (real_bytes != 4 && real_bytes != 8)) return fail(OT_ERR_INVALID, "bad ot_trace_trees_plan arguments");

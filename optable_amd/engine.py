@@ -280,11 +280,13 @@ class Engine:
         abi.check(self.lib.ot_trace_trees_plan(self._ctx, 8 if precision == "f64" else 4, int(max_trace_num), info), self.lib)
         return {"kernel": bool(info[0]), "queue": int(info[1]), "full": bool(info[2]), "lds_entries": int(info[3])}
 
-    def trace_trees(self, rays: RayBatch, max_trace_num, out: SegmentBatch = None):
+    def trace_trees(self, rays: RayBatch, max_trace_num, out: SegmentBatch = None, counts=None):
         """Whole ray trees in one launch, a lane per tree with its FIFO in LDS (ot_trace_trees_*): a SegmentBatch in the
         `slots` layout — slot k * n + i = the k-th ray of tree i in the reference's order, count[i] = rays of tree i
         (negative: the tree's queue overflowed, possible only when `trees_plan()["full"]` is False; take trace_tree then).
-        `capped` as trace_tree reports it."""
+        `capped` as trace_tree reports it.  `counts`: the interact-count table of scenes with limited surfaces
+        ([surfaces, classes], rays.id = column; default: a zeroed column per ray) — exact when no two trees of the call
+        share a column."""
         if self.scene is None:
             raise RuntimeError("upload a scene first")
         self._check_wavelengths(rays)
@@ -295,12 +297,16 @@ class Engine:
             raise ValueError("out: plain slot arrays of max_trace_num * n_rays slots in the rays' precision")
         out.count = torch.empty(n, dtype=torch.int32, device=rays.device)
         out.n_rays = n
+        n_slots = len(self.scene.limited)
+        if n_slots and counts is None:
+            counts = torch.zeros((n_slots, max(n, 1)), dtype=torch.int32, device=rays.device)
+        n_classes = 0 if counts is None else counts.shape[1]
         fn = self.lib.ot_trace_trees_f64 if prec == "f64" else self.lib.ot_trace_trees_f32
         rs, ss = rays.c_struct(), out.c_struct()
-        abi.check(fn(self._ctx, C.byref(rs), n, K, C.byref(ss), out.count.data_ptr()), self.lib)
+        abi.check(fn(self._ctx, C.byref(rs), n, K, C.byref(ss), out.count.data_ptr(), None if counts is None else counts.data_ptr(), n_classes), self.lib)
         out.capped = out.count >= K
         out.timed_out = False
-        out.counts_table = None
+        out.counts_table = counts
         return out
 
     # A lane-per-tree launch whose queues may overflow (caps beyond ~170 in double precision) is a speculation on small trees:
@@ -308,20 +314,26 @@ class Engine:
     TREES_SMALL_BATCH = 64 * 256
     TREES_SPECULATIVE_SLOTS = 1 << 20
 
-    def trace_branching(self, rays: RayBatch, max_trace_num, counts=None, max_trace_time=None):
+    def trace_branching(self, rays: RayBatch, max_trace_num, counts=None, max_trace_time=None, distinct_ids=None):
         """Ray trees by whichever path the scene and the cap allow: ONE launch with a lane per tree (`trace_trees`: [k][tree]
         slots in the reference's order) when the scene has such a kernel and its queues hold every possible tree — or, for
         larger caps, speculatively when the batch is small (a tree that overflows its queue sends the call to the
         generations) — else the generation loop (`trace_tree`: a list in generation order).  Readers take both layouts;
-        `capped` / `timed_out` are set either way."""
+        `capped` / `timed_out` are set either way.  Scenes with count-limited surfaces: the lane-per-tree kernel meets them in
+        each tree's FIFO order, which is the reference's as long as no two trees of the call share a column of `counts`
+        (`distinct_ids=True`: the caller vouches for it, as the host API's rounds do; default: such scenes take the generations)."""
         n, K = rays.n, int(max_trace_num)
-        if n and counts is None and not self.scene.limited and (max_trace_time is None or max_trace_time > 1.0):
+        gates_ok = not self.scene.limited or bool(distinct_ids)
+        if n and gates_ok and (max_trace_time is None or max_trace_time > 1.0):
             plan = self.trees_plan(rays.precision, K)
             if plan["kernel"] and (plan["full"] or (n <= self.TREES_SMALL_BATCH and n * K <= self.TREES_SPECULATIVE_SLOTS)):
-                segs = self.trace_trees(rays, K)
+                before = counts.clone() if (counts is not None and not plan["full"]) else None  # a speculation must not leave counts behind
+                segs = self.trace_trees(rays, K, counts=counts)
                 if plan["full"] or not bool((segs.count < 0).any()):
                     return segs
                 del segs
+                if before is not None:
+                    counts.copy_(before)
         return self.trace_tree(rays, K, counts=counts, max_trace_time=max_trace_time)
 
     def trace_tree(self, rays: RayBatch, max_trace_num, counts=None, out_capacity=None, max_trace_time=None):

@@ -162,7 +162,8 @@ class OpticalTable:
         fused = fused_ok and scene.max_children <= 1
 
         def run(sub):
-            return eng.trace(sub, cap, counts=counts) if fused else eng.trace_tree(sub, cap, counts=counts)
+            # (a run holds every id once: the lane-per-tree kernel's FIFO order per tree is the reference's)
+            return eng.trace(sub, cap, counts=counts) if fused else eng.trace_branching(sub, cap, counts=counts, distinct_ids=True)
 
         if n_classes == n:
             segs = run(work)
@@ -186,15 +187,21 @@ class OpticalTable:
                     out.field(f).view(cap, n)[:, idx] = part.field(f).view(cap, m)
                 out.ray.view(cap, n)[:, idx] = idx.to(torch.int32).unsqueeze(0).expand(cap, m)
         else:  # flat lists: concatenate, tree indices back to positions in `batch`
-            total = sum(part.n_valid for _, part in parts)
+            def valid(part):  # slots a round's trace filled: the first n_valid of a list; of [k][tree] slots (lane-per-tree launch) row by
+                if part.count is None:  # row, which keeps every tree's rays in their FIFO order
+                    return slice(0, part.n_valid), part.n_valid
+                keep = part.valid_mask()
+                return keep, int(keep.sum().item())
+
+            picks = [valid(part) for _, part in parts]
+            total = sum(v for _, v in picks)
             out = SegmentBatch(total, batch.precision, dev)
             out.capped = torch.zeros(n, dtype=torch.bool, device=dev)
             at = 0
-            for idx, part in parts:
-                v = part.n_valid
+            for (idx, part), (keep, v) in zip(parts, picks):
                 for f in abi.SEG_FIELDS + ("surface",):
-                    out.field(f)[at:at + v] = part.field(f)[:v]
-                out.ray[at:at + v] = idx[part.ray[:v].long()].to(torch.int32)
+                    out.field(f)[at:at + v] = part.field(f)[keep]
+                out.ray[at:at + v] = idx[part.ray[keep].long()].to(torch.int32)
                 out.capped[idx] = part.capped
                 at += v
             out.n_valid = total
@@ -393,7 +400,7 @@ class OpticalTable:
                 host_segs = segs.to_host(reference_order=True)
                 capped = _fused_capped(host_segs, cap)
             else:
-                segs = eng.trace_branching(batch, cap, counts=counts, max_trace_time=max_time)
+                segs = eng.trace_branching(batch, cap, counts=counts, max_trace_time=max_time, distinct_ids=True)  # (a round holds every id once)
                 host_segs = segs.to_host(reference_order=True)
                 capped = int(segs.capped.sum().item())
                 if capped:  # traces done by the largest truncated tree (what the cap message reports)

@@ -163,3 +163,57 @@ def test_trees_under_grids_in_single_precision():
     o, d = W.cfg3_rays(100_000, 2)
     batch = RayBatch.from_arrays(o, d, wavelength=W.WL, q=Q, precision="f32")
     _same_as_generations(table.compile(), batch, 20)
+
+
+@pytest.mark.parametrize("dove", [False, True], ids=["FE", "FM"])
+def test_trees_through_count_limited_faces_match_the_oracle(dove, oracle):
+    """A prism whose entrance face splits every ray and whose faces are count-limited (max_interact_count): a tree's rays meet
+    the gate one after the other in FIFO order — the reference's order — so the lane-per-tree kernel needs no probe pass;
+    through trace_batch (one column of the counts table per ray), against the generation kernels and the oracle."""
+    import test_gpu_presets as P
+
+    table = oa.OpticalTable()
+    table.add_components(P._parts(dove, split=0.3))
+    scene = table.compile()
+    assert scene.max_children == 2 and len(scene.limited) == 2
+    batch = P._rays(1500, "f64")
+    eng = get_engine()
+    segs = table.trace_batch(batch, max_segments=14, scene=scene)
+    assert segs.layout == "slots" and eng.last_launch()["kernel"] == 4  # the lane-per-tree kernel took it
+    got = segs.to_host(reference_order=True)
+    ref = oracle.trace(scene, batch.to_host(), max_trace_num=14)
+    assert len(ref["ray"]) > 3 * batch.n
+    np.testing.assert_array_equal(got["ray"], ref["ray"])
+    np.testing.assert_array_equal(got["surface"], ref["surface"])
+    for f in abi.SEG_FIELDS:
+        np.testing.assert_allclose(got[f], ref[f], rtol=1e-9, atol=1e-9, err_msg=f)
+    eng.upload(scene)
+    gens = eng.trace_tree(batch, 14).to_host(reference_order=True)  # the generation kernels (probe pass + per-slot scans)
+    for f in abi.SEG_FIELDS + ("ray", "surface"):
+        np.testing.assert_array_equal(got[f], gens[f], err_msg=f)
+    # the counters the trace leaves behind are the generation path's
+    table2 = eng.trace_tree(batch, 14).counts_table
+    assert torch.equal(segs.counts_table, table2)
+
+
+def test_rays_sharing_an_id_take_their_counts_in_input_order():
+    """Copies of a ray under one id (multiplexed_in_wavelength) share the counters of a limited face: the host API traces them
+    in successive rounds, each round one lane-per-tree launch over the same table."""
+    import test_gpu_presets as P
+
+    table = oa.OpticalTable()
+    table.add_components(P._parts(False, split=0.3))
+    scene = table.compile()
+    base = P._rays(300, "f64")
+    batch = base.multiplexed_in_wavelength(np.array([scenes.WL, 0.9 * scenes.WL, 1.1 * scenes.WL]))
+    eng = get_engine()
+    segs = table.trace_batch(batch, max_segments=10, scene=scene)
+    try:
+        eng.set_option(abi.OPT_TREES_LDS_ENTRIES, 1)  # (another split of the queues: same records)
+        again = table.trace_batch(batch, max_segments=10, scene=scene)
+    finally:
+        eng.set_option(abi.OPT_TREES_LDS_ENTRIES, 3)
+    a, b = segs.to_host(reference_order=True), again.to_host(reference_order=True)
+    for f in abi.SEG_FIELDS + ("ray", "surface"):
+        np.testing.assert_array_equal(a[f], b[f], err_msg=f)
+    assert torch.equal(segs.counts_table, again.counts_table)
