@@ -18,6 +18,9 @@ from optable_amd.batch import RayBatch, SegmentBatch
 from optable_amd.engine import get_engine
 
 name = sys.argv[1]
+GENLOOP = bool(os.environ.get("GENLOOP")) or name == "cfg4bgen"  # cfg4bgen: cfg4b through the generation loop instead of the default call
+if name == "cfg4bgen":
+    name = "cfg4b"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else {"cfg2": 400, "cfg3": 20}.get(name, 5)  # cfg3: enough launches that the clock ramp of the first ones does not carry the average
 SIZES = {"cfg2": 1_000_000, "cfg3": 10_000_000, "cfg4": 160_000_000, "cfg5": 12_500_000, "cfg4b": 12_800_000, "cfg3b": 2_000_000, "monitor": 1_000_000, "allfeat64": 1_000_000, "allfeat32": 1_000_000}
 n = int(os.environ.get("RAYS", SIZES[name]))
@@ -77,7 +80,7 @@ elif name in ("cfg4", "cfg4b"):
     else:
         for _ in range(max(reps, 2)):
             t0 = time.perf_counter()
-            if os.environ.get("GENLOOP"):  # the generation loop (count / recount + scan + emit per generation) instead of the default call
+            if GENLOOP:  # the generation loop (count / recount + scan + emit per generation) instead of the default call
                 segs = eng.trace_tree(batch, 12, out_capacity=batch.n * 13)
                 n_seg = segs.n_valid
             else:  # one launch, a lane per tree (k_trace_trees)
