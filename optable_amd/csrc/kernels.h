@@ -197,6 +197,10 @@ __device__ __forceinline__ void store_segment_paired(const SegsT<T>& out, int64_
     store_pair<NT>(out.ray, out.surface, slot, tree, surface, odd);
 }
 
+// set bits of a wave-uniform mask below this lane (v_mbcnt: the mask comes from scalar registers, no per-lane lane-mask constant to keep)
+__device__ __forceinline__ int rank_below(unsigned long long m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
 // The caller's ray records are read exactly once per trace: non-temporal loads keep them from displacing what is
 // re-read (per-wave records, scene image in L2 mode).  Worth 1 % on cfg 4 (11.79 -> 11.67 ms, interleaved A/B), nothing on cfg 3 / 5.
 template <class V> __device__ __forceinline__ V ld_once(const V* p) { return __builtin_nontemporal_load(p); }
@@ -329,92 +333,108 @@ __global__ __launch_bounds__(256, MINW) void k_trace_trees(SceneBlob blob, T uni
         r.n = *real_at(base, e, 9); r.pl = *real_at(base, e, 10);
         r.last = *int_at(base, e);
     };
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < n; i0 += stride) {
-        const int64_t i = i0 + threadIdx.x;
-        bool active = i < n, overflow = false;
-        RayState<T> r = {};
-        int32_t k = 0, cls = 0;            // rays processed; the tree's column of the interact-count table
-        // the two rings in one register (QL, QG <= 255): LDS ring head | entries << 8 | scratch ring head << 16 | entries << 24
-        uint32_t qs = 0;
-        auto lhead = [&]() -> int { return (int)(qs & 255u); };
-        auto llen = [&]() -> int { return (int)((qs >> 8) & 255u); };
-        auto ghead = [&]() -> int { return (int)((qs >> 16) & 255u); };
-        auto glen = [&]() -> int { return (int)(qs >> 24); };
-        auto queued = [&]() -> int { return llen() + glen(); };
-        MatCache<T> mc = {T(1)};
-        if (active) {
-            const int32_t fl = in.flags[i];
-            r = load_ray(in, i, fl);
-            if ((uint32_t)r.last >= (uint32_t)sc.n_nodes) r.last = -1;
-            if constexpr (F & F_REFRACT) mc = make_matcache<T, F>(sc, r.wl);
-            cls = in.id[i];
-            if (fl & OT_RAY_DEAD) {  // optical_component.py:349: a dead ray hits nothing and is returned as is
-                store_segment<T, false>(out, i, r, r.len, (int32_t)i, -2);
-                k = 1;
-                active = false;
-            }
-        }
-        while (__any(active)) {
-            // count-limited leaves (optical_component.py:140-149): a tree's rays meet them one after the other in FIFO order, as
-            // the reference's loop does — exact as long as no other tree of the launch shares the column (the host API's rounds)
-            const GateCtx gate = {counts, n_classes, cls, nullptr, nullptr, 0, 0};
-            const Hit<T> h = nearest_hit<T, F, GATE_PLAIN>(sc, r, active, gate);
-            if (active) {
-                const int64_t slot = (int64_t)k * n + i;
-                ++k;
-                int nk = 0;
-                RayState<T> ch[2];
-                if (h.node < 0) {
-                    store_segment<T, false>(out, slot, r, r.len, (int32_t)i, -1);
-                } else {
-                    store_segment<T, false>(out, slot, r, h.t, (int32_t)i, leaf_id_of<T, F>(sc, h.node));
-                    nk = interact<T, F, 2>(sc, r, h, ch, mc);
-                }
-                const int32_t left = cap - k;  // rays this tree may still process
-                // a first child behind an empty queue is the next ray: it stays in registers
-                const bool direct = nk > 0 && left > 0 && (qs & 0xff00ff00u) == 0;
-                int32_t pos = direct ? 1 : 0;  // queue position the next push would get, counted from the next ray to process
-                auto push = [&](const RayState<T>& c) {
-                    if (queued() + pos >= left) return;  // would never be processed (optical_table.py:138-144 drops it with the queue)
-                    if (glen() == 0 && llen() < QL) {
-                        int e = lhead() + llen();
-                        if (e >= QL) e -= QL;
-                        put(ring, e, c);
-                        qs += 1u << 8;
-                    } else if (glen() < QG) {
-                        int e = ghead() + glen();
-                        if (e >= QG) e -= QG;
-                        put(gring, e, c);
-                        qs += 1u << 24;
-                    } else {
-                        overflow = true;
-                    }
-                };
-                if (nk > 0 && !direct) push(ch[0]);
-                if (nk > 1) push(ch[1]);
-                const T wl = r.wl;
-                const int32_t has_q = r.has_q;
-                if (direct) {
-                    r = ch[0];
-                } else if ((qs & 0xff00ff00u) != 0 && left > 0 && !overflow) {
-                    if (llen() > 0) {
-                        const int e = lhead();
-                        get(ring, e, r);
-                        qs = ((qs & ~255u) | (uint32_t)(e + 1 == QL ? 0 : e + 1)) - (1u << 8);
-                    } else {
-                        const int e = ghead();
-                        get(gring, e, r);
-                        qs = ((qs & ~(255u << 16)) | ((uint32_t)(e + 1 == QG ? 0 : e + 1) << 16)) - (1u << 24);
-                    }
-                    r.wl = wl; r.has_q = has_q; r.len = Num<T>::inf();
-                } else {
+    // The trees of this wave: a contiguous share of the batch.  A lane whose tree has ended takes the next tree of the share in
+    // place (no atomics: the share is the wave's own), so a wave does not live as long as its longest tree with the other
+    // lanes idle — trees of a batch can differ by the whole cap.  Refills wait until sixteen lanes are idle (or none works):
+    // the loads of a refill are worth a pass of their own only when enough lanes take part.
+    const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    const int64_t per_wave = ((n + n_waves - 1) / n_waves + 63) / 64 * 64;
+    int64_t next = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * per_wave;  // wave-uniform
+    const int64_t end = next + per_wave < n ? next + per_wave : n;
+    bool active = false, overflow = false;
+    RayState<T> r = {};
+    int32_t i = 0, k = 0, cls = 0;  // the lane's tree; rays it has processed; its column of the interact-count table
+    // the two rings in one register (QL, QG <= 255): LDS ring head | entries << 8 | scratch ring head << 16 | entries << 24
+    uint32_t qs = 0;
+    auto lhead = [&]() -> int { return (int)(qs & 255u); };
+    auto llen = [&]() -> int { return (int)((qs >> 8) & 255u); };
+    auto ghead = [&]() -> int { return (int)((qs >> 16) & 255u); };
+    auto glen = [&]() -> int { return (int)(qs >> 24); };
+    auto queued = [&]() -> int { return llen() + glen(); };
+    MatCache<T> mc = {T(1)};
+    for (;;) {
+        const unsigned long long idle = __ballot(!active);
+        if (next < end && (__popcll(idle) >= 16 || idle == ~0ull)) {
+            const int64_t cand = next + rank_below(idle);
+            if (!active && cand < end) {
+                i = (int32_t)cand;
+                const int32_t fl = in.flags[i];
+                r = load_ray(in, i, fl);
+                if ((uint32_t)r.last >= (uint32_t)sc.n_nodes) r.last = -1;
+                if constexpr (F & F_REFRACT) mc = make_matcache<T, F>(sc, r.wl);
+                cls = in.id[i];
+                k = 0; qs = 0; overflow = false;
+                active = true;
+                if (fl & OT_RAY_DEAD) {  // optical_component.py:349: a dead ray hits nothing and is returned as is
+                    store_segment<T, false>(out, i, r, r.len, i, -2);
+                    seg_count[i] = 1;
                     active = false;
                 }
-                if (overflow) active = false;
             }
+            next += __popcll(idle);
         }
-        if (i < n) seg_count[i] = overflow ? -k : k;
+        if (!__any(active)) {
+            if (next >= end) break;
+            continue;
+        }
+        // count-limited leaves (optical_component.py:140-149): a tree's rays meet them one after the other in FIFO order, as
+        // the reference's loop does — exact as long as no other tree of the launch shares the column (the host API's rounds)
+        const GateCtx gate = {counts, n_classes, cls, nullptr, nullptr, 0, 0};
+        const Hit<T> h = nearest_hit<T, F, GATE_PLAIN>(sc, r, active, gate);
+        if (active) {
+            const int64_t slot = (int64_t)k * n + i;
+            ++k;
+            int nk = 0;
+            RayState<T> ch[2];
+            if (h.node < 0) {
+                store_segment<T, false>(out, slot, r, r.len, i, -1);
+            } else {
+                store_segment<T, false>(out, slot, r, h.t, i, leaf_id_of<T, F>(sc, h.node));
+                nk = interact<T, F, 2>(sc, r, h, ch, mc);
+            }
+            const int32_t left = cap - k;  // rays this tree may still process
+            // a first child behind an empty queue is the next ray: it stays in registers
+            const bool direct = nk > 0 && left > 0 && (qs & 0xff00ff00u) == 0;
+            int32_t pos = direct ? 1 : 0;  // queue position the next push would get, counted from the next ray to process
+            auto push = [&](const RayState<T>& c) {
+                if (queued() + pos >= left) return;  // would never be processed (optical_table.py:138-144 drops it with the queue)
+                if (glen() == 0 && llen() < QL) {
+                    int e = lhead() + llen();
+                    if (e >= QL) e -= QL;
+                    put(ring, e, c);
+                    qs += 1u << 8;
+                } else if (glen() < QG) {
+                    int e = ghead() + glen();
+                    if (e >= QG) e -= QG;
+                    put(gring, e, c);
+                    qs += 1u << 24;
+                } else {
+                    overflow = true;
+                }
+            };
+            if (nk > 0 && !direct) push(ch[0]);
+            if (nk > 1) push(ch[1]);
+            const T wl = r.wl;
+            const int32_t has_q = r.has_q;
+            if (direct) {
+                r = ch[0];
+            } else if ((qs & 0xff00ff00u) != 0 && left > 0 && !overflow) {
+                if (llen() > 0) {
+                    const int e = lhead();
+                    get(ring, e, r);
+                    qs = ((qs & ~255u) | (uint32_t)(e + 1 == QL ? 0 : e + 1)) - (1u << 8);
+                } else {
+                    const int e = ghead();
+                    get(gring, e, r);
+                    qs = ((qs & ~(255u << 16)) | ((uint32_t)(e + 1 == QG ? 0 : e + 1) << 16)) - (1u << 24);
+                }
+                r.wl = wl; r.has_q = has_q; r.len = Num<T>::inf();
+            } else {
+                active = false;
+            }
+            if (overflow) active = false;
+            if (!active) seg_count[i] = overflow ? -k : k;  // the tree is done (or its queue overflowed: the caller takes the generations)
+        }
     }
 }
 
@@ -840,10 +860,6 @@ __global__ __launch_bounds__((rolling_threads<T, F, REC_LDS>()), (rolling_minw<T
 #define OT_REFILL_FLAT_WG 256
 #define OT_REFILL_FLAT_MINW 4
 #endif
-// set bits of a wave-uniform mask below this lane (v_mbcnt: the mask comes from scalar registers, no per-lane lane-mask constant to keep)
-__device__ __forceinline__ int rank_below(unsigned long long m) {
-    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-}
 template <class T, uint32_t F> constexpr int refill_threads() {
     // (whole multiples of four waves, one per SIMD: the waves of a workgroup are dealt to the SIMDs in turn, and two workgroups of
     // ten waves put six on the first SIMD — where five fit — so only one of them ran: 2.4 waves per SIMD measured, for 5 asked)

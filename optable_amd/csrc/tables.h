@@ -63,10 +63,10 @@ template <class T> TreeKern<T> tree_kernel(int fg);
 // ... and the waves per SIMD its registers are capped for (its workgroups per CU: 256 threads = one wave per SIMD each)
 // (measured with one wave per SIMD more — 168 / 128 registers, 39 / 2 of them spilled: cfg 4 R = 0.2 6.8 instead of 4.3 ms in double precision, 3-5 % faster in single)
 template <class T> constexpr int tree_minw(int fg) { return sizeof(T) == 4 ? 3 : (fg == 3 ? 1 : 2); }
-// ... and the workgroups per CU the launch plans for: the single-precision kernels of the planar presets FB / FC come out at 118-127
+// ... and the workgroups per CU the launch plans for: the single-precision kernels of the presets FB / FC / FE come out at 118-126
 // registers under the cap of 170 (capped at 128 the allocator spills two), so four of their waves fit a SIMD
 // (tests/test_build_resources.py holds them to that)
-template <class T> constexpr int tree_groups_by_registers(int fg) { return sizeof(T) == 4 && fg <= 1 ? 4 : tree_minw<T>(fg); }
+template <class T> constexpr int tree_groups_by_registers(int fg) { return sizeof(T) == 4 && fg <= 2 ? 4 : tree_minw<T>(fg); }
 // k_gen_one (one pass per generation, decoupled look-back): fg as above; nullptr where no instantiation exists
 template <class T> GenOneKern<T> gen_one_kernel(int fg, bool lds);
 

@@ -107,12 +107,12 @@ def test_everyday_presets_keep_their_register_budgets(kernels):
 
 
 def test_single_precision_tree_kernels_fit_four_waves_per_simd(kernels):
-    """k_trace_trees in single precision (the planar presets FB = 28, FC = 732) is launched with four workgroups of four waves
+    """k_trace_trees in single precision (presets FB = 28, FC = 732, FE = 63) is launched with four workgroups of four waves
     per CU (tables.h tree_groups_by_registers): that needs 128 registers or fewer; double precision two (256)."""
     def of(real, mask):
         return [k for k in kernels if re.match(rf"_Z\d+k_trace_treesI{real}Lj{mask}E", k["name"])]
 
-    for mask in (28, 732):
+    for mask in (28, 732, 63):
         ks = of("f", mask)
         assert ks and max(k["vgpr"] for k in ks) <= 128, (mask, [(k["name"][:40], k["vgpr"]) for k in ks])
     for mask in (28, 63):
