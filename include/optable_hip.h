@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define OT_ABI_VERSION 11  /* 11: OT_OPT_GEN_AHEAD, ot_trace_trees_*; 10: ot_trace_plan, ot_probe_layouts, ot_runtime_info, OT_OPT_REFILL, OT_OPT_REFILL_TICKET, OT_OPT_POOL_JITTER, OT_OPT_GEN_ONEPASS; 9: ot_trace_tree_*, OT_OPT_BLOCK_POOL, OT_OPT_GEN_DROP_DOOMED, ot_trace_append_* holes per workgroup chunk; 8: OT_SHAPE_ASPHERE_CHEB, OT_MAT_CHEB, OT_NODE_BOX_TRUSTED, ot_trace_tiled_*, ot_bench_stream_tiled_*; 3: ot_trace_generation_f32; 4: ot_bench_stream_f32; 5: OT_OPT_LIST_CAP, ray flags bits 8..31, ot_debug_generation_mismatches; 6: ot_debug_last_launch, OT_OPT_FLAT_QUEUE, OT_OPT_LDS_RECORDS; 7: ot_trace_append_*, ot_segment_block, OT_OPT_APPEND_CHUNK, OT_OPT_INSTANCING */
+#define OT_ABI_VERSION 11  /* 11: OT_OPT_GEN_AHEAD, ot_trace_trees_*, ot_trace_trees_append_*, OT_OPT_TREES_LDS_ENTRIES; 10: ot_trace_plan, ot_probe_layouts, ot_runtime_info, OT_OPT_REFILL, OT_OPT_REFILL_TICKET, OT_OPT_POOL_JITTER, OT_OPT_GEN_ONEPASS; 9: ot_trace_tree_*, OT_OPT_BLOCK_POOL, OT_OPT_GEN_DROP_DOOMED, ot_trace_append_* holes per workgroup chunk; 8: OT_SHAPE_ASPHERE_CHEB, OT_MAT_CHEB, OT_NODE_BOX_TRUSTED, ot_trace_tiled_*, ot_bench_stream_tiled_*; 3: ot_trace_generation_f32; 4: ot_bench_stream_f32; 5: OT_OPT_LIST_CAP, ray flags bits 8..31, ot_debug_generation_mismatches; 6: ot_debug_last_launch, OT_OPT_FLAT_QUEUE, OT_OPT_LDS_RECORDS; 7: ot_trace_append_*, ot_segment_block, OT_OPT_APPEND_CHUNK, OT_OPT_INSTANCING */
 
 /* ---- status codes ------------------------------------------------------------------- */
 enum ot_status {
@@ -317,7 +317,8 @@ int ot_trace_generation_f32(ot_ctx* ctx, const ot_rays* rays, const int32_t* ray
  * ot_trace_*: slot k * n_rays + i of `out` (max_trace_num * n_rays slots) is the k-th ray of tree i in the reference's FIFO
  * order, seg_count[i] the rays tree i processed (== max_trace_num: cut short by the cap, or ended exactly there).  A queue of
  * ceil(max_trace_num / 2) rays per lane always suffices; ot_trace_trees_plan says whether the scene has such a kernel
- * (info[0]: the planar and everyday presets, image + queue fronts within the CU's LDS), how many entries its queues get
+ * (info[0] bit 0: the planar and everyday presets, image + queue fronts within the CU's LDS; bit 1: it also writes these [k][tree]
+ * slots — the planar preset; every such kernel writes the dense list of ot_trace_trees_append_*), how many entries its queues get
  * (info[1]), whether that is enough for every tree (info[2]: always, up to caps of ~170 in double precision) and how many of
  * them are in LDS (info[3]).  If not, a tree whose queue overflows reports seg_count[i] = -(rays processed so far) and the
  * caller takes ot_trace_tree_*.  OT_ERR_UNSUPPORTED when info[0] would be 0.  counts / n_count_classes as for ot_trace_*:
@@ -327,6 +328,14 @@ int ot_trace_trees_f64(ot_ctx* ctx, const ot_rays* rays, int64_t n_rays, int32_t
                        int32_t* counts, int32_t n_count_classes);
 int ot_trace_trees_f32(ot_ctx* ctx, const ot_rays* rays, int64_t n_rays, int32_t max_trace_num, const ot_segments* out, int32_t* seg_count,
                        int32_t* counts, int32_t n_count_classes);
+/* ... into the append layout of ot_trace_append_* (a dense list; *n_slots = slots claimed, records and holes): the records of
+ * a step go to consecutive slots whatever trees the lanes are on, so batches whose trees differ widely in size (lanes refill
+ * from their wave's share as their trees end) still write whole lines.  A tree's records lie at increasing addresses in FIFO
+ * order: a stable sort by `ray` is the reference's order.  seg_count / counts as above. */
+int ot_trace_trees_append_f64(ot_ctx* ctx, const ot_rays* rays, int64_t n_rays, int32_t max_trace_num, const ot_segment_block* out, int64_t* n_slots,
+                              int32_t* seg_count, int32_t* counts, int32_t n_count_classes);
+int ot_trace_trees_append_f32(ot_ctx* ctx, const ot_rays* rays, int64_t n_rays, int32_t max_trace_num, const ot_segment_block* out, int64_t* n_slots,
+                              int32_t* seg_count, int32_t* counts, int32_t n_count_classes);
 int ot_trace_trees_plan(ot_ctx* ctx, int32_t real_bytes, int32_t max_trace_num, int32_t* info /* int32[4] */);
 
 /* The whole breadth-first trace of a batch of ray trees: the loop over ot_trace_generation_* (optical_table.py:115-147) run

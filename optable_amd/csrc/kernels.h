@@ -304,11 +304,21 @@ __global__ __launch_bounds__(256, MINW) void k_trace_fused(SceneBlob blob, T uni
 // reference's order; seg_count[i] = rays processed (== cap: the cap cut the tree short or the tree ended exactly there,
 // as `budget <= 0` on the generation path).  Count-limited leaves: one column of the counts table per tree (rays that share
 // an id are the caller's successive launches, as for ot_trace_*).
+struct AppendCtl {
+    unsigned long long* cursor;  // slots claimed so far (device); the caller reads it back as *n_slots
+    int64_t capacity;
+    int32_t chunk;               // slots per claim, a multiple of 64
+};
 template <class T> constexpr int tree_entry_bytes() { return 64 * (11 * (int)sizeof(T) + 4); }
-template <class T, uint32_t F, int MINW>
+// OUT = SegsT<T>: the [k][tree] slots described above.  OUT = SegPlanes<T>: the append layout of ot_trace_append_* — the records of a
+// step go to consecutive slots of the wave's current chunk (claimed from a device-wide cursor, `ac`), whatever trees and
+// positions the lanes are on: dense, whole lines per field.  A tree stays with its lane and a wave's chunks are claimed in
+// address order, so a stable sort by `ray` is the reference's order; the unused tail of a wave's last chunk is marked ray = -1.
+template <class T, uint32_t F, int MINW, class OUT>
 __global__ __launch_bounds__(256, MINW) void k_trace_trees(SceneBlob blob, T unit, RaysT<T> in, int64_t n, int32_t cap, int32_t QL, int32_t QG,
-                                                           uint8_t* __restrict__ scratch, SegsT<T> out, int32_t* __restrict__ seg_count,
+                                                           uint8_t* __restrict__ scratch, OUT out, AppendCtl ac, int32_t* __restrict__ seg_count,
                                                            int32_t* counts, int32_t n_classes) {
+    constexpr bool APPEND = std::is_same<OUT, SegPlanes<T>>::value;
     extern __shared__ __align__(16) uint32_t lds[];
     for (int w = threadIdx.x; w < blob.n_words; w += blockDim.x) lds[w] = blob.words[w];
     __syncthreads();
@@ -352,10 +362,31 @@ __global__ __launch_bounds__(256, MINW) void k_trace_trees(SceneBlob blob, T uni
     auto glen = [&]() -> int { return (int)(qs >> 24); };
     auto queued = [&]() -> int { return llen() + glen(); };
     MatCache<T> mc = {T(1)};
+    int64_t chunk_pos = 0;  // append layout: next free slot of this wave's chunk, and how many are left in it
+    int32_t chunk_left = 0;
+    // where a lane's record of this step goes (append: every lane of the wave calls it, `writes` = the lane has a record)
+    auto place = [&](bool writes, int64_t kn_plus_i) -> int64_t {
+        if constexpr (!APPEND) return kn_plus_i;
+        else {
+            const unsigned long long writers = __ballot(writes);
+            const int need = __popcll(writers), rank = rank_below(writers);
+            int64_t fresh_pos = 0;
+            if (need > chunk_left) {  // wave-uniform: claim the next chunk; the step may straddle the two
+                const unsigned long long c0 = lane == 0 ? atomicAdd(ac.cursor, (unsigned long long)ac.chunk) : 0ull;
+                fresh_pos = (int64_t)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(c0 >> 32)) << 32) |
+                                      (uint32_t)__builtin_amdgcn_readfirstlane((int)(c0 & 0xffffffffull)));
+            }
+            const int64_t slot = rank < chunk_left ? chunk_pos + rank : fresh_pos + (rank - chunk_left);
+            if (need > chunk_left) { chunk_pos = fresh_pos + (need - chunk_left); chunk_left = ac.chunk - (need - chunk_left); }
+            else { chunk_pos += need; chunk_left -= need; }
+            return slot < ac.capacity ? slot : -1;  // an output that is too small loses records, never writes outside (the cursor tells)
+        }
+    };
     for (;;) {
         const unsigned long long idle = __ballot(!active);
         if (next < end && (__popcll(idle) >= 16 || idle == ~0ull)) {
             const int64_t cand = next + rank_below(idle);
+            bool dead = false;
             if (!active && cand < end) {
                 i = (int32_t)cand;
                 const int32_t fl = in.flags[i];
@@ -365,8 +396,12 @@ __global__ __launch_bounds__(256, MINW) void k_trace_trees(SceneBlob blob, T uni
                 cls = in.id[i];
                 k = 0; qs = 0; overflow = false;
                 active = true;
-                if (fl & OT_RAY_DEAD) {  // optical_component.py:349: a dead ray hits nothing and is returned as is
-                    store_segment<T, false>(out, i, r, r.len, i, -2);
+                dead = (fl & OT_RAY_DEAD) != 0;
+            }
+            if (__any(dead)) {  // optical_component.py:349: a dead ray hits nothing and is returned as is
+                const int64_t slot = place(dead, i);
+                if (dead) {
+                    if (slot >= 0) store_segment<T, false>(out, slot, r, r.len, i, -2);
                     seg_count[i] = 1;
                     active = false;
                 }
@@ -381,15 +416,15 @@ __global__ __launch_bounds__(256, MINW) void k_trace_trees(SceneBlob blob, T uni
         // the reference's loop does — exact as long as no other tree of the launch shares the column (the host API's rounds)
         const GateCtx gate = {counts, n_classes, cls, nullptr, nullptr, 0, 0};
         const Hit<T> h = nearest_hit<T, F, GATE_PLAIN>(sc, r, active, gate);
+        const int64_t slot = place(active, (int64_t)k * n + i);
         if (active) {
-            const int64_t slot = (int64_t)k * n + i;
             ++k;
             int nk = 0;
             RayState<T> ch[2];
             if (h.node < 0) {
-                store_segment<T, false>(out, slot, r, r.len, i, -1);
+                if (slot >= 0) store_segment<T, false>(out, slot, r, r.len, i, -1);
             } else {
-                store_segment<T, false>(out, slot, r, h.t, i, leaf_id_of<T, F>(sc, h.node));
+                if (slot >= 0) store_segment<T, false>(out, slot, r, h.t, i, leaf_id_of<T, F>(sc, h.node));
                 nk = interact<T, F, 2>(sc, r, h, ch, mc);
             }
             const int32_t left = cap - k;  // rays this tree may still process
@@ -436,6 +471,11 @@ __global__ __launch_bounds__(256, MINW) void k_trace_trees(SceneBlob blob, T uni
             if (!active) seg_count[i] = overflow ? -k : k;  // the tree is done (or its queue overflowed: the caller takes the generations)
         }
     }
+    if constexpr (APPEND) {  // the unused tail of this wave's last chunk: holes
+        int32_t* rp = ray_plane(out);
+        for (int64_t s = chunk_pos + lane; s < chunk_pos + chunk_left; s += 64)
+            if (s < ac.capacity) rp[s] = -1;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -475,11 +515,6 @@ __global__ __launch_bounds__(256, MINW) void k_trace_trees(SceneBlob blob, T uni
 // 4 cells per pass (every extra pass pays the pass's load -> trace -> store latency again); lists worked off in rounds
 // with a remainder pass instead of the FIFO ring (44 instead of 62 lanes per pass).
 static constexpr int REC_LDS_POSITIONS = 128;  // REC_LDS kernels: the first 128 positions of every wave's list keep their records in LDS
-struct AppendCtl {
-    unsigned long long* cursor;  // slots claimed so far (device); the caller reads it back as *n_slots
-    int64_t capacity;
-    int32_t chunk;               // slots per claim, a multiple of 64
-};
 template <class T> struct WaveScratch {
     uint8_t* base;
     int64_t wave_bytes;  // bytes per wave: CAP * record bytes, rounded up

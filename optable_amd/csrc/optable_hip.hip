@@ -1163,7 +1163,7 @@ struct TreesPlan { int32_t QL, QG, full, groups_per_cu; size_t lds_bytes; };
 template <class T> static bool trees_plan(const ot_ctx* c, int32_t cap, TreesPlan* p) {
     const size_t image = sizeof(T) == 8 ? c->bytes64 : c->bytes32;
     *p = TreesPlan{};
-    if (!c->has_scene || c->max_children > 2 || cap < 1 || !tree_kernel<T>(gen_preset(c->features))) return false;
+    if (!c->has_scene || c->max_children > 2 || cap < 1 || !tree_kernel<T, SegPlanes<T>>(gen_preset(c->features))) return false;
     const size_t room = 160 * 1024 - 1024, img = (image + 15) & ~(size_t)15, entry = (size_t)tree_entry_bytes<T>();
     if (img + 4 * entry > room) return false;
     const int64_t need = ((int64_t)cap + 1) / 2, fit = (int64_t)((room - img) / (4 * entry));
@@ -1183,6 +1183,31 @@ template <class T> static bool trees_plan(const ot_ctx* c, int32_t cap, TreesPla
     p->full = qg <= most;
     return true;
 }
+template <class T, class OUT>
+static int launch_trees(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t cap, const OUT& out, const AppendCtl& ac, int32_t* seg_count, int32_t* counts,
+                        int32_t n_classes) {
+    TreesPlan p;
+    if (!trees_plan<T>(c, cap, &p)) return fail(OT_ERR_UNSUPPORTED, "no tree kernel for this scene (features beyond the everyday presets, or an image that leaves no room for the queues): use ot_trace_tree_*");
+    HIP_TRY(hipSetDevice(c->device));
+    const TreeKern<T, OUT> kern = tree_kernel<T, OUT>(gen_preset(c->features));
+    if (!kern) return fail(OT_ERR_UNSUPPORTED, "this scene's tree kernel writes the append layout only (ot_trace_trees_append_*)");
+    const SceneBlob blob = make_blob<T>(c);
+    const int64_t blocks_needed = (n + 255) / 256, most = (int64_t)c->n_cus * p.groups_per_cu;  // persistent: the scratch is per workgroup
+    const int grid = (int)(blocks_needed < most ? blocks_needed : most);
+    const size_t scratch = (size_t)grid * 4 * (size_t)p.QG * tree_entry_bytes<T>();
+    if (c->trees.ensure(scratch + 256)) return fail(OT_ERR_HIP, "hipMalloc of the tree queues failed");
+    if (ac.cursor) HIP_TRY(hipMemsetAsync(ac.cursor, 0, sizeof(unsigned long long), c->stream));
+    hipEvent_t ev0, ev1;
+    int rc = timing_pair(c, &ev0, &ev1);
+    if (rc) return rc;
+    if (p.lds_bytes > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
+    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), (uint32_t)p.lds_bytes, c->stream, ev0, ev1, 0u, blob, (T)c->unit, view<T>(rays), n, cap, p.QL, p.QG,
+                          (uint8_t*)c->trees.p, out, ac, seg_count, counts, n_classes);
+    HIP_TRY(hipGetLastError());
+    const int32_t shape[8] = {4, 256, p.groups_per_cu, (int32_t)grid, (int32_t)p.lds_bytes, p.QL, p.QG, std::is_same<OUT, SegPlanes<T>>::value ? 4 : 0};
+    for (int q = 0; q < 8; ++q) c->last_launch[q] = shape[q];
+    return 0;
+}
 template <class T>
 static int trace_trees(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t cap, const ot_segments* out, int32_t* seg_count, int32_t* counts,
                        int32_t n_classes) {
@@ -1190,26 +1215,25 @@ static int trace_trees(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t cap, c
     if (rc) return rc;
     rc = check_segs(out);
     if (rc) return rc;
-    TreesPlan p;
-    if (!trees_plan<T>(c, cap, &p)) return fail(OT_ERR_UNSUPPORTED, "no tree kernel for this scene (features beyond the everyday presets, or an image that leaves no room for the queues): use ot_trace_tree_*");
     if (n == 0) return 0;
-    HIP_TRY(hipSetDevice(c->device));
-    const TreeKern<T> kern = tree_kernel<T>(gen_preset(c->features));
-    const SceneBlob blob = make_blob<T>(c);
-    const int64_t blocks_needed = (n + 255) / 256, most = (int64_t)c->n_cus * p.groups_per_cu;  // persistent: the scratch is per workgroup
-    const int grid = (int)(blocks_needed < most ? blocks_needed : most);
-    const size_t scratch = (size_t)grid * 4 * (size_t)p.QG * tree_entry_bytes<T>();
-    if (c->trees.ensure(scratch + 256)) return fail(OT_ERR_HIP, "hipMalloc of the tree queues failed");
-    hipEvent_t ev0, ev1;
-    rc = timing_pair(c, &ev0, &ev1);
+    return launch_trees<T, SegsT<T>>(c, rays, n, cap, view<T>(out), AppendCtl{nullptr, 0, 0}, seg_count, counts, n_classes);
+}
+template <class T>
+static int trace_trees_append(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t cap, const ot_segment_block* out, int64_t* n_slots, int32_t* seg_count,
+                              int32_t* counts, int32_t n_classes) {
+    int rc = check_trace_args(c, rays, n, cap, seg_count, counts, n_classes);
     if (rc) return rc;
-    if (p.lds_bytes > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
-    hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), (uint32_t)p.lds_bytes, c->stream, ev0, ev1, 0u, blob, (T)c->unit, view<T>(rays), n, cap, p.QL, p.QG,
-                          (uint8_t*)c->trees.p, view<T>(out), seg_count, counts, n_classes);
-    HIP_TRY(hipGetLastError());
-    const int32_t shape[8] = {4, 256, p.groups_per_cu, (int32_t)grid, (int32_t)p.lds_bytes, p.QL, p.QG, 0};
-    for (int q = 0; q < 8; ++q) c->last_launch[q] = shape[q];
-    return 0;
+    if (!out || !out->base || out->capacity < 0 || !n_slots) return fail(OT_ERR_INVALID, "bad segment block / n_slots");
+    if ((uintptr_t)out->base % 16 || out->capacity % 64) return fail(OT_ERR_INVALID, "segment block: base must be 16-byte aligned, capacity a multiple of 64");
+    if (out->capacity >= ((int64_t)1 << 30) / (int64_t)(sizeof(T) / 4)) return fail(OT_ERR_INVALID, "segment block: capacity must stay below 2^30 slots (2^29 in double precision) per launch");
+    HIP_TRY(hipSetDevice(c->device));
+    if (n == 0) {
+        HIP_TRY(hipMemsetAsync(n_slots, 0, sizeof(int64_t), c->stream));
+        return 0;
+    }
+    const SegPlanes<T> planes = {(uint8_t*)out->base, out->capacity};
+    const AppendCtl ac = {(unsigned long long*)n_slots, out->capacity, c->opt_append_chunk};
+    return launch_trees<T, SegPlanes<T>>(c, rays, n, cap, planes, ac, seg_count, counts, n_classes);
 }
 
 // One generation in one pass (kernels.h k_gen_one): zero the tile descriptors and the ticket, launch.  `rem`: what is left of
@@ -1377,11 +1401,21 @@ int ot_trace_trees_f32(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t max_tr
                        int32_t n_classes) {
     return trace_trees<float>(c, rays, n, max_trace_num, out, seg_count, counts, n_classes);
 }
+int ot_trace_trees_append_f64(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t max_trace_num, const ot_segment_block* out, int64_t* n_slots, int32_t* seg_count,
+                              int32_t* counts, int32_t n_classes) {
+    return trace_trees_append<double>(c, rays, n, max_trace_num, out, n_slots, seg_count, counts, n_classes);
+}
+int ot_trace_trees_append_f32(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t max_trace_num, const ot_segment_block* out, int64_t* n_slots, int32_t* seg_count,
+                              int32_t* counts, int32_t n_classes) {
+    return trace_trees_append<float>(c, rays, n, max_trace_num, out, n_slots, seg_count, counts, n_classes);
+}
 int ot_trace_trees_plan(ot_ctx* c, int32_t real_bytes, int32_t max_trace_num, int32_t* info) {
     if (!c || !info || (real_bytes != 4 && real_bytes != 8)) return fail(OT_ERR_INVALID, "bad ot_trace_trees_plan arguments");
     TreesPlan p;
     const bool ok = real_bytes == 8 ? trees_plan<double>(c, max_trace_num, &p) : trees_plan<float>(c, max_trace_num, &p);
     info[0] = ok ? 1 : 0; info[1] = p.QL + p.QG; info[2] = p.full; info[3] = p.QL;
+    if (ok && (real_bytes == 8 ? tree_kernel<double, SegsT<double>>(gen_preset(c->features)) != nullptr : tree_kernel<float, SegsT<float>>(gen_preset(c->features)) != nullptr))
+        info[0] |= 2;  // ... and writes the [k][tree] slots too
     return 0;
 }
 int ot_trace_tree_f64(ot_ctx* c, const ot_rays* rays, const int32_t* tree, int64_t n, int32_t* budget, const ot_segments* out,

@@ -31,8 +31,8 @@ template <class T>
 using GenKern = void (*)(SceneBlob, T, RaysT<T>, const int32_t*, int64_t, int32_t*, const int64_t*, SegsT<T>, int64_t, RaysOutT<T>, int32_t*,
                          int64_t, uint8_t*, unsigned long long*, const unsigned long long*, int32_t*, int32_t, const int32_t*,
                          unsigned long long*, int32_t*, T*, int32_t, uint8_t*);
-template <class T>
-using TreeKern = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, int32_t, int32_t, uint8_t*, SegsT<T>, int32_t*, int32_t*, int32_t);
+template <class T, class OUT>
+using TreeKern = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, int32_t, int32_t, uint8_t*, OUT, AppendCtl, int32_t*, int32_t*, int32_t);
 template <class T>
 using GenOneKern = void (*)(SceneBlob, T, RaysT<T>, const int32_t*, const int32_t*, int64_t, int32_t*, int64_t*, SegsT<T>, int64_t, RaysOutT<T>, int32_t*,
                             int32_t*, int64_t, unsigned long long*, uint32_t*, int32_t*, int32_t, int32_t, const int64_t*, int64_t*);
@@ -59,7 +59,7 @@ template <class T> GenKern<T> gen_kernel(int fg, bool lds, bool emit);
 template <class T> GenKern<T> gen_ahead_kernel(int fg, bool lds);
 template <class T> ProbeKern<T> probe_kernel(int fg, bool lds);
 // k_trace_trees (a lane per tree, the FIFO in LDS): fg as above; nullptr where no instantiation exists
-template <class T> TreeKern<T> tree_kernel(int fg);
+template <class T, class OUT> TreeKern<T, OUT> tree_kernel(int fg);
 // ... and the waves per SIMD its registers are capped for (its workgroups per CU: 256 threads = one wave per SIMD each)
 // (measured with one wave per SIMD more — 168 / 128 registers, 39 / 2 of them spilled: cfg 4 R = 0.2 6.8 instead of 4.3 ms in double precision, 3-5 % faster in single)
 template <class T> constexpr int tree_minw(int fg) { return sizeof(T) == 4 ? 3 : (fg == 3 ? 1 : 2); }
@@ -84,7 +84,8 @@ template <class T> GenOneKern<T> gen_one_kernel(int fg, bool lds);
     template <> GenKern<T> gen_kernel<T>(int, bool, bool);                         \
     template <> GenKern<T> gen_ahead_kernel<T>(int, bool);                         \
     template <> ProbeKern<T> probe_kernel<T>(int, bool);                          \
-    template <> TreeKern<T> tree_kernel<T>(int);                                  \
+    template <> TreeKern<T, SegsT<T>> tree_kernel<T, SegsT<T>>(int);              \
+    template <> TreeKern<T, SegPlanes<T>> tree_kernel<T, SegPlanes<T>>(int);      \
     template <> GenOneKern<T> gen_one_kernel<T>(int, bool);
 OT_DECLARE_TABLES(double)
 OT_DECLARE_TABLES(float)

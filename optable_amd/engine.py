@@ -278,32 +278,54 @@ class Engine:
         per lane would a cap of `max_trace_num` get, and is that enough for every possible tree."""
         info = (C.c_int32 * 4)()
         abi.check(self.lib.ot_trace_trees_plan(self._ctx, 8 if precision == "f64" else 4, int(max_trace_num), info), self.lib)
-        return {"kernel": bool(info[0]), "queue": int(info[1]), "full": bool(info[2]), "lds_entries": int(info[3])}
+        return {"kernel": bool(info[0] & 1), "slots": bool(info[0] & 2), "queue": int(info[1]), "full": bool(info[2]), "lds_entries": int(info[3])}
 
-    def trace_trees(self, rays: RayBatch, max_trace_num, out: SegmentBatch = None, counts=None):
-        """Whole ray trees in one launch, a lane per tree with its FIFO in LDS (ot_trace_trees_*): a SegmentBatch in the
-        `slots` layout — slot k * n + i = the k-th ray of tree i in the reference's order, count[i] = rays of tree i
-        (negative: the tree's queue overflowed, possible only when `trees_plan()["full"]` is False; take trace_tree then).
-        `capped` as trace_tree reports it.  `counts`: the interact-count table of scenes with limited surfaces
-        ([surfaces, classes], rays.id = column; default: a zeroed column per ray) — exact when no two trees of the call
-        share a column."""
+    def trace_trees(self, rays: RayBatch, max_trace_num, out: SegmentBatch = None, counts=None, layout="slots", capacity=None):
+        """Whole ray trees in one launch, a lane per tree with its FIFO on the chip (ot_trace_trees_*).
+        layout "slots": a SegmentBatch in the `slots` layout — slot k * n + i = the k-th ray of tree i in the reference's order;
+        layout "append": the dense list of ot_trace_append_* (`capacity` slots, default: what any trace of the batch can need) —
+        a stable sort by `ray` is the reference's order; the layout for batches whose trees differ widely in size.
+        count[i] = rays of tree i (negative: the tree's queue overflowed, possible only when `trees_plan()["full"]` is False;
+        take trace_tree then); `capped` as trace_tree reports it.  `counts`: the interact-count table of scenes with limited
+        surfaces ([surfaces, classes], rays.id = column; default: a zeroed column per ray) — exact when no two trees of the
+        call share a column."""
         if self.scene is None:
             raise RuntimeError("upload a scene first")
         self._check_wavelengths(rays)
         prec, n, K = rays.precision, rays.n, int(max_trace_num)
-        if out is None:
-            out = SegmentBatch(n * K, prec, rays.device)
-        if out.capacity < n * K or out.precision != prec or out.tiled or out.block is not None:
-            raise ValueError("out: plain slot arrays of max_trace_num * n_rays slots in the rays' precision")
-        out.count = torch.empty(n, dtype=torch.int32, device=rays.device)
-        out.n_rays = n
         n_slots = len(self.scene.limited)
         if n_slots and counts is None:
             counts = torch.zeros((n_slots, max(n, 1)), dtype=torch.int32, device=rays.device)
         n_classes = 0 if counts is None else counts.shape[1]
-        fn = self.lib.ot_trace_trees_f64 if prec == "f64" else self.lib.ot_trace_trees_f32
-        rs, ss = rays.c_struct(), out.c_struct()
-        abi.check(fn(self._ctx, C.byref(rs), n, K, C.byref(ss), out.count.data_ptr(), None if counts is None else counts.data_ptr(), n_classes), self.lib)
+        cp = None if counts is None else counts.data_ptr()
+        rs = rays.c_struct()
+        if layout == "append":
+            if out is None:
+                if capacity is None:  # every tree at its cap + the tail of every wave's last chunk
+                    capacity = (n * K + self.append_chunk * min(self.MAX_WAVES, (n + 63) // 64 + 1) + 63) // 64 * 64
+                out = SegmentBatch(capacity, prec, rays.device, block=True)
+            elif out.block is None or out.tiled or out.precision != prec:
+                raise ValueError("append layout needs a SegmentBatch(block=True) of the rays' precision")
+            out.count = torch.empty(n, dtype=torch.int32, device=rays.device)
+            out.n_rays, out.append, out.tiled = n, True, False
+            cursor = torch.zeros(1, dtype=torch.int64, device=rays.device)
+            if n:
+                fn = self.lib.ot_trace_trees_append_f64 if prec == "f64" else self.lib.ot_trace_trees_append_f32
+                blk = out.block_struct()
+                abi.check(fn(self._ctx, C.byref(rs), n, K, C.byref(blk), cursor.data_ptr(), out.count.data_ptr(), cp, n_classes), self.lib)
+            out.cursor, out.n_valid = cursor, None  # device scalar: read lazily (n_valid)
+        elif layout == "slots":
+            if out is None:
+                out = SegmentBatch(n * K, prec, rays.device)
+            if out.capacity < n * K or out.precision != prec or out.tiled or out.block is not None:
+                raise ValueError("out: plain slot arrays of max_trace_num * n_rays slots in the rays' precision")
+            out.count = torch.empty(n, dtype=torch.int32, device=rays.device)
+            out.n_rays = n
+            fn = self.lib.ot_trace_trees_f64 if prec == "f64" else self.lib.ot_trace_trees_f32
+            ss = out.c_struct()
+            abi.check(fn(self._ctx, C.byref(rs), n, K, C.byref(ss), out.count.data_ptr(), cp, n_classes), self.lib)
+        else:
+            raise ValueError("layout: 'slots' or 'append'")
         out.capped = out.count >= K
         out.timed_out = False
         out.counts_table = counts
@@ -315,20 +337,23 @@ class Engine:
     TREES_SPECULATIVE_SLOTS = 1 << 20
 
     def trace_branching(self, rays: RayBatch, max_trace_num, counts=None, max_trace_time=None, distinct_ids=None):
-        """Ray trees by whichever path the scene and the cap allow: ONE launch with a lane per tree (`trace_trees`: [k][tree]
-        slots in the reference's order) when the scene has such a kernel and its queues hold every possible tree — or, for
-        larger caps, speculatively when the batch is small (a tree that overflows its queue sends the call to the
-        generations) — else the generation loop (`trace_tree`: a list in generation order).  Readers take both layouts;
-        `capped` / `timed_out` are set either way.  Scenes with count-limited surfaces: the lane-per-tree kernel meets them in
-        each tree's FIFO order, which is the reference's as long as no two trees of the call share a column of `counts`
-        (`distinct_ids=True`: the caller vouches for it, as the host API's rounds do; default: such scenes take the generations)."""
+        """Ray trees by whichever path the scene and the cap allow: ONE launch with a lane per tree (`trace_trees`) when the
+        scene has such a kernel and its queues hold every possible tree — or, for larger caps, speculatively when the batch
+        is small (a tree that overflows its queue sends the call to the generations) — else the generation loop
+        (`trace_tree`: a list in generation order).  The lane-per-tree launch writes [k][tree] slots (the reference's order
+        as they lie) for small batches of planar scenes and the dense append list otherwise (whole lines per field however
+        much the trees differ in size); readers take all layouts; `capped` / `timed_out` are set either way.
+        Scenes with count-limited surfaces: the lane-per-tree kernel meets them in each tree's FIFO order, which is the
+        reference's as long as no two trees of the call share a column of `counts` (`distinct_ids=True`: the caller vouches
+        for it, as the host API's rounds do; default: such scenes take the generations)."""
         n, K = rays.n, int(max_trace_num)
         gates_ok = not self.scene.limited or bool(distinct_ids)
         if n and gates_ok and (max_trace_time is None or max_trace_time > 1.0):
             plan = self.trees_plan(rays.precision, K)
-            if plan["kernel"] and (plan["full"] or (n <= self.TREES_SMALL_BATCH and n * K <= self.TREES_SPECULATIVE_SLOTS)):
+            small = n <= self.TREES_SMALL_BATCH
+            if plan["kernel"] and (plan["full"] or (small and n * K <= self.TREES_SPECULATIVE_SLOTS)):
                 before = counts.clone() if (counts is not None and not plan["full"]) else None  # a speculation must not leave counts behind
-                segs = self.trace_trees(rays, K, counts=counts)
+                segs = self.trace_trees(rays, K, counts=counts, layout="slots" if (plan["slots"] and small) else "append")
                 if plan["full"] or not bool((segs.count < 0).any()):
                     return segs
                 del segs

@@ -39,7 +39,7 @@ def _same_as_generations(scene, batch, cap):
     eng.upload(scene)
     plan = eng.trees_plan(batch.precision, cap)
     assert plan["kernel"] and plan["full"], plan
-    trees = eng.trace_trees(batch, cap)
+    trees = eng.trace_trees(batch, cap, layout="slots" if plan["slots"] else "append")  # (the [k][tree] slots: the planar preset only)
     gens = eng.trace_tree(batch, cap)
     assert int(trees.count.min()) >= 1
     assert int(trees.count.sum()) == gens.n_valid
@@ -63,7 +63,7 @@ def test_trees_equal_generations_on_cfg4_with_reflectivity(precision, oracle):
     assert bool(trees.capped.all())
     if precision == "f64":
         small = batch.slice(0, 400)
-        got = get_engine().trace_trees(small, 12).to_host(reference_order=True)
+        got = get_engine().trace_branching(small, 12).to_host(reference_order=True)
         ref = oracle.trace(scene, small.to_host(), max_trace_num=12)
         np.testing.assert_array_equal(got["ray"], ref["ray"])
         np.testing.assert_array_equal(got["surface"], ref["surface"])
@@ -179,7 +179,7 @@ def test_trees_through_count_limited_faces_match_the_oracle(dove, oracle):
     batch = P._rays(1500, "f64")
     eng = get_engine()
     segs = table.trace_batch(batch, max_segments=14, scene=scene)
-    assert segs.layout == "slots" and eng.last_launch()["kernel"] == 4  # the lane-per-tree kernel took it
+    assert segs.count is not None and eng.last_launch()["kernel"] == 4  # the lane-per-tree kernel took it
     got = segs.to_host(reference_order=True)
     ref = oracle.trace(scene, batch.to_host(), max_trace_num=14)
     assert len(ref["ray"]) > 3 * batch.n
@@ -217,3 +217,32 @@ def test_rays_sharing_an_id_take_their_counts_in_input_order():
     for f in abi.SEG_FIELDS + ("ray", "surface"):
         np.testing.assert_array_equal(a[f], b[f], err_msg=f)
     assert torch.equal(segs.counts_table, again.counts_table)
+
+
+@pytest.mark.parametrize("precision", ["f64", "f32"])
+@pytest.mark.parametrize("away", [0.0, 0.9])
+def test_append_layout_of_the_tree_kernel_holds_the_same_records(precision, away):
+    """ot_trace_trees_append_*: the records of a step go to consecutive slots of the wave's chunk whatever trees the lanes are on
+    (a batch in which nine trees of ten are a single ray: lanes refill from their wave's share all the time) — the same
+    records as the [k][tree] slots, in the reference's order after the stable sort by tree."""
+    scene = _lattice()
+    batch = _lattice_rays(30_000, 13, precision)
+    if away:
+        gone = torch.rand(batch.n, device=batch.device) < away
+        batch.dx[gone] = -1.0
+        batch.dy[gone] = 0.0
+        batch.dz[gone] = 0.0
+    eng = get_engine()
+    eng.upload(scene)
+    slots = eng.trace_trees(batch, 24)
+    dense = eng.trace_trees(batch, 24, layout="append")
+    assert dense.layout == "append" and eng.last_launch()["kernel"] == 4
+    records = int(slots.count.sum())
+    assert torch.equal(dense.count, slots.count) and torch.equal(dense.capped, slots.capped)
+    assert records <= dense.n_valid <= records + 512 * 4096  # holes: the tail of every wave's last chunk at most
+    a, b = dense.to_host(reference_order=True), slots.to_host(reference_order=True)
+    for f in abi.SEG_FIELDS + ("ray", "surface"):
+        np.testing.assert_array_equal(a[f], b[f], err_msg=f)
+    small = eng.trace_trees(batch, 24, layout="append", capacity=4096)  # a block that is too small loses records, not memory
+    with pytest.raises(RuntimeError, match="capacity"):
+        small.n_valid

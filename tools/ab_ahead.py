@@ -52,12 +52,13 @@ def run(label, comps, batch, cap, out_cap):
         print(f"{label:44s} lane-per-tree plan {plan}")
         if plan["kernel"] and plan["full"]:
             from optable_amd.batch import SegmentBatch
-            out = SegmentBatch(batch.n * cap, batch.precision, batch.device)
+            TL = os.environ.get("TREE_LAYOUT", "slots")
+            out = SegmentBatch(batch.n * cap + (512 * 8192 if TL == "append" else 0), batch.precision, batch.device, block=(TL == "append"))
             for rnd in range(4):
                 eng.timing(True)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                segs = eng.trace_trees(batch, cap, out=out)
+                segs = eng.trace_trees(batch, cap, out=out, layout=TL)
                 torch.cuda.synchronize()
                 wall = (time.perf_counter() - t0) * 1e3
                 ms, launches = eng.timing_read()

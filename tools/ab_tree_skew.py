@@ -24,13 +24,14 @@ d[away] = [-1.0, 0.0, 0.0]  # these leave the table at once: trees of one ray
 for prec in ("f64", "f32"):
     batch = RayBatch.from_arrays(o, d, wavelength=W.WL, q=1j * np.pi * W.W0**2 / W.WL, precision=prec)
     for cap in (24, 96):
-        out = SegmentBatch(n * cap, prec, batch.device)
-        for rnd in range(3):
-            eng.timing(True); torch.cuda.synchronize()
-            segs = eng.trace_trees(batch, cap, out=out)
-            torch.cuda.synchronize(); ms, _ = eng.timing_read(); eng.timing(False)
-        print(f"{prec} cap {cap}: {ms:.3f} ms, {int(segs.count.abs().sum())} segments, plan {eng.trees_plan(prec, cap)}", flush=True)
-        del out, segs
+        for layout in ("slots", "append"):
+            out = SegmentBatch(n * cap + 512 * 8192 if layout == "append" else n * cap, prec, batch.device, block=(layout == "append"))
+            for rnd in range(3):
+                eng.timing(True); torch.cuda.synchronize()
+                segs = eng.trace_trees(batch, cap, out=out, layout=layout)
+                torch.cuda.synchronize(); ms, _ = eng.timing_read(); eng.timing(False)
+            print(f"{prec} cap {cap} {layout}: {ms:.3f} ms, {int(segs.count.abs().sum())} segments", flush=True)
+            del out, segs
         for rnd in range(2):
             eng.timing(True); torch.cuda.synchronize(); t0 = time.perf_counter()
             g = eng.trace_tree(batch, cap, out_capacity=22_000_000)

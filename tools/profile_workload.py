@@ -86,6 +86,7 @@ elif name in ("cfg4", "cfg4b"):
             else:  # one launch, a lane per tree (k_trace_trees)
                 segs = eng.trace_branching(batch, 12)
                 n_seg = int(segs.count.abs().sum())
+                assert eng.last_launch()["kernel"] == 4
             torch.cuda.synchronize()
             print(f"cfg4b: {batch.n} trees, {n_seg} segments per trace, {1e3 * (time.perf_counter() - t0):.1f} ms wall, layout {segs.layout}")
             del segs
