@@ -1,3 +1,8 @@
+#!/usr/bin/env python3
+"""Batches whose ray trees differ widely in size: a beam-splitter lattice (9 components) in which a share AWAY (default 0.9) of
+the 2e6 input rays leaves the table at once (a tree of one ray) and the rest grow bushy trees up to the cap (24 / 96).  The
+lane-per-tree kernel into [k][tree] slots and into the append layout, and the generation loop, device ms each.
+    AWAY=0.9 python tools/ab_tree_skew.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
