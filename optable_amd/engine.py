@@ -336,13 +336,29 @@ class Engine:
     TREES_SMALL_BATCH = 64 * 256
     TREES_SPECULATIVE_SLOTS = 1 << 20
 
+    def _trees_estimate(self, rays, K):
+        """Rays per tree of a large batch from a strided 1 % sample (its own lane-per-tree launch), remembered per scene, cap and
+        precision: sizes the append block (x 1.15 + the launch's slack instead of every tree at its cap) and tells batches of few
+        long trees under a large cap — the one regime in which the generation loop is faster — from the rest."""
+        n = rays.n
+        key = ("trees", id(self.scene), K, rays.precision)
+        rpr = self._records_per_ray.get(key)
+        if rpr is None:
+            m = max(n // 100, 4096)
+            idx = torch.arange(0, n, max(n // m, 1), device=rays.device)
+            sample = self.trace_trees(rays.take(idx), K, layout="append")
+            rpr = float(sample.count.abs().sum().item()) / float(idx.numel())
+            self._records_per_ray = {key: rpr}  # (one scene at a time)
+        return rpr
+
     def trace_branching(self, rays: RayBatch, max_trace_num, counts=None, max_trace_time=None, distinct_ids=None):
         """Ray trees by whichever path the scene and the cap allow: ONE launch with a lane per tree (`trace_trees`) when the
         scene has such a kernel and its queues hold every possible tree — or, for larger caps, speculatively when the batch
         is small (a tree that overflows its queue sends the call to the generations) — else the generation loop
         (`trace_tree`: a list in generation order).  The lane-per-tree launch writes [k][tree] slots (the reference's order
         as they lie) for small batches of planar scenes and the dense append list otherwise (whole lines per field however
-        much the trees differ in size); readers take all layouts; `capped` / `timed_out` are set either way.
+        much the trees differ in size; its block sized from a 1 % sample of a large batch, traced again into what the launch
+        asked for should that be too small); readers take all layouts; `capped` / `timed_out` are set either way.
         Scenes with count-limited surfaces: the lane-per-tree kernel meets them in each tree's FIFO order, which is the
         reference's as long as no two trees of the call share a column of `counts` (`distinct_ids=True`: the caller vouches
         for it, as the host API's rounds do; default: such scenes take the generations)."""
@@ -353,7 +369,24 @@ class Engine:
             small = n <= self.TREES_SMALL_BATCH
             if plan["kernel"] and (plan["full"] or (small and n * K <= self.TREES_SPECULATIVE_SLOTS)):
                 before = counts.clone() if (counts is not None and not plan["full"]) else None  # a speculation must not leave counts behind
-                segs = self.trace_trees(rays, K, counts=counts, layout="slots" if (plan["slots"] and small) else "append")
+                if plan["slots"] and small:
+                    segs = self.trace_trees(rays, K, counts=counts, layout="slots")
+                elif n * K <= 1 << 22 or self.scene.limited:  # small: the worst case costs nothing; count tables are never sampled
+                    segs = self.trace_trees(rays, K, counts=counts, layout="append")
+                else:
+                    rpr = self._trees_estimate(rays, K)
+                    if K > 48 and rpr < 0.25 * K:  # few long trees under a large cap
+                        return self.trace_tree(rays, K, counts=counts, max_trace_time=max_trace_time)
+                    slack = self.append_chunk * self.MAX_WAVES
+                    capacity = min(int(n * rpr * 1.15) + slack, n * K + slack)
+                    for _ in range(3):
+                        segs = self.trace_trees(rays, K, layout="append", capacity=(capacity + 63) // 64 * 64)
+                        need = int(segs.cursor.item())
+                        if need <= segs.capacity:
+                            break
+                        self._records_per_ray = {}
+                        del segs
+                        capacity = int(need * 1.02) + (1 << 20)  # (holes fall differently from run to run)
                 if plan["full"] or not bool((segs.count < 0).any()):
                     return segs
                 del segs

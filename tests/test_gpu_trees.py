@@ -246,3 +246,28 @@ def test_append_layout_of_the_tree_kernel_holds_the_same_records(precision, away
     small = eng.trace_trees(batch, 24, layout="append", capacity=4096)  # a block that is too small loses records, not memory
     with pytest.raises(RuntimeError, match="capacity"):
         small.n_valid
+
+
+def test_default_call_sizes_the_dense_list_from_a_sample_and_knows_when_the_generations_win():
+    """Engine.trace_branching on a large batch: rays per tree from a 1 % sample; the append block is that x 1.15 + the launch's
+    slack, not every tree at its cap; a batch of few long trees under a large cap goes to the generation loop."""
+    scene = _lattice()
+    eng = get_engine()
+    eng.upload(scene)
+    batch = _lattice_rays(400_000, 17, "f32")
+    gone = torch.rand(batch.n, device=batch.device) < 0.9
+    batch.dx[gone] = -1.0
+    batch.dy[gone] = 0.0
+    batch.dz[gone] = 0.0
+    segs = eng.trace_branching(batch, 24)
+    assert segs.layout == "append" and eng.last_launch()["kernel"] == 4
+    records = int(segs.count.sum())
+    assert records < 0.2 * batch.n * 24  # (most trees are one ray)
+    assert segs.capacity <= 1.3 * records + 512 * 8192 + 64
+    ref = eng.trace_tree(batch, 24)
+    assert records == ref.n_valid
+    a, b = segs.to_host(reference_order=True), ref.to_host(reference_order=True)
+    for f in abi.SEG_FIELDS + ("ray", "surface"):
+        np.testing.assert_array_equal(a[f], b[f], err_msg=f)
+    big = eng.trace_branching(batch, 96)  # few long trees under a large cap: generation by generation
+    assert big.layout == "list" and big.n_valid == eng.trace_trees(batch, 96, layout="append").count.sum().item()
