@@ -84,7 +84,9 @@ elif name in ("cfg4", "cfg4b"):
                 segs = eng.trace_tree(batch, 12, out_capacity=batch.n * 13)
                 n_seg = segs.n_valid
             else:  # one launch, a lane per tree (k_trace_trees)
-                segs = eng.trace_branching(batch, 12)
+                # (what Engine.trace_branching launches for this batch, into a block for every tree at its cap: the default call's 1 %
+                # sample would show up in the profile as one more, tiny launch of the same kernel)
+                segs = eng.trace_trees(batch, 12, layout="append")
                 n_seg = int(segs.count.abs().sum())
                 assert eng.last_launch()["kernel"] == 4
             torch.cuda.synchronize()
