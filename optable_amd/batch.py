@@ -225,6 +225,7 @@ class SegmentBatch:
     """
 
     tiled = append = False          # defaults for batches assembled field by field (astype, to_slots, table.py)
+    trees = False                   # True: `count[i]` rays of a ray TREE per input ray (Engine.trace_trees), not the segments of one path
     block = cursor = _n_valid = count = n_rays = None
 
     def __init__(self, capacity, precision="f64", device="cuda", block=False, tiled=False):
@@ -306,7 +307,7 @@ class SegmentBatch:
         out.ray, out.surface = self.ray.reshape(-1), self.surface.reshape(-1)
         out.count, out.n_rays, out._n_valid, out.cursor = self.count, self.n_rays, self._n_valid, None
         out.append, out.block, out.tiled = False, None, False
-        for extra in ("capped", "counts_table", "count_ids"):
+        for extra in ("capped", "counts_table", "count_ids", "trees", "timed_out"):
             if hasattr(self, extra):
                 setattr(out, extra, getattr(self, extra))
         return out
@@ -362,7 +363,7 @@ class SegmentBatch:
         out.ray, out.surface = self.ray, self.surface
         out.count, out.n_rays, out._n_valid, out.cursor = self.count, self.n_rays, self.n_valid, None
         out.append, out.block = self.append, None
-        for extra in ("capped", "counts_table", "count_ids"):
+        for extra in ("capped", "counts_table", "count_ids", "trees", "timed_out"):
             if hasattr(self, extra):
                 setattr(out, extra, getattr(self, extra))
         return out

@@ -30,7 +30,7 @@ def shard_indices_by_id(ids, rank, world):
 
 def final_state(segs):
     """[12, n_rays] tensor: each ray's last segment (non-branching [k][ray] layout)."""
-    if segs.count is None:
+    if segs.count is None or getattr(segs, "trees", False):
         raise ValueError("final_state needs a non-branching trace (slots or append layout); a ray tree has no single last segment")
     n = segs.n_rays
     if getattr(segs, "tiled", False):  # slot s at [s // 64, s % 64] of the strided field views

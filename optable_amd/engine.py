@@ -329,6 +329,7 @@ class Engine:
         out.capped = out.count >= K
         out.timed_out = False
         out.counts_table = counts
+        out.trees = True
         return out
 
     # A lane-per-tree launch whose queues may overflow (caps beyond ~170 in double precision) is a speculation on small trees:

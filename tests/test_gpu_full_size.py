@@ -186,3 +186,56 @@ def test_cfg5_shard_fp32():
     _chain_properties(segs, n, K, tol=6e-3, unit_tol=1e-6)
     _shard_equals_whole(table, batch, segs, 5_000_000, 5_400_000, K)
     torch.cuda.empty_cache()
+
+
+def test_cfg4_ray_trees_full_size_fp64():
+    """cfg 4 with reflectivity 0.2 at the size bench.py quotes (1.28e7 ray trees x 12 rays, fp64) through the default call
+    (Engine.trace_branching: one lane-per-tree launch into the dense list): every tree is cut by the cap with exactly 12
+    records, the first record of a tree is its input ray, every direction is a unit vector, energy never grows along a tree —
+    and a strided sample of 20 000 trees traced on its own through the GENERATION kernels gives the records the big launch
+    holds for those trees, bit for bit, in the reference's order."""
+    import torch
+
+    import optable_amd as oa
+    from optable_amd import workloads as W
+    from optable_amd.batch import RayBatch
+    from optable_amd.engine import get_engine
+
+    table = _table(W.cfg4_components(oa, reflectivity=0.2))
+    scene = table.compile()
+    eng = get_engine()
+    eng.upload(scene)
+    o, d, _ = W.cfg4_rays(200_000, 4, n_wavelengths=1)
+    base = RayBatch.from_arrays(o, d, wavelength=W.WL, q=1j * np.pi * W.W0**2 / W.WL, precision="f64")
+    batch = base.multiplexed_in_wavelength(np.linspace(400e-7, 1100e-7, W.CFG4_WAVELENGTHS))
+    n, K = batch.n, 12
+    segs = eng.trace_branching(batch, K)
+    assert eng.last_launch()["kernel"] == 4 and segs.layout == "append"
+    assert bool((segs.count == K).all()) and bool(segs.capped.all())
+    m = segs.n_valid
+    ray = segs.ray[:m]
+    real = ray >= 0
+    assert int(real.sum()) == n * K and m - n * K <= 512 * 8192  # holes: chunk tails only
+    norm = torch.sqrt(segs.dx[:m] ** 2 + segs.dy[:m] ** 2 + segs.dz[:m] ** 2)
+    assert float((norm - 1).abs()[real].max()) < 1e-12
+    assert float(segs.intensity[:m][real].max()) <= 1.0 + 1e-12 and float(segs.intensity[:m][real].min()) >= 0.0
+    # the first record of every tree (its lowest slot) is the input ray
+    slot = torch.arange(m, device=ray.device)
+    first = torch.full((n,), m, dtype=torch.int64, device=ray.device).scatter_reduce_(0, ray[real].long(), slot[real], "amin", include_self=True)
+    assert bool((first < m).all())
+    for f, src in (("ox", batch.ox), ("oy", batch.oy), ("oz", batch.oz), ("dx", batch.dx), ("dy", batch.dy), ("dz", batch.dz)):
+        assert torch.equal(segs.field(f)[first], src), f
+    # a strided sample of trees through the generation kernels
+    pick = torch.arange(0, n, n // 20_000, device=ray.device)
+    sample = eng.trace_tree(batch.take(pick), K).to_host(reference_order=True)
+    index_of = torch.full((n,), -1, dtype=torch.int64, device=ray.device)
+    index_of[pick] = torch.arange(pick.numel(), device=ray.device)
+    mine = real & (index_of[ray.clamp(min=0).long()] >= 0)
+    where = torch.nonzero(mine).flatten()
+    order = torch.argsort(index_of[ray[where].long()], stable=True)  # (records of a tree lie at increasing slots: FIFO order)
+    where = where[order].cpu()
+    assert where.numel() == len(sample["ray"]) == pick.numel() * K
+    np.testing.assert_array_equal(index_of[ray[where.to(ray.device)].long()].cpu().numpy(), sample["ray"])
+    np.testing.assert_array_equal(segs.surface[where.to(ray.device)].cpu().numpy(), sample["surface"])
+    for f in abi.SEG_FIELDS:
+        np.testing.assert_array_equal(segs.field(f)[where.to(ray.device)].cpu().numpy(), sample[f], err_msg=f)
