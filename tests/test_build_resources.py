@@ -48,7 +48,7 @@ def test_no_kernel_uses_scratch_or_spills_vector_registers(kernels):
 
 def test_library_stays_small(kernels):
     # round 2 shipped 461 kernels (338 of them a scan library's tuning variants) and took two minutes to build
-    assert 40 <= len(kernels) < 160, len(kernels)  # round 4: 151 (+ look-ahead emit, recount, the lane-per-tree kernels)
+    assert 40 <= len(kernels) < 160, len(kernels)  # round 4: 158 (+ look-ahead emit, recount, the lane-per-tree kernels in two output layouts)
     names = [k["name"] for k in kernels]
     assert not any("rocprim" in n or "hipcub" in n for n in names)
     assert sum("k_trace_rolling" in n for n in names) <= 48
