@@ -106,7 +106,7 @@ SYMBOLS = {
     "ot_trace_trees_f32": (C.c_int, [_vp, C.POINTER(OtRays), _i64, _i32, C.POINTER(OtSegments), _vp, _vp, _i32]),
     "ot_trace_trees_append_f64": (C.c_int, [_vp, C.POINTER(OtRays), _i64, _i32, C.POINTER(OtSegmentBlock), _vp, _vp, _vp, _i32]),
     "ot_trace_trees_append_f32": (C.c_int, [_vp, C.POINTER(OtRays), _i64, _i32, C.POINTER(OtSegmentBlock), _vp, _vp, _vp, _i32]),
-    "ot_trace_trees_plan": (C.c_int, [_vp, _i32, _i32, _vp]),
+    "ot_trace_trees_plan": (C.c_int, [_vp, _i32, _i32, _i64, _vp]),
     "ot_monitor_record_f64": (C.c_int, [_vp, C.POINTER(OtMonitor), C.POINTER(OtSegments), _i64, _vp, _i64, _vp, _vp,
                                         _vp, _vp, _vp, _vp]),
     "ot_timing_enable": (C.c_int, [_vp, C.c_int]),

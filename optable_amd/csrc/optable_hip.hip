@@ -1160,7 +1160,7 @@ static int trace_generation(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
 // within 1 GiB (caps up to ~170 in double precision); beyond that the queues are what fits and the launch is a speculation
 // on small trees (full = 0).
 struct TreesPlan { int32_t QL, QG, full, groups_per_cu; size_t lds_bytes; };
-template <class T> static bool trees_plan(const ot_ctx* c, int32_t cap, TreesPlan* p) {
+template <class T> static bool trees_plan(const ot_ctx* c, int32_t cap, int64_t n, TreesPlan* p) {
     const size_t image = sizeof(T) == 8 ? c->bytes64 : c->bytes32;
     *p = TreesPlan{};
     if (!c->has_scene || c->max_children > 2 || cap < 1 || !tree_kernel<T, SegPlanes<T>>(gen_preset(c->features))) return false;
@@ -1174,7 +1174,9 @@ template <class T> static bool trees_plan(const ot_ctx* c, int32_t cap, TreesPla
     p->lds_bytes = img + 4 * (size_t)ql * entry;
     const int by_lds = (int)((160 * 1024) / (p->lds_bytes + 256)), by_regs = tree_groups_by_registers<T>(gen_preset(c->features));  // (waves per SIMD the kernel's registers allow)
     p->groups_per_cu = by_lds < by_regs ? (by_lds < 1 ? 1 : by_lds) : by_regs;
-    const int64_t waves = (int64_t)c->n_cus * p->groups_per_cu * 4;
+    // (the scratch is per workgroup of the LAUNCH: a batch of a few trees is a few workgroups, and gets long queues out of the same 1 GiB)
+    const int64_t groups_needed = n > 0 ? (n + 255) / 256 : (int64_t)1 << 40, groups_most = (int64_t)c->n_cus * p->groups_per_cu;
+    const int64_t waves = (groups_needed < groups_most ? groups_needed : groups_most) * 4;
     int64_t most = ((int64_t)1 << 30) / (waves * (int64_t)entry);
     if (most > 255) most = 255;  // (the kernel keeps ring positions in bytes)
     // (the scratch ring alone must hold a whole queue: pushes keep going there while the LDS entries in front of them drain)
@@ -1187,7 +1189,7 @@ template <class T, class OUT>
 static int launch_trees(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t cap, const OUT& out, const AppendCtl& ac, int32_t* seg_count, int32_t* counts,
                         int32_t n_classes) {
     TreesPlan p;
-    if (!trees_plan<T>(c, cap, &p)) return fail(OT_ERR_UNSUPPORTED, "no tree kernel for this scene (features beyond the everyday presets, or an image that leaves no room for the queues): use ot_trace_tree_*");
+    if (!trees_plan<T>(c, cap, n, &p)) return fail(OT_ERR_UNSUPPORTED, "no tree kernel for this scene (features beyond the everyday presets, or an image that leaves no room for the queues): use ot_trace_tree_*");
     HIP_TRY(hipSetDevice(c->device));
     const TreeKern<T, OUT> kern = tree_kernel<T, OUT>(gen_preset(c->features));
     if (!kern) return fail(OT_ERR_UNSUPPORTED, "this scene's tree kernel writes the append layout only (ot_trace_trees_append_*)");
@@ -1409,10 +1411,10 @@ int ot_trace_trees_append_f32(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t
                               int32_t* counts, int32_t n_classes) {
     return trace_trees_append<float>(c, rays, n, max_trace_num, out, n_slots, seg_count, counts, n_classes);
 }
-int ot_trace_trees_plan(ot_ctx* c, int32_t real_bytes, int32_t max_trace_num, int32_t* info) {
+int ot_trace_trees_plan(ot_ctx* c, int32_t real_bytes, int32_t max_trace_num, int64_t n_rays, int32_t* info) {
     if (!c || !info || (real_bytes != 4 && real_bytes != 8)) return fail(OT_ERR_INVALID, "bad ot_trace_trees_plan arguments");
     TreesPlan p;
-    const bool ok = real_bytes == 8 ? trees_plan<double>(c, max_trace_num, &p) : trees_plan<float>(c, max_trace_num, &p);
+    const bool ok = real_bytes == 8 ? trees_plan<double>(c, max_trace_num, n_rays, &p) : trees_plan<float>(c, max_trace_num, n_rays, &p);
     info[0] = ok ? 1 : 0; info[1] = p.QL + p.QG; info[2] = p.full; info[3] = p.QL;
     if (ok && (real_bytes == 8 ? tree_kernel<double, SegsT<double>>(gen_preset(c->features)) != nullptr : tree_kernel<float, SegsT<float>>(gen_preset(c->features)) != nullptr))
         info[0] |= 2;  // ... and writes the [k][tree] slots too

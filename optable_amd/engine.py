@@ -273,11 +273,12 @@ class Engine:
         return out
 
     # -- branching trace: breadth-first, one generation per launch ------------------------------
-    def trees_plan(self, precision, max_trace_num):
+    def trees_plan(self, precision, max_trace_num, n_rays=0):
         """ot_trace_trees_plan: does the uploaded scene have a lane-per-tree kernel (k_trace_trees), how many queue entries
-        per lane would a cap of `max_trace_num` get, and is that enough for every possible tree."""
+        per lane would a cap of `max_trace_num` get for a batch of `n_rays` trees (0: one that fills the device), and is that
+        enough for every possible tree."""
         info = (C.c_int32 * 4)()
-        abi.check(self.lib.ot_trace_trees_plan(self._ctx, 8 if precision == "f64" else 4, int(max_trace_num), info), self.lib)
+        abi.check(self.lib.ot_trace_trees_plan(self._ctx, 8 if precision == "f64" else 4, int(max_trace_num), int(n_rays), info), self.lib)
         return {"kernel": bool(info[0] & 1), "slots": bool(info[0] & 2), "queue": int(info[1]), "full": bool(info[2]), "lds_entries": int(info[3])}
 
     def trace_trees(self, rays: RayBatch, max_trace_num, out: SegmentBatch = None, counts=None, layout="slots", capacity=None):
@@ -366,7 +367,7 @@ class Engine:
         n, K = rays.n, int(max_trace_num)
         gates_ok = not self.scene.limited or bool(distinct_ids)
         if n and gates_ok and (max_trace_time is None or max_trace_time > 1.0):
-            plan = self.trees_plan(rays.precision, K)
+            plan = self.trees_plan(rays.precision, K, n)
             small = n <= self.TREES_SMALL_BATCH
             if plan["kernel"] and (plan["full"] or (small and n * K <= self.TREES_SPECULATIVE_SLOTS)):
                 before = counts.clone() if (counts is not None and not plan["full"]) else None  # a speculation must not leave counts behind
