@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Differential fuzz of the lane-per-tree kernel (k_trace_trees): random branching scenes (tests/test_gpu_fuzz.py's generator:
+lenses, mirrors, slabs, apertures + beam splitters, partially reflecting slabs and mirrors), random batch sizes (partial waves,
+shares of uneven length), caps 1..60, 1..6 queue entries in LDS, both output layouts, count-limited surfaces included — against the generation kernels
+(ot_trace_tree_*), bit for bit in the reference's order, and (double precision, first 300 trees) against the oracle.
+    python tools/tree_fuzz.py [n_cases] [first_seed]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+
+import optable_amd as oa
+import scenes
+from optable_amd import abi
+from optable_amd.batch import RayBatch
+from optable_amd.engine import get_engine
+from oracle import oracle
+from test_gpu_fuzz import random_branching_scene
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+eng = get_engine()
+oracle.build()
+bad = skipped = 0
+for seed in range(first, first + cases):
+    rng = np.random.default_rng(770000 + seed)
+    table = oa.OpticalTable()
+    table.add_components(random_branching_scene(oa, rng))
+    scene = table.compile()
+    eng.upload(scene)
+    n = int(rng.choice([1, 63, 64, 65, 200, 1000, 5000, 20000]))
+    cap = int(rng.integers(1, 61))
+    ql = int(rng.integers(1, 7))
+    prec = "f64" if rng.uniform() < 0.6 else "f32"
+    o = np.stack([np.zeros(n), rng.uniform(-3, 3, n), rng.uniform(-0.3, 0.3, n)], 1)
+    d = np.stack([np.ones(n), rng.uniform(-0.12, 0.12, n), rng.uniform(-0.02, 0.02, n)], 1)
+    batch = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=1j * np.pi * scenes.W0**2 / scenes.WL, precision=prec)
+    eng.set_option(abi.OPT_TREES_LDS_ENTRIES, ql)
+    plan = eng.trees_plan(prec, cap, n)
+    if not plan["kernel"]:
+        skipped += 1
+        continue
+    gens = eng.trace_tree(batch, cap)  # (count-limited surfaces: a fresh column of the counts table per tree, in both paths)
+    g = gens.to_host(reference_order=True)
+    layouts = ["append"] + (["slots"] if plan["slots"] else [])
+    ok = True
+    for layout in layouts:
+        t = eng.trace_trees(batch, cap, layout=layout)
+        if not plan["full"] and bool((t.count < 0).any()):
+            continue
+        h = t.to_host(reference_order=True)
+        same = torch.equal(t.capped, gens.capped) and all(np.array_equal(h[f], g[f]) for f in abi.SEG_FIELDS + ("ray", "surface"))
+        if scene.limited:
+            same = same and torch.equal(t.counts_table, gens.counts_table)
+        if not same:
+            ok = False
+            print(f"seed {seed}: {layout} differs from the generations (n={n} cap={cap} ql={ql} {prec}, plan {plan})", flush=True)
+    if ok and prec == "f64":
+        m = min(n, 300)
+        small = batch.slice(0, m)
+        got = eng.trace_trees(small, cap, layout="append").to_host(reference_order=True)
+        ref = oracle.trace(scene, small.to_host(), max_trace_num=cap)
+        seq_g = [[] for _ in range(m)]
+        seq_r = [[] for _ in range(m)]
+        for r, s in zip(got["ray"], got["surface"]):
+            seq_g[r].append(int(s))
+        for r, s in zip(ref["ray"], ref["surface"]):
+            seq_r[r].append(int(s))
+        differ = sum(a != b for a, b in zip(seq_g, seq_r))
+        if differ > max(1, 0.01 * m):  # (a hit within an ulp of an edge may differ between compilers; more is a defect)
+            ok = False
+            print(f"seed {seed}: {differ} of {m} trees differ from the oracle (cap={cap} ql={ql})", flush=True)
+    bad += not ok
+    if seed % 20 == 19:
+        print(f"... {seed - first + 1} cases, {bad} bad, {skipped} skipped", flush=True)
+eng.set_option(abi.OPT_TREES_LDS_ENTRIES, 3)
+print(f"{cases} cases: {bad} bad, {skipped} skipped (no lane-per-tree kernel for the scene)")
+sys.exit(1 if bad else 0)
