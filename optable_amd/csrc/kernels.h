@@ -108,6 +108,9 @@ template <class T> struct SegPlanes {
 template <class T, bool NT = false>
 __device__ __forceinline__ void store_segment(const SegPlanes<T>& out, int64_t slot, const RayState<T>& r, T len, int32_t tree,
                                               int32_t surface) {
+#ifdef OT_EXP_NOSTORE  // measurement only: what the record stores cost a kernel (never in the product library)
+    if (slot != 0x7fffffffffffll) return;
+#endif
     const uint32_t s = (uint32_t)slot;
     uint8_t* b = out.base;
     asm volatile("" : "+s"(b));  // the fourteen plane bases are formed HERE, two scalar adds each, not kept in 28 registers across the pass loop
