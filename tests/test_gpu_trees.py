@@ -271,3 +271,29 @@ def test_default_call_sizes_the_dense_list_from_a_sample_and_knows_when_the_gene
         np.testing.assert_array_equal(a[f], b[f], err_msg=f)
     big = eng.trace_branching(batch, 96)  # few long trees under a large cap: generation by generation
     assert big.layout == "list" and big.n_valid == eng.trace_trees(batch, 96, layout="append").count.sum().item()
+
+
+def test_monitors_and_exports_read_tree_outputs_like_the_generation_list(tmp_path):
+    """Monitor.record and the CSV export over the outputs of the lane-per-tree kernel ([k][tree] slots, the dense list) equal
+    those over the generation kernels' list."""
+    table = oa.OpticalTable()
+    table.add_components(W.cfg4_components(oa, reflectivity=0.2))
+    scene = table.compile()
+    mon = oa.Monitor(origin=[-1.0, 0, 0], width=40, height=40)  # in front of the slab: the input rays and every reflection cross it
+    o, d, wl = W.cfg4_rays(300, 4)
+    batch = RayBatch.from_arrays(o, d, wavelength=wl, q=1j * np.pi * W.W0**2 / wl)
+    eng = get_engine()
+    eng.upload(scene)
+    outs = {"list": eng.trace_tree(batch, 12), "slots": eng.trace_trees(batch, 12, layout="slots"), "append": eng.trace_trees(batch, 12, layout="append")}
+    hits = {k: table.record_batch(mon, v) for k, v in outs.items()}
+    assert len(hits["list"]) > 0
+    for name in ("slots", "append"):
+        assert len(hits[name]) == len(hits["list"])
+        for acc in ("yList", "zList", "tYList", "IList", "tList"):
+            np.testing.assert_array_equal(getattr(hits[name], acc)(None).cpu().numpy(), getattr(hits["list"], acc)(None).cpu().numpy(), err_msg=f"{name} {acc}")
+    texts = {}
+    for name, segs in outs.items():
+        path = tmp_path / f"{name}.csv"
+        table.export_batch_csv(segs, str(path), batch)
+        texts[name] = path.read_text()
+    assert texts["slots"] == texts["list"] and texts["append"] == texts["list"]
