@@ -333,6 +333,8 @@ class Engine:
         out.trees = True
         return out
 
+    HINT_SECONDS = 1.0  # MIN_HINTING_TIME of the reference's loop (optical_table.py:85): a longer trace reports its progress at this interval
+
     # A lane-per-tree launch whose queues may overflow (caps beyond ~170 in double precision) is a speculation on small trees:
     # small batches only, and it may allocate this many slots at most.
     TREES_SMALL_BATCH = 64 * 256
@@ -439,8 +441,12 @@ class Engine:
         result = (C.c_int64 * 5)()
         cur, cur_n, written = rays, n, 0
         timed_out = None
+        # The library comes back at least once per HINT seconds: a trace that runs longer says so once per second, as the
+        # reference does per input ray (optical_table.py:99-111; here the clock is the batch's and the counts are the batch's).
+        HINT = self.HINT_SECONDS
         while cur_n > 0:
-            left = -1.0 if max_trace_time is None else max(max_trace_time - (time.time() - t_start), 0.0)
+            left_total = None if max_trace_time is None else max(max_trace_time - (time.time() - t_start), 0.0)
+            left = HINT * 1.01 if left_total is None else min(left_total, HINT * 1.01)  # (just over the interval: chains of small generations need max_seconds > 1)
             rs, ss, sa, sb = cur.c_struct(), out.c_struct(), bufs[0].c_struct(), bufs[1].c_struct()
             abi.check(tree_fn(self._ctx, C.byref(rs), tree.data_ptr(), cur_n, budget.data_ptr(), C.byref(ss), out.capacity,
                               state.data_ptr(), C.byref(sa), trees[0].data_ptr(), C.byref(sb), trees[1].data_ptr(), bufs[0].n,
@@ -454,6 +460,10 @@ class Engine:
             if cur_n == 0:
                 break
             if reason == 3:
+                elapsed = time.time() - t_start
+                if max_trace_time is None or elapsed < max_trace_time:  # a hint interval ended, not the caller's time
+                    print("Tracing... Time elapsed: {:.2f} s, Trace num: {}, Alive rays: {}, Dead rays: {}".format(elapsed, written, cur_n, written))
+                    continue
                 timed_out = torch.zeros(n, dtype=torch.bool, device=dev)
                 timed_out[tree.long()] = True  # trees with rays still queued
                 break

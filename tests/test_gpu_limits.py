@@ -191,3 +191,41 @@ def test_trees_capped_in_a_bushy_generation_drop_their_children(cap, oracle):
     np.testing.assert_array_equal(b["surface"], ref["surface"])
     np.testing.assert_allclose(b["ox"], ref["ox"], rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(b["intensity"], ref["intensity"], rtol=1e-9, atol=1e-12)
+
+
+def test_a_long_generation_loop_reports_its_progress(capsys):
+    """optical_table.py:99-111: a trace that runs longer than MIN_HINTING_TIME prints its progress once per interval.  The
+    generation loop comes back from the library at that interval (Engine.HINT_SECONDS; shortened here), says where it is and
+    goes on: the same records as the uninterrupted trace."""
+    import numpy as np
+    import torch
+
+    import optable_amd as oa
+    from optable_amd import abi
+    from optable_amd.batch import RayBatch
+    from optable_amd.engine import get_engine
+
+    L, D, R = 10 * 4 / 3, 4, 0.9
+    comps = [oa.Mirror([0, 0, 0], radius=D, reflectivity=R, transmission=1 - R).RotZ(-np.pi / 4),
+             oa.Mirror([L, 0, 0], radius=D, reflectivity=R, transmission=1 - R).RotZ(+np.pi / 4 + 0.02),
+             oa.Mirror([L, -L, 0], radius=D, reflectivity=R, transmission=1 - R).RotZ(-np.pi / 4 + 0.02),
+             oa.Mirror([0, -L, 0], radius=D, reflectivity=R, transmission=1 - R).RotZ(+np.pi / 4)]
+    table = oa.OpticalTable()
+    table.add_components(comps)
+    n = 2048
+    o = np.tile([2.0, 0, 0], (n, 1)) + np.linspace(0, 1e-3, n)[:, None] * np.array([0, 1, 0])
+    batch = RayBatch.from_arrays(o, np.tile([1.0, 0, 0], (n, 1)))
+    eng = get_engine()
+    eng.upload(table.compile())
+    whole = eng.trace_tree(batch, 300)
+    assert "Tracing..." not in capsys.readouterr().out
+    try:
+        eng.HINT_SECONDS = 0.0  # (the library comes back after every generation)
+        hinted = eng.trace_tree(batch, 300)
+    finally:
+        del eng.HINT_SECONDS  # back to the class default
+    said = capsys.readouterr().out
+    assert said.count("Tracing... Time elapsed:") >= 2 and "Alive rays:" in said
+    assert hinted.n_valid == whole.n_valid and not hinted.timed_out
+    for f in abi.SEG_FIELDS + ("ray", "surface"):
+        assert torch.equal(hinted.field(f)[: hinted.n_valid], whole.field(f)[: whole.n_valid]), f
