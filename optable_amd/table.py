@@ -8,9 +8,10 @@ liboptable_hip.so traces every ray tree; `Ray` objects are rebuilt from the segm
 only at the end.  `trace_batch` is the same path without Python objects, for 1e6+ rays.
 
 The wall-clock cap (`perfomance_limit["max_trace_time"]`, 600 s by default, optical_table.py:84-97) is honoured
-where a trace takes more than one launch: ray trees advance generation by generation and the clock is read
-after each (engine.trace_tree).  A non-branching scene is ONE launch bounded by `max_trace_num`; nothing can
-be cut inside it.  Not modelled: the per-second progress print.  Render / GUI are out of scope.
+where a trace takes more than one launch: ray trees that go generation by generation read the clock after each
+(engine.trace_tree), and say where they are once per second as the reference's loop does (optical_table.py:99-111).  A
+non-branching scene, and a batch of ray trees whose queues fit the chip (engine.trace_trees), is ONE launch bounded by
+`max_trace_num`: milliseconds, nothing can be cut inside it.  Render / GUI are out of scope.
 """
 import copy
 from typing import List, Union
