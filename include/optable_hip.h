@@ -438,8 +438,8 @@ enum ot_option {
     OT_OPT_GEN_AHEAD = 20,     /* ot_trace_tree_*, light scenes without count-limited surfaces: the emit pass of a generation also counts the
                                   children of the children it writes, and the next generation replaces its count pass over the ray records by a pass
                                   over one byte per ray (k_gen_recount): 1 (default) / 0.  Identical output either way. */
-    OT_OPT_TREES_LDS_ENTRIES = 21, /* ot_trace_trees_*: queue entries per lane kept in LDS (default 3; the rest of a tree's queue lives in a global
-                                  scratch): more entries, fewer waves per CU */
+    OT_OPT_TREES_LDS_ENTRIES = 21, /* ot_trace_trees_*: queue entries per lane kept in LDS (the rest of a tree's queue lives in a global scratch):
+                                  more entries, fewer waves per CU.  0 (default): two under caps of up to 16, three above */
     OT_OPT_POOL_JITTER = 18,   /* test knob of the block pool's cross-wave protocol: one in `value` publications of a state or control word is
                                   held back ~8000 cycles after the records it announces were written (0 = off).  Results must not change. */
     OT_OPT_GEN_DROP_DOOMED = 15 /* ot_trace_generation_*: a tree whose budget ends with this generation gets no children in `next` (they

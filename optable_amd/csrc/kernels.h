@@ -300,8 +300,8 @@ __global__ __launch_bounds__(256, MINW) void k_trace_fused(SceneBlob blob, T uni
 // Short queues — a chain of partial reflections (cfg 4 with R = 0.2: three rays at most) — never leave the LDS, and three
 // entries per lane leave room for 8 waves per CU in double precision and 16 in single, which is what the kernel's speed
 // hangs on (one wave per SIMD issues an instruction every ~4.5 cycles: 5.8-6.2 ms on cfg 4 R = 0.2 with six entries in LDS;
-// two: 4.2-4.8 ms).  A ray whose parent left an empty queue is handed over in registers.  The scratch ring alone holds a whole
-// queue (pushes keep going there while the LDS entries in front of them drain).  QL + QG < ceil(cap / 2) is allowed (large caps, small trees): a
+// two: 4.2-4.8 ms).  The scratch ring alone holds a whole queue (pushes keep going there while the LDS entries in front of
+// them drain).  QL + QG < ceil(cap / 2) is allowed (large caps, small trees): a
 // tree whose rings overflow reports -(segments so far) and the caller takes the generation path.
 // Output: the [k][tree] slots of ot_trace_* — slot k * n + i is the k-th ray of tree i in FIFO order, which IS the
 // reference's order; seg_count[i] = rays processed (== cap: the cap cut the tree short or the tree ended exactly there,
@@ -422,20 +422,11 @@ __global__ __launch_bounds__(256, MINW) void k_trace_trees(SceneBlob blob, T uni
         const int64_t slot = place(active, (int64_t)k * n + i);
         if (active) {
             ++k;
-            int nk = 0;
-            RayState<T> ch[2];
-            if (h.node < 0) {
-                if (slot >= 0) store_segment<T, false>(out, slot, r, r.len, i, -1);
-            } else {
-                if (slot >= 0) store_segment<T, false>(out, slot, r, h.t, i, leaf_id_of<T, F>(sc, h.node));
-                nk = interact<T, F, 2>(sc, r, h, ch, mc);
-            }
             const int32_t left = cap - k;  // rays this tree may still process
-            // a first child behind an empty queue is the next ray: it stays in registers
-            const bool direct = nk > 0 && left > 0 && (qs & 0xff00ff00u) == 0;
-            int32_t pos = direct ? 1 : 0;  // queue position the next push would get, counted from the next ray to process
+            // Every child goes to the queue the moment the interaction has formed it (the first is queued before the second is
+            // computed: two children live together were 40 of the kernel's registers), and the next ray is popped behind them.
             auto push = [&](const RayState<T>& c) {
-                if (queued() + pos >= left) return;  // would never be processed (optical_table.py:138-144 drops it with the queue)
+                if (queued() >= left) return;  // would never be processed (optical_table.py:138-144 drops it with the queue)
                 if (glen() == 0 && llen() < QL) {
                     int e = lhead() + llen();
                     if (e >= QL) e -= QL;
@@ -450,13 +441,15 @@ __global__ __launch_bounds__(256, MINW) void k_trace_trees(SceneBlob blob, T uni
                     overflow = true;
                 }
             };
-            if (nk > 0 && !direct) push(ch[0]);
-            if (nk > 1) push(ch[1]);
             const T wl = r.wl;
             const int32_t has_q = r.has_q;
-            if (direct) {
-                r = ch[0];
-            } else if ((qs & 0xff00ff00u) != 0 && left > 0 && !overflow) {
+            if (h.node < 0) {
+                if (slot >= 0) store_segment<T, false>(out, slot, r, r.len, i, -1);
+            } else {
+                if (slot >= 0) store_segment<T, false>(out, slot, r, h.t, i, leaf_id_of<T, F>(sc, h.node));
+                interact<T, F, 2, decltype(push)>(sc, r, h, nullptr, mc, &push);
+            }
+            if ((qs & 0xff00ff00u) != 0 && left > 0 && !overflow) {
                 if (llen() > 0) {
                     const int e = lhead();
                     get(ring, e, r);

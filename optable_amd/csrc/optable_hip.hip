@@ -100,7 +100,7 @@ struct ot_ctx {
     int32_t opt_pair = 1;  // paired 16-byte segment stores in the lane-per-ray kernel
     int32_t opt_nt = 1, opt_minw = 4, opt_blocks_per_cu = 0;  // defaults from tools/tune.py on MI355X
     Scratch gen, scan_tmp, mon, gen_rem, gen_ahead, trees;
-    int32_t opt_trees_lds = 3;  // k_trace_trees: queue entries per lane kept in LDS (the rest of a tree's queue lives in a global scratch)
+    int32_t opt_trees_lds = 0;  // k_trace_trees: queue entries per lane kept in LDS (the rest of a tree's queue lives in a global scratch); 0: by the cap
     int32_t opt_gen_ahead = 1;  // ot_trace_tree_*: the emit pass counts its children's children, the next generation skips its count pass (k_gen_pass MODE 2)
     int32_t opt_gen_onepass = -1;  // ot_trace_tree_*: one pass per generation with a decoupled look-back (k_gen_one): -1 (default) generations of up to
                                    // 65536 rays (one launch instead of six), 0 never, 1 always.  Large generations keep count + scan + emit: the
@@ -1167,7 +1167,10 @@ template <class T> static bool trees_plan(const ot_ctx* c, int32_t cap, int64_t 
     const size_t room = 160 * 1024 - 1024, img = (image + 15) & ~(size_t)15, entry = (size_t)tree_entry_bytes<T>();
     if (img + 4 * entry > room) return false;
     const int64_t need = ((int64_t)cap + 1) / 2, fit = (int64_t)((room - img) / (4 * entry));
-    int64_t ql = c->opt_trees_lds < need ? c->opt_trees_lds : need;
+    // entries in LDS: two under small caps (queues stay short: a third workgroup per CU is worth more than the third entry —
+    // cfg 4 R = 0.2: 4.05 vs 4.2 ms, bushy trees under a cap of 12: 0.56 vs 0.62), three above (cap 48: 3.35 vs 3.99)
+    const int64_t want = c->opt_trees_lds > 0 ? c->opt_trees_lds : (cap <= 16 ? 2 : 3);
+    int64_t ql = want < need ? want : need;
     if (ql > fit) ql = fit;
     if (ql > 255) ql = 255;
     p->QL = (int32_t)ql;
@@ -1645,7 +1648,7 @@ int ot_set_option(ot_ctx* c, int32_t option, int32_t value) {
         case OT_OPT_INSTANCING: c->opt_instancing = value != 0; return 0;  // takes effect at the next ot_scene_upload
         case OT_OPT_GEN_AHEAD: c->opt_gen_ahead = value != 0; return 0;
         case OT_OPT_TREES_LDS_ENTRIES:
-            if (value < 1 || value > 64) return fail(OT_ERR_INVALID, "OT_OPT_TREES_LDS_ENTRIES takes 1..64");
+            if (value < 0 || value > 64) return fail(OT_ERR_INVALID, "OT_OPT_TREES_LDS_ENTRIES takes 0 (by the cap) or 1..64");
             c->opt_trees_lds = value; return 0;
         case OT_OPT_GEN_ONEPASS:
             if (value < -1 || value > 1) return fail(OT_ERR_INVALID, "OT_OPT_GEN_ONEPASS takes -1 (small generations), 0 or 1");

@@ -60,13 +60,12 @@ template <class T> GenKern<T> gen_ahead_kernel(int fg, bool lds);
 template <class T> ProbeKern<T> probe_kernel(int fg, bool lds);
 // k_trace_trees (a lane per tree, the FIFO in LDS): fg as above; nullptr where no instantiation exists
 template <class T, class OUT> TreeKern<T, OUT> tree_kernel(int fg);
-// ... and the waves per SIMD its registers are capped for (its workgroups per CU: 256 threads = one wave per SIMD each)
-// (measured with one wave per SIMD more — 168 / 128 registers, 39 / 2 of them spilled: cfg 4 R = 0.2 6.8 instead of 4.3 ms in double precision, 3-5 % faster in single)
-template <class T> constexpr int tree_minw(int fg) { return sizeof(T) == 4 ? 3 : (fg == 3 ? 1 : 2); }
-// ... and the workgroups per CU the launch plans for: the single-precision kernels of the presets FB / FC / FE come out at 118-126
-// registers under the cap of 170 (capped at 128 the allocator spills two), so four of their waves fit a SIMD
-// (tests/test_build_resources.py holds them to that)
-template <class T> constexpr int tree_groups_by_registers(int fg) { return sizeof(T) == 4 && fg <= 2 ? 4 : tree_minw<T>(fg); }
+// ... and the waves per SIMD its registers are capped for = the workgroups per CU it can have (256 threads: one wave per SIMD
+// each).  With every child queued the moment the interaction has formed it the kernels need 71-74 registers in single precision
+// (FB; FC / FE 97, FM 111) and 124-130 in double (FE 165, FM 255): the queues' LDS decides, not the registers.
+template <class T> constexpr int tree_minw(int fg) { return sizeof(T) == 4 ? (fg == 0 ? 6 : 4) : (fg == 3 ? 2 : 3); }
+// (the double-precision planar kernels come out at 124-127 under the cap of 168: four of their waves fit a SIMD — tests/test_build_resources.py)
+template <class T> constexpr int tree_groups_by_registers(int fg) { return sizeof(T) == 8 && fg == 0 ? 4 : tree_minw<T>(fg); }
 // k_gen_one (one pass per generation, decoupled look-back): fg as above; nullptr where no instantiation exists
 template <class T> GenOneKern<T> gen_one_kernel(int fg, bool lds);
 

@@ -1517,9 +1517,12 @@ __device__ __forceinline__ void surf_normal(const Scene<T>& sc, const DNode<T>& 
 // Children of a hit.  Writes the first MAXK lab-frame children into kids[] and returns how many
 // the interaction emits (which can exceed MAXK = 1: the fused kernel treats that as "this tree
 // branches" and hands the ray back to the host, see k_trace_fused).
-template <class T, uint32_t F, int MAXK>
+// SINK (MAXK > 1): a callable that takes every outgoing ray the moment it is complete, instead of `kids` — the lane-per-tree
+// kernel queues the first child before the second is formed, so that the two are never live together (k_trace_trees).
+struct NoSink {};
+template <class T, uint32_t F, int MAXK, class SINK = NoSink>
 __device__ __forceinline__ int interact(const Scene<T>& sc, const RayState<T>& r, const Hit<T>& h, RayState<T>* kids,
-                                        const MatCache<T>& mc) {
+                                        const MatCache<T>& mc, SINK* sink = nullptr) {
     const NodeRef<T> nr = node_ref<T, F>(sc, h.node);
     const DNode<T>& nd = *nr.nd;
     if (nd.inter == OT_INT_BLOCK) return 0;
@@ -1549,7 +1552,8 @@ __device__ __forceinline__ int interact(const Scene<T>& sc, const RayState<T>& r
             k.I = I; k.qr = qr; k.qi = qi; k.n = n; k.pl = pl;
             // constant indices only: kids[nk] with a run-time nk would put both children into private scratch
             // (240 B per lane in the fp64 generation kernel of round 1)
-            if (nk == 0) kids[0] = k;
+            if constexpr (!std::is_same<SINK, NoSink>::value) (*sink)(k);
+            else if (nk == 0) kids[0] = k;
             else kids[MAXK > 1 ? 1 : 0] = k;
         }
         ++nk;

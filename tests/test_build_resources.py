@@ -106,15 +106,13 @@ def test_everyday_presets_keep_their_register_budgets(kernels):
     assert all32 and min(k["vgpr"] for k in all32) > 150  # (what the split is measured against)
 
 
-def test_single_precision_tree_kernels_fit_four_waves_per_simd(kernels):
-    """k_trace_trees in single precision (presets FB = 28, FC = 732, FE = 63) is launched with four workgroups of four waves
-    per CU (tables.h tree_groups_by_registers): that needs 128 registers or fewer; double precision two (256)."""
+def test_tree_kernels_keep_the_registers_their_launch_plans_for(kernels):
+    """k_trace_trees is launched with as many 256-thread workgroups per CU as tables.h tree_groups_by_registers says its registers
+    allow (and the queues' LDS leaves room for): single precision 6 for the planar preset FB = 28 (80 registers), 4 for FC = 732,
+    FE = 63, FM = 319 (128); double precision 4 for FB (128), 3 for FE (168), 2 for FM (256)."""
     def of(real, mask):
         return [k for k in kernels if re.match(rf"_Z\d+k_trace_treesI{real}Lj{mask}E", k["name"])]
 
-    for mask in (28, 732, 63):
-        ks = of("f", mask)
-        assert ks and max(k["vgpr"] for k in ks) <= 128, (mask, [(k["name"][:40], k["vgpr"]) for k in ks])
-    for mask in (28, 63):
-        ks = of("d", mask)
-        assert ks and max(k["vgpr"] for k in ks) <= 256, (mask, [(k["name"][:40], k["vgpr"]) for k in ks])
+    for real, mask, most in (("f", 28, 80), ("f", 732, 128), ("f", 63, 128), ("f", 319, 128), ("d", 28, 128), ("d", 63, 168), ("d", 319, 256)):
+        ks = of(real, mask)
+        assert ks and max(k["vgpr"] for k in ks) <= most, (real, mask, [(k["name"][:40], k["vgpr"]) for k in ks])

@@ -91,7 +91,7 @@ def test_deep_queues_spill_into_the_scratch_ring_and_keep_their_order(lds_entrie
         plan = eng.trees_plan(precision, 48)
         assert plan["lds_entries"] == min(lds_entries, 6 if precision == "f64" else 13) and plan["queue"] == plan["lds_entries"] + 24
     finally:
-        eng.set_option(abi.OPT_TREES_LDS_ENTRIES, 3)
+        eng.set_option(abi.OPT_TREES_LDS_ENTRIES, 0)
 
 
 def test_trees_whose_rays_all_escape_or_die():
@@ -212,7 +212,7 @@ def test_rays_sharing_an_id_take_their_counts_in_input_order():
         eng.set_option(abi.OPT_TREES_LDS_ENTRIES, 1)  # (another split of the queues: same records)
         again = table.trace_batch(batch, max_segments=10, scene=scene)
     finally:
-        eng.set_option(abi.OPT_TREES_LDS_ENTRIES, 3)
+        eng.set_option(abi.OPT_TREES_LDS_ENTRIES, 0)
     a, b = segs.to_host(reference_order=True), again.to_host(reference_order=True)
     for f in abi.SEG_FIELDS + ("ray", "surface"):
         np.testing.assert_array_equal(a[f], b[f], err_msg=f)

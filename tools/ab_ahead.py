@@ -46,7 +46,7 @@ def run(label, comps, batch, cap, out_cap):
             del segs
     eng.set_option(abi.OPT_GEN_ONEPASS, -1)
     eng.set_option(abi.OPT_GEN_AHEAD, 1)
-    for ql in [int(q) for q in os.environ.get("QL", "3").split(",")]:
+    for ql in [int(q) for q in os.environ.get("QL", "0").split(",")]:
         eng.set_option(abi.OPT_TREES_LDS_ENTRIES, ql)
         plan = eng.trees_plan(batch.precision, cap)
         print(f"{label:44s} lane-per-tree plan {plan}")
@@ -65,7 +65,7 @@ def run(label, comps, batch, cap, out_cap):
                 eng.timing(False)
                 print(f"{label:44s} round {rnd} lane per tree  device {ms:8.3f} ms  wall {wall:8.3f} ms  {launches:4d} timed regions  {int(segs.count.abs().sum())} segments  {eng.last_launch()}", flush=True)
             del out, segs
-    eng.set_option(abi.OPT_TREES_LDS_ENTRIES, 3)
+    eng.set_option(abi.OPT_TREES_LDS_ENTRIES, 0)
 
 
 only = set(filter(None, os.environ.get("ONLY", "").split(",")))

@@ -77,6 +77,6 @@ for seed in range(first, first + cases):
     bad += not ok
     if seed % 20 == 19:
         print(f"... {seed - first + 1} cases, {bad} bad, {skipped} skipped", flush=True)
-eng.set_option(abi.OPT_TREES_LDS_ENTRIES, 3)
+eng.set_option(abi.OPT_TREES_LDS_ENTRIES, 0)
 print(f"{cases} cases: {bad} bad, {skipped} skipped (no lane-per-tree kernel for the scene)")
 sys.exit(1 if bad else 0)
