@@ -356,6 +356,7 @@ def survey_branching(oa, eng, device):
     segs, ms, launches, wall = timed(lambda: eng.trace_branching(batch, 12))
     per_tree = eng.last_launch()["kernel"] == 4  # (k_trace_trees; its output: [k][tree] slots or the dense append list, both with a count per tree)
     n_seg = int(segs.count.abs().sum()) if per_tree else int(segs.n_valid)
+    segs_layout = segs.layout
     del segs
     # ... and the generation loop (count / look-ahead, scan, emit per generation): what caps beyond the LDS queues take
     gsegs, gms, glaunches, gwall = timed(lambda: eng.trace_tree(batch, 12, out_capacity=batch.n * 13))
@@ -367,7 +368,7 @@ def survey_branching(oa, eng, device):
     alg_gen = n_seg * 104 * 2 + (n_seg - batch.n) * 104
     rec = {"workload": "cfg4 with reflectivity 0.2: 1.28e7 ray trees (2e5 rays x 64 wavelengths) x 12 segments, fp64",
            "rays": batch.n, "dtype": "f64", "leaf_surfaces": scene.n_leaves,
-           "kernel": "k_trace_trees<double> (a lane per tree, FIFO in LDS, one launch, append layout)" if per_tree else "k_gen_pass<double> per generation",
+           "kernel": f"k_trace_trees<double> (a lane per tree, FIFO in LDS, one launch, {segs_layout} layout)" if per_tree else "k_gen_pass<double> per generation",
            "launches": int(launches), "ms_per_trace": ms, "wall_ms_per_trace": wall * 1e3, "segments_per_ray": n_seg / batch.n,
            "segments_per_s": n_seg / (ms / 1e3), "intersections_per_s": n_seg * scene.n_leaves / (ms / 1e3),
            "algorithmic_gbs": alg / (ms / 1e3) / 1e9, "hbm_frac": alg / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, "bound": "hbm",

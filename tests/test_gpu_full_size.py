@@ -190,7 +190,7 @@ def test_cfg5_shard_fp32():
 
 def test_cfg4_ray_trees_full_size_fp64():
     """cfg 4 with reflectivity 0.2 at the size bench.py quotes (1.28e7 ray trees x 12 rays, fp64) through the default call
-    (Engine.trace_branching: one lane-per-tree launch into the dense list): every tree is cut by the cap with exactly 12
+    (one lane-per-tree launch; the dense list): every tree is cut by the cap with exactly 12
     records, the first record of a tree is its input ray, every direction is a unit vector, energy never grows along a tree —
     and a strided sample of 20 000 trees traced on its own through the GENERATION kernels gives the records the big launch
     holds for those trees, bit for bit, in the reference's order."""
