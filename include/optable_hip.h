@@ -320,8 +320,9 @@ int ot_trace_generation_f32(ot_ctx* ctx, const ot_rays* rays, const int32_t* ray
  * (info[0] bit 0: the planar and everyday presets, image + queue fronts within the CU's LDS; bit 1: it also writes these [k][tree]
  * slots — the planar preset; every such kernel writes the dense list of ot_trace_trees_append_*), how many entries its queues get
  * (info[1]), whether that is enough for every tree (info[2]: always, up to caps of ~170 in double precision for a batch that
- * fills the device and of 510 for a few hundred trees — the scratch is per workgroup of the launch) and how many of them are in
- * LDS (info[3]).  If not, a tree whose queue overflows reports seg_count[i] = -(rays processed so far) and the
+ * fills the device and of 510 for a few hundred trees — the scratch is per workgroup of the launch) how many of them are in
+ * LDS (info[3]), and for ot_trace_trees_append_* the slots a wave claims at a time (info[4]) and the waves of the launch (info[5]):
+ * a block of n_rays * max_trace_num + info[4] * info[5] slots holds any trace of the batch.  If not, a tree whose queue overflows reports seg_count[i] = -(rays processed so far) and the
  * caller takes ot_trace_tree_*.  OT_ERR_UNSUPPORTED when info[0] would be 0.  counts / n_count_classes as for ot_trace_*:
  * a tree meets count-limited surfaces in the reference's FIFO order; trees that share a column (rays.id) in one launch get
  * the remaining counts in unspecified order — the caller's rounds, as for ot_trace_*. */
@@ -338,7 +339,7 @@ int ot_trace_trees_append_f64(ot_ctx* ctx, const ot_rays* rays, int64_t n_rays, 
 int ot_trace_trees_append_f32(ot_ctx* ctx, const ot_rays* rays, int64_t n_rays, int32_t max_trace_num, const ot_segment_block* out, int64_t* n_slots,
                               int32_t* seg_count, int32_t* counts, int32_t n_count_classes);
 int ot_trace_trees_plan(ot_ctx* ctx, int32_t real_bytes, int32_t max_trace_num, int64_t n_rays /* 0: a batch that fills the device */,
-                        int32_t* info /* int32[4] */);
+                        int32_t* info /* int32[8] */);
 
 /* The whole breadth-first trace of a batch of ray trees: the loop over ot_trace_generation_* (optical_table.py:115-147) run
  * by the library — per generation one launch sequence and ONE 16-byte read-back.  `state` is device int64[2] = {segment

@@ -1159,7 +1159,7 @@ static int trace_generation(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
 // ceil(cap / 2) entries a tree can need in a per-wave global scratch, as long as the scratch of all resident waves stays
 // within 1 GiB (caps up to ~170 in double precision); beyond that the queues are what fits and the launch is a speculation
 // on small trees (full = 0).
-struct TreesPlan { int32_t QL, QG, full, groups_per_cu; size_t lds_bytes; };
+struct TreesPlan { int32_t QL, QG, full, groups_per_cu, grid, chunk; size_t lds_bytes; };
 template <class T> static bool trees_plan(const ot_ctx* c, int32_t cap, int64_t n, TreesPlan* p) {
     const size_t image = sizeof(T) == 8 ? c->bytes64 : c->bytes32;
     *p = TreesPlan{};
@@ -1179,7 +1179,16 @@ template <class T> static bool trees_plan(const ot_ctx* c, int32_t cap, int64_t 
     p->groups_per_cu = by_lds < by_regs ? (by_lds < 1 ? 1 : by_lds) : by_regs;
     // (the scratch is per workgroup of the LAUNCH: a batch of a few trees is a few workgroups, and gets long queues out of the same 1 GiB)
     const int64_t groups_needed = n > 0 ? (n + 255) / 256 : (int64_t)1 << 40, groups_most = (int64_t)c->n_cus * p->groups_per_cu;
-    const int64_t waves = (groups_needed < groups_most ? groups_needed : groups_most) * 4;
+    p->grid = (int32_t)(groups_needed < groups_most ? groups_needed : groups_most);
+    const int64_t waves = (int64_t)p->grid * 4;
+    // Append output: slots per claim.  A wave waits for its claim (one atomic on ONE device-wide cursor, ~2 us) at the occupancy of this
+    // kernel: 512-slot chunks were 12 % of a cfg 4 R = 0.2 trace (4.06 -> 3.55 ms with 2048+).  As large as leaves the unused chunk tails
+    // (one per wave) within a sixteenth of the output, 8192 at most, OT_OPT_APPEND_CHUNK at least.
+    {
+        const int64_t sixteenth = n > 0 ? (n * (int64_t)cap) / (waves * 16) / 64 * 64 : 8192;
+        const int64_t most_chunk = sixteenth < 8192 ? sixteenth : 8192;
+        p->chunk = (int32_t)(most_chunk > c->opt_append_chunk ? most_chunk : c->opt_append_chunk);
+    }
     int64_t most = ((int64_t)1 << 30) / (waves * (int64_t)entry);
     if (most > 255) most = 255;  // (the kernel keeps ring positions in bytes)
     // (the scratch ring alone must hold a whole queue: pushes keep going there while the LDS entries in front of them drain)
@@ -1197,17 +1206,18 @@ static int launch_trees(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t cap, 
     const TreeKern<T, OUT> kern = tree_kernel<T, OUT>(gen_preset(c->features));
     if (!kern) return fail(OT_ERR_UNSUPPORTED, "this scene's tree kernel writes the append layout only (ot_trace_trees_append_*)");
     const SceneBlob blob = make_blob<T>(c);
-    const int64_t blocks_needed = (n + 255) / 256, most = (int64_t)c->n_cus * p.groups_per_cu;  // persistent: the scratch is per workgroup
-    const int grid = (int)(blocks_needed < most ? blocks_needed : most);
+    const int grid = p.grid;  // persistent: the scratch is per workgroup
     const size_t scratch = (size_t)grid * 4 * (size_t)p.QG * tree_entry_bytes<T>();
     if (c->trees.ensure(scratch + 256)) return fail(OT_ERR_HIP, "hipMalloc of the tree queues failed");
     if (ac.cursor) HIP_TRY(hipMemsetAsync(ac.cursor, 0, sizeof(unsigned long long), c->stream));
+    AppendCtl ctl = ac;
+    if (ac.cursor) ctl.chunk = p.chunk;
     hipEvent_t ev0, ev1;
     int rc = timing_pair(c, &ev0, &ev1);
     if (rc) return rc;
     if (p.lds_bytes > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
     hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), (uint32_t)p.lds_bytes, c->stream, ev0, ev1, 0u, blob, (T)c->unit, view<T>(rays), n, cap, p.QL, p.QG,
-                          (uint8_t*)c->trees.p, out, ac, seg_count, counts, n_classes);
+                          (uint8_t*)c->trees.p, out, ctl, seg_count, counts, n_classes);
     HIP_TRY(hipGetLastError());
     const int32_t shape[8] = {4, 256, p.groups_per_cu, (int32_t)grid, (int32_t)p.lds_bytes, p.QL, p.QG, std::is_same<OUT, SegPlanes<T>>::value ? 4 : 0};
     for (int q = 0; q < 8; ++q) c->last_launch[q] = shape[q];
@@ -1419,6 +1429,7 @@ int ot_trace_trees_plan(ot_ctx* c, int32_t real_bytes, int32_t max_trace_num, in
     TreesPlan p;
     const bool ok = real_bytes == 8 ? trees_plan<double>(c, max_trace_num, n_rays, &p) : trees_plan<float>(c, max_trace_num, n_rays, &p);
     info[0] = ok ? 1 : 0; info[1] = p.QL + p.QG; info[2] = p.full; info[3] = p.QL;
+    info[4] = p.chunk; info[5] = p.grid * 4; info[6] = info[7] = 0;
     if (ok && (real_bytes == 8 ? tree_kernel<double, SegsT<double>>(gen_preset(c->features)) != nullptr : tree_kernel<float, SegsT<float>>(gen_preset(c->features)) != nullptr))
         info[0] |= 2;  // ... and writes the [k][tree] slots too
     return 0;

@@ -277,9 +277,10 @@ class Engine:
         """ot_trace_trees_plan: does the uploaded scene have a lane-per-tree kernel (k_trace_trees), how many queue entries
         per lane would a cap of `max_trace_num` get for a batch of `n_rays` trees (0: one that fills the device), and is that
         enough for every possible tree."""
-        info = (C.c_int32 * 4)()
+        info = (C.c_int32 * 8)()
         abi.check(self.lib.ot_trace_trees_plan(self._ctx, 8 if precision == "f64" else 4, int(max_trace_num), int(n_rays), info), self.lib)
-        return {"kernel": bool(info[0] & 1), "slots": bool(info[0] & 2), "queue": int(info[1]), "full": bool(info[2]), "lds_entries": int(info[3])}
+        return {"kernel": bool(info[0] & 1), "slots": bool(info[0] & 2), "queue": int(info[1]), "full": bool(info[2]), "lds_entries": int(info[3]),
+                "chunk": int(info[4]), "waves": int(info[5])}
 
     def trace_trees(self, rays: RayBatch, max_trace_num, out: SegmentBatch = None, counts=None, layout="slots", capacity=None):
         """Whole ray trees in one launch, a lane per tree with its FIFO on the chip (ot_trace_trees_*).
@@ -303,7 +304,8 @@ class Engine:
         if layout == "append":
             if out is None:
                 if capacity is None:  # every tree at its cap + the tail of every wave's last chunk
-                    capacity = (n * K + self.append_chunk * min(self.MAX_WAVES, (n + 63) // 64 + 1) + 63) // 64 * 64
+                    plan = self.trees_plan(prec, K, n)
+                    capacity = (n * K + plan["chunk"] * plan["waves"] + 63) // 64 * 64
                 out = SegmentBatch(capacity, prec, rays.device, block=True)
             elif out.block is None or out.tiled or out.precision != prec:
                 raise ValueError("append layout needs a SegmentBatch(block=True) of the rays' precision")
@@ -386,7 +388,7 @@ class Engine:
                         # single precision, where a step is short: 0.29 vs 0.42 ms on 1e6 bushy trees under a cap of 12 (double: 0.57
                         # either way, cfg 4 R = 0.2 4.29 vs 4.07 for the dense list)
                         return self.trace_trees(rays, K, layout="slots")
-                    slack = self.append_chunk * self.MAX_WAVES
+                    slack = plan["chunk"] * plan["waves"]
                     capacity = min(int(n * rpr * 1.15) + slack, n * K + slack)
                     for _ in range(3):
                         segs = self.trace_trees(rays, K, layout="append", capacity=(capacity + 63) // 64 * 64)

@@ -215,7 +215,8 @@ def test_cfg4_ray_trees_full_size_fp64():
     m = segs.n_valid
     ray = segs.ray[:m]
     real = ray >= 0
-    assert int(real.sum()) == n * K and m - n * K <= 512 * 8192  # holes: chunk tails only
+    plan = eng.trees_plan("f64", K, n)
+    assert int(real.sum()) == n * K and m - n * K <= plan["chunk"] * plan["waves"] <= n * K // 16 + 512 * plan["waves"]  # holes: chunk tails only
     norm = torch.sqrt(segs.dx[:m] ** 2 + segs.dy[:m] ** 2 + segs.dz[:m] ** 2)
     assert float((norm - 1).abs()[real].max()) < 1e-12
     assert float(segs.intensity[:m][real].max()) <= 1.0 + 1e-12 and float(segs.intensity[:m][real].min()) >= 0.0

@@ -21,6 +21,8 @@ from optable_amd.engine import get_engine
 if os.environ.get("OT_LIB"):  # kernel-variant experiments: an alternative build of the library
     abi.LIB_PATH = os.path.abspath(os.environ["OT_LIB"])
 eng = get_engine()
+if os.environ.get("CHUNK"):  # slots per claim of the append layouts
+    eng.set_option(abi.OPT_APPEND_CHUNK, int(os.environ["CHUNK"]))
 MODES = [int(m) for m in os.environ.get("MODES", "0,1,2").split(",")]
 Q = 1j * np.pi * W.W0**2 / W.WL
 
@@ -48,12 +50,13 @@ def run(label, comps, batch, cap, out_cap):
     eng.set_option(abi.OPT_GEN_AHEAD, 1)
     for ql in [int(q) for q in os.environ.get("QL", "0").split(",")]:
         eng.set_option(abi.OPT_TREES_LDS_ENTRIES, ql)
-        plan = eng.trees_plan(batch.precision, cap)
+        plan = eng.trees_plan(batch.precision, cap, batch.n)
         print(f"{label:44s} lane-per-tree plan {plan}")
         if plan["kernel"] and plan["full"]:
             from optable_amd.batch import SegmentBatch
             TL = os.environ.get("TREE_LAYOUT", "slots")
-            out = SegmentBatch(batch.n * cap + (512 * 8192 if TL == "append" else 0), batch.precision, batch.device, block=(TL == "append"))
+            slack = plan["chunk"] * plan["waves"] if TL == "append" else 0
+            out = SegmentBatch(batch.n * cap + slack, batch.precision, batch.device, block=(TL == "append"))
             for rnd in range(4):
                 eng.timing(True)
                 torch.cuda.synchronize()

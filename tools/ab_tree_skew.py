@@ -30,7 +30,8 @@ for prec in ("f64", "f32"):
     batch = RayBatch.from_arrays(o, d, wavelength=W.WL, q=1j * np.pi * W.W0**2 / W.WL, precision=prec)
     for cap in (24, 96):
         for layout in ("slots", "append"):
-            out = SegmentBatch(n * cap + 512 * 8192 if layout == "append" else n * cap, prec, batch.device, block=(layout == "append"))
+            plan = eng.trees_plan(prec, cap, n)
+            out = SegmentBatch(n * cap + plan["chunk"] * plan["waves"] if layout == "append" else n * cap, prec, batch.device, block=(layout == "append"))
             for rnd in range(3):
                 eng.timing(True); torch.cuda.synchronize()
                 segs = eng.trace_trees(batch, cap, out=out, layout=layout)
