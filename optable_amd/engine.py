@@ -335,6 +335,7 @@ class Engine:
         out.trees = True
         return out
 
+    LANE_PER_TREE = True  # False: trace_branching always takes the generation loop (A/B measurements)
     HINT_SECONDS = 1.0  # MIN_HINTING_TIME of the reference's loop (optical_table.py:85): a longer trace reports its progress at this interval
 
     # A lane-per-tree launch whose queues may overflow (caps beyond ~170 in double precision) is a speculation on small trees:
@@ -370,7 +371,7 @@ class Engine:
         for it, as the host API's rounds do; default: such scenes take the generations)."""
         n, K = rays.n, int(max_trace_num)
         gates_ok = not self.scene.limited or bool(distinct_ids)
-        if n and gates_ok and (max_trace_time is None or max_trace_time > 1.0):
+        if n and gates_ok and self.LANE_PER_TREE and (max_trace_time is None or max_trace_time > 1.0):
             plan = self.trees_plan(rays.precision, K, n)
             small = n <= self.TREES_SMALL_BATCH
             if plan["kernel"] and (plan["full"] or (small and n * K <= self.TREES_SPECULATIVE_SLOTS)):

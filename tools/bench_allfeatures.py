@@ -3,7 +3,7 @@
 its `max_interact_count` faces (examples/prism_refl.py), a DovePrism (polygon faces in tilted planes, examples/dove_prism.py),
 a Block with a round hole (boolean aperture), a BiConvexLens (spherical faces) and a mirror — 1e6 rays, cap 16, in both
 precisions, non-branching and with 10 % reflecting lens faces (ray trees, count gates).  Library hipEvent time + launch shape.
-    python tools/bench_allfeatures.py [n_rays]      env: ONLY=f32|f64, OT_LIB"""
+    python tools/bench_allfeatures.py [n_rays]      env: ONLY=f32|f64, OT_LIB, GENLOOP=1 (ray trees through the generation loop)"""
 import os
 import sys
 import time
@@ -24,6 +24,8 @@ if os.environ.get('OT_LIB'):
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 K = 16
 eng = get_engine()
+if os.environ.get("GENLOOP"):  # ray trees generation by generation instead of the lane-per-tree launch
+    eng.LANE_PER_TREE = False
 
 
 def scene(reflect):
