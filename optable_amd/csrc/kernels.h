@@ -297,13 +297,14 @@ __global__ __launch_bounds__(256, MINW) void k_trace_fused(SceneBlob blob, T uni
 // and pops are conflict-free / coalesced whatever the lanes' positions: QL entries in LDS hold the FRONT of the queue, QG
 // entries in a per-wave global scratch (L2-resident: written and read back by the same lane within microseconds) the rest.
 // A push goes to LDS while nothing is queued in the scratch and LDS has room, else to the scratch; a pop takes LDS first.
-// Short queues — a chain of partial reflections (cfg 4 with R = 0.2: three rays at most) — never leave the LDS, and three
-// entries per lane leave room for 8 waves per CU in double precision, two for 12, which is what the kernel's speed hangs on
-// (one wave per SIMD issues an instruction every ~4.5 cycles: 5.8-6.2 ms on cfg 4 R = 0.2 with six entries in LDS; three
-// entries: 4.2-4.3 ms; two: 4.0-4.1).  Every child is queued the moment the interaction has formed it (SINK below) and the next
-// ray is popped behind them: both children of a hit live in registers at once were 40 of the kernel's 200.  The scratch ring
-// alone holds a whole queue (pushes keep going there while the LDS entries in front of them drain).  QL + QG < ceil(cap / 2) is allowed (large caps, small trees): a
-// tree whose rings overflow reports -(segments so far) and the caller takes the generation path.
+// Short queues — a chain of partial reflections (cfg 4 with R = 0.2: three rays at most) — hardly leave the LDS; three entries
+// per lane leave room for 8 waves per CU in double precision, two for 12, which is what the kernel's speed hangs on (one wave
+// per SIMD issues an instruction every ~4.5 cycles: 5.8-6.2 ms on cfg 4 R = 0.2 with six entries in LDS; three entries: 4.2-4.3;
+// two: 4.0-4.1; with claims of 2048+ slots instead of 512, below: 3.6-3.9).  Every child is queued the moment the interaction has
+// formed it (SINK, trace_core.h interact) and the next ray is popped behind them: both children of a hit live in registers at
+// once were 40 of the kernel's 200.  The scratch ring alone holds a whole queue (pushes keep going there while the LDS entries in
+// front of them drain).  QL + QG < ceil(cap / 2) is allowed (large caps, small trees): a tree whose rings overflow reports
+// -(segments so far) and the caller takes the generation path.
 // Output: the [k][tree] slots of ot_trace_* — slot k * n + i is the k-th ray of tree i in FIFO order, which IS the
 // reference's order; seg_count[i] = rays processed (== cap: the cap cut the tree short or the tree ended exactly there,
 // as `budget <= 0` on the generation path).  Count-limited leaves: one column of the counts table per tree (rays that share
