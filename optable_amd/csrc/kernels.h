@@ -460,6 +460,7 @@ __global__ __launch_bounds__(256, MINW) void k_trace_trees(SceneBlob blob, T uni
                     const int e = ghead();
                     get(gring, e, r);
                     qs = ((qs & ~(255u << 16)) | ((uint32_t)(e + 1 == QG ? 0 : e + 1) << 16)) - (1u << 24);
+                    if (glen() == 0) qs &= ~(255u << 16);  // an empty ring starts over at its first entry: the scratch a lane touches is its longest queue, not QG
                 }
                 r.wl = wl; r.has_q = has_q; r.len = Num<T>::inf();
             } else {
