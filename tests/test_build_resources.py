@@ -116,3 +116,20 @@ def test_tree_kernels_keep_the_registers_their_launch_plans_for(kernels):
     for real, mask, most in (("f", 28, 80), ("f", 732, 128), ("f", 63, 128), ("f", 319, 128), ("d", 28, 128), ("d", 63, 168), ("d", 319, 256)):
         ks = of(real, mask)
         assert ks and max(k["vgpr"] for k in ks) <= most, (real, mask, [(k["name"][:40], k["vgpr"]) for k in ks])
+
+
+def test_production_kernels_keep_their_scalar_spills_in_check(kernels):
+    """Scalar registers that do not fit are kept in lanes of a vector register (v_writelane / v_readlane: 4-cycle vector instructions
+    on gfx950).  The kernels the BASELINE configs select: cfg 2 / cfg 4 (lane per ray, double) and the lane-per-tree kernel within 32;
+    the two heavy single-precision kernels carry more (the pass loop of cfg 3: 40; the block pool of cfg 5: 55 — none of them inside
+    the search) and must not grow."""
+    def spills(pattern):
+        ks = [k for k in kernels if re.match(pattern, k["name"])]
+        assert ks, pattern
+        return max(k["sgpr_spill"] for k in ks)
+
+    assert spills(r"_Z13k_trace_fusedIdLj24ELb1ELi4ELb1E") <= 32          # cfg 2: FA, image in LDS, 4 waves per SIMD, non-temporal
+    assert spills(r"_Z13k_trace_fusedIdLj28ELb1ELi1ELb1E") <= 32          # cfg 4: FB
+    assert spills(r"_Z13k_trace_treesIdLj28ELi\dE9SegPlanes") <= 32       # cfg 4 with reflectivity: ray trees
+    assert spills(r"_Z15k_trace_rollingIfLj1180ELb1ELb1ELb1E9SegPlanes") <= 44   # cfg 3
+    assert spills(r"_Z12k_trace_poolIfLj86ELb1E9SegPlanes") <= 60                # cfg 5
