@@ -43,17 +43,16 @@ template <> GenOneKern<T> gen_one_kernel<T>(int fg, bool lds) {
     return nullptr;
 }
 
-// k_trace_trees: the planar preset, planar scenes under grids (single precision, as their generation kernels) and the everyday
-// parts; 2 waves per SIMD in double precision (the rarer shapes: 1 — 256 registers would spill), 3 in single: the register
+// k_trace_trees: every preset (the all-features one included: 148 registers in single precision, 263 in double — one wave per SIMD,
+// as its generation kernels); 2 waves per SIMD in double precision (the rarer shapes: 1 — 256 registers would spill), 3 in single: the register
 // caps the queues' LDS leaves room for (tables.h tree_minw)
 template <class OUT> static TreeKern<T, OUT> pick_tree(int fg) {
     if (fg == 0) return k_trace_trees<T, FB, tree_minw<T>(0), OUT>;
     if constexpr (std::is_same<OUT, SegPlanes<T>>::value) {  // (the [k][tree] slots: the planar preset only — every preset writes the dense list)
-        if constexpr (sizeof(T) == 4) {
-            if (fg == 1) return k_trace_trees<T, FC, tree_minw<T>(1), OUT>;
-        }
+        if (fg == 1) return k_trace_trees<T, FC, tree_minw<T>(1), OUT>;
         if (fg == 2) return k_trace_trees<T, FE, tree_minw<T>(2), OUT>;
         if (fg == 3) return k_trace_trees<T, FM, tree_minw<T>(3), OUT>;
+        if (fg == 4) return k_trace_trees<T, F_ALL, tree_minw<T>(4), OUT>;  // grids AND curved / exotic shapes: every scene has a lane-per-tree kernel
     }
     return nullptr;
 }

@@ -19,7 +19,7 @@ from optable_amd import abi
 from optable_amd.batch import RayBatch
 from optable_amd.engine import get_engine
 from oracle import oracle
-from test_gpu_fuzz import random_branching_scene
+from test_gpu_fuzz import random_branching_scene, random_large_scene
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -29,7 +29,13 @@ bad = skipped = 0
 for seed in range(first, first + cases):
     rng = np.random.default_rng(770000 + seed)
     table = oa.OpticalTable()
-    table.add_components(random_branching_scene(oa, rng))
+    if rng.uniform() < 0.15:  # grids, lens arrays, dispersion (the all-features preset) + something that splits
+        comps = random_large_scene(oa, rng)
+        comps.append(oa.BeamSplitter([rng.uniform(2, 20), rng.uniform(-2, 2), 0.0], width=3, height=3, eta=rng.uniform(0.3, 0.7)).RotZ(rng.uniform(-1, 1)))
+        comps.append(oa.Mirror([rng.uniform(2, 25), rng.uniform(-3, 3), 0.0], radius=1.5, reflectivity=0.6, transmission=0.4).RotZ(rng.uniform(-1, 1)))
+    else:
+        comps = random_branching_scene(oa, rng)
+    table.add_components(comps)
     scene = table.compile()
     eng.upload(scene)
     n = int(rng.choice([1, 63, 64, 65, 200, 1000, 5000, 20000]))
