@@ -72,7 +72,7 @@ elif name in ("cfg4", "cfg4b"):
             eng.stream_ceiling(warm_in, 3, warm_out)
         torch.cuda.synchronize()
         del warm_in, warm_out
-        reps = max(reps, 10)
+        reps = max(reps, 12)
         for _ in range(reps):
             eng.trace(batch, 3, out=out, layout=LAYOUT)
         torch.cuda.synchronize()

@@ -147,6 +147,15 @@ for wdir in sorted(glob.glob(os.path.join(raw, "*"))):
     rec = {"workload": w, "kernel": short, "calls": int(top["Calls"]), "avg_ns": float(top["AverageNs"]),
            "min_ns": float(top["MinNs"]), "max_ns": float(top["MaxNs"]),
            "all_kernels_ns_per_run": {short_name(r["Name"]): float(r["TotalDurationNs"]) for r in rows}}
+    # per-launch durations of the dominant kernel from the kernel trace: the first two launches of a profile touch their output
+    # pages for the first time (cfg 4: 66 GB) and run 2-8 % long; the steady launches behind them are what call-to-call spread means
+    traces = glob.glob(os.path.join(wdir, "trace", "*", "*_kernel_trace.csv"))
+    if traces:
+        durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(traces[0])) if short_name(r["Kernel_Name"]) == short]
+        if len(durs) > 4:
+            steady = durs[2:]
+            rec["steady_launches"] = {"launches": len(steady), "avg_ns": sum(steady) / len(steady), "min_ns": min(steady), "max_ns": max(steady),
+                                      "spread": (max(steady) - min(steady)) / (sum(steady) / len(steady)), "first_two_ns": durs[:2]}
     acc = collections.defaultdict(list)
     for r in counter_rows(wdir):
         if short_name(r["Kernel_Name"]) == short:
