@@ -17,6 +17,7 @@
 
 #define N 4
 #define K 2
+#define KT 4   /* cap of the ray-tree trace below: max_trace_num */
 #define CHECK_HIP(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 2; } } while (0)
 #define CHECK_OT(x) do { int r_ = (x); if (r_ != 0) { fprintf(stderr, "optable_hip error %d: %s (%s:%d)\n", r_, ot_last_error(), __FILE__, __LINE__); return 3; } } while (0)
 
@@ -66,8 +67,8 @@ int main(void) {
     memset(&segs, 0, sizeof segs);
     void** sf[12] = {&segs.ox, &segs.oy, &segs.oz, &segs.dx, &segs.dy, &segs.dz, &segs.length, &segs.intensity, &segs.q_re,
                      &segs.q_im, &segs.n, &segs.pathlength};
-    for (int f = 0; f < 12; ++f) if (upload(sf[f], NULL, sizeof(double) * N * K)) return 2;
-    if (upload((void**)&segs.ray, NULL, sizeof(int32_t) * N * K) || upload((void**)&segs.surface, NULL, sizeof(int32_t) * N * K)) return 2;
+    for (int f = 0; f < 12; ++f) if (upload(sf[f], NULL, sizeof(double) * N * KT)) return 2;   /* (room for the ray trees below) */
+    if (upload((void**)&segs.ray, NULL, sizeof(int32_t) * N * KT) || upload((void**)&segs.surface, NULL, sizeof(int32_t) * N * KT)) return 2;
     int32_t* seg_count = NULL;
     if (upload((void**)&seg_count, NULL, sizeof(int32_t) * N)) return 2;
 
@@ -90,6 +91,31 @@ int main(void) {
         if (fabs(dx[k1] + h[3][i]) > 1e-15 || fabs(ox[k1] - 2.0) > 1e-12) bad++;
         printf("ray %d: hit at t = %.12f (expected %.12f), returns with dx = %+.12f\n", i, len[k0], expect, dx[k1]);
     }
+    /* Ray trees: the same mirror half transmitting — every hit emits two rays (reflected, then transmitted:
+     * optical_component.py:536-570).  One launch, a lane per tree, [k][tree] slots in the reference's FIFO order:
+     * the input ray up to the mirror, the reflected ray, the transmitted ray. */
+    mirror.reflectivity = 0.5; mirror.transmission = 0.5;
+    scene.max_children = 2;
+    CHECK_OT(ot_scene_upload(ctx, &scene));
+    int32_t plan[8];
+    CHECK_OT(ot_trace_trees_plan(ctx, 8, KT, N, plan));
+    printf("lane-per-tree kernel: %s, queue entries per lane %d (%d of them in LDS), enough for every tree: %s\n",
+           (plan[0] & 1) ? "yes" : "no", plan[1], plan[3], plan[2] ? "yes" : "no");
+    if (!(plan[0] & 2) || !plan[2]) bad++;                /* this scene (planar preset) also writes [k][tree] slots; a cap of KT needs KT / 2 entries */
+    CHECK_OT(ot_trace_trees_f64(ctx, &rays, N, KT, &segs, seg_count, NULL, 0));
+    CHECK_OT(ot_ctx_synchronize(ctx));
+    double inten[N * KT], tdx[N * KT];
+    int32_t tsurf[N * KT];
+    CHECK_HIP(hipMemcpy(tdx, segs.dx, sizeof tdx, hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(inten, segs.intensity, sizeof inten, hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(tsurf, segs.surface, sizeof tsurf, hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(cnt, seg_count, sizeof cnt, hipMemcpyDeviceToHost));
+    for (int i = 0; i < N; ++i) {
+        if (cnt[i] != 3 || tsurf[i] != 0 || tsurf[N + i] != -1 || tsurf[2 * N + i] != -1) bad++;
+        if (fabs(tdx[N + i] + h[3][i]) > 1e-15 || fabs(tdx[2 * N + i] - h[3][i]) > 1e-15) bad++;   /* reflected, then transmitted */
+        if (fabs(inten[N + i] - 0.5) > 1e-15 || fabs(inten[2 * N + i] - 0.5) > 1e-15) bad++;
+    }
+    printf("ray trees: %d rays per tree, children at half the intensity\n", (int)cnt[0]);
     /* error path: a NULL field is refused with a message, nothing is launched */
     ot_rays broken = rays;
     broken.q_im = NULL;

@@ -25,3 +25,4 @@ def test_plain_c_client_traces_through_the_abi(tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.strip().endswith("OK")
     assert "NULL field" in out.stdout
+    assert "lane-per-tree kernel: yes" in out.stdout and "ray trees: 3 rays per tree" in out.stdout  # ot_trace_trees_plan / ot_trace_trees_f64 from C
