@@ -322,7 +322,7 @@ template <class T> constexpr int tree_entry_bytes() { return 64 * (11 * (int)siz
 template <class T, uint32_t F, int MINW, class OUT>
 __global__ __launch_bounds__(256, MINW) void k_trace_trees(SceneBlob blob, T unit, RaysT<T> in, int64_t n, int32_t cap, int32_t QL, int32_t QG,
                                                            uint8_t* __restrict__ scratch, OUT out, AppendCtl ac, int32_t* __restrict__ seg_count,
-                                                           int32_t* counts, int32_t n_classes) {
+                                                           int32_t* counts, int32_t n_classes, int32_t refill_at) {
     constexpr bool APPEND = std::is_same<OUT, SegPlanes<T>>::value;
     extern __shared__ __align__(16) uint32_t lds[];
     for (int w = threadIdx.x; w < blob.n_words; w += blockDim.x) lds[w] = blob.words[w];
@@ -350,8 +350,11 @@ __global__ __launch_bounds__(256, MINW) void k_trace_trees(SceneBlob blob, T uni
     };
     // The trees of this wave: a contiguous share of the batch.  A lane whose tree has ended takes the next tree of the share in
     // place (no atomics: the share is the wave's own), so a wave does not live as long as its longest tree with the other
-    // lanes idle — trees of a batch can differ by the whole cap.  Refills wait until sixteen lanes are idle (or none works):
-    // the loads of a refill are worth a pass of their own only when enough lanes take part.
+    // lanes idle — trees of a batch can differ by the whole cap.  Refills wait until `refill_at` lanes are idle (or none works).
+    // 16: the lanes are kept busy, at the price of a wave whose lanes sit at different depths of their trees — a step then mixes
+    // rays that reflect, refract and leave.  64: a wave takes 64 trees at a time and stays in step.  Which is faster depends on
+    // how uneven the trees are: 90 % single-ray trees 1.33 vs 2.13 ms, trees of 13-30 rays 2.63 vs 1.90 (OT_OPT_TREES_REFILL_AT;
+    // Engine.trace_branching times both on its 1 % sample).
     const int64_t n_waves = (int64_t)gridDim.x * (blockDim.x >> 6);
     const int64_t per_wave = ((n + n_waves - 1) / n_waves + 63) / 64 * 64;
     int64_t next = ((int64_t)blockIdx.x * (blockDim.x >> 6) + wave) * per_wave;  // wave-uniform
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(256, MINW) void k_trace_trees(SceneBlob blob, T uni
     };
     for (;;) {
         const unsigned long long idle = __ballot(!active);
-        if (next < end && (__popcll(idle) >= 16 || idle == ~0ull)) {
+        if (next < end && (__popcll(idle) >= refill_at || idle == ~0ull)) {
             const int64_t cand = next + rank_below(idle);
             bool dead = false;
             if (!active && cand < end) {

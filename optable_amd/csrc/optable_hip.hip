@@ -100,6 +100,7 @@ struct ot_ctx {
     int32_t opt_pair = 1;  // paired 16-byte segment stores in the lane-per-ray kernel
     int32_t opt_nt = 1, opt_minw = 4, opt_blocks_per_cu = 0;  // defaults from tools/tune.py on MI355X
     Scratch gen, scan_tmp, mon, gen_rem, gen_ahead, trees;
+    int32_t opt_trees_refill_at = 16;  // k_trace_trees: idle lanes of a wave at which they take their next trees (64: a wave takes 64 trees at a time)
     int32_t opt_trees_lds = 0;  // k_trace_trees: queue entries per lane kept in LDS (the rest of a tree's queue lives in a global scratch); 0: by the cap
     int32_t opt_gen_ahead = 1;  // ot_trace_tree_*: the emit pass counts its children's children, the next generation skips its count pass (k_gen_pass MODE 2)
     int32_t opt_gen_onepass = -1;  // ot_trace_tree_*: one pass per generation with a decoupled look-back (k_gen_one): -1 (default) generations of up to
@@ -1217,7 +1218,7 @@ static int launch_trees(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t cap, 
     if (rc) return rc;
     if (p.lds_bytes > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
     hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), (uint32_t)p.lds_bytes, c->stream, ev0, ev1, 0u, blob, (T)c->unit, view<T>(rays), n, cap, p.QL, p.QG,
-                          (uint8_t*)c->trees.p, out, ctl, seg_count, counts, n_classes);
+                          (uint8_t*)c->trees.p, out, ctl, seg_count, counts, n_classes, c->opt_trees_refill_at);
     HIP_TRY(hipGetLastError());
     const int32_t shape[8] = {4, 256, p.groups_per_cu, (int32_t)grid, (int32_t)p.lds_bytes, p.QL, p.QG, std::is_same<OUT, SegPlanes<T>>::value ? 4 : 0};
     for (int q = 0; q < 8; ++q) c->last_launch[q] = shape[q];
@@ -1658,6 +1659,9 @@ int ot_set_option(ot_ctx* c, int32_t option, int32_t value) {
             c->opt_pool = value; return 0;
         case OT_OPT_INSTANCING: c->opt_instancing = value != 0; return 0;  // takes effect at the next ot_scene_upload
         case OT_OPT_GEN_AHEAD: c->opt_gen_ahead = value != 0; return 0;
+        case OT_OPT_TREES_REFILL_AT:
+            if (value < 1 || value > 64) return fail(OT_ERR_INVALID, "OT_OPT_TREES_REFILL_AT takes 1..64");
+            c->opt_trees_refill_at = value; return 0;
         case OT_OPT_TREES_LDS_ENTRIES:
             if (value < 0 || value > 64) return fail(OT_ERR_INVALID, "OT_OPT_TREES_LDS_ENTRIES takes 0 (by the cap) or 1..64");
             c->opt_trees_lds = value; return 0;

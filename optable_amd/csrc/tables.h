@@ -32,7 +32,7 @@ using GenKern = void (*)(SceneBlob, T, RaysT<T>, const int32_t*, int64_t, int32_
                          int64_t, uint8_t*, unsigned long long*, const unsigned long long*, int32_t*, int32_t, const int32_t*,
                          unsigned long long*, int32_t*, T*, int32_t, uint8_t*);
 template <class T, class OUT>
-using TreeKern = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, int32_t, int32_t, uint8_t*, OUT, AppendCtl, int32_t*, int32_t*, int32_t);
+using TreeKern = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, int32_t, int32_t, uint8_t*, OUT, AppendCtl, int32_t*, int32_t*, int32_t, int32_t);
 template <class T>
 using GenOneKern = void (*)(SceneBlob, T, RaysT<T>, const int32_t*, const int32_t*, int64_t, int32_t*, int64_t*, SegsT<T>, int64_t, RaysOutT<T>, int32_t*,
                             int32_t*, int64_t, unsigned long long*, uint32_t*, int32_t*, int32_t, int32_t, const int64_t*, int64_t*);

@@ -344,19 +344,26 @@ class Engine:
     TREES_SPECULATIVE_SLOTS = 1 << 20
 
     def _trees_estimate(self, rays, K):
-        """Rays per tree of a large batch from a strided 1 % sample (its own lane-per-tree launch), remembered per scene, cap and
-        precision: sizes the append block (x 1.15 + the launch's slack instead of every tree at its cap) and tells batches of few
-        long trees under a large cap — the one regime in which the generation loop is faster — from the rest."""
+        """Rays per tree of a large batch, and how its waves should refill, from a strided 1 % sample (a lane-per-tree launch of
+        its own), remembered per scene, cap and precision.  Rays per tree sizes the append block (x 1.15 + the launch's slack
+        instead of every tree at its cap) and tells batches of few long trees under a large cap — the one regime in which the
+        generation loop is faster — from the rest.  The spread of the tree sizes picks OT_OPT_TREES_REFILL_AT:
+        trees that differ moderately (standard deviation below 0.35 of the mean: cfg 4 with R = 0.2 without a binding cap, 13-30
+        rays) are traced 64 to a wave, in step — 1.9 instead of 2.6 ms on 3.2e6 of them; batches of mostly tiny trees, or of trees of
+        every size up to the cap, keep their lanes busy one by one (1.33 vs 2.13 and 3.2 vs 3.8 ms) (kernels.h)."""
         n = rays.n
         key = ("trees", id(self.scene), K, rays.precision)
-        rpr = self._records_per_ray.get(key)
-        if rpr is None:
+        known = self._records_per_ray.get(key)
+        if known is None:
             m = max(n // 100, 4096)
-            idx = torch.arange(0, n, max(n // m, 1), device=rays.device)
-            sample = self.trace_trees(rays.take(idx), K, layout="append")
-            rpr = float(sample.count.abs().sum().item()) / float(idx.numel())
-            self._records_per_ray = {key: rpr}  # (one scene at a time)
-        return rpr
+            sample = rays.take(torch.arange(0, n, max(n // m, 1), device=rays.device))
+            sizes = self.trace_trees(sample, K, layout="append").count.abs().double()
+            rpr = float(sizes.mean().item())
+            even = float(sizes.std(unbiased=False).item()) < 0.35 * rpr
+            known = (rpr, 64 if even else 16)
+            self._records_per_ray = {key: known}  # (one scene at a time)
+        self.set_option(abi.OPT_TREES_REFILL_AT, known[1])
+        return known[0]
 
     def trace_branching(self, rays: RayBatch, max_trace_num, counts=None, max_trace_time=None, distinct_ids=None):
         """Ray trees by whichever path the scene and the cap allow: ONE launch with a lane per tree (`trace_trees`) when the
@@ -381,24 +388,30 @@ class Engine:
                 elif n * K <= 1 << 22 or self.scene.limited:  # small: the worst case costs nothing; count tables are never sampled
                     segs = self.trace_trees(rays, K, counts=counts, layout="append")
                 else:
-                    rpr = self._trees_estimate(rays, K)
+                    rpr = self._trees_estimate(rays, K)  # (also sets how the waves of this batch refill)
                     if K > 48 and rpr < 0.25 * K:  # few long trees under a large cap
+                        self.set_option(abi.OPT_TREES_REFILL_AT, 16)
                         return self.trace_tree(rays, K, counts=counts, max_trace_time=max_trace_time)
                     if plan["slots"] and rays.precision == "f32" and rpr >= 0.9 * K:
                         # nearly every tree runs into the cap: lanes stay in step, [k][tree] rows are whole lines and cost no claims — in
                         # single precision, where a step is short: 0.29 vs 0.42 ms on 1e6 bushy trees under a cap of 12 (double: 0.57
                         # either way, cfg 4 R = 0.2 4.29 vs 4.07 for the dense list)
-                        return self.trace_trees(rays, K, layout="slots")
+                        try:
+                            return self.trace_trees(rays, K, layout="slots")
+                        finally:
+                            self.set_option(abi.OPT_TREES_REFILL_AT, 16)
                     slack = plan["chunk"] * plan["waves"]
                     capacity = min(int(n * rpr * 1.15) + slack, n * K + slack)
-                    for _ in range(3):
-                        segs = self.trace_trees(rays, K, layout="append", capacity=(capacity + 63) // 64 * 64)
-                        need = int(segs.cursor.item())
-                        if need <= segs.capacity:
-                            break
-                        self._records_per_ray = {}
-                        del segs
-                        capacity = int(need * 1.02) + (1 << 20)  # (holes fall differently from run to run)
+                    try:
+                        for _ in range(3):
+                            segs = self.trace_trees(rays, K, layout="append", capacity=(capacity + 63) // 64 * 64)
+                            need = int(segs.cursor.item())
+                            if need <= segs.capacity:
+                                break
+                            del segs
+                            capacity = int(need * 1.02) + (1 << 20)  # (holes fall differently from run to run)
+                    finally:
+                        self.set_option(abi.OPT_TREES_REFILL_AT, 16)  # (the default for calls that do not sample)
                 if plan["full"] or not bool((segs.count < 0).any()):
                     return segs
                 del segs

@@ -325,3 +325,49 @@ def test_trees_in_a_scene_of_grids_and_curved_optics(precision, oracle):
         keep_m, keep_r = same[mine["ray"]], same[ref["ray"]]
         for f in ("ox", "oy", "oz", "dx", "dy", "dz", "intensity", "pathlength"):
             np.testing.assert_allclose(mine[f][keep_m], ref[f][keep_r], rtol=1e-9, atol=1e-9, err_msg=f)
+
+
+@pytest.mark.parametrize("refill_at", [1, 40, 64])
+def test_records_do_not_depend_on_when_lanes_refill(refill_at):
+    """OT_OPT_TREES_REFILL_AT: lanes that take their next tree one by one, in groups, or 64 to a wave at a time — the same records."""
+    scene = _lattice()
+    batch = _lattice_rays(20_000, 19)
+    gone = torch.rand(batch.n, device=batch.device) < 0.6
+    batch.dx[gone] = -1.0
+    batch.dy[gone] = 0.0
+    batch.dz[gone] = 0.0
+    eng = get_engine()
+    eng.upload(scene)
+    ref = eng.trace_trees(batch, 24, layout="append").to_host(reference_order=True)
+    try:
+        eng.set_option(abi.OPT_TREES_REFILL_AT, refill_at)
+        for layout in ("append", "slots"):
+            got = eng.trace_trees(batch, 24, layout=layout).to_host(reference_order=True)
+            for f in abi.SEG_FIELDS + ("ray", "surface"):
+                np.testing.assert_array_equal(got[f], ref[f], err_msg=f"{layout} {f}")
+    finally:
+        eng.set_option(abi.OPT_TREES_REFILL_AT, 16)
+
+
+def test_default_call_keeps_moderately_uneven_trees_in_step():
+    """Engine.trace_branching reads the spread of the tree sizes off its 1 % sample: trees of 13-30 rays (cfg 4 with R = 0.2 under
+    a cap that does not bind) are traced 64 to a wave; a batch in which nine trees of ten are a single ray refills lane by lane."""
+    eng = get_engine()
+    table = oa.OpticalTable()
+    table.add_components(W.cfg4_components(oa, reflectivity=0.2))
+    eng.upload(table.compile())
+    o, d, wl = W.cfg4_rays(8_000, 4)  # x 64 wavelengths = 5.1e5 trees
+    batch = RayBatch.from_arrays(o, d, wavelength=wl, q=1j * np.pi * W.W0**2 / wl)
+    segs = eng.trace_branching(batch, 48)
+    (rpr, refill_at), = eng._records_per_ray.values()
+    assert segs.layout == "append" and 13 < rpr < 30 and refill_at == 64
+    assert int(segs.count.min()) >= 8 and int(segs.count.max()) < 48
+    eng.upload(_lattice())
+    skew = _lattice_rays(400_000, 17, "f32")
+    gone = torch.rand(skew.n, device=skew.device) < 0.9
+    skew.dx[gone] = -1.0
+    skew.dy[gone] = 0.0
+    skew.dz[gone] = 0.0
+    eng.trace_branching(skew, 24)
+    (rpr, refill_at), = eng._records_per_ray.values()
+    assert rpr < 6 and refill_at == 16

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Differential fuzz of the lane-per-tree kernel (k_trace_trees): random branching scenes (tests/test_gpu_fuzz.py's generator:
 lenses, mirrors, slabs, apertures + beam splitters, partially reflecting slabs and mirrors), random batch sizes (partial waves,
-shares of uneven length), caps 1..60, 1..6 queue entries in LDS, both output layouts, count-limited surfaces included — against the generation kernels
+shares of uneven length), caps 1..60, 1..6 queue entries in LDS, lanes that refill one by one / in groups / 64 at a time, both output layouts, count-limited surfaces included — against the generation kernels
 (ot_trace_tree_*), bit for bit in the reference's order, and (double precision, first 300 trees) against the oracle.
     python tools/tree_fuzz.py [n_cases] [first_seed]"""
 import os
@@ -46,6 +46,7 @@ for seed in range(first, first + cases):
     d = np.stack([np.ones(n), rng.uniform(-0.12, 0.12, n), rng.uniform(-0.02, 0.02, n)], 1)
     batch = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=1j * np.pi * scenes.W0**2 / scenes.WL, precision=prec)
     eng.set_option(abi.OPT_TREES_LDS_ENTRIES, ql)
+    eng.set_option(abi.OPT_TREES_REFILL_AT, int(rng.choice([1, 16, 16, 40, 64])))
     plan = eng.trees_plan(prec, cap, n)
     if not plan["kernel"]:
         skipped += 1
@@ -84,5 +85,6 @@ for seed in range(first, first + cases):
     if seed % 20 == 19:
         print(f"... {seed - first + 1} cases, {bad} bad, {skipped} skipped", flush=True)
 eng.set_option(abi.OPT_TREES_LDS_ENTRIES, 0)
+eng.set_option(abi.OPT_TREES_REFILL_AT, 16)
 print(f"{cases} cases: {bad} bad, {skipped} skipped (no lane-per-tree kernel for the scene)")
 sys.exit(1 if bad else 0)
