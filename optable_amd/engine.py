@@ -41,6 +41,8 @@ class Engine:
         abi.check(self.lib.ot_ctx_create(device, C.c_void_p(stream), C.byref(self._ctx)), self.lib)
         self.scene = None
         self.append_chunk = 512  # OT_OPT_APPEND_CHUNK as last set through set_option (the library's default)
+        self.trees_refill_at = 16  # OT_OPT_TREES_REFILL_AT likewise
+        self._policy_sets_refill = False
         self._records_per_ray = {}  # (scene, cap, precision) -> records per ray seen in a sample trace (append capacity estimates)
         self._layout_choice = {}    # (scene, precision) -> "slots" | "tiled" measured on the workload itself (tune_layout)
         # An ot_ctx holds one scene and one set of scratch buffers: calls on it are serialised (include/
@@ -362,7 +364,11 @@ class Engine:
             even = float(sizes.std(unbiased=False).item()) < 0.35 * rpr
             known = (rpr, 64 if even else 16)
             self._records_per_ray = {key: known}  # (one scene at a time)
-        self.set_option(abi.OPT_TREES_REFILL_AT, known[1])
+        self._policy_sets_refill = True
+        try:
+            self.set_option(abi.OPT_TREES_REFILL_AT, known[1])
+        finally:
+            self._policy_sets_refill = False
         return known[0]
 
     def trace_branching(self, rays: RayBatch, max_trace_num, counts=None, max_trace_time=None, distinct_ids=None):
@@ -390,7 +396,7 @@ class Engine:
                 else:
                     rpr = self._trees_estimate(rays, K)  # (also sets how the waves of this batch refill)
                     if K > 48 and rpr < 0.25 * K:  # few long trees under a large cap
-                        self.set_option(abi.OPT_TREES_REFILL_AT, 16)
+                        self.set_option(abi.OPT_TREES_REFILL_AT, self.trees_refill_at)
                         return self.trace_tree(rays, K, counts=counts, max_trace_time=max_trace_time)
                     if plan["slots"] and rays.precision == "f32" and rpr >= 0.9 * K:
                         # nearly every tree runs into the cap: lanes stay in step, [k][tree] rows are whole lines and cost no claims — in
@@ -399,7 +405,7 @@ class Engine:
                         try:
                             return self.trace_trees(rays, K, layout="slots")
                         finally:
-                            self.set_option(abi.OPT_TREES_REFILL_AT, 16)
+                            self.set_option(abi.OPT_TREES_REFILL_AT, self.trees_refill_at)
                     slack = plan["chunk"] * plan["waves"]
                     capacity = min(int(n * rpr * 1.15) + slack, n * K + slack)
                     try:
@@ -411,7 +417,7 @@ class Engine:
                             del segs
                             capacity = int(need * 1.02) + (1 << 20)  # (holes fall differently from run to run)
                     finally:
-                        self.set_option(abi.OPT_TREES_REFILL_AT, 16)  # (the default for calls that do not sample)
+                        self.set_option(abi.OPT_TREES_REFILL_AT, self.trees_refill_at)  # (the default for calls that do not sample)
                 if plan["full"] or not bool((segs.count < 0).any()):
                     return segs
                 del segs
@@ -587,6 +593,8 @@ class Engine:
         abi.check(self.lib.ot_set_option(self._ctx, option, value), self.lib)
         if option == abi.OPT_APPEND_CHUNK:
             self.append_chunk = int(value)  # (the capacity estimates of the append layout count holes in chunks)
+        if option == abi.OPT_TREES_REFILL_AT and not self._policy_sets_refill:
+            self.trees_refill_at = int(value)  # (what the caller asked for: trace_branching's own choice for a batch is undone after it)
 
     def stream_ceiling(self, rays: RayBatch, max_segments, out: SegmentBatch):
         """Same bytes as `trace` with no tracing (roofline companion), in the layout of `out` (slots or tiled)."""
