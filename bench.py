@@ -357,6 +357,7 @@ def survey_branching(oa, eng, device):
     per_tree = eng.last_launch()["kernel"] == 4  # (k_trace_trees; its output: [k][tree] slots or the dense append list, both with a count per tree)
     n_seg = int(segs.count.abs().sum()) if per_tree else int(segs.n_valid)
     segs_layout = segs.layout
+    tree_launch = dict(eng.last_launch(), plan=eng.trees_plan("f64", 12, batch.n)) if per_tree else None  # workgroups per CU, queue entries in LDS / scratch, claim size
     del segs
     # ... and the generation loop (count / look-ahead, scan, emit per generation): what caps beyond the LDS queues take
     gsegs, gms, glaunches, gwall = timed(lambda: eng.trace_tree(batch, 12, out_capacity=batch.n * 13))
@@ -376,6 +377,8 @@ def survey_branching(oa, eng, device):
                                "ms_per_trace": gms, "wall_ms_per_trace": gwall * 1e3, "algorithmic_gbs": alg_gen / (gms / 1e3) / 1e9,
                                "hbm_frac": alg_gen / (gms / 1e3) / 1e9 / HBM_PEAK_GBS},
            "generation_mismatches": eng.generation_mismatches()}
+    if tree_launch:
+        rec["launch"] = tree_launch
     counters = committed_counters("cfg4b")
     if counters:
         rec["sq_counters"] = counters
