@@ -317,8 +317,8 @@ int ot_trace_generation_f32(ot_ctx* ctx, const ot_rays* rays, const int32_t* ray
  * ot_trace_*: slot k * n_rays + i of `out` (max_trace_num * n_rays slots) is the k-th ray of tree i in the reference's FIFO
  * order, seg_count[i] the rays tree i processed (== max_trace_num: cut short by the cap, or ended exactly there).  A queue of
  * ceil(max_trace_num / 2) rays per lane always suffices; ot_trace_trees_plan says whether the scene has such a kernel
- * (info[0] bit 0: the planar and everyday presets, image + queue fronts within the CU's LDS; bit 1: it also writes these [k][tree]
- * slots — the planar preset; every such kernel writes the dense list of ot_trace_trees_append_*), how many entries its queues get
+ * (info[0] bit 0: every scene whose image and queue fronts fit the CU's LDS; bit 1: it also writes these [k][tree] slots — scenes
+ * of the planar preset; every such kernel writes the dense list of ot_trace_trees_append_*), how many entries its queues get
  * (info[1]), whether that is enough for every tree (info[2]: always, up to caps of ~170 in double precision for a batch that
  * fills the device and of 510 for a few hundred trees — the scratch is per workgroup of the launch) how many of them are in
  * LDS (info[3]), and for ot_trace_trees_append_* the slots a wave claims at a time (info[4]) and the waves of the launch (info[5]):
