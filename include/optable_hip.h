@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define OT_ABI_VERSION 11  /* 11: OT_OPT_GEN_AHEAD, ot_trace_trees_*, ot_trace_trees_append_*, OT_OPT_TREES_LDS_ENTRIES, OT_OPT_TREES_REFILL_AT; 10: ot_trace_plan, ot_probe_layouts, ot_runtime_info, OT_OPT_REFILL, OT_OPT_REFILL_TICKET, OT_OPT_POOL_JITTER, OT_OPT_GEN_ONEPASS; 9: ot_trace_tree_*, OT_OPT_BLOCK_POOL, OT_OPT_GEN_DROP_DOOMED, ot_trace_append_* holes per workgroup chunk; 8: OT_SHAPE_ASPHERE_CHEB, OT_MAT_CHEB, OT_NODE_BOX_TRUSTED, ot_trace_tiled_*, ot_bench_stream_tiled_*; 3: ot_trace_generation_f32; 4: ot_bench_stream_f32; 5: OT_OPT_LIST_CAP, ray flags bits 8..31, ot_debug_generation_mismatches; 6: ot_debug_last_launch, OT_OPT_FLAT_QUEUE, OT_OPT_LDS_RECORDS; 7: ot_trace_append_*, ot_segment_block, OT_OPT_APPEND_CHUNK, OT_OPT_INSTANCING */
+#define OT_ABI_VERSION 11  /* 11: OT_OPT_GEN_AHEAD, ot_trace_trees_*, ot_trace_trees_append_*, OT_OPT_TREES_LDS_ENTRIES, OT_OPT_TREES_REFILL_AT, OT_OPT_TREES_FLAT; 10: ot_trace_plan, ot_probe_layouts, ot_runtime_info, OT_OPT_REFILL, OT_OPT_REFILL_TICKET, OT_OPT_POOL_JITTER, OT_OPT_GEN_ONEPASS; 9: ot_trace_tree_*, OT_OPT_BLOCK_POOL, OT_OPT_GEN_DROP_DOOMED, ot_trace_append_* holes per workgroup chunk; 8: OT_SHAPE_ASPHERE_CHEB, OT_MAT_CHEB, OT_NODE_BOX_TRUSTED, ot_trace_tiled_*, ot_bench_stream_tiled_*; 3: ot_trace_generation_f32; 4: ot_bench_stream_f32; 5: OT_OPT_LIST_CAP, ray flags bits 8..31, ot_debug_generation_mismatches; 6: ot_debug_last_launch, OT_OPT_FLAT_QUEUE, OT_OPT_LDS_RECORDS; 7: ot_trace_append_*, ot_segment_block, OT_OPT_APPEND_CHUNK, OT_OPT_INSTANCING */
 
 /* ---- status codes ------------------------------------------------------------------- */
 enum ot_status {
@@ -439,6 +439,8 @@ enum ot_option {
     OT_OPT_GEN_AHEAD = 20,     /* ot_trace_tree_*, light scenes without count-limited surfaces: the emit pass of a generation also counts the
                                   children of the children it writes, and the next generation replaces its count pass over the ray records by a pass
                                   over one byte per ray (k_gen_recount): 1 (default) / 0.  Identical output either way. */
+    OT_OPT_TREES_FLAT = 23,    /* ot_trace_trees_*: planar scenes under a top-level grid of leaves search through the wave-wide pair queue of the
+                                  heavy non-branching kernel (OT_OPT_FLAT_QUEUE) instead of a grid walk per lane: 1 (default) / 0.  Identical records. */
     OT_OPT_TREES_REFILL_AT = 22, /* ot_trace_trees_*: idle lanes of a wave at which they take the next trees of the wave's share (default 16: lanes
                                   kept busy; 64: a wave takes 64 trees at a time and its lanes stay at the same depth of their trees — faster
                                   when trees differ moderately in size, slower when most are tiny).  Identical records either way. */

@@ -53,6 +53,8 @@ template <class OUT> static TreeKern<T, OUT> pick_tree(int fg) {
         if (fg == 2) return k_trace_trees<T, FE, tree_minw<T>(2), OUT>;
         if (fg == 3) return k_trace_trees<T, FM, tree_minw<T>(3), OUT>;
         if (fg == 4) return k_trace_trees<T, F_ALL, tree_minw<T>(4), OUT>;  // grids AND curved / exotic shapes: every scene has a lane-per-tree kernel
+        if (fg == 5) return k_trace_trees<T, FR | F_FLAT, tree_minw<T>(5), OUT>;   // planar scenes under a top-level grid of leaves: the pair queue
+        if (fg == 6) return k_trace_trees<T, FRP | F_FLAT, tree_minw<T>(6), OUT>;  // ... with polygon / boolean apertures
     }
     return nullptr;
 }

@@ -322,7 +322,7 @@ template <class T> constexpr int tree_entry_bytes() { return 64 * (11 * (int)siz
 template <class T, uint32_t F, int MINW, class OUT>
 __global__ __launch_bounds__(256, MINW) void k_trace_trees(SceneBlob blob, T unit, RaysT<T> in, int64_t n, int32_t cap, int32_t QL, int32_t QG,
                                                            uint8_t* __restrict__ scratch, OUT out, AppendCtl ac, int32_t* __restrict__ seg_count,
-                                                           int32_t* counts, int32_t n_classes, int32_t refill_at) {
+                                                           int32_t* counts, int32_t n_classes, int32_t refill_at, int32_t flat_cap) {
     constexpr bool APPEND = std::is_same<OUT, SegPlanes<T>>::value;
     extern __shared__ __align__(16) uint32_t lds[];
     for (int w = threadIdx.x; w < blob.n_words; w += blockDim.x) lds[w] = blob.words[w];
@@ -331,6 +331,24 @@ __global__ __launch_bounds__(256, MINW) void k_trace_trees(SceneBlob blob, T uni
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr size_t EB = tree_entry_bytes<T>();
     uint8_t* const ring = reinterpret_cast<uint8_t*>(lds) + (((size_t)blob.n_words * 4 + 15) & ~(size_t)15) + (size_t)wave * QL * EB;
+    // F_FLAT (planar scenes under a top-level grid of leaves: cfg 3 with reflecting slabs): the search of a step is the wave-wide pair
+    // queue of the heavy non-branching kernel (flat_grid_hit) — candidates of all 64 current rays, tested with full lanes — instead
+    // of a grid walk per lane; its key table and queue sit behind the rings of all waves.
+    FlatLds<T> flat = {nullptr, nullptr, nullptr, 0};
+    FlatGrid<T> flat_grid = {};
+    if constexpr ((F & F_FLAT) != 0) {
+        const int per_wave = (FlatLds<T>::fixed_bytes + flat_cap * 2 + 15) & ~15;
+        uint8_t* fb = reinterpret_cast<uint8_t*>(lds) + (((size_t)blob.n_words * 4 + 15) & ~(size_t)15) + (size_t)(blockDim.x >> 6) * QL * EB + (size_t)wave * per_wave;
+        flat.key = reinterpret_cast<unsigned long long*>(fb);
+        if constexpr (sizeof(T) == 8) flat.node = reinterpret_cast<int32_t*>(fb + 64 * 8);
+        flat.queue = reinterpret_cast<uint16_t*>(fb + FlatLds<T>::fixed_bytes);
+        flat.queue_cap = flat_cap;
+        for (int q = lane; q < flat_cap; q += 64) flat.queue[q] = 0;  // markers only; every round leaves it zeroed again
+        flat_grid = flat_grid_header<T, true>(sc);
+    }
+#ifdef OT_STAMP
+    unsigned long long tree_st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tree_st_last = 0;  // (the diagnostic build's stamps of flat_grid_hit: unused here)
+#endif
     uint8_t* const gring = scratch + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * (size_t)QG * EB;
     auto real_at = [&](uint8_t* base, int e, int f) -> T* { return reinterpret_cast<T*>(base + (size_t)e * EB) + f * 64 + lane; };
     auto int_at = [&](uint8_t* base, int e) -> int32_t* { return reinterpret_cast<int32_t*>(base + (size_t)e * EB + 64 * 11 * sizeof(T)) + lane; };
@@ -423,7 +441,16 @@ __global__ __launch_bounds__(256, MINW) void k_trace_trees(SceneBlob blob, T uni
         // count-limited leaves (optical_component.py:140-149): a tree's rays meet them one after the other in FIFO order, as
         // the reference's loop does — exact as long as no other tree of the launch shares the column (the host API's rounds)
         const GateCtx gate = {counts, n_classes, cls, nullptr, nullptr, 0, 0};
-        const Hit<T> h = nearest_hit<T, F, GATE_PLAIN>(sc, r, active, gate);
+        Hit<T> h;
+        if constexpr ((F & F_FLAT) != 0) {
+#ifdef OT_STAMP
+            h = flat_grid_hit<T, F, GATE_PLAIN>(sc, flat_grid, r, active, gate, flat, lane, tree_st_acc, tree_st_last);
+#else
+            h = flat_grid_hit<T, F, GATE_PLAIN>(sc, flat_grid, r, active, gate, flat, lane);
+#endif
+        } else {
+            h = nearest_hit<T, F, GATE_PLAIN>(sc, r, active, gate);
+        }
         const int64_t slot = place(active, (int64_t)k * n + i);
         if (active) {
             ++k;

@@ -100,6 +100,7 @@ struct ot_ctx {
     int32_t opt_pair = 1;  // paired 16-byte segment stores in the lane-per-ray kernel
     int32_t opt_nt = 1, opt_minw = 4, opt_blocks_per_cu = 0;  // defaults from tools/tune.py on MI355X
     Scratch gen, scan_tmp, mon, gen_rem, gen_ahead, trees;
+    int32_t opt_trees_flat = 1;        // k_trace_trees: planar scenes under a top-level grid of leaves search through the wave-wide pair queue
     int32_t opt_trees_refill_at = 16;  // k_trace_trees: idle lanes of a wave at which they take their next trees (64: a wave takes 64 trees at a time)
     int32_t opt_trees_lds = 0;  // k_trace_trees: queue entries per lane kept in LDS (the rest of a tree's queue lives in a global scratch); 0: by the cap
     int32_t opt_gen_ahead = 1;  // ot_trace_tree_*: the emit pass counts its children's children, the next generation skips its count pass (k_gen_pass MODE 2)
@@ -1160,12 +1161,29 @@ static int trace_generation(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
 // ceil(cap / 2) entries a tree can need in a per-wave global scratch, as long as the scratch of all resident waves stays
 // within 1 GiB (caps up to ~170 in double precision); beyond that the queues are what fits and the launch is a speculation
 // on small trees (full = 0).
-struct TreesPlan { int32_t QL, QG, full, groups_per_cu, grid, chunk; size_t lds_bytes; };
+struct TreesPlan { int32_t QL, QG, full, groups_per_cu, grid, chunk, preset, flat_cap; size_t lds_bytes; };
+// Planar scenes under a top-level grid of leaves search through the wave-wide pair queue of the heavy non-branching kernel
+// (launch_rolling's flat_ok, flat_grid_hit): the tree kernel's presets 5 (FR) / 6 (FRP).  0: the scene does not qualify.
+static int32_t trees_flat_cap(const ot_ctx* c, int* preset) {
+    using namespace preset;
+    const uint32_t need = c->features;
+    const int fr = (c->root_grid >= 0 && (need & ~FR) == 0) ? 5 : ((c->root_grid >= 0 && (need & ~FRP) == 0) ? 6 : 0);
+    const int32_t flat_full = 64 * FLAT_CELLS * (c->root_max_items > 0 ? c->root_max_items : 1);
+    const int32_t flat_room = c->opt_flat > 1 ? c->opt_flat : 512;
+    const int32_t flat_cap = flat_full < flat_room ? flat_full : flat_room;
+    if (!c->opt_flat || !fr || c->root_pack < 0 || flat_cap > 8192 || c->n_runs != 0 || c->n_slots > 0) return 0;
+    *preset = fr;
+    return flat_cap;
+}
 template <class T> static bool trees_plan(const ot_ctx* c, int32_t cap, int64_t n, TreesPlan* p) {
     const size_t image = sizeof(T) == 8 ? c->bytes64 : c->bytes32;
     *p = TreesPlan{};
-    if (!c->has_scene || c->max_children > 2 || cap < 1 || !tree_kernel<T, SegPlanes<T>>(gen_preset(c->features))) return false;
-    const size_t room = 160 * 1024 - 1024, img = (image + 15) & ~(size_t)15, entry = (size_t)tree_entry_bytes<T>();
+    if (!c->has_scene || c->max_children > 2 || cap < 1) return false;
+    p->preset = gen_preset(c->features);
+    p->flat_cap = c->opt_trees_flat ? trees_flat_cap(c, &p->preset) : 0;
+    if (!tree_kernel<T, SegPlanes<T>>(p->preset)) return false;
+    const size_t flat_bytes = p->flat_cap ? (((size_t)(FlatLds<T>::fixed_bytes + (size_t)p->flat_cap * 2) + 15) & ~(size_t)15) : 0;  // per wave (kernels.h)
+    const size_t room = 160 * 1024 - 1024, img = ((image + 15) & ~(size_t)15) + 4 * flat_bytes, entry = (size_t)tree_entry_bytes<T>();
     if (img + 4 * entry > room) return false;
     const int64_t need = ((int64_t)cap + 1) / 2, fit = (int64_t)((room - img) / (4 * entry));
     // entries in LDS: two under small caps (queues stay short: a third workgroup per CU is worth more than the third entry —
@@ -1174,9 +1192,12 @@ template <class T> static bool trees_plan(const ot_ctx* c, int32_t cap, int64_t 
     int64_t ql = want < need ? want : need;
     if (ql > fit) ql = fit;
     if (ql > 255) ql = 255;
+    // (... but never a third entry that leaves a CU with ONE workgroup where two would fit with two entries: cfg 3 with reflecting
+    // slabs in double precision, image + pair queues + rings: 4.1 ms with three entries, 3.3-3.7 with two)
+    if (c->opt_trees_lds <= 0 && ql == 3 && (160 * 1024) / (img + 4 * 3 * entry + 256) < 2 && (160 * 1024) / (img + 4 * 2 * entry + 256) >= 2) ql = 2;
     p->QL = (int32_t)ql;
     p->lds_bytes = img + 4 * (size_t)ql * entry;
-    const int by_lds = (int)((160 * 1024) / (p->lds_bytes + 256)), by_regs = tree_groups_by_registers<T>(gen_preset(c->features));  // (waves per SIMD the kernel's registers allow)
+    const int by_lds = (int)((160 * 1024) / (p->lds_bytes + 256)), by_regs = tree_groups_by_registers<T>(p->preset);  // (waves per SIMD the kernel's registers allow)
     p->groups_per_cu = by_lds < by_regs ? (by_lds < 1 ? 1 : by_lds) : by_regs;
     // (the scratch is per workgroup of the LAUNCH: a batch of a few trees is a few workgroups, and gets long queues out of the same 1 GiB)
     const int64_t groups_needed = n > 0 ? (n + 255) / 256 : (int64_t)1 << 40, groups_most = (int64_t)c->n_cus * p->groups_per_cu;
@@ -1204,7 +1225,7 @@ static int launch_trees(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t cap, 
     TreesPlan p;
     if (!trees_plan<T>(c, cap, n, &p)) return fail(OT_ERR_UNSUPPORTED, "no tree kernel for this scene (features beyond the everyday presets, or an image that leaves no room for the queues): use ot_trace_tree_*");
     HIP_TRY(hipSetDevice(c->device));
-    const TreeKern<T, OUT> kern = tree_kernel<T, OUT>(gen_preset(c->features));
+    const TreeKern<T, OUT> kern = tree_kernel<T, OUT>(p.preset);
     if (!kern) return fail(OT_ERR_UNSUPPORTED, "this scene's tree kernel writes the append layout only (ot_trace_trees_append_*)");
     const SceneBlob blob = make_blob<T>(c);
     const int grid = p.grid;  // persistent: the scratch is per workgroup
@@ -1218,9 +1239,9 @@ static int launch_trees(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t cap, 
     if (rc) return rc;
     if (p.lds_bytes > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds_bytes));
     hipExtLaunchKernelGGL(kern, dim3(grid), dim3(256), (uint32_t)p.lds_bytes, c->stream, ev0, ev1, 0u, blob, (T)c->unit, view<T>(rays), n, cap, p.QL, p.QG,
-                          (uint8_t*)c->trees.p, out, ctl, seg_count, counts, n_classes, c->opt_trees_refill_at);
+                          (uint8_t*)c->trees.p, out, ctl, seg_count, counts, n_classes, c->opt_trees_refill_at, p.flat_cap);
     HIP_TRY(hipGetLastError());
-    const int32_t shape[8] = {4, 256, p.groups_per_cu, (int32_t)grid, (int32_t)p.lds_bytes, p.QL, p.QG, std::is_same<OUT, SegPlanes<T>>::value ? 4 : 0};
+    const int32_t shape[8] = {4, 256, p.groups_per_cu, (int32_t)grid, (int32_t)p.lds_bytes, p.QL, p.QG, (std::is_same<OUT, SegPlanes<T>>::value ? 4 : 0) | (p.flat_cap ? 1 : 0)};
     for (int q = 0; q < 8; ++q) c->last_launch[q] = shape[q];
     return 0;
 }
@@ -1431,7 +1452,7 @@ int ot_trace_trees_plan(ot_ctx* c, int32_t real_bytes, int32_t max_trace_num, in
     const bool ok = real_bytes == 8 ? trees_plan<double>(c, max_trace_num, n_rays, &p) : trees_plan<float>(c, max_trace_num, n_rays, &p);
     info[0] = ok ? 1 : 0; info[1] = p.QL + p.QG; info[2] = p.full; info[3] = p.QL;
     info[4] = p.chunk; info[5] = p.grid * 4; info[6] = info[7] = 0;
-    if (ok && (real_bytes == 8 ? tree_kernel<double, SegsT<double>>(gen_preset(c->features)) != nullptr : tree_kernel<float, SegsT<float>>(gen_preset(c->features)) != nullptr))
+    if (ok && (real_bytes == 8 ? tree_kernel<double, SegsT<double>>(p.preset) != nullptr : tree_kernel<float, SegsT<float>>(p.preset) != nullptr))
         info[0] |= 2;  // ... and writes the [k][tree] slots too
     return 0;
 }
@@ -1659,6 +1680,7 @@ int ot_set_option(ot_ctx* c, int32_t option, int32_t value) {
             c->opt_pool = value; return 0;
         case OT_OPT_INSTANCING: c->opt_instancing = value != 0; return 0;  // takes effect at the next ot_scene_upload
         case OT_OPT_GEN_AHEAD: c->opt_gen_ahead = value != 0; return 0;
+        case OT_OPT_TREES_FLAT: c->opt_trees_flat = value != 0; return 0;
         case OT_OPT_TREES_REFILL_AT:
             if (value < 1 || value > 64) return fail(OT_ERR_INVALID, "OT_OPT_TREES_REFILL_AT takes 1..64");
             c->opt_trees_refill_at = value; return 0;

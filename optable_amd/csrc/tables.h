@@ -32,7 +32,7 @@ using GenKern = void (*)(SceneBlob, T, RaysT<T>, const int32_t*, int64_t, int32_
                          int64_t, uint8_t*, unsigned long long*, const unsigned long long*, int32_t*, int32_t, const int32_t*,
                          unsigned long long*, int32_t*, T*, int32_t, uint8_t*);
 template <class T, class OUT>
-using TreeKern = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, int32_t, int32_t, uint8_t*, OUT, AppendCtl, int32_t*, int32_t*, int32_t, int32_t);
+using TreeKern = void (*)(SceneBlob, T, RaysT<T>, int64_t, int32_t, int32_t, int32_t, uint8_t*, OUT, AppendCtl, int32_t*, int32_t*, int32_t, int32_t, int32_t);
 template <class T>
 using GenOneKern = void (*)(SceneBlob, T, RaysT<T>, const int32_t*, const int32_t*, int64_t, int32_t*, int64_t*, SegsT<T>, int64_t, RaysOutT<T>, int32_t*,
                             int32_t*, int64_t, unsigned long long*, uint32_t*, int32_t*, int32_t, int32_t, const int64_t*, int64_t*);
@@ -59,7 +59,7 @@ template <class T> GenKern<T> gen_kernel(int fg, bool lds, bool emit);
 template <class T> GenKern<T> gen_ahead_kernel(int fg, bool lds);
 template <class T> ProbeKern<T> probe_kernel(int fg, bool lds);
 // k_trace_trees (a lane per tree, the FIFO in LDS): fg as above; nullptr where no instantiation exists
-template <class T, class OUT> TreeKern<T, OUT> tree_kernel(int fg);
+template <class T, class OUT> TreeKern<T, OUT> tree_kernel(int fg);  // fg 5 / 6: the planar presets FR / FRP with the wave-wide pair queue (F_FLAT)
 // ... and the waves per SIMD its registers are capped for = the workgroups per CU it can have (256 threads: one wave per SIMD
 // each).  With every child queued the moment the interaction has formed it the kernels need 71-74 registers in single precision
 // (FB; FC / FE 97, FM 111) and 124-130 in double (FE 165, FM 255): the queues' LDS decides, not the registers.

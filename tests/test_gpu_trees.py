@@ -371,3 +371,32 @@ def test_default_call_keeps_moderately_uneven_trees_in_step():
     eng.trace_branching(skew, 24)
     (rpr, refill_at), = eng._records_per_ray.values()
     assert rpr < 6 and refill_at == 16
+
+
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+def test_pair_queue_search_of_the_tree_kernel_finds_the_same_hits(precision):
+    """Planar scenes under a top-level grid of leaves (cfg 3 with reflecting slabs): the lane-per-tree kernel searches through the
+    wave-wide pair queue of the heavy non-branching kernel (OT_OPT_TREES_FLAT, flat_grid_hit) — the same records as with a grid
+    walk per lane, and as the generation kernels."""
+    table = oa.OpticalTable()
+    table.add_components(W.cfg3_components(oa, slab_reflectivity=0.1))
+    scene = table.compile()
+    o, d = W.cfg3_rays(60_000, 2)
+    batch = RayBatch.from_arrays(o, d, wavelength=W.WL, q=Q, precision=precision)
+    eng = get_engine()
+    trees, with_queue = _same_as_generations(scene, batch, 20)
+    assert eng.last_launch is not None
+    eng.upload(scene)
+    queue_launch = None
+    try:
+        queue = eng.trace_trees(batch, 20, layout="append")
+        queue_launch = eng.last_launch()
+        eng.set_option(abi.OPT_TREES_FLAT, 0)
+        walk = eng.trace_trees(batch, 20, layout="append")
+        walk_launch = eng.last_launch()
+    finally:
+        eng.set_option(abi.OPT_TREES_FLAT, 1)
+    assert queue_launch["pair_queue"] & 1 and not walk_launch["pair_queue"] & 1
+    a, b = queue.to_host(reference_order=True), walk.to_host(reference_order=True)
+    for f in abi.SEG_FIELDS + ("ray", "surface"):
+        np.testing.assert_array_equal(a[f], b[f], err_msg=f)

@@ -19,22 +19,31 @@ from optable_amd import abi
 from optable_amd.batch import RayBatch
 from optable_amd.engine import get_engine
 from oracle import oracle
-from test_gpu_fuzz import random_branching_scene, random_large_scene
+from test_gpu_fuzz import random_branching_scene, random_large_scene, random_planar_scene
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 eng = get_engine()
 oracle.build()
-bad = skipped = 0
+bad = skipped = flat = 0
 for seed in range(first, first + cases):
     rng = np.random.default_rng(770000 + seed)
     table = oa.OpticalTable()
-    if rng.uniform() < 0.15:  # grids, lens arrays, dispersion (the all-features preset) + something that splits
+    pick = rng.uniform()
+    if pick < 0.15:  # planar components under a top-level grid (the pair-queue presets; with irises: polygon / boolean apertures) + splitters
+        comps = random_planar_scene(oa, rng, irises=bool(rng.integers(0, 2)))
+        for _ in range(int(rng.integers(1, 4))):
+            comps.append(oa.BeamSplitter([rng.uniform(3, 35), rng.uniform(-5, 5), 0.0], width=2.5, height=2, eta=rng.uniform(0.3, 0.7)).RotZ(rng.uniform(-1.5, 1.5)))
+        comps.append(oa.GlassSlab([rng.uniform(3, 35), rng.uniform(-4, 4), 0.0], width=2, height=2, thickness=0.4, n1=1, n2=1.5, reflectivity=0.15).RotZ(rng.uniform(-0.5, 0.5)))
+        wide = True
+    elif pick < 0.30:  # grids, lens arrays, dispersion (the all-features preset) + something that splits
         comps = random_large_scene(oa, rng)
         comps.append(oa.BeamSplitter([rng.uniform(2, 20), rng.uniform(-2, 2), 0.0], width=3, height=3, eta=rng.uniform(0.3, 0.7)).RotZ(rng.uniform(-1, 1)))
         comps.append(oa.Mirror([rng.uniform(2, 25), rng.uniform(-3, 3), 0.0], radius=1.5, reflectivity=0.6, transmission=0.4).RotZ(rng.uniform(-1, 1)))
+        wide = True
     else:
         comps = random_branching_scene(oa, rng)
+        wide = False
     table.add_components(comps)
     scene = table.compile()
     eng.upload(scene)
@@ -42,7 +51,8 @@ for seed in range(first, first + cases):
     cap = int(rng.integers(1, 61))
     ql = int(rng.integers(1, 7))
     prec = "f64" if rng.uniform() < 0.6 else "f32"
-    o = np.stack([np.zeros(n), rng.uniform(-3, 3, n), rng.uniform(-0.3, 0.3, n)], 1)
+    half = 6 if wide else 3
+    o = np.stack([np.zeros(n), rng.uniform(-half, half, n), rng.uniform(-0.3, 0.3, n)], 1)
     d = np.stack([np.ones(n), rng.uniform(-0.12, 0.12, n), rng.uniform(-0.02, 0.02, n)], 1)
     batch = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=1j * np.pi * scenes.W0**2 / scenes.WL, precision=prec)
     eng.set_option(abi.OPT_TREES_LDS_ENTRIES, ql)
@@ -57,6 +67,7 @@ for seed in range(first, first + cases):
     ok = True
     for layout in layouts:
         t = eng.trace_trees(batch, cap, layout=layout)
+        flat += eng.last_launch()["pair_queue"] & 1
         if not plan["full"] and bool((t.count < 0).any()):
             continue
         h = t.to_host(reference_order=True)
@@ -86,5 +97,5 @@ for seed in range(first, first + cases):
         print(f"... {seed - first + 1} cases, {bad} bad, {skipped} skipped", flush=True)
 eng.set_option(abi.OPT_TREES_LDS_ENTRIES, 0)
 eng.set_option(abi.OPT_TREES_REFILL_AT, 16)
-print(f"{cases} cases: {bad} bad, {skipped} skipped (no lane-per-tree kernel for the scene)")
+print(f"{cases} cases: {bad} bad, {skipped} skipped (no lane-per-tree kernel for the scene); {flat} launches searched through the pair queue")
 sys.exit(1 if bad else 0)
