@@ -18,9 +18,9 @@ from optable_amd.batch import RayBatch, SegmentBatch
 from optable_amd.engine import get_engine
 
 name = sys.argv[1]
-GENLOOP = bool(os.environ.get("GENLOOP")) or name == "cfg4bgen"  # cfg4bgen: cfg4b through the generation loop instead of the default call
-if name == "cfg4bgen":
-    name = "cfg4b"
+GENLOOP = bool(os.environ.get("GENLOOP")) or name in ("cfg4bgen", "cfg3bgen")  # ...gen: the same trees through the generation loop instead of the default call
+if name in ("cfg4bgen", "cfg3bgen"):
+    name = name[:-3]
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else {"cfg2": 400, "cfg3": 20}.get(name, 5)  # cfg3: enough launches that the clock ramp of the first ones does not carry the average
 SIZES = {"cfg2": 1_000_000, "cfg3": 10_000_000, "cfg4": 160_000_000, "cfg5": 12_500_000, "cfg4b": 12_800_000, "cfg3b": 2_000_000, "monitor": 1_000_000, "allfeat64": 1_000_000, "allfeat32": 1_000_000}
 n = int(os.environ.get("RAYS", SIZES[name]))
@@ -98,11 +98,17 @@ elif name == "cfg3b":  # heavy branching: cfg 3 with 10 % reflecting slab faces,
     eng.upload(table.compile())
     o, d = W.cfg3_rays(n, 2)
     batch = RayBatch.from_arrays(o, d, wavelength=W.WL, q=Q(W.WL), precision="f32")
-    for _ in range(max(reps // 2, 2)):
+    for _ in range(max(reps, 2)):
         t0 = time.perf_counter()
-        segs = eng.trace_tree(batch, 20, out_capacity=batch.n * 21)
+        if GENLOOP:
+            segs = eng.trace_tree(batch, 20, out_capacity=batch.n * 21)
+            n_seg = segs.n_valid
+        else:  # what Engine.trace_branching launches for this batch (the lane-per-tree kernel with the pair-queue search), without its 1 % sample
+            segs = eng.trace_trees(batch, 20, layout="append")
+            n_seg = int(segs.count.abs().sum())
         torch.cuda.synchronize()
-        print(f"cfg3b: {batch.n} trees, {segs.n_valid} segments, {1e3 * (time.perf_counter() - t0):.1f} ms wall")
+        print(f"cfg3b: {batch.n} trees, {n_seg} segments per trace, {1e3 * (time.perf_counter() - t0):.1f} ms wall, layout {segs.layout}")
+        del segs
 elif name in ("allfeat64", "allfeat32"):  # a light scene of the reference's example parts (tools/bench_allfeatures.py): the FM preset
     prec = "f64" if name.endswith("64") else "f32"
     table = oa.OpticalTable()

@@ -19,7 +19,7 @@ import sys
 raw, dst = sys.argv[1], sys.argv[2]
 os.makedirs(dst, exist_ok=True)
 OURS = ("k_trace_", "k_gen_", "k_mon_", "k_stream_")
-RECORD_BYTES = {"cfg2": 104, "cfg4": 104, "cfg4b": 104, "cfg3": 56, "cfg5": 56, "allfeat64": 104, "allfeat32": 56}  # per ray record and per segment record
+RECORD_BYTES = {"cfg2": 104, "cfg4": 104, "cfg4b": 104, "cfg3b": 56, "cfg3": 56, "cfg5": 56, "allfeat64": 104, "allfeat32": 56}  # per ray record and per segment record
 N_SIMD, N_XCD, N_CU = 1024, 8, 256
 HERE = os.path.dirname(os.path.abspath(__file__))
 
