@@ -1188,7 +1188,9 @@ template <class T> static bool trees_plan(const ot_ctx* c, int32_t cap, int64_t 
     const int64_t need = ((int64_t)cap + 1) / 2, fit = (int64_t)((room - img) / (4 * entry));
     // entries in LDS: two under small caps (queues stay short: a third workgroup per CU is worth more than the third entry —
     // cfg 4 R = 0.2: 4.05 vs 4.2 ms, bushy trees under a cap of 12: 0.56 vs 0.62), three above (cap 48: 3.35 vs 3.99)
-    const int64_t want = c->opt_trees_lds > 0 ? c->opt_trees_lds : (cap <= 16 ? 2 : 3);
+    // ... and ONE where the search is the pair queue (heavy planar scenes: their image and queues take the LDS, and a fourth workgroup
+    // per CU is worth more than entries — cfg 3 with reflecting slabs 1.38 / 1.49 / 1.85 ms with one / two / three)
+    const int64_t want = c->opt_trees_lds > 0 ? c->opt_trees_lds : (p->flat_cap ? 1 : (cap <= 16 ? 2 : 3));
     int64_t ql = want < need ? want : need;
     if (ql > fit) ql = fit;
     if (ql > 255) ql = 255;
@@ -1211,7 +1213,8 @@ template <class T> static bool trees_plan(const ot_ctx* c, int32_t cap, int64_t 
         const int64_t most_chunk = sixteenth < 8192 ? sixteenth : 8192;
         p->chunk = (int32_t)(most_chunk > c->opt_append_chunk ? most_chunk : c->opt_append_chunk);
     }
-    int64_t most = ((int64_t)1 << 30) / (waves * (int64_t)entry);
+    const int64_t scratch_entry = 64 * (sizeof(T) == 8 ? 96 : 48);  // lane-major records of 12 words (kernels.h)
+    int64_t most = ((int64_t)1 << 30) / (waves * scratch_entry);
     if (most > 255) most = 255;  // (the kernel keeps ring positions in bytes)
     // (the scratch ring alone must hold a whole queue: pushes keep going there while the LDS entries in front of them drain)
     const int64_t qg = need > ql ? need : 0;
@@ -1229,7 +1232,7 @@ static int launch_trees(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t cap, 
     if (!kern) return fail(OT_ERR_UNSUPPORTED, "this scene's tree kernel writes the append layout only (ot_trace_trees_append_*)");
     const SceneBlob blob = make_blob<T>(c);
     const int grid = p.grid;  // persistent: the scratch is per workgroup
-    const size_t scratch = (size_t)grid * 4 * (size_t)p.QG * tree_entry_bytes<T>();
+    const size_t scratch = (size_t)grid * 4 * (size_t)p.QG * 64 * (sizeof(T) == 8 ? 96 : 48);
     if (c->trees.ensure(scratch + 256)) return fail(OT_ERR_HIP, "hipMalloc of the tree queues failed");
     if (ac.cursor) HIP_TRY(hipMemsetAsync(ac.cursor, 0, sizeof(unsigned long long), c->stream));
     AppendCtl ctl = ac;

@@ -64,8 +64,7 @@ template <class T, class OUT> TreeKern<T, OUT> tree_kernel(int fg);  // fg 5 / 6
 // each).  With every child queued the moment the interaction has formed it the kernels need 71-74 registers in single precision
 // (FB; FC / FE 97, FM 111) and 124-130 in double (FE 165, FM 255): the queues' LDS decides, not the registers.
 template <class T> constexpr int tree_minw(int fg) { return sizeof(T) == 4 ? (fg == 0 ? 6 : (fg == 4 ? 3 : 4)) : (fg == 4 ? 1 : (fg == 3 ? 2 : 3)); }
-// (the double-precision planar kernels come out at 124-127 under the cap of 168: four of their waves fit a SIMD — tests/test_build_resources.py)
-template <class T> constexpr int tree_groups_by_registers(int fg) { return sizeof(T) == 8 && fg == 0 ? 4 : tree_minw<T>(fg); }
+template <class T> constexpr int tree_groups_by_registers(int fg) { return tree_minw<T>(fg); }
 // k_gen_one (one pass per generation, decoupled look-back): fg as above; nullptr where no instantiation exists
 template <class T> GenOneKern<T> gen_one_kernel(int fg, bool lds);
 

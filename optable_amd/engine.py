@@ -348,8 +348,7 @@ class Engine:
     def _trees_estimate(self, rays, K):
         """Rays per tree of a large batch, and how its waves should refill, from a strided 1 % sample (a lane-per-tree launch of
         its own), remembered per scene, cap and precision.  Rays per tree sizes the append block (x 1.15 + the launch's slack
-        instead of every tree at its cap) and tells batches of few long trees under a large cap — the one regime in which the
-        generation loop is faster — from the rest.  The spread of the tree sizes picks OT_OPT_TREES_REFILL_AT:
+        instead of every tree at its cap).  The spread of the tree sizes picks OT_OPT_TREES_REFILL_AT:
         trees that differ moderately (standard deviation below 0.35 of the mean: cfg 4 with R = 0.2 without a binding cap, 13-30
         rays) are traced 64 to a wave, in step — 1.9 instead of 2.6 ms on 3.2e6 of them; batches of mostly tiny trees, or of trees of
         every size up to the cap, keep their lanes busy one by one (1.33 vs 2.13 and 3.2 vs 3.8 ms) (kernels.h)."""
@@ -395,9 +394,6 @@ class Engine:
                     segs = self.trace_trees(rays, K, counts=counts, layout="append")
                 else:
                     rpr = self._trees_estimate(rays, K)  # (also sets how the waves of this batch refill)
-                    if K > 48 and rpr < 0.25 * K:  # few long trees under a large cap
-                        self.set_option(abi.OPT_TREES_REFILL_AT, self.trees_refill_at)
-                        return self.trace_tree(rays, K, counts=counts, max_trace_time=max_trace_time)
                     if plan["slots"] and rays.precision == "f32" and rpr >= 0.9 * K:
                         # nearly every tree runs into the cap: lanes stay in step, [k][tree] rows are whole lines and cost no claims — in
                         # single precision, where a step is short: 0.29 vs 0.42 ms on 1e6 bushy trees under a cap of 12 (double: 0.57

@@ -248,9 +248,9 @@ def test_append_layout_of_the_tree_kernel_holds_the_same_records(precision, away
         small.n_valid
 
 
-def test_default_call_sizes_the_dense_list_from_a_sample_and_knows_when_the_generations_win():
+def test_default_call_sizes_the_dense_list_from_a_sample():
     """Engine.trace_branching on a large batch: rays per tree from a 1 % sample; the append block is that x 1.15 + the launch's
-    slack, not every tree at its cap; a batch of few long trees under a large cap goes to the generation loop."""
+    slack, not every tree at its cap — also for few long trees under a large cap."""
     scene = _lattice()
     eng = get_engine()
     eng.upload(scene)
@@ -269,8 +269,8 @@ def test_default_call_sizes_the_dense_list_from_a_sample_and_knows_when_the_gene
     a, b = segs.to_host(reference_order=True), ref.to_host(reference_order=True)
     for f in abi.SEG_FIELDS + ("ray", "surface"):
         np.testing.assert_array_equal(a[f], b[f], err_msg=f)
-    big = eng.trace_branching(batch, 96)  # few long trees under a large cap: generation by generation
-    assert big.layout == "list" and big.n_valid == eng.trace_trees(batch, 96, layout="append").count.sum().item()
+    big = eng.trace_branching(batch, 96)  # few long trees under a large cap: queues of 48 rays per lane, most of them in the scratch ring
+    assert big.layout == "append" and int(big.count.sum()) == eng.trace_tree(batch, 96).n_valid
 
 
 def test_monitors_and_exports_read_tree_outputs_like_the_generation_list(tmp_path):
