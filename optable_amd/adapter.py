@@ -171,7 +171,23 @@ def lower_material(mat):
 
 # ---------------------------------------------------------------------------------------------
 # interactions (reference optable/optical_component.py)
+def host_hook(comp):
+    """True when `comp.interact_local` is the USER's: defined by a class outside this package and outside the reference
+    package (optical_component.py:235-240 is the subclassing hook).  Such a leaf keeps its place in the device scene — the
+    nearest-hit search, its boxes and its count gate are the kernels' — and its physics is the user's Python, called by
+    `table.ray_tracing` on the rays the device found to hit it (table.py: _trace_hooked)."""
+    if comp.__dict__.get("_builtin_physics"):  # table.interact_leaf_local: the built-in physics below a user's override
+        return False
+    for klass in type(comp).__mro__:
+        if "interact_local" in klass.__dict__:
+            root = (klass.__module__ or "").split(".")[0]
+            return root not in ("optable_amd", "optable")
+    return False
+
+
 def lower_interaction(comp):
+    if host_hook(comp):
+        return dict(kind=BLOCK, host_hook=True)  # the device ends the ray at the hit; the host asks the user what it emits
     if hasattr(comp, "lower_interaction"):
         return comp.lower_interaction()
     names = _mro_names(comp)

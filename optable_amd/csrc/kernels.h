@@ -1675,7 +1675,7 @@ __global__ __launch_bounds__(256) void k_gen_pass(SceneBlob blob, T unit, RaysT<
     // its children was a sixth of the bytes of a cfg 4 (R = 0.2) trace.  The count pass decides (it is the one that may
     // read budgets), bit 3 of the code byte tells the emit pass.
     bool doomed = (c & 8) != 0;
-    if (!EMIT && active && drop_doomed) {
+    if (!EMIT && active && (drop_doomed & 1)) {
         const int64_t last_needed = head + bud - 1;
         doomed = last_needed < n && tree[last_needed] == my_tree;
     }
@@ -1747,7 +1747,7 @@ __global__ __launch_bounds__(256) void k_gen_pass(SceneBlob blob, T unit, RaysT<
         st<GEN_NT>(next.I + d, real ? k.I : T(0)); st<GEN_NT>(next.n + d, k.n); st<GEN_NT>(next.pl + d, k.pl);
         next.flags[d] = real ? ((fl & OT_RAY_HAS_Q) | ((k.last + 1) << 8)) : OT_RAY_DEAD;
         next.id[d] = cls;
-        next_tree[d] = my_tree;
+        next_tree[d] = (drop_doomed & 2) ? (int32_t)i : my_tree;  // bit 1 (OT_OPT_GEN_PARENT_INDEX): the parent's input index, for hosts that keep an object per ray
     };
     if (c_nk > 0) put(nk > 0 ? ch[0] : r, d0, nk > 0);
     if (c_nk > 1) put(nk > 1 ? ch[1] : r, d0 + 1, nk > 1);

@@ -59,6 +59,7 @@ struct ot_ctx {
     int32_t n_phys = 0, n_runs = 0, runs_word64 = 0, runs_word32 = 0;  // instanced runs folded by fill_blob (trace_core.h NodeRef)
     int32_t opt_append_chunk = 512;  // append layout: slots per claim
     int32_t opt_instancing = 1;      // fold lattice children into instanced runs at upload
+    bool opt_gen_parent = false;     // ot_trace_generation_*: next_tree[] = index of the parent ray (OT_OPT_GEN_PARENT_INDEX)
     int32_t opt_gen_drop = 1;        // generation kernels: children of a tree whose budget ends with this generation are not emitted
     int32_t opt_gen_reuse = -1;      // generation kernels: emit pass rebuilds the count pass's hit instead of searching again (-1 auto)
     double unit = 1e-2;
@@ -1053,7 +1054,9 @@ template <class T>
 static int trace_generation(ot_ctx* c, const ot_rays* rays, const int32_t* tree, int64_t n, int32_t* budget,
                             const ot_segments* out, int64_t out_capacity, int64_t* seg_cursor, const ot_rays* next,
                             int32_t* next_tree, int64_t next_capacity, int64_t* n_next, int32_t* counts,
-                            int32_t n_classes, uint8_t* ahead_in = nullptr, uint8_t* ahead_out = nullptr) {
+                            int32_t n_classes, uint8_t* ahead_in = nullptr, uint8_t* ahead_out = nullptr, bool parent_index = false) {
+    // parent_index (OT_OPT_GEN_PARENT_INDEX, the single-generation entry points only): next_tree[] receives the input index of each
+    // child's parent instead of its tree id.
     // ahead_in: the bytes the emit pass of the generation before left for these rays (children per ray if processed): no count
     // pass over the rays, k_gen_recount instead.  ahead_out: where this emit pass leaves them for the next generation (of
     // next_capacity bytes); NULL: plain emit.  Both live outside c->gen, which may be reallocated between generations.
@@ -1148,7 +1151,7 @@ static int trace_generation(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
     hipLaunchKernelGGL(k_emit, dim3(g1), dim3(block), lds_bytes, c->stream, blob, (T)c->unit, view<T>(rays), tree, n, budget,
                        (const int64_t*)(totals + 2), view<T>(out), out_capacity, view_out<T>(next), next_tree, next_capacity, code, wave_total,
                        (const unsigned long long*)wave_prefix, counts, n_classes, (const int32_t*)rank, mismatch, hit_node, hit_t,
-                       c->opt_gen_drop ? 1 : 0, ahead_out);
+                       (c->opt_gen_drop ? 1 : 0) | (parent_index ? 2 : 0), ahead_out);
     if (ns > 0)
         hipLaunchKernelGGL(k_gen_counts, dim3(g1), dim3(block), 0, c->stream, tree, rays->id, n, ns, rank, probe, c->slot_max, counts,
                            n_classes);
@@ -1477,14 +1480,14 @@ int ot_trace_generation_f64(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
                             int32_t* next_tree, int64_t next_capacity, int64_t* n_next, int32_t* counts,
                             int32_t n_classes) {
     return trace_generation<double>(c, rays, tree, n, budget, out, out_capacity, seg_cursor, next, next_tree, next_capacity, n_next,
-                                    counts, n_classes);
+                                    counts, n_classes, nullptr, nullptr, c && c->opt_gen_parent);
 }
 int ot_trace_generation_f32(ot_ctx* c, const ot_rays* rays, const int32_t* tree, int64_t n, int32_t* budget,
                             const ot_segments* out, int64_t out_capacity, int64_t* seg_cursor, const ot_rays* next,
                             int32_t* next_tree, int64_t next_capacity, int64_t* n_next, int32_t* counts,
                             int32_t n_classes) {
     return trace_generation<float>(c, rays, tree, n, budget, out, out_capacity, seg_cursor, next, next_tree, next_capacity, n_next,
-                                   counts, n_classes);
+                                   counts, n_classes, nullptr, nullptr, c && c->opt_gen_parent);
 }
 
 int ot_monitor_record_f64(ot_ctx* c, const ot_monitor* mon, const ot_segments* segs, int64_t n, const int32_t* seg_count,
@@ -1684,6 +1687,7 @@ int ot_set_option(ot_ctx* c, int32_t option, int32_t value) {
         case OT_OPT_INSTANCING: c->opt_instancing = value != 0; return 0;  // takes effect at the next ot_scene_upload
         case OT_OPT_GEN_AHEAD: c->opt_gen_ahead = value != 0; return 0;
         case OT_OPT_TREES_FLAT: c->opt_trees_flat = value != 0; return 0;
+        case OT_OPT_GEN_PARENT_INDEX: c->opt_gen_parent = value != 0; return 0;
         case OT_OPT_TREES_REFILL_AT:
             if (value < 1 || value > 64) return fail(OT_ERR_INVALID, "OT_OPT_TREES_REFILL_AT takes 1..64");
             c->opt_trees_refill_at = value; return 0;

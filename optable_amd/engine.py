@@ -70,6 +70,17 @@ class Engine:
         self._records_per_ray = {}
         self._layout_choice = {}
 
+    def _refuse_hooks(self):
+        """Whole-trace launches cannot call back into Python: a scene with user-defined `interact_local` leaves
+        (CompiledScene.hooks) is traced generation by generation by `table.ray_tracing` (table.py: _trace_hooked), where
+        the device finds the hits and the user's method says what they emit."""
+        if self.scene is not None and getattr(self.scene, "hooks", None):
+            from .scene import SceneError
+
+            names = sorted({type(c).__name__ for c in self.scene.hooks.values()})
+            raise SceneError(f"{', '.join(names)}: a user-defined interact_local runs on the host; trace such a scene with "
+                             "table.ray_tracing (Ray objects) — the batch entry points are whole-trace device launches")
+
     def _check_wavelengths(self, rays):
         """Scenes with a dispersion SERIES (Material(n = callable), fitted over a wavelength interval: materials.py) say
         nothing outside that interval; the reference would call the function there.  Refuse rather than extrapolate."""
@@ -136,6 +147,7 @@ class Engine:
         1.15 + the launch's chunk slack; the rare batch that needs more is traced again into a block of the size the
         first launch reported); pass what the job needs to skip the estimate: if that turns out too small a RuntimeError
         names the size that fits."""
+        self._refuse_hooks()
         if self.scene is None:
             raise RuntimeError("upload a scene first")
         n, K = rays.n, int(max_segments)
@@ -293,6 +305,7 @@ class Engine:
         take trace_tree then); `capped` as trace_tree reports it.  `counts`: the interact-count table of scenes with limited
         surfaces ([surfaces, classes], rays.id = column; default: a zeroed column per ray) — exact when no two trees of the
         call share a column."""
+        self._refuse_hooks()
         if self.scene is None:
             raise RuntimeError("upload a scene first")
         self._check_wavelengths(rays)
@@ -381,6 +394,7 @@ class Engine:
         Scenes with count-limited surfaces: the lane-per-tree kernel meets them in each tree's FIFO order, which is the
         reference's as long as no two trees of the call share a column of `counts` (`distinct_ids=True`: the caller vouches
         for it, as the host API's rounds do; default: such scenes take the generations)."""
+        self._refuse_hooks()
         n, K = rays.n, int(max_trace_num)
         gates_ok = not self.scene.limited or bool(distinct_ids)
         if n and gates_ok and self.LANE_PER_TREE and (max_trace_time is None or max_trace_time > 1.0):
@@ -428,6 +442,7 @@ class Engine:
         ["max_trace_time"]`), honoured at generation granularity — the clock is read after every generation of
         the whole batch, and once it has run out the rays still queued are dropped, as the reference drops a
         tree's queue (`:138-144`); the trees they belonged to are reported in `capped` (`timed_out` says why)."""
+        self._refuse_hooks()
         import time
 
         t_start = time.time()
@@ -505,11 +520,14 @@ class Engine:
             out.capped = out.capped | timed_out
         return out
 
-    def generation_step(self, rays: RayBatch, counts=None):
+    def generation_step(self, rays: RayBatch, counts=None, tree=None):
         """ONE generation of the breadth-first trace: every input ray is processed once (nearest hit,
         interaction).  Returns (segments, children, parent): a SegmentBatch with one record per input ray
         (slot i = ray i), the emitted rays as a RayBatch in parent order then child order, and for each of them
-        the index of its parent.  This is `component.interact(ray)` for a batch (optical_component.py:337-378)."""
+        the index of its parent.  This is `component.interact(ray)` for a batch (optical_component.py:337-378).
+        `tree` (int32 per ray, ascending: a generation lists its rays tree by tree): which rays belong to one ray tree — the
+        rays of a tree meet a count-limited surface one after the other in input order, as the reference's FIFO makes them
+        (optical_component.py:140-149, 359-362); default: every ray a tree of its own."""
         if self.scene is None:
             raise RuntimeError("upload a scene first")
         prec = rays.precision
@@ -521,9 +539,15 @@ class Engine:
         if n == 0:
             return out, RayBatch(0, prec, dev), torch.zeros(0, dtype=torch.int32, device=dev)
         fan = max(self.scene.max_children, 1)
-        budget = torch.full((n,), 2, dtype=torch.int32, device=dev)  # (one ray per tree, room for one more: the children are wanted)
         state = torch.zeros(2, dtype=torch.int64, device=dev)
-        tree = torch.arange(n, dtype=torch.int32, device=dev)
+        if tree is None:
+            tree = torch.arange(n, dtype=torch.int32, device=dev)
+            budget = torch.full((n,), 2, dtype=torch.int32, device=dev)  # (one ray per tree, room for one more: the children are wanted)
+        else:
+            tree = torch.as_tensor(tree, dtype=torch.int32, device=dev).contiguous()
+            if tree.numel() != n or (n > 1 and bool((tree[1:] < tree[:-1]).any())) or int(tree[0]) < 0:
+                raise ValueError("tree: one non-negative id per ray, ascending")
+            budget = torch.full((int(tree[-1]) + 1,), n + 1, dtype=torch.int32, device=dev)  # (every ray processed, children wanted)
         nxt = RayBatch(n * fan, prec, dev, initialise=False)
         nxt_tree = torch.empty(n * fan, dtype=torch.int32, device=dev)
         n_slots = len(self.scene.limited)
@@ -531,10 +555,14 @@ class Engine:
             counts = torch.zeros((n_slots, n), dtype=torch.int32, device=dev)
         n_classes = 0 if counts is None else counts.shape[1]
         rs, ss, ns = rays.c_struct(), out.c_struct(), nxt.c_struct()
-        abi.check(gen_fn(
-            self._ctx, C.byref(rs), tree.data_ptr(), n, budget.data_ptr(), C.byref(ss), out.capacity,
-            state.data_ptr(), C.byref(ns), nxt_tree.data_ptr(), nxt.n, state.data_ptr() + 8,
-            None if counts is None else counts.data_ptr(), n_classes), self.lib)
+        self.set_option(abi.OPT_GEN_PARENT_INDEX, 1)  # nxt_tree = the parent's index, whatever `tree` groups
+        try:
+            abi.check(gen_fn(
+                self._ctx, C.byref(rs), tree.data_ptr(), n, budget.data_ptr(), C.byref(ss), out.capacity,
+                state.data_ptr(), C.byref(ns), nxt_tree.data_ptr(), nxt.n, state.data_ptr() + 8,
+                None if counts is None else counts.data_ptr(), n_classes), self.lib)
+        finally:
+            self.set_option(abi.OPT_GEN_PARENT_INDEX, 0)
         written, n_next = state.tolist()
         out.n_valid, out.counts_table = int(written), counts
         kids = nxt.slice(0, int(n_next))

@@ -39,6 +39,7 @@ class CompiledScene:
         self.aux = (C.c_double * max(len(aux), 1))(*aux)
         self.n_aux = len(aux)
         self.leaves = leaves        # leaf_id -> component
+        self.hooks = {}             # leaf_id -> component whose interact_local is the user's Python (adapter.host_hook)
         self.limited = limited      # count_slot -> component
         self.max_children = max_children
         self.unit = unit
@@ -68,7 +69,7 @@ class _Builder:
         self.accelerate = accelerate
         self.nodes, self.materials, self.aux = [], [], []
         self.mat_index = {}
-        self.leaves, self.limited = [], []
+        self.leaves, self.limited, self.hooks = [], [], {}
         self.wavelength_range = None  # metres: where every fitted dispersion series of the scene is valid
         self.leaf_pose = []   # per leaf: (transform_matrix, origin, local box) for the fresh lab boxes (_trust_boxes)
         self.groups = []      # node indices of the groups, in node order
@@ -246,6 +247,8 @@ class _Builder:
             node.max_interact_count, node.count_slot = int(comp.max_interact_count), len(self.limited)
             self.limited.append(comp)
         node.leaf_id = len(self.leaves)
+        if inter.get("host_hook"):
+            self.hooks[node.leaf_id] = comp
         self.leaves.append(comp)
         self.leaf_pose.append((np.asarray(comp.transform_matrix, dtype=float), np.asarray(comp.origin, dtype=float),
                                np.asarray(surf.get_bbox_local(), dtype=float)))
@@ -383,6 +386,7 @@ def _flattenable_leaves(b, top):
 
 
 ROOT_GRID_MIN_TOP = 12
+ROOT_GRID_ASPECT = 1.0  # (experiment knob: > 1 = more, narrower cells along the first grid axis)
 ROOT_GRID_CELLS_PER_COMPONENT = 1.0
 
 
@@ -411,8 +415,8 @@ def _root_grid(b, tops):
     # bench_configs.py): 1 cell per component is 1.45x faster than 4 — every extra cell a ray steps through
     # is a divergent DDA iteration for its whole wave, which costs more than the few extra candidate tests.
     cells_target = ROOT_GRID_CELLS_PER_COMPONENT * len(tops)
-    g0 = int(np.clip(round(np.sqrt(cells_target * span[0] / span[1])), 1, 64))
-    g1 = int(np.clip(round(np.sqrt(cells_target * span[1] / span[0])), 1, 64))
+    g0 = int(np.clip(round(np.sqrt(cells_target * span[0] / span[1]) * ROOT_GRID_ASPECT), 1, 64))
+    g1 = int(np.clip(round(np.sqrt(cells_target * span[1] / span[0]) / ROOT_GRID_ASPECT), 1, 64))
     size = [span[0] / g0, span[1] / g1]
     inv = [1.0 / size[0], 1.0 / size[1]]
     cells = [[] for _ in range(g0 * g1)]
@@ -461,5 +465,7 @@ def compile_scene(components, unit=1e-2, accelerate=True) -> CompiledScene:
     for g in b.groups:
         b._maybe_grid(b.nodes[g], g)
     root = _root_grid(b, tops) if accelerate and all_trusted else -1
-    return CompiledScene(b.nodes, b.materials, b.aux, b.leaves, b.limited, b.max_children, unit, root, b.always_branches,
-                         b.wavelength_range)
+    scene = CompiledScene(b.nodes, b.materials, b.aux, b.leaves, b.limited, b.max_children, unit, root, b.always_branches,
+                          b.wavelength_range)
+    scene.hooks = b.hooks
+    return scene

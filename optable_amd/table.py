@@ -362,7 +362,7 @@ class OpticalTable:
     # -- List[Ray] plumbing ------------------------------------------------------------------------
     def _trace_objects(self, rays, cap, max_time=MAX_TRACE_TIME):
         with _engine().lock:  # upload + every trace of this call as one unit (see Engine.lock)
-            return self._trace_objects_locked(rays, cap, max_time)
+            return OpticalTable._trace_objects_locked(self, rays, cap, max_time)  # (`self` may be the reference package's table: adapter.install)
 
     def _trace_objects_locked(self, rays, cap, max_time=MAX_TRACE_TIME):
         import torch
@@ -395,6 +395,12 @@ class OpticalTable:
         for rnd in range(int(rounds.max()) + 1):
             pick = np.nonzero(rounds == rnd)[0]
             sub = [rays[k] for k in pick]
+            if scene.hooks:  # leaves whose interact_local is the user's Python: generation by generation, device search + host physics
+                chunks, capped = OpticalTable._trace_hooked(self, eng, scene, sub, cls[pick], cap, counts, max_time)
+                total_capped += capped
+                for k, chunk in zip(pick, chunks):
+                    per_ray[k] = chunk
+                continue
             batch = _pack(sub, cls[pick], eng.device, scene.unit)
             if scene.max_children <= 1 and cap <= _FUSED_MAX_SEGMENTS:
                 segs = eng.trace(batch, cap, counts=counts)
@@ -419,6 +425,96 @@ class OpticalTable:
         for mon in self.monitors:
             record_monitor_hits(mon, traced)
         return traced, total_capped
+
+
+    def _trace_hooked(self, eng, scene, sources, cls, cap, counts, max_time):
+        """Ray trees through a scene with USER-DEFINED components (subclasses that override `interact_local`,
+        optical_component.py:235-240).  The trees advance generation by generation: the device finds every queued ray's
+        nearest hit among ALL leaves (boxes, grids, count gates, the strict first minimum: `Engine.generation_step`, the
+        kernels of every other trace) and emits the children of the built-in leaves; for a ray whose winner is a hooked leaf
+        the user's method gets the ray in the leaf's frame and its return is taken to the lab frame — the statements of
+        optical_component.py:354-372.  Within a tree, generation order is the reference's FIFO order (optical_table.py:
+        115-134): a hit contributes [truncated ray, its dead children ...] to the output and its live children to the queue;
+        the cap counts pops per tree and drops what is still queued (:93-98, :138-144).  Deviation, by design: the reference
+        calls `interact_local` on every component a ray geometrically hits and discards all results but the nearest's (:119-
+        123); here only the nearest hit's is called, which is the same for a method without side effects.
+        Returns (per-tree lists of finished rays, number of trees the cap or the clock cut)."""
+        import time
+
+        t0 = time.time()
+        n = len(sources)
+        done = [[] for _ in range(n)]
+        pops, cut = [0] * n, [False] * n
+        queue = [(r, t) for t, r in enumerate(sources)]
+        while queue:
+            if time.time() - t0 >= max_time:
+                for _, t in queue:
+                    cut[t] = True
+                break
+            live = []
+            for r, t in queue:
+                if pops[t] < cap:
+                    pops[t] += 1
+                    live.append((r, t))
+            if not live:
+                break
+            m = len(live)
+            eng.upload(scene)  # (a hook may have used the engine for a scene of its own: intersect_point_local)
+            batch = _pack([r for r, _ in live], np.asarray(cls)[[t for _, t in live]], eng.device, scene.unit)
+            segs, kids, parent = eng.generation_step(batch, counts, tree=[t for _, t in live])  # (a tree's rays meet a count gate in FIFO order)
+            surface = segs.surface[:m].cpu().numpy()
+            length = segs.length[:m].cpu().numpy()
+            kid = {f: kids.field(f).cpu().numpy() for f in abi.RAY_FIELDS} if kids.n else None
+            first = np.searchsorted(parent.cpu().numpy(), np.arange(m + 1))  # children come in parent order
+            queue = []
+            for i, (r, t) in enumerate(live):
+                if surface[i] < 0:  # escaped, or dead on input: archived as it is (optical_table.py:133-134)
+                    done[t].append(_clone_rays([r])[0])
+                    continue
+                stub = _clone_rays([r])[0]
+                stub.length, stub.alive = float(length[i]), False
+                done[t].append(stub)
+                comp = scene.hooks.get(int(surface[i]))
+                if comp is None:
+                    children = [_child_ray(r, kid, j) for j in range(first[i], first[i + 1])]
+                else:
+                    children = _call_hook(comp, r)
+                for c in children:
+                    if c.alive:
+                        queue.append((c, t))
+                    else:
+                        done[t].append(c)
+        capped = [cut[t] or pops[t] >= cap for t in range(n)]
+        if any(capped):
+            self._last_trace_num = max(pops[t] for t in range(n) if capped[t])
+        return done, int(sum(capped))
+
+
+def _call_hook(comp, ray):
+    """The user's `interact_local` on a lab-frame ray the device found to hit `comp` first: local frame in, lab frame out
+    (optical_component.py:354, 366-372)."""
+    out = comp.interact_local(comp.ray_to_local_coordinates(ray))
+    if out is None:
+        return []
+    return [comp.ray_to_lab_coordinates(c) for c in out]
+
+
+def _child_ray(parent, kid, j):
+    """Ray object of child `j` of a generation step's output: the parent's clone (it keeps _id, wavelength, unit and user
+    attributes, like the copy chain upstream) with the traced fields replaced."""
+    from .materials import Material
+
+    child = _clone_rays([parent])[0]
+    d = child.__dict__
+    d["origin"] = np.array([kid["ox"][j], kid["oy"][j], kid["oz"][j]])
+    d["_direction"] = np.array([kid["dx"][j], kid["dy"][j], kid["dz"][j]])
+    d["intensity"] = float(kid["intensity"][j])
+    d["length"], d["alive"] = None, True
+    if parent.qo is not None:
+        d["qo"] = complex(kid["q_re"][j], kid["q_im"][j])
+    d["_n"] = Material("Constant", n=float(kid["n"][j]))
+    d["_pathlength"] = float(kid["pathlength"][j])
+    return child
 
 
 def _clone_rays(rays):
@@ -512,7 +608,7 @@ def _scatter_segments(host_segs, sources, pick, per_ray):
         per_ray[pick[t]].append(seg)
 
 
-def interact_component(comp, ray):
+def interact_component(comp, ray, call_hooks=True):
     """`component.interact(ray)` (optical_component.py:337-378; component_group.py:93-122 for groups) through
     the engine: one generation step over a scene made of this component alone.  Returns `(t, [truncated,
     *children])` or `(None, None)`; interact counters of the component (and of a group's children: every
@@ -544,6 +640,9 @@ def interact_component(comp, ray):
     truncated = _clone_rays([ray])[0]
     truncated.length, truncated.alive = t, False
     out = [truncated]
+    hook = scene.hooks.get(int(segs.surface[0].item())) if call_hooks else None
+    if hook is not None:  # the leaf's physics is the user's Python (a group is asked for the leaf that was hit)
+        return t, out + _call_hook(hook, ray)
     if kids.n:
         k = {f: kids.field(f).cpu().numpy() for f in abi.RAY_FIELDS}
         for j in range(kids.n):
@@ -572,7 +671,9 @@ def _pose_free_copy(comp):
 def interact_leaf_local(comp, ray_local):
     """`leaf.interact_local(ray_local)` (optical_component.py:536-570, 617-717, 930-948): the rays a hit emits,
     in the leaf's frame; an empty list when the local ray misses (upstream would fail on `P is None` there)."""
-    _, rays = interact_component(_pose_free_copy(comp), ray_local)
+    probe = _pose_free_copy(comp)
+    probe._builtin_physics = True  # a user's override that calls super().interact_local() gets the class's own physics here
+    _, rays = interact_component(probe, ray_local)
     return [] if rays is None else rays[1:]
 
 
@@ -580,7 +681,7 @@ def intersect_leaf_local(comp, ray_local):
     """`leaf.intersect_point_local(ray_local)` (optical_component.py:151-233): the ray is already in the
     leaf's frame, so the leaf is traced with an identity pose; count gates do not apply here."""
     probe = _pose_free_copy(comp)
-    t, rays = interact_component(probe, ray_local)
+    t, rays = interact_component(probe, ray_local, call_hooks=False)  # (a user's interact_local asks for the hit point: no recursion)
     if t is None:
         return None, None
     return np.asarray(ray_local.origin, dtype=float) + t * np.asarray(ray_local.direction, dtype=float), t

@@ -19,7 +19,7 @@ def golden(name):
 
 def build(name, **kw):
     np.random.seed(12345)
-    sc = scenes.SCENES[name](oa, **kw)
+    sc = {**scenes.SCENES, **scenes.HOOKED_SCENES}[name](oa, **kw)
     table = oa.OpticalTable()
     table.add_components(sc["components"])
     table.add_monitors(sc["monitors"])

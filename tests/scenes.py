@@ -263,6 +263,71 @@ def g24_callables(ns):
     return dict(components=[lens, slab, mirror], monitors=[], rays=rays, limit={"max_trace_num": 24})
 
 
+def g25_user_components(ns):
+    """User-defined components (optical_component.py:235-240: `interact_local` is the subclassing hook): a transmission
+    grating written against the public API (three orders, the hit point asked from `intersect_point_local`), a mirror
+    subclass that post-processes `super().interact_local()` and lets weak rays die, an absorber that emits nothing — next
+    to built-in parts that branch on the device (a slab with reflectivity) and a count-limited mirror; one grating sits
+    inside a group (lab AABB gate).  The classes are built here from `ns`, so the reference and this package run the
+    very same user code."""
+
+    class Grating(ns.OpticalComponent):
+        def __init__(self, origin, radius=1.0, pitch=2e-4, **kwargs):
+            super().__init__(origin, **kwargs)
+            self.surface = ns.Circle(radius)
+            self.pitch = pitch
+
+        def get_bbox_local(self):
+            return self.surface.get_bbox_local()
+
+        def interact_local(self, ray):
+            P, t = self.intersect_point_local(ray)
+            out = []
+            for order, share in ((-1, 0.25), (0, 0.5), (1, 0.25)):
+                d = np.array(ray.direction, dtype=float)
+                d[1] += order * ray.wavelength / self.pitch
+                s = 1.0 - d[1] ** 2 - d[2] ** 2
+                if s <= 0:
+                    continue  # evanescent order
+                d[0] = np.sign(d[0]) * np.sqrt(s)
+                out.append(ray.copy(origin=P, direction=d, intensity=ray.intensity * share,
+                                    qo=None if ray.qo is None else ray.q_at_z(t), _pathlength=ray.pathlength(float(t))))
+            return out
+
+    class LossyMirror(ns.Mirror):
+        def interact_local(self, ray):
+            rays = super().interact_local(ray)
+            for r in rays:
+                r.intensity *= 0.6
+                if r.intensity < 0.05:
+                    r.alive = False  # archived at once, never traced (optical_table.py:126-130)
+            return rays
+
+    class Absorber(ns.OpticalComponent):
+        def __init__(self, origin, **kwargs):
+            super().__init__(origin, **kwargs)
+            self.surface = ns.Rectangle(3, 3)
+
+        def get_bbox_local(self):
+            return self.surface.get_bbox_local()
+
+        def interact_local(self, ray):
+            return []
+
+    grating = Grating([4, 0, 0], radius=1.2).RotZ(0.1)
+    slab = ns.GlassSlab([8, 0, 0], width=4, height=4, thickness=0.5, n1=1, n2=1.5, reflectivity=0.1).RotZ(0.2)
+    group = ns.ComponentGroup([12, 0, 0])
+    group.add_component(Grating([12, 0.6, 0], radius=0.5, pitch=3e-4))
+    group.add_component(ns.Lens([12, -0.6, 0], focal_length=5.0, radius=0.5))
+    lossy = LossyMirror([16, 0, 0], radius=3.0).RotZ(np.pi + 0.02)
+    gate = ns.Mirror([-2, 0, 0], radius=3.0, max_interact_count=1)
+    absorber = Absorber([6, 5, 0]).RotZ(-np.pi / 2)
+    rays = [ns.Ray([0, y, z], [1, dy, 0], wavelength=wl, w0=W0)
+            for wl, y, z, dy in ((633e-7, 0.0, 0.0, 0.0), (633e-7, 0.4, 0.1, 0.01), (450e-7, -0.5, -0.2, 0.02), (850e-7, 0.7, 0.0, -0.03))]
+    rays.append(ns.Ray([0, 2.5, 0], [1, 0.45, 0], wavelength=633e-7))  # past the grating, into the absorber; no q
+    return dict(components=[grating, slab, group, lossy, gate, absorber], monitors=[], rays=rays, limit={"max_trace_num": 150})
+
+
 SCENES = {
     "g24_callables": g24_callables,
     "g01_gaussian_beam": g01_gaussian_beam, "g02_cfg2": g02_cfg2, "g03_chromatic": g03_chromatic,
@@ -272,6 +337,9 @@ SCENES = {
     "g13_count_shadow": g13_count_shadow, "g15_cfg4": g15_cfg4, "g16_misc": g16_misc, "g18_fifo_gate": g18_fifo_gate,
     "g19_units_and_disorder": g19_units_and_disorder, "g21_ties": g21_ties,
 }
+
+
+HOOKED_SCENES = {"g25_user_components": g25_user_components}  # (the C oracle has no callbacks: reference fixture vs device only)
 
 
 def interact_cases(ns):

@@ -21,6 +21,9 @@ eng = get_engine()
 if os.environ.get('RGC'):  # experiment: top-level grid resolution (cells per component)
     import optable_amd.scene as _scene
     _scene.ROOT_GRID_CELLS_PER_COMPONENT = float(os.environ['RGC'])
+if os.environ.get('RGA'):  # experiment: aspect of the top-level grid's cells
+    import optable_amd.scene as _scene
+    _scene.ROOT_GRID_ASPECT = float(os.environ['RGA'])
 if os.environ.get('GENDROP'):  # generation kernels: children of trees whose budget ends with this generation (0: emit them)
     eng.set_option(abi.OPT_GEN_DROP_DOOMED, int(os.environ['GENDROP']))
 if os.environ.get('LDSKB'):

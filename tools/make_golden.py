@@ -60,7 +60,7 @@ def ray_rows(rays):
 
 
 def run(name):
-    sc = scenes.SCENES[name](ref)
+    sc = {**scenes.SCENES, **scenes.HOOKED_SCENES}[name](ref)
     table = ref.OpticalTable()
     table.add_components(sc["components"])
     table.add_monitors(sc["monitors"])
@@ -216,7 +216,7 @@ def calibrate_fixture():
 
 
 if __name__ == "__main__":
-    names = sys.argv[1:] or list(scenes.SCENES)
+    names = sys.argv[1:] or list(scenes.SCENES) + list(scenes.HOOKED_SCENES)
     for nm in names:
         if nm in ("g14_slab", "g17_abcd", "g20_interact", "g22_calibrate", "g23_exports"):
             continue
