@@ -83,7 +83,7 @@ struct ot_ctx {
     int32_t opt_kernel = 0;  // 0 auto, 1 fused (lane per ray), 2 rolling lists (the heavy-scene kernel)
     int32_t last_launch[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // ot_debug_last_launch
     // heavy-scene launch plan per precision (a dozen occupancy queries): recomputed after an upload or an option change
-    struct RollingPlan { uint64_t epoch = 0; int wpb = 4, per_cu = 1; int32_t cap = 128, capl = 0; bool lds = false, rec_lds = false; size_t lds_bytes = 0; };
+    struct RollingPlan { uint64_t epoch = 0; int wpb = 4, per_cu = 1; int32_t cap = 128, capl = 0, flat_cap = 0; bool lds = false, rec_lds = false; size_t lds_bytes = 0; };
     RollingPlan plan[2][2];  // [precision][output layout]
     uint64_t plan_epoch = 1;
     int32_t opt_refill = 0;      // mixed scenes: rays in registers, refilled in place (k_trace_refill): 0 never (the lists; default: the two tie on cfg 3
@@ -808,10 +808,11 @@ static int launch_rolling(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, 
     if (plan.epoch != c->plan_epoch) {
         struct Try { int waves = 0, wpb = 0, per_cu = 0; int32_t cap = 0, capl = 0; size_t lds = 0; };
         // most waves per CU for one placement: image in LDS or not, the first `capl` records of every list in LDS
+        size_t flat_b = flat_bytes;  // per wave, for the queue room under evaluation (below)
         auto evaluate = [&](bool lds_img, int32_t CAP, int32_t CAPL, Try& best) -> int {
             const void* k = (const void*)rolling_kernel<T, OUT>(fr, flat_ok, lds_img, CAPL > 0);
             if (!k) return 0;
-            const size_t per_wave = (size_t)CAP * entry + flat_bytes + rec_bytes * CAPL;
+            const size_t per_wave = (size_t)CAP * entry + flat_b + rec_bytes * CAPL;
             for (int wpb = 4; wpb * 64 <= rolling_max_threads<T>(fr, flat_ok, CAPL > 0); wpb += 4) {
                 const size_t lds_b = (lds_img ? img : 0) + (size_t)wpb * per_wave;
                 if (lds_b > 158 * 1024) continue;
@@ -824,6 +825,16 @@ static int launch_rolling(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, 
         };
         Try chosen;
         bool lds_img = false;
+        int32_t room_sel = flat_cap;
+        // The pair queue's room is LDS that every wave holds: 512 pairs are 1 KB, and with the records of the live rays in LDS the
+        // sixteenth wave of a CU can hang on the last few hundred bytes (cfg 3's scene under grids whose fullest cell holds four or
+        // five leaves instead of three: 12 waves per CU instead of 16, 2.6-3.0 ms instead of 2.15-2.25 — tools/sweep_root_grid.py).
+        // A round that overflows a smaller queue defers lanes and costs a few per cent; a lost quarter of the waves costs 25 %.
+        // So the room is the largest of 512, 448, ... 192 (>= one lane's worst case of 168) that keeps the most waves resident;
+        // OT_OPT_FLAT_QUEUE > 1 still sets it by hand.
+        auto choose = [&]() -> int {
+        chosen = Try();
+        lds_img = false;
         // (1) image in LDS, records in LDS: all of them (mixed lists) or the front of the list (generation-pure lists).
         //     Taken when at least 12 waves per CU still fit (OT_OPT_LDS_RECORDS = 1: whenever it fits at all).
         const int rec_lds_min_waves = c->opt_rec_lds > 0 ? 4 : 12;
@@ -848,7 +859,26 @@ static int launch_rolling(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, 
             const int rc = evaluate(false, cap0, 0, chosen);
             if (rc) return rc;
         }
+        return 0;
+        };
+        int rc_choose = choose();
+        if (rc_choose) return rc_choose;
+        if (flat_ok && c->opt_flat == 1 && flat_cap > 192) {
+            const Try first = chosen;
+            const bool first_img = lds_img;
+            Try best_t = first;
+            bool best_img = first_img;
+            for (int32_t room = flat_cap - 64; room >= 192; room -= 64) {
+                flat_b = ((size_t)(FlatLds<T>::fixed_bytes + (size_t)room * 2) + 15) & ~(size_t)15;
+                rc_choose = choose();
+                if (rc_choose) return rc_choose;
+                if (chosen.waves > best_t.waves) { best_t = chosen; best_img = lds_img; room_sel = room; }
+            }
+            chosen = best_t;
+            lds_img = best_img;
+        }
         if (!chosen.waves) return fail(OT_ERR_UNSUPPORTED, "no k_trace_rolling launch configuration fits this scene image");
+        plan.flat_cap = room_sel;
         plan.epoch = c->plan_epoch; plan.wpb = chosen.wpb; plan.per_cu = chosen.per_cu; plan.cap = chosen.cap; plan.capl = chosen.capl; plan.lds = lds_img;
         plan.rec_lds = chosen.capl > 0; plan.lds_bytes = chosen.lds;
     }
@@ -881,7 +911,7 @@ static int launch_rolling(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, 
     int rc = timing_pair(c, &ev0, &ev1);
     if (rc) return rc;
     hipExtLaunchKernelGGL(kr, dim3(gridr), dim3(64 * wpb), (uint32_t)lds_r, c->stream, ev0, ev1, 0u, blob, (T)c->unit, view<T>(rays), n,
-                          K, out, ac, seg_count, counts, n_classes, ws, CAP, CAPL, queue, mix ? 1 : 0, flat_ok ? flat_cap : 0);
+                          K, out, ac, seg_count, counts, n_classes, ws, CAP, CAPL, queue, mix ? 1 : 0, flat_ok ? plan.flat_cap : 0);
     HIP_TRY(hipGetLastError());
     const int32_t shape[8] = {2, 64 * wpb, per_cu_r, gridr, (int32_t)lds_r, CAP, mix ? 1 : 0, (flat_ok ? 1 : 0) | (plan.rec_lds ? 2 : 0) | (append ? 4 : 0)};
     for (int q = 0; q < 8; ++q) c->last_launch[q] = shape[q];

@@ -386,6 +386,7 @@ def _flattenable_leaves(b, top):
 
 
 ROOT_GRID_MIN_TOP = 12
+ROOT_GRID_DIMS = None   # (g0, g1): the top-level grid's cells per axis, overriding the rule below (Engine.tune_root_grid, experiments)
 ROOT_GRID_ASPECT = 1.0  # (experiment knob: > 1 = more, narrower cells along the first grid axis)
 ROOT_GRID_CELLS_PER_COMPONENT = 1.0
 
@@ -417,6 +418,8 @@ def _root_grid(b, tops):
     cells_target = ROOT_GRID_CELLS_PER_COMPONENT * len(tops)
     g0 = int(np.clip(round(np.sqrt(cells_target * span[0] / span[1]) * ROOT_GRID_ASPECT), 1, 64))
     g1 = int(np.clip(round(np.sqrt(cells_target * span[1] / span[0]) / ROOT_GRID_ASPECT), 1, 64))
+    if ROOT_GRID_DIMS is not None:
+        g0, g1 = (int(np.clip(g, 1, 64)) for g in ROOT_GRID_DIMS)
     size = [span[0] / g0, span[1] / g1]
     inv = [1.0 / size[0], 1.0 / size[1]]
     cells = [[] for _ in range(g0 * g1)]
