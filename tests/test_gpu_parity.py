@@ -446,6 +446,39 @@ def test_pair_queue_round_that_does_not_fit_defers_lanes(prec):
         assert torch.equal(a.field(f)[valid], c.field(f)[valid]), f
 
 
+def test_pair_queue_room_does_not_cost_resident_waves():
+    """The pair queue's room is LDS every wave holds.  Under a grid whose fullest cell lists five leaves the worst case of a
+    round is 640 pairs and the room used to be 512 (1 KB): with the records of the live rays in LDS the sixteenth wave of a CU
+    no longer fit and the plan fell to 12 (cfg 3's scene under an 8 x 3 grid: 2.95 instead of 2.6 ms, tools/sweep_root_grid.py).
+    The plan now takes the largest room that keeps the most waves (optable_hip.hip launch_rolling); a round that overflows it
+    defers lanes.  Same records as under the default grid, bit for bit: a grid only accelerates."""
+    import torch
+    import optable_amd as oa
+    import optable_amd.scene as scene_mod
+    from optable_amd.batch import RayBatch
+    from optable_amd.engine import get_engine
+
+    comps, gen, _, K = CASES["cfg3"]
+    eng = get_engine()
+    q = 1j * np.pi * scenes.W0**2 / scenes.WL
+    o, d = gen(200_003)
+    batch = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=q, precision="f32")
+    a = _table(comps(oa)).trace_batch(batch, max_segments=K, layout="append")
+    waves_default = eng.last_launch()["threads"] // 64 * eng.last_launch()["workgroups_per_cu"]
+    try:
+        scene_mod.ROOT_GRID_DIMS = (8, 3)
+        table = _table(comps(oa))
+        b = table.trace_batch(batch, max_segments=K, layout="append")
+    finally:
+        scene_mod.ROOT_GRID_DIMS = None
+    launch = eng.last_launch()
+    assert launch["pair_queue"] & 1
+    assert launch["threads"] // 64 * launch["workgroups_per_cu"] == waves_default == 16
+    ha, hb = a.to_host(reference_order=True), b.to_host(reference_order=True)
+    for f in ha:
+        np.testing.assert_array_equal(ha[f], hb[f], err_msg=f)
+
+
 @pytest.mark.parametrize("prec", ["f64", "f32"])
 def test_pair_queue_winner_that_fails_its_own_box_takes_the_per_lane_walk(prec, oracle):
     """In the pair queue a leaf's own AABB test (component_group.py:104-107) is applied to the WINNER of a ray, not to
