@@ -135,13 +135,121 @@ def _boolean_plane(surf):
     return low
 
 
+def _recognise_user_surface(surf):
+    """Device form of a USER-DEFINED surface (a `Surface` subclass with its own `f`, `normal`, `within_boundary`,
+    `get_bbox_local`: surfaces.py:5-65), found by MEASURING the object, or an AdapterError that says what was measured.
+    The reference treats every surface through these four methods (optical_component.py:151-233, 536-717), so a user
+    surface that is numerically the same function as a shape the kernels know gets that shape's kernels and the reference's
+    results.  Two families are recognised, both verified on sample points before anything is accepted:
+      planar   f(P) = c * x, normal +x, an aperture that is the disc or the centred rectangle of its box  -> CIRCLE / RECT
+      revolved f(P) = c * (x + F(r)), r = |(y, z)|, aperture r <= R with R the half-width of its box, normal (and `roc`, if the
+               surface has one) equal to the reference ASphere's for that F (surfaces.py:339-423)          -> the verified
+               Chebyshev series of F (shapes.lower_asphere_callable: the device form of ASphere(R, callable))
+    Anything else — a saddle, an off-axis section, an aperture with a hole — is refused: an implicit function in Python has
+    no device form, and evaluating it on the host would be a CPU path of the hot loop."""
+    name = type(surf).__name__
+
+    def refuse(why):
+        return AdapterError(f"user-defined surface {name}: {why}; recognised are planar surfaces with a disc or centred-rectangle "
+                            "aperture and surfaces of revolution x = -F(r) about the local x axis")
+
+    try:
+        box = np.array([float(v) for v in surf.get_bbox_local()])
+    except Exception as exc:  # noqa: BLE001
+        raise refuse(f"get_bbox_local() failed ({exc})") from exc
+    if box.shape != (6,) or not np.all(np.isfinite(box)):
+        raise refuse("its local box is not six finite numbers")
+    x0, x1, y0, y1, z0, z1 = box
+    P3 = lambda x, y, z: np.array([x, y, z], dtype=float)  # noqa: E731
+    f = lambda P: float(surf.f(P))  # noqa: E731
+    rng = np.random.default_rng(20240611)
+    try:
+        c = f(P3(1, 0, 0)) - f(P3(0, 0, 0))
+        if not np.isfinite(c) or c == 0.0:
+            raise refuse("f does not depend linearly on x")
+        scale = max(abs(x0), abs(x1), abs(y0), abs(y1), abs(z0), abs(z1), 1e-300)
+        if bool(getattr(surf, "planar", True)):
+            hy, hz = 0.5 * (y1 - y0), 0.5 * (z1 - z0)
+            if abs(y0 + y1) > 1e-12 * scale or abs(z0 + z1) > 1e-12 * scale or hy <= 0 or hz <= 0:
+                raise refuse("its aperture box is not centred on the local origin")
+            for _ in range(64):
+                P = P3(rng.uniform(-scale, scale), rng.uniform(-1.2 * hy, 1.2 * hy), rng.uniform(-1.2 * hz, 1.2 * hz))
+                if abs(f(P) - c * P[0]) > 1e-12 * abs(c) * scale:
+                    raise refuse("planar, but f(P) is not c * x")
+                if not np.allclose(np.asarray(surf.normal(P), dtype=float), [1.0, 0.0, 0.0], atol=1e-12):
+                    raise refuse("planar, but its normal is not +x")
+            pts = [P3(0.0, rng.uniform(-1.2 * hy, 1.2 * hy), rng.uniform(-1.2 * hz, 1.2 * hz)) for _ in range(400)]
+            pts += [P3(0.0, s * hy * (1 + e), 0.0) for s in (-1, 1) for e in (-1e-6, 1e-6)]
+            pts += [P3(0.0, 0.0, s * hz * (1 + e)) for s in (-1, 1) for e in (-1e-6, 1e-6)]
+            pts += [P3(0.0, s * hy * 0.9, t * hz * 0.9) for s in (-1, 1) for t in (-1, 1)]  # corners: inside the rectangle, outside the disc
+            got = np.array([bool(surf.within_boundary(P)) for P in pts])
+            yz = np.array([[P[1], P[2]] for P in pts])
+            if abs(hy - hz) <= 1e-12 * scale and np.array_equal(got, np.hypot(yz[:, 0], yz[:, 1]) <= hy):
+                return Lowered(shapes.CIRCLE, [hy])
+            if np.array_equal(got, (np.abs(yz[:, 0]) <= hy) & (np.abs(yz[:, 1]) <= hz)):
+                return Lowered(shapes.RECT, [hy, hz])
+            raise refuse("planar, but its aperture is neither the disc nor the rectangle of its box")
+        R = y1
+        if R <= 0 or max(abs(y0 + R), abs(z0 + R), abs(z1 - R)) > 1e-12 * scale:
+            raise refuse("its box is not the square -R..R in y and z that a surface of revolution about x has")
+        F = lambda r: f(P3(0.0, r, 0.0)) / c  # noqa: E731   x = -F(r)
+        for _ in range(96):
+            r, th, x = rng.uniform(0, 1.2 * R), rng.uniform(0, 2 * np.pi), rng.uniform(-scale, scale)
+            P = P3(x, r * np.cos(th), r * np.sin(th))
+            want = c * (x + F(r))
+            if abs(f(P) - want) > 1e-11 * max(abs(want), abs(c) * scale):
+                raise refuse("f(P) is not c * (x + F(r)) with r the distance from the x axis")
+        twin = shapes.ASphere(R, F)
+        for k in range(200):
+            r = R * (1 + 1e-6) if k == 0 else (R * (1 - 1e-6) if k == 1 else rng.uniform(0, 1.3 * R))
+            th = rng.uniform(0, 2 * np.pi)
+            P = P3(-F(min(r, R)), r * np.cos(th), r * np.sin(th))
+            if bool(surf.within_boundary(P)) != (r <= R):
+                raise refuse("its aperture is not r <= R")
+            if r <= R:
+                if not np.allclose(np.asarray(surf.normal(P), dtype=float), twin.normal(P), rtol=0, atol=2e-7):
+                    raise refuse("its normal differs from the normal of x = -F(r) (unit vector along (1, F' y / r, F' z / r))")
+                if callable(getattr(surf, "roc", None)) and r > 1e-3 * R:
+                    a, b = float(surf.roc(P)), float(twin.roc(P))
+                    if not np.isclose(a, b, rtol=1e-5, atol=0):
+                        raise refuse("its roc(P) differs from the radius of curvature of x = -F(r)")
+        low = shapes.lower_asphere_callable(float(R), F)
+    except AdapterError:
+        raise
+    except NotImplementedError as exc:  # the series fit's own refusal (a kink, a pole, F undefined out to the box corner)
+        raise refuse(str(exc)) from exc
+    except Exception as exc:  # noqa: BLE001 - the user's methods failed on a probe point
+        raise refuse(f"probing it failed ({type(exc).__name__}: {exc})") from exc
+    return low
+
+
+def _user_overrides(surf):
+    """True when a class OUTSIDE this package and the reference package defines one of the four methods a surface is known by
+    (a subclass of Circle that cuts a hole into `within_boundary`, say): the built-in lowering would ignore it."""
+    for klass in type(surf).__mro__:
+        if (klass.__module__ or "").split(".")[0] in ("optable_amd", "optable"):
+            return False
+        if any(m in klass.__dict__ for m in ("f", "normal", "within_boundary", "get_bbox_local")):
+            return True
+    return False
+
+
 def lower_surface(surf):
+    if _user_overrides(surf):
+        return _recognise_user_surface(surf)  # measured, never assumed from the base class (see there)
     if hasattr(surf, "lower"):
-        return surf.lower()
+        try:
+            return surf.lower()
+        except NotImplementedError:
+            if type(surf).lower is not shapes.Surface.lower:
+                raise
+            return _recognise_user_surface(surf)  # a user's subclass of this package's Surface: measured (see there)
     fn = _SURFACES.get(type(surf).__name__)
     if fn is None:
         if _closure_operands(surf) is not None:  # the closure-based Plane.union / subtract of the reference
             return _boolean_plane(surf)
+        if all(callable(getattr(surf, m, None)) for m in ("f", "normal", "within_boundary", "get_bbox_local")):
+            return _recognise_user_surface(surf)  # a user's subclass of the reference's Surface
         raise AdapterError(f"surface {type(surf).__name__} has no device form")
     return fn(surf)
 

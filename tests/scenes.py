@@ -328,8 +328,101 @@ def g25_user_components(ns):
     return dict(components=[grating, slab, group, lossy, gate, absorber], monitors=[], rays=rays, limit={"max_trace_num": 150})
 
 
+def user_surface_classes(ns):
+    """User-defined surfaces (surfaces.py:5-65: f / normal / within_boundary / get_bbox_local are the whole contract) and
+    components carrying them, built from `ns` so that the reference and this package run the very same user code."""
+
+    class Paraboloid(ns.Surface):
+        """x = -r^2 / (4 focal): concave towards +x."""
+
+        def __init__(self, focal, radius):
+            super().__init__()
+            self.planar = False
+            self.focal, self.radius = focal, radius
+
+        def f(self, P):
+            return P[0] + (P[1] ** 2 + P[2] ** 2) / (4 * self.focal)
+
+        def normal(self, P):
+            n = np.array([1.0, P[1] / (2 * self.focal), P[2] / (2 * self.focal)])
+            return n / np.linalg.norm(n)
+
+        def within_boundary(self, P):
+            return P[1] ** 2 + P[2] ** 2 <= self.radius**2
+
+        def get_bbox_local(self):
+            sag, R = self.radius**2 / (4 * self.focal), self.radius
+            return (min(-sag, 0.0), max(-sag, 0.0), -R, R, -R, R)
+
+    class Hyperboloid(Paraboloid):
+        """x = -b (sqrt(1 + r^2 / a^2) - 1), scaled by 2.5: f need not have unit slope in x."""
+
+        def __init__(self, a, b, radius):
+            ns.Surface.__init__(self)
+            self.planar = False
+            self.a, self.b, self.radius = a, b, radius
+
+        def _F(self, r2):
+            return self.b * (np.sqrt(1 + r2 / self.a**2) - 1)
+
+        def f(self, P):
+            return 2.5 * (P[0] + self._F(P[1] ** 2 + P[2] ** 2))
+
+        def normal(self, P):
+            k = self.b / (self.a**2 * np.sqrt(1 + (P[1] ** 2 + P[2] ** 2) / self.a**2))
+            n = np.array([1.0, k * P[1], k * P[2]])
+            return n / np.linalg.norm(n)
+
+        def get_bbox_local(self):
+            sag, R = self._F(self.radius**2), self.radius
+            return (-sag, 0.0, -R, R, -R, R)
+
+    class Slit(ns.Plane):
+        def __init__(self, width, height):
+            super().__init__()
+            self.width, self.height = width, height
+
+        def within_boundary(self, P):
+            return abs(P[1]) <= self.width / 2 and abs(P[2]) <= self.height / 2
+
+        def get_bbox_local(self):
+            return (0, 0, -self.width / 2, self.width / 2, -self.height / 2, self.height / 2)
+
+    class Saddle(Paraboloid):  # not a surface of revolution: must be refused
+        def f(self, P):
+            return P[0] + (P[1] ** 2 - P[2] ** 2) / (4 * self.focal)
+
+    class CurvedMirror(ns.BaseMirror):
+        def __init__(self, origin, surface, **kwargs):
+            super().__init__(origin, **kwargs)
+            self.surface = surface
+
+    class CurvedInterface(ns.BaseRefraciveSurface):
+        def __init__(self, origin, surface, **kwargs):
+            super().__init__(origin, **kwargs)
+            self.surface = surface
+
+    return dict(Paraboloid=Paraboloid, Hyperboloid=Hyperboloid, Slit=Slit, Saddle=Saddle, CurvedMirror=CurvedMirror,
+                CurvedInterface=CurvedInterface)
+
+
+def g26_user_surfaces(ns):
+    """A parabolic mirror, a hyperbolic glass interface (front of a thick lens whose back is a built-in plane face), and a
+    rectangular slit aperture on a partially transmitting mirror — all three surfaces user classes.  Rays parallel to the
+    axis, tilted ones and one that misses the slit."""
+    U = user_surface_classes(ns)
+    front = U["CurvedInterface"]([6, 0, 0], U["Hyperboloid"](3.0, 1.2, 1.5), n1=1.0, n2=1.5).RotZ(np.pi)
+    back = ns.CircleRefractive([6.9, 0, 0], radius=1.5, n1=1.0, n2=1.5)
+    parabola = U["CurvedMirror"]([14, 0, 0], U["Paraboloid"](4.0, 2.0)).RotZ(np.pi + 0.01)
+    slit = U["CurvedMirror"]([2, 0, 0], U["Slit"](1.2, 0.8), reflectivity=0.3, transmission=0.7).RotZ(0.05)
+    rays = [ns.Ray([0, y, z], [1, dy, dz], wavelength=wl, w0=W0)
+            for wl, y, z, dy, dz in ((633e-7, 0.0, 0.0, 0.0, 0.0), (633e-7, 0.3, 0.1, 0.0, 0.0), (633e-7, -0.45, -0.2, 0.01, 0.0),
+                                     (450e-7, 0.2, 0.3, -0.02, 0.01), (850e-7, -0.1, -0.35, 0.015, -0.01), (633e-7, 0.9, 0.0, 0.0, 0.0))]
+    return dict(components=[slit, front, back, parabola], monitors=[], rays=rays, limit={"max_trace_num": 40})
+
+
 SCENES = {
-    "g24_callables": g24_callables,
+    "g24_callables": g24_callables, "g26_user_surfaces": g26_user_surfaces,
     "g01_gaussian_beam": g01_gaussian_beam, "g02_cfg2": g02_cfg2, "g03_chromatic": g03_chromatic,
     "g04_glass_slab": g04_glass_slab, "g05_cavity": g05_cavity, "g06_mirror_pair": g06_mirror_pair,
     "g07_spherical_lenses": g07_spherical_lenses, "g08_asphere": g08_asphere, "g09_cfg5": g09_cfg5,

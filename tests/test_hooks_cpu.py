@@ -38,3 +38,48 @@ def test_hooked_leaves_keep_their_place_in_the_scene():
         np.testing.assert_allclose(np.array(node.origin[:]), comp.origin)
     assert scene.max_children == 2  # the slab's faces split on the device
     assert len(scene.limited) == 1
+
+
+def test_user_surfaces_are_recognised_by_measurement_or_refused():
+    """User `Surface` subclasses (surfaces.py:5-65): a surface of revolution x = -F(r) gets the verified series of its F (the
+    device form of ASphere(R, callable)), a planar surface with the rectangle of its box as aperture the rectangle; a saddle, an
+    aperture with a hole and a wrong normal are refused with what was measured."""
+    import pytest
+    import scenes
+    from optable_amd import shapes
+    from optable_amd.scene import SceneError, compile_scene
+
+    table, sc = helpers.build("g26_user_surfaces")
+    scene = table.compile()
+    nodes = [n for n in scene.nodes[: scene.n_nodes] if n.kind == abi.NODE_LEAF]
+    assert [n.shape for n in nodes] == [shapes.RECT, shapes.ASPHERE_CHEB, shapes.CIRCLE, shapes.ASPHERE_CHEB]
+    assert not scene.hooks  # surfaces are device forms, not callbacks
+    np.testing.assert_allclose(nodes[0].p[:2], [0.6, 0.4])
+    np.testing.assert_allclose(nodes[1].lbox[:], sc["components"][1].surface.get_bbox_local())  # the USER's box bounds the root scan
+    U = scenes.user_surface_classes(oa)
+    with pytest.raises(SceneError, match="not c \\* \\(x \\+ F\\(r\\)\\)"):
+        compile_scene([U["CurvedMirror"]([0, 0, 0], U["Saddle"](4.0, 2.0))])
+
+    class Annulus(oa.Circle):
+        def within_boundary(self, P):
+            return 0.5 <= np.hypot(P[1], P[2]) <= self.radius
+
+    with pytest.raises(SceneError, match="neither the disc nor the rectangle"):
+        compile_scene([U["CurvedMirror"]([0, 0, 0], Annulus(1.0))])
+
+    class Flipped(U["Paraboloid"]):
+        def normal(self, P):
+            return -super().normal(P)
+
+    with pytest.raises(SceneError, match="normal differs"):
+        compile_scene([U["CurvedMirror"]([0, 0, 0], Flipped(4.0, 2.0))])
+
+    class Disc(oa.Plane):  # a user's own circle
+        def within_boundary(self, P):
+            return P[1] ** 2 + P[2] ** 2 <= 0.49
+
+        def get_bbox_local(self):
+            return (0, 0, -0.7, 0.7, -0.7, 0.7)
+
+    leaf = [n for n in compile_scene([U["CurvedMirror"]([0, 0, 0], Disc())]).nodes[:1]][0]
+    assert leaf.shape == shapes.CIRCLE and leaf.p[0] == pytest.approx(0.7)
