@@ -580,20 +580,20 @@ def main():
         heavy_wl = scene.n_nodes >= 24
         plan = eng.plan(prec, n, MAX_SEG)
         layout = "slots" if heavy_wl else plan["layout"]
+        cand = {}  # output buffers per slot layout (light scenes: both, so that the choice is measured on the buffers that are timed)
         if not heavy_wl:
             # ... and since the real trace on the real buffers can come out the other way round than the generic stream probe
-            # (seen: probe 119 vs 136 us for tiles, trace 126 vs 118 against them), the workload itself is measured in both
-            # layouts first (Engine.tune_layout: 20 launches each, what a caller who cares would do) and the faster one runs
-            tuned = eng.tune_layout(batches[0], MAX_SEG)
-            layout = tuned["chosen"]
-            extra["layout_probe"] = {"stream_probe_slots_us": plan["probe_us"][0], "stream_probe_tiled_us": plan["probe_us"][1],
-                                     "stream_probe_says": plan["layout"], "trace_slots_us": tuned.get("slots"), "trace_tiled_us": tuned.get("tiled"),
-                                     "chosen": layout,
-                                     "note": "stream probe: cfg 2's streams with no tracing, 2^20 rays, both slot layouts (ot_probe_layouts, once per "
-                                             "context: what layout=\"auto\" uses by default); trace: this workload, 20 launches per layout before "
-                                             "the warm-up (Engine.tune_layout) — the faster one is the layout of the timed region"}
+            # (seen: probe 119 vs 136 us for tiles, trace 126 vs 118 against them; and a tune on ONE buffer pair before the
+            # clocks had settled chose tiles at 119 vs 130 us where the timed region then ran 125 vs 119 against them), the
+            # workload itself is measured in both layouts ON THE BUFFERS OF THE TIMED REGION, after the pre-load, interleaved:
+            # three rounds of 20 rotating launches per layout, the minimum of a layout's rounds counts, the faster one runs.
+            out_bytes = n * MAX_SEG * bytes_rec * n_inputs
+            free_b = torch.cuda.mem_get_info(batches[0].device)[0]
+            both = 2 * out_bytes < 0.8 * free_b and plan["kernel"] == 1 and bool(plan["tiled_ok"])
+            for lay in (("slots", "tiled") if both else (layout,)):
+                cand[lay] = [SegmentBatch(n * MAX_SEG, prec, batches[0].device, tiled=(lay == "tiled")) for _ in range(n_inputs)]
         extra["output_layout"] = layout
-        outs = [SegmentBatch(n * MAX_SEG, prec, batches[0].device, tiled=(layout == "tiled")) for _ in range(n_inputs)]
+        outs = cand[layout] if cand else [SegmentBatch(n * MAX_SEG, prec, batches[0].device) for _ in range(n_inputs)]
 
         def step(s):
             eng.trace(batches[s % n_inputs], MAX_SEG, out=outs[s % n_inputs], layout=layout)
@@ -625,6 +625,33 @@ def main():
                 torch.cuda.synchronize()
         torch.cuda.synchronize()
         extra["preload_launches"] = preload
+        if len(cand) == 2:
+            tev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            rounds = {"slots": [], "tiled": []}
+            for rnd in range(3):
+                for lay in (("slots", "tiled") if rnd % 2 == 0 else ("tiled", "slots")):
+                    for s in range(3):
+                        eng.trace(batches[s % n_inputs], MAX_SEG, out=cand[lay][s % n_inputs], layout=lay)
+                    tev[0].record()
+                    for s in range(20):
+                        eng.trace(batches[s % n_inputs], MAX_SEG, out=cand[lay][s % n_inputs], layout=lay)
+                    tev[1].record()
+                    torch.cuda.synchronize()
+                    rounds[lay].append(tev[0].elapsed_time(tev[1]) / 20 * 1e3)
+            probe_says = layout
+            layout = "tiled" if min(rounds["tiled"]) < min(rounds["slots"]) else "slots"
+            outs = cand[layout]
+            extra["output_layout"] = layout
+            extra["layout_probe"] = {"stream_probe_slots_us": plan["probe_us"][0], "stream_probe_tiled_us": plan["probe_us"][1],
+                                     "stream_probe_says": probe_says, "trace_slots_us": rounds["slots"], "trace_tiled_us": rounds["tiled"],
+                                     "chosen": layout,
+                                     "note": "stream probe: cfg 2's streams with no tracing, 2^20 rays, both slot layouts (ot_probe_layouts, once per "
+                                             "context: what layout=\"auto\" uses by default); trace: this workload on the buffers of the timed region, "
+                                             "after the pre-load, three interleaved rounds of 20 rotating launches per layout (us per launch by round) "
+                                             "— the layout with the faster best round is the layout of the timed region"}
+            if 2 * n * MAX_SEG * bytes_rec * n_inputs > 8e9:  # (large workloads: the loser's buffers go back before the timed region)
+                del cand["tiled" if layout == "slots" else "slots"]
+                torch.cuda.empty_cache()
         for s in range(args.warmup):
             step(s)
         # Timed region: K launches back to back, bracketed by barrier + synchronize (wall clock -> `value`) and by ONE
@@ -664,7 +691,7 @@ def main():
         if not heavy_wl and world == 1:
             # the same K launches into the OTHER slot layout (the one the probe did not choose), for comparison
             other = "slots" if layout == "tiled" else "tiled"
-            outs_o = [SegmentBatch(n * MAX_SEG, prec, batches[0].device, tiled=(other == "tiled")) for _ in range(n_inputs)]
+            outs_o = cand.get(other) or [SegmentBatch(n * MAX_SEG, prec, batches[0].device, tiled=(other == "tiled")) for _ in range(n_inputs)]
             for s in range(args.warmup + 3):
                 eng.trace(batches[s % n_inputs], MAX_SEG, out=outs_o[s % n_inputs], layout=other)
             torch.cuda.synchronize()
@@ -682,7 +709,8 @@ def main():
             sc_ms, sc_n = eng.timing_read()
             eng.timing(False)
             extra["other_layout"] = {"layout": other, "kernel_us": other_us, "stream_ceiling_us": sc_ms / max(sc_n, 1) * 1e3,
-                                     "note": "the same trace into the slot layout the device probe did NOT choose"}
+                                     "note": "the same trace into the slot layout the measurement before the timed region did NOT choose"}
+            cand.pop(other, None)
             del outs_o
             torch.cuda.empty_cache()
         if world == 1 and not args.no_sustained:

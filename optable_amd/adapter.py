@@ -339,8 +339,11 @@ def install(optable_module):
         cap = _table.MAX_TRACE_NUM
         if perfomance_limit is not None and "max_trace_num" in perfomance_limit:
             cap = int(perfomance_limit["max_trace_num"])
-        if len(rays) and cap > 0:
-            traced, capped = _table.OpticalTable._trace_objects(self, list(rays), cap)
+        max_time = _table.MAX_TRACE_TIME
+        if perfomance_limit is not None and "max_trace_time" in perfomance_limit:
+            max_time = float(perfomance_limit["max_trace_time"])
+        if len(rays) and cap > 0 and max_time > 0:
+            traced, capped = _table.OpticalTable._trace_objects(self, list(rays), cap, max_time)
             if capped:
                 print(f"Ray tracing time exceeds the maximum tracing time after {cap} traces. ({capped} ray tree(s) truncated)")
             self.rays.extend(traced)

@@ -92,3 +92,38 @@ def test_single_call_api_and_batch_refusal():
     batch = RayBatch.from_arrays(np.zeros((4, 3)), np.tile([1.0, 0, 0], (4, 1)), wavelength=633e-7, device="cuda")
     with pytest.raises(SceneError, match="ray_tracing"):
         table.trace_batch(batch, 5)
+
+
+def test_install_serves_a_foreign_table_class():
+    """`optable_amd.install(module)` patches the ORIGINAL package's OpticalTable: its instances are not this package's
+    class, so the patched method must not rely on any method of `optable_amd.OpticalTable` being on `self`.  The reference
+    does not travel to the GPU box; a stand-in module with the attributes `install` touches (a table class that only holds
+    lists, the way optical_table.py:20-55 does) shows that the whole object path — compile, trace, ray trees, user hooks,
+    monitors — runs for such an object."""
+    import types
+
+    class ForeignTable:
+        def __init__(self):
+            self.components, self.monitors, self.rays, self.unit = [], [], [], 1e-2
+
+        def ray_tracing(self, rays, perfomance_limit=None):
+            raise AssertionError("the original loop must not run")
+
+    class ForeignMonitor(oa.Monitor):
+        pass
+
+    module = types.SimpleNamespace(OpticalTable=ForeignTable, Monitor=ForeignMonitor, Ray=oa.Ray)
+    undo = oa.install(module)
+    try:
+        for mirror_cls in (oa.Mirror, PythonMirror):
+            native, rays = _cavity(mirror_cls)
+            foreign = ForeignTable()
+            foreign.components = list(native.components)
+            want = rays_to_segs(native.ray_tracing(rays, perfomance_limit={"max_trace_num": 40}))
+            got = rays_to_segs(foreign.ray_tracing(rays, perfomance_limit={"max_trace_num": 40}))
+            assert len(got["ox"]) == len(want["ox"]) > 100
+            for f in want:
+                np.testing.assert_array_equal(got[f], want[f], err_msg=f)
+    finally:
+        undo()
+    assert "compile" not in ForeignTable.__dict__
