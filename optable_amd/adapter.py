@@ -179,6 +179,7 @@ def _recognise_user_surface(surf):
                 if not np.allclose(np.asarray(surf.normal(P), dtype=float), [1.0, 0.0, 0.0], atol=1e-12):
                     raise refuse("planar, but its normal is not +x")
             pts = [P3(0.0, rng.uniform(-1.2 * hy, 1.2 * hy), rng.uniform(-1.2 * hz, 1.2 * hz)) for _ in range(400)]
+            pts += [P3(0.0, y, z) for y in np.linspace(-1.1 * hy, 1.1 * hy, 47) for z in np.linspace(-1.1 * hz, 1.1 * hz, 47)]  # (a hole or a notch larger than ~5 % of the box is seen)
             pts += [P3(0.0, s * hy * (1 + e), 0.0) for s in (-1, 1) for e in (-1e-6, 1e-6)]
             pts += [P3(0.0, 0.0, s * hz * (1 + e)) for s in (-1, 1) for e in (-1e-6, 1e-6)]
             pts += [P3(0.0, s * hy * 0.9, t * hz * 0.9) for s in (-1, 1) for t in (-1, 1)]  # corners: inside the rectangle, outside the disc
@@ -200,9 +201,9 @@ def _recognise_user_surface(surf):
             if abs(f(P) - want) > 1e-11 * max(abs(want), abs(c) * scale):
                 raise refuse("f(P) is not c * (x + F(r)) with r the distance from the x axis")
         twin = shapes.ASphere(R, F)
-        for k in range(200):
-            r = R * (1 + 1e-6) if k == 0 else (R * (1 - 1e-6) if k == 1 else rng.uniform(0, 1.3 * R))
-            th = rng.uniform(0, 2 * np.pi)
+        for k in range(600):
+            r = R * (1 + 1e-6) if k == 0 else (R * (1 - 1e-6) if k == 1 else (rng.uniform(0, 1.3 * R) if k < 200 else 1.25 * R * ((k - 200) % 20 + 0.5) / 20))
+            th = rng.uniform(0, 2 * np.pi) if k < 200 else 2 * np.pi * ((k - 200) // 20) / 20  # (then a polar grid: 20 radii x 20 angles)
             P = P3(-F(min(r, R)), r * np.cos(th), r * np.sin(th))
             if bool(surf.within_boundary(P)) != (r <= R):
                 raise refuse("its aperture is not r <= R")
