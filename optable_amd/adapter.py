@@ -235,22 +235,51 @@ def _user_overrides(surf):
     return False
 
 
+def _surface_state(surf):
+    """What a user surface's measurement depends on: its class and its instance attributes (numbers, strings, arrays by value;
+    anything else by identity)."""
+    items = []
+    for k, v in sorted(vars(surf).items()):
+        if k.startswith("_ot_"):
+            continue
+        if isinstance(v, (int, float, bool, str, type(None))):
+            items.append((k, v))
+        elif isinstance(v, np.ndarray):
+            items.append((k, v.tobytes()))
+        elif isinstance(v, (tuple, list)):
+            items.append((k, repr(v)))
+        else:
+            items.append((k, id(v)))
+    return (type(surf), tuple(items))
+
+
+def _measured(surf):
+    """`_recognise_user_surface`, remembered on the object while its state stands: the measurement is ~1,500 calls of the user's
+    methods and a series fit (20-60 ms), and `table.ray_tracing` compiles the scene on every call."""
+    state = _surface_state(surf)
+    memo = surf.__dict__.get("_ot_lowered")
+    if memo is None or memo[0] != state:
+        memo = (state, _recognise_user_surface(surf))
+        surf.__dict__["_ot_lowered"] = memo
+    return memo[1]
+
+
 def lower_surface(surf):
     if _user_overrides(surf):
-        return _recognise_user_surface(surf)  # measured, never assumed from the base class (see there)
+        return _measured(surf)  # measured, never assumed from the base class (see _recognise_user_surface)
     if hasattr(surf, "lower"):
         try:
             return surf.lower()
         except NotImplementedError:
             if type(surf).lower is not shapes.Surface.lower:
                 raise
-            return _recognise_user_surface(surf)  # a user's subclass of this package's Surface: measured (see there)
+            return _measured(surf)  # a user's subclass of this package's Surface: measured (see _recognise_user_surface)
     fn = _SURFACES.get(type(surf).__name__)
     if fn is None:
         if _closure_operands(surf) is not None:  # the closure-based Plane.union / subtract of the reference
             return _boolean_plane(surf)
         if all(callable(getattr(surf, m, None)) for m in ("f", "normal", "within_boundary", "get_bbox_local")):
-            return _recognise_user_surface(surf)  # a user's subclass of the reference's Surface
+            return _measured(surf)  # a user's subclass of the reference's Surface
         raise AdapterError(f"surface {type(surf).__name__} has no device form")
     return fn(surf)
 

@@ -83,3 +83,32 @@ def test_user_surfaces_are_recognised_by_measurement_or_refused():
 
     leaf = [n for n in compile_scene([U["CurvedMirror"]([0, 0, 0], Disc())]).nodes[:1]][0]
     assert leaf.shape == shapes.CIRCLE and leaf.p[0] == pytest.approx(0.7)
+
+
+def test_a_user_surface_is_measured_once_per_state():
+    """The measurement (1,500 calls of the user's methods + a series fit) is remembered on the surface while its attributes
+    stand — `table.ray_tracing` compiles on every call — and repeated when one changes."""
+    import scenes
+    from optable_amd.scene import compile_scene
+
+    U = scenes.user_surface_classes(oa)
+    surf = U["Paraboloid"](4.0, 2.0)
+    calls = {"n": 0}
+    inner = surf.f
+
+    def counting_f(P):
+        calls["n"] += 1
+        return inner(P)
+
+    type(surf).f = lambda self, P: counting_f(P)  # (a class attribute: instance state is what the memo is keyed on)
+    mirror = U["CurvedMirror"]([0, 0, 0], surf)
+    a = compile_scene([mirror])
+    first = calls["n"]
+    assert first > 100
+    b = compile_scene([mirror])
+    assert calls["n"] == first
+    np.testing.assert_array_equal(np.array(a.aux[: a.n_aux]), np.array(b.aux[: b.n_aux]))
+    surf.radius = 1.5
+    c = compile_scene([mirror])
+    assert calls["n"] > first
+    assert c.nodes[0].p[0] == 1.5
