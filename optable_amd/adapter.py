@@ -325,7 +325,19 @@ def host_hook(comp):
 
 def lower_interaction(comp):
     if host_hook(comp):
-        return dict(kind=BLOCK, host_hook=True)  # the device ends the ray at the hit; the host asks the user what it emits
+        # The host asks the user's method what a hit emits.  When the class ALSO has built-in physics underneath the override (a
+        # Mirror subclass whose interact_local post-processes super()'s rays), the device computes those children with the hit, so
+        # that `super().interact_local(ray)` inside the hook is answered from the generation that found the hit instead of a
+        # launch of its own (table.py: _HOOK_MEMO); otherwise the leaf simply ends the ray.
+        try:
+            comp.__dict__["_builtin_physics"] = True
+            inner = dict(lower_interaction(comp))
+        except NotImplementedError:
+            inner = dict(kind=BLOCK)
+        finally:
+            comp.__dict__.pop("_builtin_physics", None)
+        inner["host_hook"] = True
+        return inner
     if hasattr(comp, "lower_interaction"):
         return comp.lower_interaction()
     names = _mro_names(comp)

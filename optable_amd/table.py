@@ -477,8 +477,8 @@ class OpticalTable:
                 comp = scene.hooks.get(int(surface[i]))
                 if comp is None:
                     children = [_child_ray(r, kid, j) for j in range(first[i], first[i + 1])]
-                else:
-                    children = _call_hook(comp, r)
+                else:  # (the children the device emitted for a hooked leaf are its class's built-in physics: the hook may ask for them)
+                    children = _call_hook(comp, r, length[i], (lambda r=r, a=first[i], b=first[i + 1]: [_child_ray(r, kid, j) for j in range(a, b)]))
                 for c in children:
                     if c.alive:
                         queue.append((c, t))
@@ -490,10 +490,35 @@ class OpticalTable:
         return done, int(sum(capped))
 
 
-def _call_hook(comp, ray):
+# What the device already knows about the ray a hook is being called for: id(local ray) -> (component, local origin, local
+# direction, t, built-in children in the lab frame or None).  A hook that starts with `P, t = self.intersect_point_local(ray)`
+# (every interact_local upstream does: optical_component.py:543, 624, 936) or calls `super().interact_local(ray)` asks for
+# exactly that hit again; answering from here saves a one-ray launch per question (0.6 ms each: 126 -> 50 ms per call on the
+# scene of fixture g25).  Only for the very ray object handed to the hook, and only while it still has the origin and direction
+# it was handed over with; any other question goes to the device.
+_HOOK_MEMO = {}
+
+
+def _memo_for(comp, ray_local):
+    memo = _HOOK_MEMO.get(id(ray_local))
+    if memo is None or memo[0] is not comp:
+        return None
+    if not (np.array_equal(memo[1], ray_local.origin) and np.array_equal(memo[2], ray_local.direction)):
+        return None
+    return memo
+
+
+def _call_hook(comp, ray, t=None, builtin_children=None):
     """The user's `interact_local` on a lab-frame ray the device found to hit `comp` first: local frame in, lab frame out
-    (optical_component.py:354, 366-372)."""
-    out = comp.interact_local(comp.ray_to_local_coordinates(ray))
+    (optical_component.py:354, 366-372).  `t`: the hit distance the device found; `builtin_children`: a callable giving the
+    lab-frame rays the class's own physics emits for this hit (or None)."""
+    local = comp.ray_to_local_coordinates(ray)
+    if t is not None:
+        _HOOK_MEMO[id(local)] = (comp, local.origin.copy(), local.direction.copy(), float(t), builtin_children)
+    try:
+        out = comp.interact_local(local)
+    finally:
+        _HOOK_MEMO.pop(id(local), None)
     if out is None:
         return []
     return [comp.ray_to_lab_coordinates(c) for c in out]
@@ -642,7 +667,7 @@ def interact_component(comp, ray, call_hooks=True):
     out = [truncated]
     hook = scene.hooks.get(int(segs.surface[0].item())) if call_hooks else None
     if hook is not None:  # the leaf's physics is the user's Python (a group is asked for the leaf that was hit)
-        return t, out + _call_hook(hook, ray)
+        return t, out + _call_hook(hook, ray, t)
     if kids.n:
         k = {f: kids.field(f).cpu().numpy() for f in abi.RAY_FIELDS}
         for j in range(kids.n):
@@ -671,6 +696,9 @@ def _pose_free_copy(comp):
 def interact_leaf_local(comp, ray_local):
     """`leaf.interact_local(ray_local)` (optical_component.py:536-570, 617-717, 930-948): the rays a hit emits,
     in the leaf's frame; an empty list when the local ray misses (upstream would fail on `P is None` there)."""
+    memo = _memo_for(comp, ray_local)
+    if memo is not None and memo[4] is not None:  # asked from inside a hook about the hit the device has just found
+        return [comp.ray_to_local_coordinates(c) for c in memo[4]()]
     probe = _pose_free_copy(comp)
     probe._builtin_physics = True  # a user's override that calls super().interact_local() gets the class's own physics here
     _, rays = interact_component(probe, ray_local)
@@ -680,6 +708,10 @@ def interact_leaf_local(comp, ray_local):
 def intersect_leaf_local(comp, ray_local):
     """`leaf.intersect_point_local(ray_local)` (optical_component.py:151-233): the ray is already in the
     leaf's frame, so the leaf is traced with an identity pose; count gates do not apply here."""
+    memo = _memo_for(comp, ray_local)
+    if memo is not None:  # asked from inside a hook about the hit the device has just found
+        t = memo[3]
+        return np.asarray(ray_local.origin, dtype=float) + t * np.asarray(ray_local.direction, dtype=float), t
     probe = _pose_free_copy(comp)
     t, rays = interact_component(probe, ray_local, call_hooks=False)  # (a user's interact_local asks for the hit point: no recursion)
     if t is None:

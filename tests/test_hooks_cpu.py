@@ -34,7 +34,9 @@ def test_hooked_leaves_keep_their_place_in_the_scene():
     nodes = [n for n in scene.nodes[: scene.n_nodes] if n.kind == abi.NODE_LEAF]
     for leaf_id, comp in scene.hooks.items():
         node = nodes[leaf_id]
-        assert node.leaf_id == leaf_id and node.interaction == BLOCK
+        # a hooked leaf ends the ray on the device — unless its class has physics of its own under the override (LossyMirror is a
+        # Mirror): then the device computes those children too, for the hook's `super().interact_local(ray)` (table._HOOK_MEMO)
+        assert node.leaf_id == leaf_id and node.interaction == (oa.components.MIRROR if type(comp).__name__ == "LossyMirror" else BLOCK)
         np.testing.assert_allclose(np.array(node.origin[:]), comp.origin)
     assert scene.max_children == 2  # the slab's faces split on the device
     assert len(scene.limited) == 1
