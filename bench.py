@@ -480,7 +480,12 @@ def survey_latency(oa):
     # measured segment rates (2.7e3 / 3.0e3 segments per second), build container, single thread
     cases = [("cfg1 examples/gaussian_beam.py: 6 rays -> 13 segments (non-branching, one launch)", W.gaussian_beam_scene, None, 11.5),
              ("examples/chromatic_aberration.py: 3 rays, every hit branches -> 59 segments (ray trees)", W.chromatic_scene, None, 59 / 2.7e3 * 1e3),
-             ("cfg2 scene at 100 rays, cap 5 -> 500 segments", cfg2_small, {"max_trace_num": 5}, 500 / 3.0e3 * 1e3)]
+             ("cfg2 scene at 100 rays, cap 5 -> 500 segments", cfg2_small, {"max_trace_num": 5}, 500 / 3.0e3 * 1e3),
+             # user-defined parts (optical_component.py:235-240, surfaces.py:5-65): the reference's time measured in the build
+             # container on the same scene (workloads.user_parts_scene with the reference's classes: 95-112 ms per call)
+             ("user-defined parts: a grating whose interact_local is Python + a parabolic mirror whose surface is a user class, "
+              "3 rays -> 120 segments (device search per generation, the user's method per grating hit)", W.user_parts_scene,
+              {"max_trace_num": 40}, 105.0)]
     out = []
     for label, make, limit, ref_ms in cases:
         comps, rays = make(oa)

@@ -228,7 +228,7 @@ def _user_overrides(surf):
     """True when a class OUTSIDE this package and the reference package defines one of the four methods a surface is known by
     (a subclass of Circle that cuts a hole into `within_boundary`, say): the built-in lowering would ignore it."""
     for klass in type(surf).__mro__:
-        if (klass.__module__ or "").split(".")[0] in ("optable_amd", "optable"):
+        if _library_class(klass):
             return False
         if any(m in klass.__dict__ for m in ("f", "normal", "within_boundary", "get_bbox_local")):
             return True
@@ -309,6 +309,13 @@ def lower_material(mat):
 
 # ---------------------------------------------------------------------------------------------
 # interactions (reference optable/optical_component.py)
+def _library_class(klass):
+    """A class of this package or of the reference package (not the synthetic user parts of optable_amd.workloads, which stand
+    for a user's script)."""
+    module = klass.__module__ or ""
+    return module.split(".")[0] in ("optable_amd", "optable") and module != "optable_amd.workloads"
+
+
 def host_hook(comp):
     """True when `comp.interact_local` is the USER's: defined by a class outside this package and outside the reference
     package (optical_component.py:235-240 is the subclassing hook).  Such a leaf keeps its place in the device scene — the
@@ -318,8 +325,7 @@ def host_hook(comp):
         return False
     for klass in type(comp).__mro__:
         if "interact_local" in klass.__dict__:
-            root = (klass.__module__ or "").split(".")[0]
-            return root not in ("optable_amd", "optable")
+            return not _library_class(klass)
     return False
 
 

@@ -117,6 +117,61 @@ def chromatic_scene(ns):
     return [slab], rays
 
 
+def user_parts_scene(ns):
+    """A scene with USER-DEFINED parts, written against the public API as they would be for the reference (optical_component.py:
+    235-240, surfaces.py:5-65): a three-order transmission grating (its `interact_local` is Python), a thin lens, a slab whose
+    faces split, and a parabolic mirror whose surface is a user class.  Three rays, 40 traces per tree.  Returns (components, rays)."""
+
+    class Grating(ns.OpticalComponent):
+        def __init__(self, origin, radius, pitch, **kwargs):
+            super().__init__(origin, **kwargs)
+            self.surface, self.pitch = ns.Circle(radius), pitch
+
+        def get_bbox_local(self):
+            return self.surface.get_bbox_local()
+
+        def interact_local(self, ray):
+            P, t = self.intersect_point_local(ray)
+            out = []
+            for order, share in ((-1, 0.25), (0, 0.5), (1, 0.25)):
+                d = np.array(ray.direction, dtype=float)
+                d[1] += order * ray.wavelength / self.pitch
+                d[0] = np.sign(d[0]) * np.sqrt(max(1.0 - d[1] ** 2 - d[2] ** 2, 0.0))
+                out.append(ray.copy(origin=P, direction=d, intensity=ray.intensity * share,
+                                    qo=None if ray.qo is None else ray.q_at_z(t), _pathlength=ray.pathlength(float(t))))
+            return out
+
+    class Paraboloid(ns.Surface):
+        def __init__(self, focal, radius):
+            super().__init__()
+            self.planar, self.focal, self.radius = False, focal, radius
+
+        def f(self, P):
+            return P[0] + (P[1] ** 2 + P[2] ** 2) / (4 * self.focal)
+
+        def normal(self, P):
+            n = np.array([1.0, P[1] / (2 * self.focal), P[2] / (2 * self.focal)])
+            return n / np.linalg.norm(n)
+
+        def within_boundary(self, P):
+            return P[1] ** 2 + P[2] ** 2 <= self.radius**2
+
+        def get_bbox_local(self):
+            R, sag = self.radius, self.radius**2 / (4 * self.focal)
+            return (-sag, 0.0, -R, R, -R, R)
+
+    class ParabolicMirror(ns.BaseMirror):
+        def __init__(self, origin, focal, radius, **kwargs):
+            super().__init__(origin, **kwargs)
+            self.surface = Paraboloid(focal, radius)
+
+    comps = [Grating([3, 0, 0], radius=1.0, pitch=4e-4), ns.Lens([6, 0, 0], focal_length=6.0, radius=1.5),
+             ns.GlassSlab([9, 0, 0], width=3, height=3, thickness=0.4, n1=1, n2=1.5, reflectivity=0.1).RotZ(0.1),
+             ParabolicMirror([12, 0, 0], focal=3.0, radius=2.0).RotZ(np.pi)]
+    rays = [ns.Ray([0, y, 0], [1, 0, 0], wavelength=633e-7, w0=50e-4) for y in (-0.3, 0.0, 0.3)]
+    return comps, rays
+
+
 class Workload:
     """One BASELINE config: what to build, what to trace, at which total size and precision."""
 
