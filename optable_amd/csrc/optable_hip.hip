@@ -829,7 +829,8 @@ static int launch_rolling(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, 
         // The pair queue's room is LDS that every wave holds: 512 pairs are 1 KB, and with the records of the live rays in LDS the
         // sixteenth wave of a CU can hang on the last few hundred bytes (cfg 3's scene under grids whose fullest cell holds four or
         // five leaves instead of three: 12 waves per CU instead of 16, 2.6-3.0 ms instead of 2.15-2.25 — tools/sweep_root_grid.py).
-        // A round that overflows a smaller queue defers lanes and costs a few per cent; a lost quarter of the waves costs 25 %.
+        // A round that overflows a smaller queue defers lanes and costs little (cfg 3 with room for 192 pairs where its worst case is
+        // 384: 2.165 against 2.13-2.17 ms at 256 ... 512); a lost quarter of the waves costs 25 %.
         // So the room is the largest of 512, 448, ... 192 (>= one lane's worst case of 168) that keeps the most waves resident;
         // OT_OPT_FLAT_QUEUE > 1 still sets it by hand.
         auto choose = [&]() -> int {
