@@ -873,7 +873,9 @@ static int launch_rolling(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t K, 
                 flat_b = ((size_t)(FlatLds<T>::fixed_bytes + (size_t)room * 2) + 15) & ~(size_t)15;
                 rc_choose = choose();
                 if (rc_choose) return rc_choose;
-                if (chosen.waves > best_t.waves) { best_t = chosen; best_img = lds_img; room_sel = room; }
+                // (the policy of choose() first — records in LDS when at least 12 waves fit — then the number of waves)
+                const bool rec_new = chosen.capl > 0, rec_old = best_t.capl > 0;
+                if ((rec_new && !rec_old) || (rec_new == rec_old && chosen.waves > best_t.waves)) { best_t = chosen; best_img = lds_img; room_sel = room; }
             }
             chosen = best_t;
             lds_img = best_img;
