@@ -1,6 +1,7 @@
 """Shared test plumbing: build a parity scene with optable_amd, pack its rays, compare segment
 streams against the committed golden fixtures (tests/golden/*.npz, generated from the
 reference by tools/make_golden.py)."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -68,3 +69,41 @@ def assert_segments_match(got, gold, has_q_of_tree, rtol=RTOL, atol=1e-9):
     np.testing.assert_array_equal(hq, gold["seg_has_q"])
     q = got["q_re"] + 1j * got["q_im"]
     np.testing.assert_allclose(q[hq], gold["seg_q"][hq], rtol=rtol, atol=atol)
+
+
+def stored_scene(gold):
+    """A CompiledScene from the tables a fixture holds (tools/make_golden.py real_example_fixture: this package's
+    compiler run on the reference's own object graph in the build container; the objects do not travel, the tables do)."""
+    import types
+
+    from optable_amd.scene import CompiledScene
+
+    n_nodes, n_mat, n_lim, max_children, root_grid, always, n_leaves = (int(x) for x in gold["meta"])
+    sc = object.__new__(CompiledScene)
+    sc.nodes = (abi.OtNode * max(n_nodes, 1)).from_buffer_copy(gold["nodes"].tobytes())
+    sc.n_nodes = n_nodes
+    sc.materials = (abi.OtMaterial * max(n_mat, 1)).from_buffer_copy(gold["materials"].tobytes())
+    sc.n_materials = n_mat
+    aux = np.ascontiguousarray(gold["aux"], dtype=np.float64)
+    sc.aux = (C.c_double * max(len(aux), 1))(*aux.tolist())
+    sc.n_aux = len(aux)
+    sc.leaves = [None] * n_leaves
+    sc.limited = [types.SimpleNamespace(max_interact_count=int(m), _interact_count={}) for m in gold["limited_max"]]
+    sc.hooks = {}
+    sc.max_children, sc.unit, sc.root_grid = max_children, float(gold["unit"][0]), root_grid
+    sc.always_branches, sc.wavelength_range = bool(always), None
+    return sc
+
+
+def fixture_rays_host(gold):
+    """The fixture's input rays as the dict of host arrays `pack_host` builds from Ray objects."""
+    n = len(gold["in_intensity"])
+    o, d, q = gold["in_origin"], gold["in_direction"], gold["in_q"]
+    has_q = gold["in_has_q"]
+    host = dict(ox=o[:, 0], oy=o[:, 1], oz=o[:, 2], dx=d[:, 0], dy=d[:, 1], dz=d[:, 2], wavelength=gold["in_wavelength"],
+                q_re=np.where(has_q, q.real, 0.0), q_im=np.where(has_q, q.imag, 0.0), intensity=gold["in_intensity"],
+                n=gold["in_n"], pathlength=gold["in_pathlength"])
+    host = {k: np.ascontiguousarray(v, dtype=np.float64) for k, v in host.items()}
+    host["id"] = np.arange(n, dtype=np.int32)
+    host["flags"] = np.where(has_q, abi.RAY_HAS_Q, 0).astype(np.int32) | np.where(gold["in_alive"], 0, abi.RAY_DEAD).astype(np.int32)
+    return host

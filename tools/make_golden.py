@@ -199,6 +199,56 @@ def interact_fixture():
     print("g20_interact:", names)
 
 
+def real_example_fixture():
+    """g27: the reference's largest example as it stands (examples/ripa_gen2_lensless.py: a multi-pass cavity of micro-mirror
+    arrays, 7,689 leaf surfaces in nested groups, count-limited prism faces, ONE Gaussian ray that is reflected about three
+    thousand times; the author's own research scene).  The script is executed from /root/reference up to and including its
+    `table.ray_tracing(...)` call (the rest renders); what is stored is DATA: the scene as this package's compiler flattens the
+    reference's object graph (`ot_node` / material / aux tables: poses, shapes, coefficients), the input ray and every output
+    segment in the order the reference returned them.  The GPU test uploads the tables and traces the ray."""
+    import contextlib
+    import io
+    import time
+
+    import optable_amd as oa
+
+    path = "/root/reference/examples/ripa_gen2_lensless.py"
+    src = open(path).read()
+    cut = src.index("\n", src.index("table.ray_tracing(R1rays0")) + 1
+    env = {"__name__": "__main__", "__file__": path}
+    cwd = os.getcwd()
+    os.chdir(os.path.dirname(path))
+    t0 = time.time()
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            exec(compile(src[:cut], path, "exec"), env)
+    finally:
+        os.chdir(cwd)
+    seconds = time.time() - t0
+    table, rays = env["table"], env["R1rays0"]
+    scene = oa.compile_scene(table.components, getattr(table, "unit", 1e-2))
+    out = {}
+    for key, val in ray_rows(rays).items():
+        out["in_" + key] = val
+    for key, val in ray_rows(table.rays).items():
+        out["seg_" + key] = val
+    out["seg_tree"] = np.zeros(len(table.rays), dtype=np.int32)
+    out["nodes"] = np.frombuffer(bytes(scene.nodes), dtype=np.uint8)
+    out["materials"] = np.frombuffer(bytes(scene.materials), dtype=np.uint8)
+    out["aux"] = np.array(scene.aux[: scene.n_aux], dtype=float)
+    out["meta"] = np.array([scene.n_nodes, scene.n_materials, len(scene.limited), scene.max_children, scene.root_grid,
+                            int(scene.always_branches), scene.n_leaves], dtype=np.int64)
+    out["unit"] = np.array([scene.unit])
+    limited_max = [int(c.max_interact_count) for c in scene.limited]
+    out["limited_max"] = np.array(limited_max, dtype=np.int64)
+    out["counts"] = np.array([c._interact_count.get(rays[0]._id, 0) for c in scene.limited], dtype=np.int32)
+    out["max_trace_num"] = np.array([100000])
+    out["reference_seconds"] = np.array([seconds])
+    np.savez_compressed(os.path.join(OUT, "g27_real_example.npz"), **out)
+    print(f"g27_real_example: {scene.n_leaves} leaves, {scene.n_nodes} nodes, {len(table.rays)} segments, reference {seconds:.1f} s "
+          f"(scene construction included)")
+
+
 def calibrate_fixture():
     """g22: OpticalTable.calibrate_symmetric_4f (optical_table.py:299-422), a caller of the hot path: the cost
     terms at a fixed (F1, F2) and the Nelder-Mead result for two criteria."""
@@ -218,7 +268,7 @@ def calibrate_fixture():
 if __name__ == "__main__":
     names = sys.argv[1:] or list(scenes.SCENES) + list(scenes.HOOKED_SCENES)
     for nm in names:
-        if nm in ("g14_slab", "g17_abcd", "g20_interact", "g22_calibrate", "g23_exports"):
+        if nm in ("g14_slab", "g17_abcd", "g20_interact", "g22_calibrate", "g23_exports", "g27_real_example"):
             continue
         np.random.seed(12345)
         run(nm)
@@ -232,6 +282,8 @@ if __name__ == "__main__":
     if not sys.argv[1:] or "g23_exports" in sys.argv[1:]:
         np.random.seed(12345)
         exports_fixture()
+    if "g27_real_example" in sys.argv[1:]:  # (18 s of the reference: on request only)
+        real_example_fixture()
     if not sys.argv[1:] or "g20_interact" in sys.argv[1:]:
         np.random.seed(12345)
         interact_fixture()
