@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define OT_ABI_VERSION 12  /* 12: OT_OPT_GEN_PARENT_INDEX; 11: OT_OPT_GEN_AHEAD, ot_trace_trees_*, ot_trace_trees_append_*, OT_OPT_TREES_LDS_ENTRIES, OT_OPT_TREES_REFILL_AT, OT_OPT_TREES_FLAT; 10: ot_trace_plan, ot_probe_layouts, ot_runtime_info, OT_OPT_REFILL, OT_OPT_REFILL_TICKET, OT_OPT_POOL_JITTER, OT_OPT_GEN_ONEPASS; 9: ot_trace_tree_*, OT_OPT_BLOCK_POOL, OT_OPT_GEN_DROP_DOOMED, ot_trace_append_* holes per workgroup chunk; 8: OT_SHAPE_ASPHERE_CHEB, OT_MAT_CHEB, OT_NODE_BOX_TRUSTED, ot_trace_tiled_*, ot_bench_stream_tiled_*; 3: ot_trace_generation_f32; 4: ot_bench_stream_f32; 5: OT_OPT_LIST_CAP, ray flags bits 8..31, ot_debug_generation_mismatches; 6: ot_debug_last_launch, OT_OPT_FLAT_QUEUE, OT_OPT_LDS_RECORDS; 7: ot_trace_append_*, ot_segment_block, OT_OPT_APPEND_CHUNK, OT_OPT_INSTANCING */
+#define OT_ABI_VERSION 13  /* 13: OT_OPT_TREES_GLOBAL_IMAGE, tree kernels for scenes beyond the LDS; 12: OT_OPT_GEN_PARENT_INDEX; 11: OT_OPT_GEN_AHEAD, ot_trace_trees_*, ot_trace_trees_append_*, OT_OPT_TREES_LDS_ENTRIES, OT_OPT_TREES_REFILL_AT, OT_OPT_TREES_FLAT; 10: ot_trace_plan, ot_probe_layouts, ot_runtime_info, OT_OPT_REFILL, OT_OPT_REFILL_TICKET, OT_OPT_POOL_JITTER, OT_OPT_GEN_ONEPASS; 9: ot_trace_tree_*, OT_OPT_BLOCK_POOL, OT_OPT_GEN_DROP_DOOMED, ot_trace_append_* holes per workgroup chunk; 8: OT_SHAPE_ASPHERE_CHEB, OT_MAT_CHEB, OT_NODE_BOX_TRUSTED, ot_trace_tiled_*, ot_bench_stream_tiled_*; 3: ot_trace_generation_f32; 4: ot_bench_stream_f32; 5: OT_OPT_LIST_CAP, ray flags bits 8..31, ot_debug_generation_mismatches; 6: ot_debug_last_launch, OT_OPT_FLAT_QUEUE, OT_OPT_LDS_RECORDS; 7: ot_trace_append_*, ot_segment_block, OT_OPT_APPEND_CHUNK, OT_OPT_INSTANCING */
 
 /* ---- status codes ------------------------------------------------------------------- */
 enum ot_status {
@@ -439,6 +439,8 @@ enum ot_option {
     OT_OPT_GEN_AHEAD = 20,     /* ot_trace_tree_*, light scenes without count-limited surfaces: the emit pass of a generation also counts the
                                   children of the children it writes, and the next generation replaces its count pass over the ray records by a pass
                                   over one byte per ray (k_gen_recount): 1 (default) / 0.  Identical output either way. */
+    OT_OPT_TREES_GLOBAL_IMAGE = 25, /* ot_trace_trees_*: scenes whose image no LDS holds (thousands of leaves) are traced by the all-features tree kernel
+                                  that reads the image from global memory; 1 = every scene takes that kernel (test knob: results must not change), 0 default */
     OT_OPT_GEN_PARENT_INDEX = 24, /* ot_trace_generation_*: 1 = next_tree[] receives, for every emitted ray, the INDEX of its parent in this call's
                                   `rays` instead of the parent's tree id (0, default).  For a host that keeps an object per ray and needs to know whose
                                   child a ray is while `tree` groups the rays for the FIFO-exact count gates: the object API's trace through scenes

@@ -7,7 +7,7 @@ __graft_entry__ as g; g.build()"` or `make -C optable_amd/csrc`).
 import ctypes as C
 import os
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "liboptable_hip.so")
 
@@ -72,7 +72,7 @@ NODE_CHECK_AABB, NODE_GRID, NODE_BOX_TRUSTED = 1, 2, 4
 MAT_CONST, MAT_SELLMEIER, MAT_CHEB = 0, 1, 2
 RAY_HAS_Q, RAY_DEAD = 1, 2
 OPT_NT_STORES, OPT_MIN_WAVES, OPT_BLOCKS_PER_CU, OPT_KERNEL, OPT_LDS_LIMIT_KB, OPT_LIST_CAP, OPT_PAIR_STORES, OPT_MIX_GENERATIONS, OPT_FLAT_QUEUE, OPT_LDS_RECORDS = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
-OPT_APPEND_CHUNK, OPT_INSTANCING, OPT_GEN_REUSE, OPT_BLOCK_POOL, OPT_GEN_DROP_DOOMED, OPT_REFILL, OPT_REFILL_TICKET, OPT_POOL_JITTER, OPT_GEN_ONEPASS, OPT_GEN_AHEAD, OPT_TREES_LDS_ENTRIES, OPT_TREES_REFILL_AT, OPT_TREES_FLAT, OPT_GEN_PARENT_INDEX = 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24
+OPT_APPEND_CHUNK, OPT_INSTANCING, OPT_GEN_REUSE, OPT_BLOCK_POOL, OPT_GEN_DROP_DOOMED, OPT_REFILL, OPT_REFILL_TICKET, OPT_POOL_JITTER, OPT_GEN_ONEPASS, OPT_GEN_AHEAD, OPT_TREES_LDS_ENTRIES, OPT_TREES_REFILL_AT, OPT_TREES_FLAT, OPT_GEN_PARENT_INDEX, OPT_TREES_GLOBAL_IMAGE = 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25
 
 # every symbol the header declares, with its ctypes signature
 _vp, _i32, _i64 = C.c_void_p, C.c_int32, C.c_int64

@@ -46,7 +46,13 @@ template <> GenOneKern<T> gen_one_kernel<T>(int fg, bool lds) {
 // k_trace_trees: every preset (the all-features one included: 148 registers in single precision, 263 in double — one wave per SIMD,
 // as its generation kernels); 2 waves per SIMD in double precision (the rarer shapes: 1 — 256 registers would spill), 3 in single: the register
 // caps the queues' LDS leaves room for (tables.h tree_minw)
-template <class OUT> static TreeKern<T, OUT> pick_tree(int fg) {
+template <class OUT> static TreeKern<T, OUT> pick_tree(int fg, bool lds) {
+    if (!lds) {  // image read from global memory (scenes no LDS holds): the all-features preset, dense list
+        if constexpr (std::is_same<OUT, SegPlanes<T>>::value) {
+            if (fg == 4) return k_trace_trees<T, F_ALL, tree_minw<T>(4), OUT, false>;
+        }
+        return nullptr;
+    }
     if (fg == 0) return k_trace_trees<T, FB, tree_minw<T>(0), OUT>;
     if constexpr (std::is_same<OUT, SegPlanes<T>>::value) {  // (the [k][tree] slots: the planar preset only — every preset writes the dense list)
         if (fg == 1) return k_trace_trees<T, FC, tree_minw<T>(1), OUT>;
@@ -58,5 +64,5 @@ template <class OUT> static TreeKern<T, OUT> pick_tree(int fg) {
     }
     return nullptr;
 }
-template <> TreeKern<T, SegsT<T>> tree_kernel<T, SegsT<T>>(int fg) { return pick_tree<SegsT<T>>(fg); }
-template <> TreeKern<T, SegPlanes<T>> tree_kernel<T, SegPlanes<T>>(int fg) { return pick_tree<SegPlanes<T>>(fg); }
+template <> TreeKern<T, SegsT<T>> tree_kernel<T, SegsT<T>>(int fg, bool lds) { return pick_tree<SegsT<T>>(fg, lds); }
+template <> TreeKern<T, SegPlanes<T>> tree_kernel<T, SegPlanes<T>>(int fg, bool lds) { return pick_tree<SegPlanes<T>>(fg, lds); }

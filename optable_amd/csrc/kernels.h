@@ -319,18 +319,29 @@ template <class T> constexpr int tree_entry_bytes() { return 64 * (11 * (int)siz
 // step go to consecutive slots of the wave's current chunk (claimed from a device-wide cursor, `ac`), whatever trees and
 // positions the lanes are on: dense, whole lines per field.  A tree stays with its lane and a wave's chunks are claimed in
 // address order, so a stable sort by `ray` is the reference's order; the unused tail of a wave's last chunk is marked ray = -1.
-template <class T, uint32_t F, int MINW, class OUT>
+// IMG_LDS = false (the all-features preset only): the scene image is read where the upload left it (global memory: L2) and the
+// LDS holds the queues alone — scenes whose image no LDS holds (the reference's largest example, examples/ripa_gen2_lensless.py:
+// 7,689 leaves, ONE ray reflected three thousand times) get their trees in one launch too instead of a launch sequence per
+// generation with three searches each (fixture g27: 324 ms -> see DESIGN 4.5a).
+template <class T, uint32_t F, int MINW, class OUT, bool IMG_LDS = true>
 __global__ __launch_bounds__(256, MINW) void k_trace_trees(SceneBlob blob, T unit, RaysT<T> in, int64_t n, int32_t cap, int32_t QL, int32_t QG,
                                                            uint8_t* __restrict__ scratch, OUT out, AppendCtl ac, int32_t* __restrict__ seg_count,
                                                            int32_t* counts, int32_t n_classes, int32_t refill_at, int32_t flat_cap) {
     constexpr bool APPEND = std::is_same<OUT, SegPlanes<T>>::value;
+    static_assert(IMG_LDS || (F & F_FLAT) == 0, "the pair queue reads the image from LDS");
     extern __shared__ __align__(16) uint32_t lds[];
-    for (int w = threadIdx.x; w < blob.n_words; w += blockDim.x) lds[w] = blob.words[w];
-    __syncthreads();
-    const Scene<T> sc = bind_scene<T>(lds, blob, unit);
+    const uint32_t* base = blob.words;
+    size_t img_bytes = 0;
+    if constexpr (IMG_LDS) {
+        for (int w = threadIdx.x; w < blob.n_words; w += blockDim.x) lds[w] = blob.words[w];
+        __syncthreads();
+        base = lds;
+        img_bytes = ((size_t)blob.n_words * 4 + 15) & ~(size_t)15;
+    }
+    const Scene<T> sc = bind_scene<T>(base, blob, unit);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr size_t EB = tree_entry_bytes<T>();
-    uint8_t* const ring = reinterpret_cast<uint8_t*>(lds) + (((size_t)blob.n_words * 4 + 15) & ~(size_t)15) + (size_t)wave * QL * EB;
+    uint8_t* const ring = reinterpret_cast<uint8_t*>(lds) + img_bytes + (size_t)wave * QL * EB;
     // F_FLAT (planar scenes under a top-level grid of leaves: cfg 3 with reflecting slabs): the search of a step is the wave-wide pair
     // queue of the heavy non-branching kernel (flat_grid_hit) — candidates of all 64 current rays, tested with full lanes — instead
     // of a grid walk per lane; its key table and queue sit behind the rings of all waves.
@@ -338,7 +349,7 @@ __global__ __launch_bounds__(256, MINW) void k_trace_trees(SceneBlob blob, T uni
     FlatGrid<T> flat_grid = {};
     if constexpr ((F & F_FLAT) != 0) {
         const int per_wave = (FlatLds<T>::fixed_bytes + flat_cap * 2 + 15) & ~15;
-        uint8_t* fb = reinterpret_cast<uint8_t*>(lds) + (((size_t)blob.n_words * 4 + 15) & ~(size_t)15) + (size_t)(blockDim.x >> 6) * QL * EB + (size_t)wave * per_wave;
+        uint8_t* fb = reinterpret_cast<uint8_t*>(lds) + img_bytes + (size_t)(blockDim.x >> 6) * QL * EB + (size_t)wave * per_wave;
         flat.key = reinterpret_cast<unsigned long long*>(fb);
         if constexpr (sizeof(T) == 8) flat.node = reinterpret_cast<int32_t*>(fb + 64 * 8);
         flat.queue = reinterpret_cast<uint16_t*>(fb + FlatLds<T>::fixed_bytes);

@@ -101,6 +101,7 @@ struct ot_ctx {
     int32_t opt_pair = 1;  // paired 16-byte segment stores in the lane-per-ray kernel
     int32_t opt_nt = 1, opt_minw = 4, opt_blocks_per_cu = 0;  // defaults from tools/tune.py on MI355X
     Scratch gen, scan_tmp, mon, gen_rem, gen_ahead, trees;
+    int32_t opt_trees_global = 0;      // k_trace_trees: 1 = every scene through the all-features kernel that reads its image from global memory (test knob)
     int32_t opt_trees_flat = 1;        // k_trace_trees: planar scenes under a top-level grid of leaves search through the wave-wide pair queue
     int32_t opt_trees_refill_at = 16;  // k_trace_trees: idle lanes of a wave at which they take their next trees (64: a wave takes 64 trees at a time)
     int32_t opt_trees_lds = 0;  // k_trace_trees: queue entries per lane kept in LDS (the rest of a tree's queue lives in a global scratch); 0: by the cap
@@ -1197,7 +1198,7 @@ static int trace_generation(ot_ctx* c, const ot_rays* rays, const int32_t* tree,
 // ceil(cap / 2) entries a tree can need in a per-wave global scratch, as long as the scratch of all resident waves stays
 // within 1 GiB (caps up to ~170 in double precision); beyond that the queues are what fits and the launch is a speculation
 // on small trees (full = 0).
-struct TreesPlan { int32_t QL, QG, full, groups_per_cu, grid, chunk, preset, flat_cap; size_t lds_bytes; };
+struct TreesPlan { int32_t QL, QG, full, groups_per_cu, grid, chunk, preset, flat_cap, img_global; size_t lds_bytes; };
 // Planar scenes under a top-level grid of leaves search through the wave-wide pair queue of the heavy non-branching kernel
 // (launch_rolling's flat_ok, flat_grid_hit): the tree kernel's presets 5 (FR) / 6 (FRP).  0: the scene does not qualify.
 static int32_t trees_flat_cap(const ot_ctx* c, int* preset) {
@@ -1219,8 +1220,14 @@ template <class T> static bool trees_plan(const ot_ctx* c, int32_t cap, int64_t 
     p->flat_cap = c->opt_trees_flat ? trees_flat_cap(c, &p->preset) : 0;
     if (!tree_kernel<T, SegPlanes<T>>(p->preset)) return false;
     const size_t flat_bytes = p->flat_cap ? (((size_t)(FlatLds<T>::fixed_bytes + (size_t)p->flat_cap * 2) + 15) & ~(size_t)15) : 0;  // per wave (kernels.h)
-    const size_t room = 160 * 1024 - 1024, img = ((image + 15) & ~(size_t)15) + 4 * flat_bytes, entry = (size_t)tree_entry_bytes<T>();
-    if (img + 4 * entry > room) return false;
+    const size_t room = 160 * 1024 - 1024, entry = (size_t)tree_entry_bytes<T>();
+    size_t img = ((image + 15) & ~(size_t)15) + 4 * flat_bytes;
+    if (img + 4 * entry > room || c->opt_trees_global) {  // (OT_OPT_TREES_GLOBAL_IMAGE: test knob, every scene takes this path)
+        // an image no LDS holds (thousands of leaves): the all-features kernel reads it from global memory (L2), the LDS holds queues alone
+        if (!tree_kernel<T, SegPlanes<T>>(4, false)) return false;
+        p->preset = 4; p->flat_cap = 0; p->img_global = 1;
+        img = 0;
+    }
     const int64_t need = ((int64_t)cap + 1) / 2, fit = (int64_t)((room - img) / (4 * entry));
     // entries in LDS: two under small caps (queues stay short: a third workgroup per CU is worth more than the third entry —
     // cfg 4 R = 0.2: 4.05 vs 4.2 ms, bushy trees under a cap of 12: 0.56 vs 0.62), three above (cap 48: 3.35 vs 3.99)
@@ -1264,7 +1271,7 @@ static int launch_trees(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t cap, 
     TreesPlan p;
     if (!trees_plan<T>(c, cap, n, &p)) return fail(OT_ERR_UNSUPPORTED, "no tree kernel for this scene (features beyond the everyday presets, or an image that leaves no room for the queues): use ot_trace_tree_*");
     HIP_TRY(hipSetDevice(c->device));
-    const TreeKern<T, OUT> kern = tree_kernel<T, OUT>(p.preset);
+    const TreeKern<T, OUT> kern = tree_kernel<T, OUT>(p.preset, !p.img_global);
     if (!kern) return fail(OT_ERR_UNSUPPORTED, "this scene's tree kernel writes the append layout only (ot_trace_trees_append_*)");
     const SceneBlob blob = make_blob<T>(c);
     const int grid = p.grid;  // persistent: the scratch is per workgroup
@@ -1491,7 +1498,7 @@ int ot_trace_trees_plan(ot_ctx* c, int32_t real_bytes, int32_t max_trace_num, in
     const bool ok = real_bytes == 8 ? trees_plan<double>(c, max_trace_num, n_rays, &p) : trees_plan<float>(c, max_trace_num, n_rays, &p);
     info[0] = ok ? 1 : 0; info[1] = p.QL + p.QG; info[2] = p.full; info[3] = p.QL;
     info[4] = p.chunk; info[5] = p.grid * 4; info[6] = info[7] = 0;
-    if (ok && (real_bytes == 8 ? tree_kernel<double, SegsT<double>>(p.preset) != nullptr : tree_kernel<float, SegsT<float>>(p.preset) != nullptr))
+    if (ok && (real_bytes == 8 ? tree_kernel<double, SegsT<double>>(p.preset, !p.img_global) != nullptr : tree_kernel<float, SegsT<float>>(p.preset, !p.img_global) != nullptr))
         info[0] |= 2;  // ... and writes the [k][tree] slots too
     return 0;
 }
@@ -1721,6 +1728,7 @@ int ot_set_option(ot_ctx* c, int32_t option, int32_t value) {
         case OT_OPT_GEN_AHEAD: c->opt_gen_ahead = value != 0; return 0;
         case OT_OPT_TREES_FLAT: c->opt_trees_flat = value != 0; return 0;
         case OT_OPT_GEN_PARENT_INDEX: c->opt_gen_parent = value != 0; return 0;
+        case OT_OPT_TREES_GLOBAL_IMAGE: c->opt_trees_global = value != 0; return 0;
         case OT_OPT_TREES_REFILL_AT:
             if (value < 1 || value > 64) return fail(OT_ERR_INVALID, "OT_OPT_TREES_REFILL_AT takes 1..64");
             c->opt_trees_refill_at = value; return 0;

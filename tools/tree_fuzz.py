@@ -21,6 +21,7 @@ from optable_amd.engine import get_engine
 from oracle import oracle
 from test_gpu_fuzz import random_branching_scene, random_large_scene, random_planar_scene
 
+GLOBAL_IMAGE = bool(os.environ.get("GLOBAL_IMAGE"))  # every case through the global-image tree kernel
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 eng = get_engine()
@@ -57,6 +58,7 @@ for seed in range(first, first + cases):
     batch = RayBatch.from_arrays(o, d, wavelength=scenes.WL, q=1j * np.pi * scenes.W0**2 / scenes.WL, precision=prec)
     eng.set_option(abi.OPT_TREES_LDS_ENTRIES, ql)
     eng.set_option(abi.OPT_TREES_REFILL_AT, int(rng.choice([1, 16, 16, 40, 64])))
+    eng.set_option(abi.OPT_TREES_GLOBAL_IMAGE, int(GLOBAL_IMAGE or rng.uniform() < 0.15))  # (the kernel of scenes no LDS holds, on scenes it does)
     plan = eng.trees_plan(prec, cap, n)
     if not plan["kernel"]:
         skipped += 1
@@ -97,5 +99,6 @@ for seed in range(first, first + cases):
         print(f"... {seed - first + 1} cases, {bad} bad, {skipped} skipped", flush=True)
 eng.set_option(abi.OPT_TREES_LDS_ENTRIES, 0)
 eng.set_option(abi.OPT_TREES_REFILL_AT, 16)
+eng.set_option(abi.OPT_TREES_GLOBAL_IMAGE, 0)
 print(f"{cases} cases: {bad} bad, {skipped} skipped (no lane-per-tree kernel for the scene); {flat} launches searched through the pair queue")
 sys.exit(1 if bad else 0)
