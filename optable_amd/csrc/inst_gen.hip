@@ -46,10 +46,11 @@ template <> GenOneKern<T> gen_one_kernel<T>(int fg, bool lds) {
 // k_trace_trees: every preset (the all-features one included: 148 registers in single precision, 263 in double — one wave per SIMD,
 // as its generation kernels); 2 waves per SIMD in double precision (the rarer shapes: 1 — 256 registers would spill), 3 in single: the register
 // caps the queues' LDS leaves room for (tables.h tree_minw)
-template <class OUT> static TreeKern<T, OUT> pick_tree(int fg, bool lds) {
-    if (!lds) {  // image read from global memory (scenes no LDS holds): the all-features preset, dense list
+template <class OUT> static TreeKern<T, OUT> pick_tree(int fg, int img) {
+    if (img != 1) {  // scenes no LDS holds: the all-features preset, dense list; img 2 = node records in LDS, tables in global memory; 0 = all global
         if constexpr (std::is_same<OUT, SegPlanes<T>>::value) {
-            if (fg == 4) return k_trace_trees<T, F_ALL, tree_minw<T>(4), OUT, false>;
+            if (fg == 4 && img == 2) return k_trace_trees<T, F_ALL, tree_minw<T>(4), OUT, 2>;
+            if (fg == 4 && img == 0) return k_trace_trees<T, F_ALL, tree_minw<T>(4), OUT, 0>;
         }
         return nullptr;
     }
@@ -64,5 +65,5 @@ template <class OUT> static TreeKern<T, OUT> pick_tree(int fg, bool lds) {
     }
     return nullptr;
 }
-template <> TreeKern<T, SegsT<T>> tree_kernel<T, SegsT<T>>(int fg, bool lds) { return pick_tree<SegsT<T>>(fg, lds); }
-template <> TreeKern<T, SegPlanes<T>> tree_kernel<T, SegPlanes<T>>(int fg, bool lds) { return pick_tree<SegPlanes<T>>(fg, lds); }
+template <> TreeKern<T, SegsT<T>> tree_kernel<T, SegsT<T>>(int fg, int img) { return pick_tree<SegsT<T>>(fg, img); }
+template <> TreeKern<T, SegPlanes<T>> tree_kernel<T, SegPlanes<T>>(int fg, int img) { return pick_tree<SegPlanes<T>>(fg, img); }

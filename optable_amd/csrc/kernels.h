@@ -319,26 +319,33 @@ template <class T> constexpr int tree_entry_bytes() { return 64 * (11 * (int)siz
 // step go to consecutive slots of the wave's current chunk (claimed from a device-wide cursor, `ac`), whatever trees and
 // positions the lanes are on: dense, whole lines per field.  A tree stays with its lane and a wave's chunks are claimed in
 // address order, so a stable sort by `ray` is the reference's order; the unused tail of a wave's last chunk is marked ray = -1.
-// IMG_LDS = false (the all-features preset only): the scene image is read where the upload left it (global memory: L2) and the
-// LDS holds the queues alone — scenes whose image no LDS holds (the reference's largest example, examples/ripa_gen2_lensless.py:
-// 7,689 leaves, ONE ray reflected three thousand times) get their trees in one launch too instead of a launch sequence per
-// generation with three searches each (fixture g27: 324 ms -> see DESIGN 4.5a).
-template <class T, uint32_t F, int MINW, class OUT, bool IMG_LDS = true>
+// IMG (the all-features preset only has the other two): 1 = the whole scene image in LDS; 2 = the node and material records in LDS,
+// the aux tables (poses of instanced runs, grids, polygons, series) read where the upload left them (global memory: L2); 0 = everything
+// read from global memory.  Scenes whose image no LDS holds (the reference's largest example, examples/ripa_gen2_lensless.py: 7,689
+// leaves, ONE ray reflected three thousand times) get their trees in one launch too, instead of a launch sequence per generation
+// with three searches each (fixture g27: 324 ms -> see DESIGN 4.5a).
+template <class T, uint32_t F, int MINW, class OUT, int IMG = 1>
 __global__ __launch_bounds__(256, MINW) void k_trace_trees(SceneBlob blob, T unit, RaysT<T> in, int64_t n, int32_t cap, int32_t QL, int32_t QG,
                                                            uint8_t* __restrict__ scratch, OUT out, AppendCtl ac, int32_t* __restrict__ seg_count,
                                                            int32_t* counts, int32_t n_classes, int32_t refill_at, int32_t flat_cap) {
     constexpr bool APPEND = std::is_same<OUT, SegPlanes<T>>::value;
-    static_assert(IMG_LDS || (F & F_FLAT) == 0, "the pair queue reads the image from LDS");
+    static_assert(IMG == 1 || (F & F_FLAT) == 0, "the pair queue reads the image from LDS");
     extern __shared__ __align__(16) uint32_t lds[];
     const uint32_t* base = blob.words;
     size_t img_bytes = 0;
-    if constexpr (IMG_LDS) {
-        for (int w = threadIdx.x; w < blob.n_words; w += blockDim.x) lds[w] = blob.words[w];
+    if constexpr (IMG != 0) {
+        const int head_words = IMG == 1 ? blob.n_words : (int)(((size_t)blob.n_phys * sizeof(DNode<T>) + (size_t)blob.n_mats * sizeof(DMat<T>)) / 4);
+        for (int w = threadIdx.x; w < head_words; w += blockDim.x) lds[w] = blob.words[w];
         __syncthreads();
         base = lds;
-        img_bytes = ((size_t)blob.n_words * 4 + 15) & ~(size_t)15;
+        img_bytes = ((size_t)head_words * 4 + 15) & ~(size_t)15;
     }
-    const Scene<T> sc = bind_scene<T>(base, blob, unit);
+    Scene<T> sc_bound = bind_scene<T>(IMG == 2 ? blob.words : base, blob, unit);
+    if constexpr (IMG == 2) {  // tables (and the run table's head, read above) from global memory, records from LDS
+        sc_bound.nodes = reinterpret_cast<const DNode<T>*>(lds);
+        sc_bound.mats = reinterpret_cast<const DMat<T>*>(sc_bound.nodes + blob.n_phys);
+    }
+    const Scene<T> sc = sc_bound;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr size_t EB = tree_entry_bytes<T>();
     uint8_t* const ring = reinterpret_cast<uint8_t*>(lds) + img_bytes + (size_t)wave * QL * EB;

@@ -55,6 +55,7 @@ struct ot_ctx {
     bool has_scene = false;
     void *blob64 = nullptr, *blob32 = nullptr;
     size_t bytes64 = 0, bytes32 = 0;
+    size_t head64 = 0, head32 = 0;  // node + material records at the front of the image (k_trace_trees IMG = 2 keeps these in LDS)
     int32_t n_nodes = 0, n_mats = 0, n_aux = 0, n_slots = 0, max_children = 0;
     int32_t n_phys = 0, n_runs = 0, runs_word64 = 0, runs_word32 = 0;  // instanced runs folded by fill_blob (trace_core.h NodeRef)
     int32_t opt_append_chunk = 512;  // append layout: slots per claim
@@ -600,6 +601,8 @@ int ot_scene_upload(ot_ctx* c, const ot_scene_desc* s) {
     if (!b64.empty()) HIP_TRY(hipMemcpy(c->blob64, b64.data(), b64.size(), hipMemcpyHostToDevice));
     if (!b32.empty()) HIP_TRY(hipMemcpy(c->blob32, b32.data(), b32.size(), hipMemcpyHostToDevice));
     c->bytes64 = b64.size(); c->bytes32 = b32.size();
+    c->head64 = sizeof(DNode<double>) * (size_t)n_phys + sizeof(DMat<double>) * (size_t)s->n_materials;
+    c->head32 = sizeof(DNode<float>) * (size_t)n_phys + sizeof(DMat<float>) * (size_t)s->n_materials;
     c->n_nodes = s->n_nodes; c->n_mats = s->n_materials; c->n_aux = s->n_aux;
     c->n_slots = s->n_count_slots; c->max_children = s->max_children; c->unit = s->unit;
     c->features = scene_features(s);
@@ -1224,9 +1227,13 @@ template <class T> static bool trees_plan(const ot_ctx* c, int32_t cap, int64_t 
     size_t img = ((image + 15) & ~(size_t)15) + 4 * flat_bytes;
     if (img + 4 * entry > room || c->opt_trees_global) {  // (OT_OPT_TREES_GLOBAL_IMAGE: test knob, every scene takes this path)
         // an image no LDS holds (thousands of leaves): the all-features kernel reads it from global memory (L2), the LDS holds queues alone
-        if (!tree_kernel<T, SegPlanes<T>>(4, false)) return false;
+        if (!tree_kernel<T, SegPlanes<T>>(4, 0)) return false;
         p->preset = 4; p->flat_cap = 0; p->img_global = 1;
         img = 0;
+        // ... and the node and material records alone in LDS when they leave room for the queues (instanced runs fold thousands of
+        // lattice members into a few records: the walk's dependent reads then come from LDS, only poses and grids from L2)
+        const size_t head = ((size_t)(sizeof(T) == 8 ? c->head64 : c->head32) + 15) & ~(size_t)15;
+        if (head > 0 && head + 4 * 3 * entry <= room / 2 && c->opt_trees_global != 2 && tree_kernel<T, SegPlanes<T>>(4, 2)) { p->img_global = 2; img = head; }
     }
     const int64_t need = ((int64_t)cap + 1) / 2, fit = (int64_t)((room - img) / (4 * entry));
     // entries in LDS: two under small caps (queues stay short: a third workgroup per CU is worth more than the third entry —
@@ -1271,7 +1278,7 @@ static int launch_trees(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t cap, 
     TreesPlan p;
     if (!trees_plan<T>(c, cap, n, &p)) return fail(OT_ERR_UNSUPPORTED, "no tree kernel for this scene (features beyond the everyday presets, or an image that leaves no room for the queues): use ot_trace_tree_*");
     HIP_TRY(hipSetDevice(c->device));
-    const TreeKern<T, OUT> kern = tree_kernel<T, OUT>(p.preset, !p.img_global);
+    const TreeKern<T, OUT> kern = tree_kernel<T, OUT>(p.preset, p.img_global == 0 ? 1 : (p.img_global == 2 ? 2 : 0));
     if (!kern) return fail(OT_ERR_UNSUPPORTED, "this scene's tree kernel writes the append layout only (ot_trace_trees_append_*)");
     const SceneBlob blob = make_blob<T>(c);
     const int grid = p.grid;  // persistent: the scratch is per workgroup
@@ -1498,7 +1505,7 @@ int ot_trace_trees_plan(ot_ctx* c, int32_t real_bytes, int32_t max_trace_num, in
     const bool ok = real_bytes == 8 ? trees_plan<double>(c, max_trace_num, n_rays, &p) : trees_plan<float>(c, max_trace_num, n_rays, &p);
     info[0] = ok ? 1 : 0; info[1] = p.QL + p.QG; info[2] = p.full; info[3] = p.QL;
     info[4] = p.chunk; info[5] = p.grid * 4; info[6] = info[7] = 0;
-    if (ok && (real_bytes == 8 ? tree_kernel<double, SegsT<double>>(p.preset, !p.img_global) != nullptr : tree_kernel<float, SegsT<float>>(p.preset, !p.img_global) != nullptr))
+    if (ok && (real_bytes == 8 ? tree_kernel<double, SegsT<double>>(p.preset, p.img_global ? 0 : 1) != nullptr : tree_kernel<float, SegsT<float>>(p.preset, p.img_global ? 0 : 1) != nullptr))
         info[0] |= 2;  // ... and writes the [k][tree] slots too
     return 0;
 }
@@ -1728,7 +1735,7 @@ int ot_set_option(ot_ctx* c, int32_t option, int32_t value) {
         case OT_OPT_GEN_AHEAD: c->opt_gen_ahead = value != 0; return 0;
         case OT_OPT_TREES_FLAT: c->opt_trees_flat = value != 0; return 0;
         case OT_OPT_GEN_PARENT_INDEX: c->opt_gen_parent = value != 0; return 0;
-        case OT_OPT_TREES_GLOBAL_IMAGE: c->opt_trees_global = value != 0; return 0;
+        case OT_OPT_TREES_GLOBAL_IMAGE: c->opt_trees_global = value < 0 ? 0 : (value > 2 ? 2 : value); return 0;  // 1: records in LDS when they fit; 2: everything from global memory
         case OT_OPT_TREES_REFILL_AT:
             if (value < 1 || value > 64) return fail(OT_ERR_INVALID, "OT_OPT_TREES_REFILL_AT takes 1..64");
             c->opt_trees_refill_at = value; return 0;

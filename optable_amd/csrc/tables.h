@@ -59,7 +59,7 @@ template <class T> GenKern<T> gen_kernel(int fg, bool lds, bool emit);
 template <class T> GenKern<T> gen_ahead_kernel(int fg, bool lds);
 template <class T> ProbeKern<T> probe_kernel(int fg, bool lds);
 // k_trace_trees (a lane per tree, the FIFO in LDS): fg as above; nullptr where no instantiation exists
-template <class T, class OUT> TreeKern<T, OUT> tree_kernel(int fg, bool lds = true);  // fg 5 / 6: the planar presets FR / FRP with the wave-wide pair queue (F_FLAT); lds = false: image read from global memory (fg 4, append output)
+template <class T, class OUT> TreeKern<T, OUT> tree_kernel(int fg, int img = 1);  // fg 5 / 6: the planar presets FR / FRP with the wave-wide pair queue (F_FLAT); img: 1 whole image in LDS, 2 node records in LDS + tables in global memory, 0 all global (2 / 0: fg 4, append output)
 // ... and the waves per SIMD its registers are capped for = the workgroups per CU it can have (256 threads: one wave per SIMD
 // each).  With every child queued the moment the interaction has formed it the kernels need 71-74 registers in single precision
 // (FB; FC / FE 97, FM 111) and 124-130 in double (FE 165, FM 255): the queues' LDS decides, not the registers.
@@ -82,8 +82,8 @@ template <class T> GenOneKern<T> gen_one_kernel(int fg, bool lds);
     template <> GenKern<T> gen_kernel<T>(int, bool, bool);                         \
     template <> GenKern<T> gen_ahead_kernel<T>(int, bool);                         \
     template <> ProbeKern<T> probe_kernel<T>(int, bool);                          \
-    template <> TreeKern<T, SegsT<T>> tree_kernel<T, SegsT<T>>(int, bool);              \
-    template <> TreeKern<T, SegPlanes<T>> tree_kernel<T, SegPlanes<T>>(int, bool);      \
+    template <> TreeKern<T, SegsT<T>> tree_kernel<T, SegsT<T>>(int, int);              \
+    template <> TreeKern<T, SegPlanes<T>> tree_kernel<T, SegPlanes<T>>(int, int);      \
     template <> GenOneKern<T> gen_one_kernel<T>(int, bool);
 OT_DECLARE_TABLES(double)
 OT_DECLARE_TABLES(float)

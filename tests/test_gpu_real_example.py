@@ -42,8 +42,12 @@ def test_the_reference_s_largest_example_matches_segment_by_segment():
     assert len(got["ray"]) == len(gold["seg_tree"]) == 3202
     helpers.assert_segments_match(got, gold, gold["in_has_q"])
     np.testing.assert_array_equal(counts[:, 0], gold["counts"])
+    eng.timing(True)
     t0 = time.perf_counter()
     run()
     seconds = time.perf_counter() - t0
-    print(f"g27: 3202 segments through 7689 leaves in {seconds * 1e3:.1f} ms (reference {float(gold['reference_seconds'][0]):.1f} s)")
+    kernel_ms, launches = eng.timing_read()
+    eng.timing(False)
+    print(f"g27: 3202 segments through 7689 leaves in {seconds * 1e3:.1f} ms, {kernel_ms:.1f} ms of it in {launches} launch(es) "
+          f"(reference {float(gold['reference_seconds'][0]):.1f} s); launch: {eng.last_launch()}")
     assert seconds < 0.1 * float(gold["reference_seconds"][0])
