@@ -506,7 +506,57 @@ def survey_latency(oa):
         out.append({"workload": label, "rays": len(rays), "segments": len(res), "calls": len(ts), "median_ms_per_call": statistics.median(ts),
                     "p10_ms": ts[len(ts) // 10], "p90_ms": ts[9 * len(ts) // 10], "reference_python_ms": ref_ms,
                     "speedup_vs_reference": ref_ms / statistics.median(ts)})
+    real = real_example_latency(oa)
+    if real:
+        out.append(real)
     return out
+
+
+def real_example_latency(oa):
+    """The reference's LARGEST example as the reference itself ran it (examples/ripa_gen2_lensless.py: a multi-pass cavity of
+    micro-mirror arrays, 7,689 leaf surfaces, ONE Gaussian ray, cap 1e5 -> 3,202 segments; 16.8 s there, scene construction
+    included).  The reference's objects do not travel to the GPU box; the scene does, as the tables this package's compiler made of
+    them, with the ray and every output segment (tests/golden/g27_real_example.npz, tools/make_golden.py real_example_fixture;
+    tests/test_gpu_real_example.py compares segment by segment).  Timed: ray upload, the trace (ONE launch: the lane-per-tree
+    kernel that reads the image from global memory) and the read-back of all segments in the reference's order."""
+    import statistics
+
+    import numpy as np
+    import torch
+    from optable_amd import abi
+    from optable_amd.batch import RayBatch
+    from optable_amd.engine import get_engine
+    from optable_amd.scene import CompiledScene
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "g27_real_example.npz")
+    if not os.path.exists(path):
+        return None
+    gold = dict(np.load(path))
+    scene = CompiledScene.from_tables(gold)
+    eng = get_engine()
+    cap = int(gold["max_trace_num"][0])
+    has_q = gold["in_has_q"]
+    flags = np.where(has_q, abi.RAY_HAS_Q, 0).astype(np.int32)
+    ts, segments = [], 0
+    with eng.lock:
+        eng.upload(scene)
+        for it in range(8):
+            t0 = time.perf_counter()
+            batch = RayBatch.from_arrays(gold["in_origin"], gold["in_direction"], wavelength=gold["in_wavelength"], intensity=gold["in_intensity"],
+                                         q=np.where(has_q, gold["in_q"], 0j), n_index=gold["in_n"], pathlength=gold["in_pathlength"],
+                                         ids=np.arange(len(has_q), dtype=np.int32), device=eng.device, normalize=False)
+            batch.flags.copy_(torch.from_numpy(flags))
+            counts = torch.zeros((len(scene.limited), 1), dtype=torch.int32, device=eng.device)
+            got = eng.trace_branching(batch, cap, counts=counts, distinct_ids=True).to_host(reference_order=True)
+            ts.append((time.perf_counter() - t0) * 1e3)
+            segments = len(got["ray"])
+    ref_ms = float(gold["reference_seconds"][0]) * 1e3
+    ok = segments == len(gold["seg_tree"]) and bool(np.allclose(got["length"], gold["seg_length"], rtol=1e-6, atol=1e-9))
+    return {"workload": "the reference's largest example as it stands (examples/ripa_gen2_lensless.py: 7,689 leaf surfaces, ONE ray, cap 1e5): "
+                        "scene tables + ray from fixture g27, one launch of the lane-per-tree kernel for scenes no LDS holds",
+            "rays": int(len(has_q)), "segments": segments, "calls": len(ts) - 2, "median_ms_per_call": statistics.median(ts[2:]),
+            "first_call_ms": ts[0], "reference_python_ms": ref_ms, "speedup_vs_reference": ref_ms / statistics.median(ts[2:]),
+            "segments_match_the_reference": ok}
 
 
 def main():

@@ -59,6 +59,39 @@ class CompiledScene:
         d.root_grid = self.root_grid
         return d
 
+    # -- a compiled scene as plain arrays (to keep one, or to carry a scene to a machine its Python objects cannot go to) -----
+    def to_tables(self):
+        """dict of numpy arrays: the node / material records as bytes, the aux table, and the scalars `from_tables` needs."""
+        return {"nodes": np.frombuffer(bytes(self.nodes), dtype=np.uint8).copy(),
+                "materials": np.frombuffer(bytes(self.materials), dtype=np.uint8).copy(),
+                "aux": np.array(self.aux[: self.n_aux], dtype=float),
+                "meta": np.array([self.n_nodes, self.n_materials, len(self.limited), self.max_children, self.root_grid,
+                                  int(self.always_branches), self.n_leaves], dtype=np.int64),
+                "unit": np.array([self.unit]),
+                "limited_max": np.array([int(c.max_interact_count) for c in self.limited], dtype=np.int64)}
+
+    @classmethod
+    def from_tables(cls, tables):
+        """The scene `to_tables` described.  Its `leaves` / `limited` entries are placeholders (there are no component objects
+        to write interact counts back to): for `Engine.trace*` / the oracle, which only read the tables."""
+        import types
+
+        n_nodes, n_mat, _, max_children, root_grid, always, n_leaves = (int(x) for x in tables["meta"])
+        sc = object.__new__(cls)
+        sc.nodes = (abi.OtNode * max(n_nodes, 1)).from_buffer_copy(np.ascontiguousarray(tables["nodes"]).tobytes())
+        sc.n_nodes = n_nodes
+        sc.materials = (abi.OtMaterial * max(n_mat, 1)).from_buffer_copy(np.ascontiguousarray(tables["materials"]).tobytes())
+        sc.n_materials = n_mat
+        aux = np.ascontiguousarray(tables["aux"], dtype=np.float64)
+        sc.aux = (C.c_double * max(len(aux), 1))(*aux.tolist())
+        sc.n_aux = len(aux)
+        sc.leaves = [None] * n_leaves
+        sc.limited = [types.SimpleNamespace(max_interact_count=int(m), _interact_count={}) for m in tables["limited_max"]]
+        sc.hooks = {}
+        sc.max_children, sc.unit, sc.root_grid = max_children, float(tables["unit"][0]), root_grid
+        sc.always_branches, sc.wavelength_range = bool(always), None
+        return sc
+
     def node_table(self):
         """Numpy view of the node records (for tests)."""
         return np.ctypeslib.as_array(self.nodes)[: self.n_nodes] if self.n_nodes else np.zeros(0)

@@ -74,25 +74,9 @@ def assert_segments_match(got, gold, has_q_of_tree, rtol=RTOL, atol=1e-9):
 def stored_scene(gold):
     """A CompiledScene from the tables a fixture holds (tools/make_golden.py real_example_fixture: this package's
     compiler run on the reference's own object graph in the build container; the objects do not travel, the tables do)."""
-    import types
-
     from optable_amd.scene import CompiledScene
 
-    n_nodes, n_mat, n_lim, max_children, root_grid, always, n_leaves = (int(x) for x in gold["meta"])
-    sc = object.__new__(CompiledScene)
-    sc.nodes = (abi.OtNode * max(n_nodes, 1)).from_buffer_copy(gold["nodes"].tobytes())
-    sc.n_nodes = n_nodes
-    sc.materials = (abi.OtMaterial * max(n_mat, 1)).from_buffer_copy(gold["materials"].tobytes())
-    sc.n_materials = n_mat
-    aux = np.ascontiguousarray(gold["aux"], dtype=np.float64)
-    sc.aux = (C.c_double * max(len(aux), 1))(*aux.tolist())
-    sc.n_aux = len(aux)
-    sc.leaves = [None] * n_leaves
-    sc.limited = [types.SimpleNamespace(max_interact_count=int(m), _interact_count={}) for m in gold["limited_max"]]
-    sc.hooks = {}
-    sc.max_children, sc.unit, sc.root_grid = max_children, float(gold["unit"][0]), root_grid
-    sc.always_branches, sc.wavelength_range = bool(always), None
-    return sc
+    return CompiledScene.from_tables(gold)
 
 
 def fixture_rays_host(gold):

@@ -233,14 +233,7 @@ def real_example_fixture():
     for key, val in ray_rows(table.rays).items():
         out["seg_" + key] = val
     out["seg_tree"] = np.zeros(len(table.rays), dtype=np.int32)
-    out["nodes"] = np.frombuffer(bytes(scene.nodes), dtype=np.uint8)
-    out["materials"] = np.frombuffer(bytes(scene.materials), dtype=np.uint8)
-    out["aux"] = np.array(scene.aux[: scene.n_aux], dtype=float)
-    out["meta"] = np.array([scene.n_nodes, scene.n_materials, len(scene.limited), scene.max_children, scene.root_grid,
-                            int(scene.always_branches), scene.n_leaves], dtype=np.int64)
-    out["unit"] = np.array([scene.unit])
-    limited_max = [int(c.max_interact_count) for c in scene.limited]
-    out["limited_max"] = np.array(limited_max, dtype=np.int64)
+    out.update(scene.to_tables())
     out["counts"] = np.array([c._interact_count.get(rays[0]._id, 0) for c in scene.limited], dtype=np.int32)
     out["max_trace_num"] = np.array([100000])
     out["reference_seconds"] = np.array([seconds])
