@@ -371,7 +371,7 @@ class Engine:
     # A lane-per-tree launch whose queues may overflow (caps beyond ~170 in double precision) is a speculation on small trees:
     # small batches only, and it may allocate this many slots at most.
     TREES_SMALL_BATCH = 64 * 256
-    TREES_SPECULATIVE_SLOTS = 1 << 20
+    TREES_SPECULATIVE_SLOTS = 1 << 22  # (440 MB of records in double precision; 40 rays under the reference's largest example's cap of 1e5)
 
     def _trees_estimate(self, rays, K):
         """Rays per tree of a large batch, and how its waves should refill, from a strided 1 % sample (a lane-per-tree launch of
