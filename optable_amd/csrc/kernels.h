@@ -336,14 +336,19 @@ __global__ __launch_bounds__(256, MINW) void k_trace_trees(SceneBlob blob, T uni
     if constexpr (IMG != 0) {
         const int head_words = IMG == 1 ? blob.n_words : (int)(((size_t)blob.n_phys * sizeof(DNode<T>) + (size_t)blob.n_mats * sizeof(DMat<T>)) / 4);
         for (int w = threadIdx.x; w < head_words; w += blockDim.x) lds[w] = blob.words[w];
+        // IMG = 2: the run table too (four words per run) — node_ref walks it for every node index behind the first run, one
+        // dependent read per run: from global memory that was a chain of L2 round trips per node visited
+        const int run_words = IMG == 2 ? 4 * blob.n_runs : 0;
+        for (int w = threadIdx.x; w < run_words; w += blockDim.x) lds[head_words + w] = blob.words[blob.runs_word + w];
         __syncthreads();
         base = lds;
-        img_bytes = ((size_t)head_words * 4 + 15) & ~(size_t)15;
+        img_bytes = ((size_t)(head_words + run_words) * 4 + 15) & ~(size_t)15;
     }
     Scene<T> sc_bound = bind_scene<T>(IMG == 2 ? blob.words : base, blob, unit);
-    if constexpr (IMG == 2) {  // tables (and the run table's head, read above) from global memory, records from LDS
+    if constexpr (IMG == 2) {  // the aux tables from global memory; records and the run table from LDS
         sc_bound.nodes = reinterpret_cast<const DNode<T>*>(lds);
         sc_bound.mats = reinterpret_cast<const DMat<T>*>(sc_bound.nodes + blob.n_phys);
+        sc_bound.runs = reinterpret_cast<const int32_t*>(lds) + ((size_t)blob.n_phys * sizeof(DNode<T>) + (size_t)blob.n_mats * sizeof(DMat<T>)) / 4;
     }
     const Scene<T> sc = sc_bound;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -1232,7 +1232,7 @@ template <class T> static bool trees_plan(const ot_ctx* c, int32_t cap, int64_t 
         img = 0;
         // ... and the node and material records alone in LDS when they leave room for the queues (instanced runs fold thousands of
         // lattice members into a few records: the walk's dependent reads then come from LDS, only poses and grids from L2)
-        const size_t head = ((size_t)(sizeof(T) == 8 ? c->head64 : c->head32) + 15) & ~(size_t)15;
+        const size_t head = ((size_t)(sizeof(T) == 8 ? c->head64 : c->head32) + 16 * (size_t)c->n_runs + 15) & ~(size_t)15;  // records + the run table
         if (head > 0 && head + 4 * 3 * entry <= room / 2 && c->opt_trees_global != 2 && tree_kernel<T, SegPlanes<T>>(4, 2)) { p->img_global = 2; img = head; }
     }
     const int64_t need = ((int64_t)cap + 1) / 2, fit = (int64_t)((room - img) / (4 * entry));
