@@ -317,7 +317,9 @@ int ot_trace_generation_f32(ot_ctx* ctx, const ot_rays* rays, const int32_t* ray
  * ot_trace_*: slot k * n_rays + i of `out` (max_trace_num * n_rays slots) is the k-th ray of tree i in the reference's FIFO
  * order, seg_count[i] the rays tree i processed (== max_trace_num: cut short by the cap, or ended exactly there).  A queue of
  * ceil(max_trace_num / 2) rays per lane always suffices; ot_trace_trees_plan says whether the scene has such a kernel
- * (info[0] bit 0: every scene whose image and queue fronts fit the CU's LDS; bit 1: it also writes these [k][tree] slots — scenes
+ * (info[0] bit 0: every scene — one whose image and queue fronts fit the CU's LDS through the kernel of its preset, a larger one (thousands
+ * of leaves) through the all-features kernel that keeps the node records in LDS, or nothing but the queues, and reads the tables from
+ * global memory: dense list only; bit 1: it also writes these [k][tree] slots — scenes
  * of the planar preset; every such kernel writes the dense list of ot_trace_trees_append_*), how many entries its queues get
  * (info[1]), whether that is enough for every tree (info[2]: always, up to caps of ~170 in double precision for a batch that
  * fills the device and of 510 for a few hundred trees — the scratch is per workgroup of the launch) how many of them are in

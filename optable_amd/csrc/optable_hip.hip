@@ -1276,7 +1276,7 @@ template <class T, class OUT>
 static int launch_trees(ot_ctx* c, const ot_rays* rays, int64_t n, int32_t cap, const OUT& out, const AppendCtl& ac, int32_t* seg_count, int32_t* counts,
                         int32_t n_classes) {
     TreesPlan p;
-    if (!trees_plan<T>(c, cap, n, &p)) return fail(OT_ERR_UNSUPPORTED, "no tree kernel for this scene (features beyond the everyday presets, or an image that leaves no room for the queues): use ot_trace_tree_*");
+    if (!trees_plan<T>(c, cap, n, &p)) return fail(OT_ERR_UNSUPPORTED, "no tree kernel for this scene (a hit that emits more than two rays, or no room for the queues): use ot_trace_tree_*");
     HIP_TRY(hipSetDevice(c->device));
     const TreeKern<T, OUT> kern = tree_kernel<T, OUT>(p.preset, p.img_global == 0 ? 1 : (p.img_global == 2 ? 2 : 0));
     if (!kern) return fail(OT_ERR_UNSUPPORTED, "this scene's tree kernel writes the append layout only (ot_trace_trees_append_*)");
