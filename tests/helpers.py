@@ -91,3 +91,18 @@ def fixture_rays_host(gold):
     host["id"] = np.arange(n, dtype=np.int32)
     host["flags"] = np.where(has_q, abi.RAY_HAS_Q, 0).astype(np.int32) | np.where(gold["in_alive"], 0, abi.RAY_DEAD).astype(np.int32)
     return host
+
+
+EXAMPLES = os.path.join(GOLDEN, "examples")
+
+
+def example_names():
+    return sorted(f[:-4] for f in os.listdir(EXAMPLES) if f.endswith(".npz"))
+
+
+def example_rays_host(gold):
+    """Input rays of an examples/ fixture in the ot_rays layout (class ids; wavelengths in the scene's unit as table._pack does)."""
+    host = fixture_rays_host(gold)
+    host["id"] = gold["in_class"].astype(np.int32)
+    host["wavelength"] = host["wavelength"] * gold["in_unit_scale"]
+    return host

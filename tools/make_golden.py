@@ -242,6 +242,98 @@ def real_example_fixture():
           f"(scene construction included)")
 
 
+def all_examples_fixture():
+    """examples/*.py of the reference, every one as it stands: the script is executed from /root/reference with
+    `OpticalTable.ray_tracing` wrapped — the FIRST call is let through, recorded (the table's scene as this package's compiler
+    flattens the reference's objects, the input rays, every output segment in the order returned, interact counts) and the script
+    is stopped there (what follows renders or optimises).  One .npz per example under tests/golden/examples/; scripts that never
+    trace (material plots, colour maps) are listed as such.  DATA only: tables, rays, segments."""
+    import contextlib
+    import glob
+    import io
+    import time
+
+    import optable_amd as oa
+
+    class Stop(Exception):
+        pass
+
+    outdir = os.path.join(OUT, "examples")
+    os.makedirs(outdir, exist_ok=True)
+    original = ref.OpticalTable.ray_tracing
+    summary = []
+    for path in sorted(glob.glob("/root/reference/examples/*.py")):
+        name = os.path.splitext(os.path.basename(path))[0]
+        seen = {}
+
+        def wrapped(self, rays, perfomance_limit=None):
+            rays_in = [rays] if isinstance(rays, ref.Ray) else list(rays)
+            before = len(self.rays)
+            scene = oa.compile_scene(self.components, getattr(self, "unit", 1e-2))  # poses as they are at the call
+            ids = [r._id for r in rays_in]
+            counts0 = [[c._interact_count.get(i, 0) for i in dict.fromkeys(ids)] for c in scene.limited]
+            t0 = time.time()
+            segs, tree = [], []
+            for i, ray in enumerate(rays_in):  # optical_table.py:66-70, keeping the tree index
+                traced = self._single_ray_tracing(ray, perfomance_limit=perfomance_limit)
+                self.rays.extend(traced)
+                segs.extend(traced)
+                tree.extend([i] * len(traced))
+            seen.update(scene=scene, rays=rays_in, segs=segs, tree=tree, limit=perfomance_limit, seconds=time.time() - t0, counts0=counts0,
+                        accumulated=before)
+            raise Stop()
+
+        ref.OpticalTable.ray_tracing = wrapped
+        env = {"__name__": "__main__", "__file__": path}
+        cwd = os.getcwd()
+        os.chdir(os.path.dirname(path))
+        np.random.seed(12345)
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                exec(compile(open(path).read(), path, "exec"), env)
+            status = "never traces"
+        except Stop:
+            status = "traced"
+        except Exception as exc:  # noqa: BLE001 - a script that fails before its first trace (a missing file, a display)
+            status = f"stopped before its first trace: {type(exc).__name__}: {exc}"
+        finally:
+            os.chdir(cwd)
+            ref.OpticalTable.ray_tracing = original
+            import matplotlib.pyplot as plt
+
+            plt.close("all")
+        if status != "traced":
+            summary.append((name, status))
+            continue
+        if name == "ripa_gen2_lensless":  # fixture g27 (real_example_fixture) is this example: 328 KB once
+            summary.append((name, "see ../g27_real_example.npz (7,689 leaves, 1 ray -> 3,202 segments, cap 100000)"))
+            continue
+        scene, rays = seen["scene"], seen["rays"]
+        out = {}
+        for key, val in ray_rows(rays).items():
+            out["in_" + key] = val
+        ids = [r._id for r in rays]
+        class_of = {}
+        out["in_class"] = np.array([class_of.setdefault(i, len(class_of)) for i in ids], dtype=np.int32)
+        out["in_unit_scale"] = np.array([getattr(r, "unit", scene.unit) / scene.unit for r in rays], dtype=float)
+        for key, val in ray_rows(seen["segs"]).items():
+            out["seg_" + key] = val
+        out["seg_tree"] = np.array(seen["tree"], dtype=np.int32)
+        out.update(scene.to_tables())
+        cap = 2000 if not seen["limit"] or "max_trace_num" not in seen["limit"] else int(seen["limit"]["max_trace_num"])
+        out["max_trace_num"] = np.array([cap])
+        out["counts_before"] = np.array(seen["counts0"], dtype=np.int32).reshape(len(scene.limited), len(class_of))
+        out["counts"] = np.array([[c._interact_count.get(i, 0) for i in class_of] for c in scene.limited], dtype=np.int32).reshape(len(scene.limited), len(class_of))
+        out["reference_seconds"] = np.array([seen["seconds"]])
+        np.savez_compressed(os.path.join(outdir, name + ".npz"), **out)
+        summary.append((name, f"{len(rays)} rays, {scene.n_leaves} leaves -> {len(seen['segs'])} segments, cap {cap}, reference {seen['seconds']:.2f} s"))
+    with open(os.path.join(outdir, "INDEX.txt"), "w") as fh:
+        fh.write("# examples/*.py of the reference at their first OpticalTable.ray_tracing call (tools/make_golden.py all_examples_fixture)\n")
+        for name, line in summary:
+            fh.write(f"{name}: {line}\n")
+            print(f"{name}: {line}")
+
+
 def calibrate_fixture():
     """g22: OpticalTable.calibrate_symmetric_4f (optical_table.py:299-422), a caller of the hot path: the cost
     terms at a fixed (F1, F2) and the Nelder-Mead result for two criteria."""
@@ -261,7 +353,7 @@ def calibrate_fixture():
 if __name__ == "__main__":
     names = sys.argv[1:] or list(scenes.SCENES) + list(scenes.HOOKED_SCENES)
     for nm in names:
-        if nm in ("g14_slab", "g17_abcd", "g20_interact", "g22_calibrate", "g23_exports", "g27_real_example"):
+        if nm in ("g14_slab", "g17_abcd", "g20_interact", "g22_calibrate", "g23_exports", "g27_real_example", "examples"):
             continue
         np.random.seed(12345)
         run(nm)
@@ -275,6 +367,8 @@ if __name__ == "__main__":
     if not sys.argv[1:] or "g23_exports" in sys.argv[1:]:
         np.random.seed(12345)
         exports_fixture()
+    if "examples" in sys.argv[1:]:  # (every example of the reference at its first trace: ~40 s, on request only)
+        all_examples_fixture()
     if "g27_real_example" in sys.argv[1:]:  # (18 s of the reference: on request only)
         real_example_fixture()
     if not sys.argv[1:] or "g20_interact" in sys.argv[1:]:
