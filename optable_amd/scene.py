@@ -111,6 +111,18 @@ class _Builder:
 
     # -- materials -----------------------------------------------------------------------
     def material(self, mat):
+        # (lattice groups name the same Material objects thousands of times: remembered by identity while this compile runs —
+        # the objects are alive in the components — before the value-keyed table below is asked)
+        by_id = self.__dict__.setdefault("_mat_by_id", {})
+        hit = by_id.get(id(mat)) if hasattr(mat, "device_spec") else None
+        if hit is not None:
+            return hit
+        index = self._material_index(mat)
+        if hasattr(mat, "device_spec"):
+            by_id[id(mat)] = index
+        return index
+
+    def _material_index(self, mat):
         if not hasattr(mat, "device_spec"):
             mat = Material("Constant", float(mat))
         spec = mat.device_spec()
@@ -119,7 +131,10 @@ class _Builder:
 
             raise SceneError(f"Material {mat.name!r} is defined by a Python callable that has no device form: "
                              f"{callable_spec.why or 'not a function of the wavelength the compiler can sample'}")
-        key = (spec[0],) + tuple(np.ravel(np.concatenate([np.ravel(x) for x in spec[1:]])).tolist())
+        if spec[0] == "const":  # (the common case by far: a number, no arrays to flatten)
+            key = ("const", float(spec[1]))
+        else:
+            key = (spec[0],) + tuple(np.ravel(np.concatenate([np.ravel(x) for x in spec[1:]])).tolist())
         if key not in self.mat_index:
             rec = abi.OtMaterial()
             if spec[0] == "const":
