@@ -111,18 +111,6 @@ class _Builder:
 
     # -- materials -----------------------------------------------------------------------
     def material(self, mat):
-        # (lattice groups name the same Material objects thousands of times: remembered by identity while this compile runs —
-        # the objects are alive in the components — before the value-keyed table below is asked)
-        by_id = self.__dict__.setdefault("_mat_by_id", {})
-        hit = by_id.get(id(mat)) if hasattr(mat, "device_spec") else None
-        if hit is not None:
-            return hit
-        index = self._material_index(mat)
-        if hasattr(mat, "device_spec"):
-            by_id[id(mat)] = index
-        return index
-
-    def _material_index(self, mat):
         if not hasattr(mat, "device_spec"):
             mat = Material("Constant", float(mat))
         spec = mat.device_spec()
