@@ -343,31 +343,33 @@ def _trust_boxes(b):
     lab = np.einsum("nij,ncj->nci", M, lb[:, _CORNERS]) + org[:, None, :]          # [n, 8, 3]
     fresh = np.stack([lab[:, :, 0].min(1), lab[:, :, 0].max(1), lab[:, :, 1].min(1), lab[:, :, 1].max(1),
                       lab[:, :, 2].min(1), lab[:, :, 2].max(1)], axis=1)
-    leaf_nodes = [i for i, nd in enumerate(b.nodes) if nd.kind == abi.NODE_LEAF]
+    nodes = b.nodes
+    leaf_nodes = [i for i, nd in enumerate(nodes) if nd.kind == abi.NODE_LEAF]
     tol = 1e-9 * (1.0 + np.abs(fresh).max(axis=1))
-    everything = True
-    node_fresh = {}
-    for i in leaf_nodes:
-        nd = b.nodes[i]
-        f = fresh[nd.leaf_id]
-        node_fresh[i] = f
-        if not (nd.flags & abi.NODE_CHECK_AABB) and not any(nd.aabb[:]):
-            nd.flags |= abi.NODE_BOX_TRUSTED  # no cached box in play: the fresh one is filled in by compile_scene
-            continue
-        c = np.array(nd.aabb[:])
-        t = tol[nd.leaf_id]
-        ok = bool(np.all(c[0::2] <= f[0::2] + t) and np.all(c[1::2] >= f[1::2] - t))
+    # all leaves at once (a lattice scene has thousands): cached box against fresh box, flags set in one sweep
+    lid = np.array([nodes[i].leaf_id for i in leaf_nodes], dtype=np.int64)
+    gated = np.array([bool(nodes[i].flags & abi.NODE_CHECK_AABB) for i in leaf_nodes])
+    cached = np.array([nodes[i].aabb[:] for i in leaf_nodes], dtype=float).reshape(-1, 6)
+    f_leaf = fresh[lid]
+    t_leaf = tol[lid][:, None]
+    no_box = ~gated & ~cached.any(axis=1)  # no cached box in play: the fresh one is filled in by compile_scene
+    holds = (cached[:, 0::2] <= f_leaf[:, 0::2] + t_leaf).all(axis=1) & (cached[:, 1::2] >= f_leaf[:, 1::2] - t_leaf).all(axis=1)
+    trusted = no_box | holds
+    everything = bool(trusted.all())
+    for i, ok in zip(leaf_nodes, trusted.tolist()):
         if ok:
-            nd.flags |= abi.NODE_BOX_TRUSTED
-        everything &= ok
-    for g in reversed(b.groups):  # inner groups first: a group's fresh box is the union of what lies below it
-        nd = b.nodes[g]
-        below = [node_fresh[i] for i in range(g + 1, nd.end) if b.nodes[i].kind == abi.NODE_LEAF]
-        if not below:
+            nodes[i].flags |= abi.NODE_BOX_TRUSTED
+    node_fresh = np.full((len(nodes), 6), np.nan)
+    node_fresh[leaf_nodes] = f_leaf
+    is_leaf = np.zeros(len(nodes), dtype=bool)
+    is_leaf[leaf_nodes] = True
+    for g in reversed(b.groups):  # a group's fresh box is the union of the leaves that lie below it
+        nd = nodes[g]
+        below = node_fresh[g + 1:nd.end][is_leaf[g + 1:nd.end]]
+        if not len(below):
             nd.flags |= abi.NODE_BOX_TRUSTED
             continue
-        f = np.array(below)
-        f = np.array([f[:, 0].min(), f[:, 1].max(), f[:, 2].min(), f[:, 3].max(), f[:, 4].min(), f[:, 5].max()])
+        f = np.array([below[:, 0].min(), below[:, 1].max(), below[:, 2].min(), below[:, 3].max(), below[:, 4].min(), below[:, 5].max()])
         c = np.array(nd.aabb[:])
         t = 1e-9 * (1.0 + np.abs(f).max())
         ok = bool(np.all(c[0::2] <= f[0::2] + t) and np.all(c[1::2] >= f[1::2] - t))
