@@ -54,7 +54,7 @@ def test_no_kernel_uses_scratch_or_spills_vector_registers(kernels):
 
 def test_library_stays_small(kernels):
     # round 2 shipped 461 kernels (338 of them a scan library's tuning variants) and took two minutes to build
-    assert 40 <= len(kernels) < 170, len(kernels)  # round 4: 165 (+ look-ahead emit, recount, the lane-per-tree kernels of every preset)
+    assert 40 <= len(kernels) < 172, len(kernels)  # round 4: 169 (+ look-ahead emit, recount, the lane-per-tree kernels of every preset)
     names = [k["name"] for k in kernels]
     assert not any("rocprim" in n or "hipcub" in n for n in names)
     assert sum("k_trace_rolling" in n for n in names) <= 48
