@@ -6,6 +6,8 @@ import os, sys, time
 ROOT=os.environ.get("GRAFT_REPO_ROOT", "/root/repo"); sys.path.insert(0, ROOT)
 import numpy as np, torch
 from optable_amd import abi
+if os.environ.get('OT_LIB'):  # an A/B build of the library (make -C optable_amd/csrc variant V=... EXTRA=...)
+    abi.LIB_PATH = os.path.abspath(os.environ['OT_LIB'])
 from optable_amd.batch import RayBatch
 from optable_amd.engine import get_engine
 from optable_amd.scene import CompiledScene
